@@ -1,0 +1,340 @@
+#!/usr/bin/env python
+"""Generate the committed golden vectors by running the REFERENCE's own Python on CPU.
+
+Runs only in the build container (needs /root/reference).  The reference's native CUDA
+extension cannot execute here, so ``hashencoder.backend._backend`` is the CPU oracle
+(oracle/hashenc_oracle.c); everything above it -- hashgrid.py's autograd Functions and
+HashEncoder, model/{network,base_networks,ray_sampler,density,embedder}.py,
+utils/{rend_util,general}.py -- is the reference's unmodified code.  The hash/index rule
+itself is pinned independently by known-answer vectors (tests/test_oracle_kat.py) and by the
+reference's pure-torch twin ``HashEncoder.torch_forward`` (case ``twin_*`` below).
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Fixtures are DATA: inputs (incl. every parameter tensor and every captured RNG draw) and the
+reference's outputs/gradients.  No reference source is stored.
+"""
+import contextlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_shims  # noqa: E402
+from oracle import hashenc  # noqa: E402
+
+hg = ref_shims.install(hashenc.OracleBackend())
+torch.Tensor.get_device = lambda self: "cpu"  # general.quad2rotation does .to(t.get_device())
+ref_network = ref_shims.import_ref("model.network")
+ref_general = ref_shims.import_ref("utils.general")
+ref_rend = ref_shims.import_ref("utils.rend_util")
+
+
+# ------------------------------------------------------------------ RNG capture
+class DrawLog:
+    def __init__(self):
+        self.draws = []
+
+
+@contextlib.contextmanager
+def capture_draws(log):
+    """Record every CPU random draw the reference makes inside forward (ray_sampler.py:58,148,158;
+    network.py:318-330), in call order."""
+    o_rand, o_perm, o_int, o_like, o_unif = (torch.rand, torch.randperm, torch.randint,
+                                             torch.rand_like, torch.Tensor.uniform_)
+
+    def rec(kind, t):
+        log.draws.append((kind, t.detach().clone()))
+        return t
+
+    torch.rand = lambda *a, **k: rec("rand", o_rand(*a, **k))
+    torch.randperm = lambda *a, **k: rec("randperm", o_perm(*a, **k))
+    torch.randint = lambda *a, **k: rec("randint", o_int(*a, **k))
+    torch.rand_like = lambda *a, **k: rec("rand_like", o_like(*a, **k))
+    torch.Tensor.uniform_ = lambda self, *a, **k: rec("uniform_", o_unif(self, *a, **k))
+    try:
+        yield log
+    finally:
+        torch.rand, torch.randperm, torch.randint, torch.rand_like = o_rand, o_perm, o_int, o_like
+        torch.Tensor.uniform_ = o_unif
+
+
+# ------------------------------------------------------------------ configs
+def model_conf(coarse_grid, fine_grid, n_samples, n_eval, n_extra):
+    def sdf(dims, g):
+        return dict(d_in=3, d_out=1, dims=dims, geometric_init=True, bias=0.6, skip_in=[],
+                    weight_norm=True, multires=6, inside_outside=True, use_grid_feature=True,
+                    base_size=g[0], end_size=g[1], logmap=g[2], num_levels=g[3], level_dim=g[4],
+                    divide_factor=1.0, embedding_method="nerf")
+    return ref_shims.Conf(
+        feature_vector_size=64, scene_bounding_sphere=1.0, use_warp_loss=False,
+        mapping_patchsizes=[1], tracking_patchsizes=[1], sampling_method="important",
+        density_method="volsdf_gridpredefined",
+        implicit_network=dict(coarse=sdf([64], coarse_grid), fine=sdf([64, 64, 64], fine_grid)),
+        rendering_network=dict(mode="idr", d_in=9, d_out=3, dims=[64, 64], weight_norm=True,
+                               multires_view=4, per_image_code=False, use_grid_feature=True),
+        gridpredefinedensity={},
+        ray_sampler=dict(near=0.0, N_samples=n_samples, N_samples_eval=n_eval, N_samples_extra=n_extra),
+    )
+
+
+class _DS:
+    img_res = (680, 1200)
+
+
+def build_model(seed, coarse_grid, fine_grid, colour_grid, n_samples, n_eval, n_extra, emb_scale):
+    """Reference SLAMNetwork with reduced-size tables.  The colour encoder is hard-coded to a
+    1 GiB table (base_networks.py:265-284); it is swapped for the reference's own HashEncoder
+    class with a small geometry that keeps 16 levels x 2 features."""
+    torch.manual_seed(seed)
+    conf = model_conf(coarse_grid, fine_grid, n_samples, n_eval, n_extra)
+    # build with a throw-away tiny colour grid to avoid allocating 1 GiB: patch the class default
+    RN = ref_shims.import_ref("model.base_networks").RenderingNetwork
+    HE = hg.HashEncoder
+    orig = HE.__init__
+
+    def small_init(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16,
+                   log2_hashmap_size=19, desired_resolution=None):
+        if log2_hashmap_size == 24:  # the hard-coded colour grid
+            base_resolution, desired_resolution, log2_hashmap_size = colour_grid
+        orig(self, input_dim, num_levels, level_dim, per_level_scale, base_resolution, log2_hashmap_size,
+             desired_resolution)
+
+    HE.__init__ = small_init
+    try:
+        model = ref_network.SLAMNetwork(conf, dataset=_DS(), n_images=4)
+    finally:
+        HE.__init__ = orig
+    g = torch.Generator().manual_seed(seed + 100)
+    for enc, sc in ((model.implicit_network.coarse.encoding, emb_scale[0]),
+                    (model.implicit_network.fine.encoding, emb_scale[1]),
+                    (model.rendering_network.encoding, emb_scale[2])):
+        enc.embeddings.data = (torch.rand(enc.embeddings.shape, generator=g) * 2 - 1) * sc
+    # perturb weight_g so weight-norm is exercised away from its init point
+    for n, p in model.named_parameters():
+        if n.endswith("weight_g"):
+            p.data = p.data * (1 + 0.1 * (torch.rand(p.shape, generator=g) - 0.5))
+    return model, conf
+
+
+def synth_inputs(seed, bs, n_pix):
+    g = torch.Generator().manual_seed(seed)
+    H, W = _DS.img_res
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 600.0
+    K[0, 2], K[1, 2] = 599.5, 339.5
+    K[0, 1] = 0.3  # exercise the skew term of lift()
+    idx = torch.randint(H * W, (bs, n_pix), generator=g)
+    uv = torch.stack([(idx % W).float(), (idx // W).float()], -1)
+    cam = torch.zeros(bs, 7)
+    cam[:, 0] = 1.0
+    cam[:, :4] += 0.05 * torch.randn(bs, 4, generator=g)   # NOT unit: two_s = 2/|q|^2 matters
+    cam[:, 4:] = torch.tensor([0.1, 0.0, -0.2]) + 0.05 * torch.randn(bs, 3, generator=g)
+    return uv, cam, K[None].repeat(bs, 1, 1)
+
+
+def t2n(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.detach().cpu().numpy()
+        else:
+            out[k] = np.asarray(v)
+    return out
+
+
+def objective(out, gt, mode):
+    """Scalar used to pull gradients through every differentiable output (terms follow
+    model/loss.py:57-110 in form; the weights are arbitrary but fixed)."""
+    loss = (out["rgb_values"].reshape(-1, 3) - gt["rgb"]).abs().mean()
+    if mode == "mapping":
+        loss = loss + 0.1 * (out["depth_values"].reshape(-1, 1) - gt["depth"]).abs().mean()
+        n = torch.nn.functional.normalize(out["normal_map"].reshape(-1, 3), p=2, dim=-1)
+        loss = loss + 0.05 * (n - gt["normal"]).abs().sum(-1).mean() + 0.05 * (1 - (n * gt["normal"]).sum(-1)).mean()
+        g1, g2 = out["grad_theta"], out["grad_theta_nei"]
+        loss = loss + 0.1 * ((g1.norm(2, dim=1) - 1) ** 2).mean()
+        n1 = g1 / (g1.norm(2, dim=1).unsqueeze(-1) + 1e-5)
+        n2 = g2 / (g2.norm(2, dim=1).unsqueeze(-1) + 1e-5)
+        loss = loss + 0.005 * torch.norm(n1 - n2, dim=-1).mean()
+        loss = loss + 0.01 * out["entropy"]
+    return loss
+
+
+def full_case(name, seed, mode, stage, color_stage, bs, n_pix, training=True, poisson=False,
+              grids=None, samples=(10, 32, 6)):
+    coarse_grid, fine_grid, colour_grid = grids or ((4, 4, 8, 4, 8), (4, 32, 10, 8, 4), (4, 64, 10))
+    model, conf = build_model(seed, coarse_grid, fine_grid, colour_grid, *samples,
+                              emb_scale=(0.05, 0.05, 0.5))
+    model.train(training)
+    uv, cam, K = synth_inputs(seed + 1, bs, n_pix)
+    g = torch.Generator().manual_seed(seed + 2)
+    if poisson:
+        model.voxels.copy_(torch.poisson(torch.full(model.voxels.shape, 50.0), generator=g))
+    voxels_in = model.voxels.clone()
+    cam = cam.clone().requires_grad_(True)
+    pose = ref_general.get_camera_from_tensor(cam)
+    gt = {"rgb": torch.rand(bs * n_pix, 3, generator=g), "depth": torch.rand(bs * n_pix, 1, generator=g) * 2,
+          "normal": torch.nn.functional.normalize(torch.randn(bs * n_pix, 3, generator=g), dim=-1)}
+    log = DrawLog()
+    torch.manual_seed(seed + 3)
+    with capture_draws(log):
+        out = model({"intrinsics": K, "uv": uv, "pose": pose}, torch.arange(bs), {}, mode=mode,
+                    stage=stage, color_stage=color_stage, frame_idx=1)
+    rec = {"in_uv": uv, "in_cam": cam, "in_K": K, "in_pose": pose, "in_voxels": voxels_in,
+           "meta_mode": mode, "meta_stage": stage, "meta_color_stage": color_stage,
+           "meta_training": int(training), "meta_samples": np.array(samples),
+           "meta_coarse_grid": np.array(coarse_grid), "meta_fine_grid": np.array(fine_grid),
+           "meta_colour_grid": np.array(colour_grid)}
+    kinds = [k for k, _ in log.draws]
+    if training:
+        assert kinds[:3] == ["rand", "randperm", "randint"], kinds
+        rec["draw_t_rand"], rec["draw_extra_idx"] = log.draws[0][1], log.draws[1][1][: samples[2]]
+        rec["draw_eik_idx"] = log.draws[2][1]
+        if mode == "mapping":
+            assert kinds[3:] == ["uniform_", "rand_like"], kinds
+            rec["draw_eik_uniform"], rec["draw_eik_jitter"] = log.draws[3][1], log.draws[4][1]
+    else:
+        assert kinds == ["randint"], kinds
+        rec["draw_eik_idx"] = log.draws[0][1]
+    for k, v in model.state_dict().items():
+        rec["param_" + k] = v
+    for k in ("rgb", "rgb_values", "depth_values", "z_vals", "depth_vals", "sdf", "weights", "entropy",
+              "normal_map", "grad_theta", "grad_theta_nei"):
+        if k in out:
+            rec["out_" + k] = out[k]
+    rec["out_voxels"] = model.voxels.clone()
+    if training:
+        loss = objective(out, gt, mode)
+        loss.backward()
+        rec["out_loss"] = loss
+        rec["grad_cam"] = cam.grad
+        for n, p in model.named_parameters():
+            rec["grad_" + n] = p.grad if p.grad is not None else torch.zeros(0)
+        for k, v in gt.items():
+            rec["gt_" + k] = v
+    # a1/a17 on their own
+    d, o = ref_rend.get_camera_params(uv, pose.detach(), K)
+    rec["out_ray_dirs"], rec["out_cam_loc"] = d, o
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **t2n(rec))
+    print(name, "loss" in locals() and float(loss), {k: tuple(v.shape) for k, v in rec.items()
+                                                     if k.startswith("out_") and hasattr(v, "shape")})
+
+
+def encoder_case(name, seed, L, C, base, end, logmap, n_pts, emb_scale=1.0):
+    """Function-level vectors through the reference's wrappers (hashgrid.py:13-134,199-215):
+    forward, Jacobian contraction, table scatter, and the two second-backward products."""
+    torch.manual_seed(seed)
+    enc = hg.HashEncoder(input_dim=3, num_levels=L, level_dim=C, per_level_scale=2, base_resolution=base,
+                         log2_hashmap_size=logmap, desired_resolution=end)
+    g = torch.Generator().manual_seed(seed)
+    enc.embeddings.data = (torch.rand(enc.embeddings.shape, generator=g) * 2 - 1) * emb_scale
+    x = torch.rand(n_pts, 3, generator=g) * 2 - 1
+    x[0] = torch.tensor([-1.0, -1.0, -1.0])      # maps to 0 exactly
+    x[1] = torch.tensor([1.0, 1.0, 1.0])         # maps to 1 exactly (corner +1 rows, weight 0)
+    x[2] = torch.tensor([1.0, -0.3, 0.25])
+    x[3] = torch.tensor([1.0001, 0.0, 0.0])      # out of range -> zeros
+    x[4] = torch.tensor([0.2, -1.5, 0.0])        # out of range -> zeros
+    x[5] = x[6].clone()                          # duplicate cell (scatter contention)
+    x = x.requires_grad_(True)
+    v = torch.randn(n_pts, L * C, generator=g).requires_grad_(True)   # upstream grad of the value
+    q = torch.randn(n_pts, 3, generator=g)                            # upstream grad of grad_inputs
+    r = torch.randn(n_pts, L * C, generator=g)
+    y = enc(x)
+    (gx,) = torch.autograd.grad(y, x, v, create_graph=True)
+    first_emb = torch.autograd.grad(y, enc.embeddings, v, retain_graph=True)[0]
+    loss2 = (gx * q).sum() + (y * r).sum()
+    loss2.backward()
+    rec = dict(meta_grid=np.array([L, C, base, end, logmap]), in_x=x, in_v=v, in_q=q, in_r=r,
+               param_embeddings=enc.embeddings, param_offsets=enc.offsets,
+               meta_per_level_scale=np.float64(enc.per_level_scale),
+               out_y=y, out_gx=gx, out_first_emb=first_emb, out_emb_grad=enc.embeddings.grad,
+               out_v_grad=v.grad, out_x_grad=x.grad)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **t2n(rec))
+    print(name, tuple(enc.embeddings.shape), enc.offsets.tolist())
+
+
+def twin_case(name, seed, L, C, base, end, n_pts):
+    """The reference's pure-torch twin (hashgrid.py:217-299): dense levels, interior points."""
+    torch.manual_seed(seed)
+    enc = hg.HashEncoder(input_dim=3, num_levels=L, level_dim=C, per_level_scale=2, base_resolution=base,
+                         log2_hashmap_size=19, desired_resolution=end)
+    g = torch.Generator().manual_seed(seed)
+    enc.embeddings.data = torch.rand(enc.embeddings.shape, generator=g) * 2 - 1
+    # the twin sizes each level from a float64 scale, the kernel from float32 exp2f; they only
+    # describe the same grid when both give the same resolution -- true for this geometry
+    # (and for the shipped 32->32, 32->128, 16->2048 grids), checked here.
+    for lv in range(L):
+        f64 = int(np.ceil(np.exp2(lv * np.log2(enc.per_level_scale)) * base - 1)) + 1
+        assert f64 == hashenc.level_geometry(enc.offsets.numpy(), lv, np.log2(enc.per_level_scale), base)[2]
+    x = (torch.rand(n_pts, 3, generator=g) * 2 - 1) * 0.98
+    x.requires_grad_(True)
+    y = enc.torch_forward(x)
+    v = torch.randn(y.shape, generator=g)
+    (gx,) = torch.autograd.grad(y, x, v)
+    rec = dict(meta_grid=np.array([L, C, base, end, 19]), in_x=x, in_v=v, param_embeddings=enc.embeddings,
+               param_offsets=enc.offsets, meta_per_level_scale=np.float64(enc.per_level_scale),
+               out_y=y, out_gx=gx)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **t2n(rec))
+    print(name, tuple(enc.embeddings.shape))
+
+
+def sparse_colour_case(name, seed, n_pts):
+    """Real colour-grid geometry (16x2, 16->2048, 2^24 rows/level, base_networks.py:265-284) incl.
+    the uint32 stride wrap at resolution 2048.  The 1 GiB table is stored sparsely: only rows
+    the points touch are kept (value = f(row)), everything else is zero on both sides."""
+    L, C, base, end, logmap = 16, 2, 16, 2048, 24
+    pls = np.exp2(np.log2(end / base) / (L - 1))
+    offs, tot = [], 0
+    for i in range(L):
+        res = int(np.ceil(base * pls ** i))
+        offs.append(tot)
+        tot += min(2 ** logmap, res ** 3)
+    offs.append(tot)
+    offsets = torch.tensor(offs, dtype=torch.int32)
+    g = torch.Generator().manual_seed(seed)
+    x01 = torch.rand(n_pts, 3, generator=g)
+    x01[0] = torch.tensor([1.0, 1.0, 1.0])
+    x01[1] = torch.tensor([0.0, 0.5, 1.0])
+    S = np.log2(pls)
+    # enumerate touched rows with the oracle's own index rule, fill them from a row-keyed formula
+    emb = torch.zeros(tot, C)   # lazily committed by the OS; only touched rows are written
+    rows = set()
+    for lv in range(L):
+        row0, nrows, res, scale = hashenc.level_geometry(offs, lv, S, base)
+        cell = np.floor(x01.numpy() * np.float32(scale)).astype(np.uint32)
+        for p in range(n_pts):
+            for corner in range(8):
+                q = [int(cell[p, d]) + ((corner >> d) & 1) for d in range(3)]
+                rows.add(row0 + hashenc.level_row(nrows, res, q))
+    rows = torch.tensor(sorted(rows), dtype=torch.long)
+    vals = torch.stack([torch.sin(rows.double() * 0.37), torch.cos(rows.double() * 0.11)], -1).float()
+    emb[rows] = vals
+    emb.requires_grad_(True)
+    x01.requires_grad_(True)
+    y = hg.hash_encode(x01, emb, offsets, pls, base, True)
+    v = torch.randn(y.shape, generator=g)
+    (gx,) = torch.autograd.grad(y, x01, v)
+    rec = dict(meta_grid=np.array([L, C, base, end, logmap]), meta_per_level_scale=np.float64(pls),
+               in_x01=x01, in_v=v, param_rows=rows, param_vals=vals, param_offsets=offsets,
+               out_y=y, out_gx=gx)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **t2n(rec))
+    print(name, len(rows), "rows touched of", tot)
+
+
+if __name__ == "__main__":
+    encoder_case("enc_coarse", 1, L=4, C=8, base=8, end=8, logmap=19, n_pts=64)
+    encoder_case("enc_fine", 2, L=8, C=4, base=4, end=40, logmap=10, n_pts=64)
+    encoder_case("enc_colour", 3, L=16, C=2, base=4, end=128, logmap=11, n_pts=64)
+    twin_case("twin_dense", 4, L=5, C=4, base=8, end=40, n_pts=128)
+    sparse_colour_case("enc_colour_real_sparse", 5, n_pts=24)
+    full_case("full_tracking", 10, "tracking", "fine", "highfreq", bs=1, n_pix=24)
+    full_case("full_tracking_poisson", 11, "tracking", "fine", "highfreq", bs=1, n_pix=16, poisson=True)
+    full_case("full_mapping", 12, "mapping", "fine", "highfreq", bs=2, n_pix=8, poisson=True)
+    full_case("full_mapping_coarse_base", 13, "mapping", "coarse", "base", bs=2, n_pix=8)
+    full_case("full_vis_eval", 14, "vis", "fine", "highfreq", bs=1, n_pix=16, training=False)

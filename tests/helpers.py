@@ -1,0 +1,72 @@
+"""Shared test helpers: load golden fixtures, rebuild oracle configs from them."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def tt(a):
+    return torch.from_numpy(np.array(a))
+
+
+def params_of(fx, device="cpu"):
+    return {k[len("param_"):]: tt(v).to(device) for k, v in fx.items() if k.startswith("param_")}
+
+
+def oracle_config(fx):
+    from oracle import render_ref as R
+    cg, fg, col = fx["meta_coarse_grid"], fx["meta_fine_grid"], fx["meta_colour_grid"]
+    ns, ne, nx = [int(v) for v in fx["meta_samples"]]
+    mk = lambda g: R.make_grid_spec(int(g[3]), int(g[4]), int(g[0]), int(g[1]), int(g[2]))
+    return R.RenderConfig(
+        coarse=R.SdfNetSpec(mk(cg), n_linear=2), fine=R.SdfNetSpec(mk(fg), n_linear=4),
+        colour_grid=R.make_grid_spec(16, 2, int(col[0]), int(col[1]), int(col[2])),
+        n_samples=ns, n_samples_eval=ne, n_samples_extra=nx)
+
+
+def draws_of(fx, device="cpu"):
+    d = {}
+    for k in ("t_rand", "extra_idx", "eik_idx", "eik_uniform", "eik_jitter"):
+        if "draw_" + k in fx:
+            d[k] = tt(fx["draw_" + k]).to(device)
+    return d
+
+
+def golden_objective(out, fx, mode):
+    """Same scalar as tests/golden/make_golden.py::objective."""
+    import torch.nn.functional as F
+    gt_rgb = tt(fx["gt_rgb"]).to(out["rgb_values"].device)
+    loss = (out["rgb_values"].reshape(-1, 3) - gt_rgb).abs().mean()
+    if mode == "mapping":
+        dev = gt_rgb.device
+        gt_d, gt_n = tt(fx["gt_depth"]).to(dev), tt(fx["gt_normal"]).to(dev)
+        loss = loss + 0.1 * (out["depth_values"].reshape(-1, 1) - gt_d).abs().mean()
+        n = F.normalize(out["normal_map"].reshape(-1, 3), p=2, dim=-1)
+        loss = loss + 0.05 * (n - gt_n).abs().sum(-1).mean() + 0.05 * (1 - (n * gt_n).sum(-1)).mean()
+        g1, g2 = out["grad_theta"], out["grad_theta_nei"]
+        loss = loss + 0.1 * ((g1.norm(2, dim=1) - 1) ** 2).mean()
+        n1 = g1 / (g1.norm(2, dim=1).unsqueeze(-1) + 1e-5)
+        n2 = g2 / (g2.norm(2, dim=1).unsqueeze(-1) + 1e-5)
+        loss = loss + 0.005 * torch.norm(n1 - n2, dim=-1).mean()
+        loss = loss + 0.01 * out["entropy"]
+    return loss
+
+
+def assert_close(a, b, atol, rtol, what=""):
+    a = torch.as_tensor(np.array(a) if not isinstance(a, torch.Tensor) else a).detach().cpu().double()
+    b = torch.as_tensor(np.array(b) if not isinstance(b, torch.Tensor) else b).detach().cpu().double()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    if bad.any():
+        i = int(torch.argmax(err - tol))
+        raise AssertionError(f"{what}: {int(bad.sum())}/{a.numel()} off; worst |{a.flatten()[i]:.8g} - "
+                             f"{b.flatten()[i]:.8g}| = {err.flatten()[i]:.3g} (atol {atol}, rtol {rtol})")

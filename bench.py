@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py -- rays/s of one NICER-SLAM *tracking iteration*  on MI355X.
+
+One "step" = one pass of the hot path over one synthetic batch: camera 7-vector -> c2w -> rays -> hierarchical
+sampler (E=640 SDF evaluations/ray) -> S=128 composite samples/ray through the three grid encoders + SDF/colour MLPs
+-> SDF->density composite -> L1(rgb) -> backward to the pose gradient -> Adam step on the camera.  Real shipped
+network/grid sizes (1 GiB colour table), fp32, synthetic inputs already resident in HBM when the clock starts.
+N > 1: every rank renders its own 1024-ray shard (rays are independent given replicated parameters) and the only
+exchange is one RCCL all-reduce of the 7-float pose gradient + loss per step  ->  "scaling": "weak".
+
+    python bench.py [--gpus N --steps K --warmup W]       (N>1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured streaming copy)
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step")
+    ap.add_argument("--samples", type=int, default=128, help="composite samples per ray (N_samples = S-34)")
+    ap.add_argument("--engine", default="auto", choices=["auto", "fused", "composed"])
+    ap.add_argument("--param-grads", action="store_true",
+                    help="also produce (and discard) table/MLP gradients like the reference's tracking loop")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=64)
+    return ap.parse_args()
+
+
+class DS:
+    img_res = (680, 1200)
+
+
+def make_model(args, device):
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    torch.manual_seed(0)
+    conf = replica_model_conf(n_samples=args.samples - 34, n_samples_eval=640, n_samples_extra=32, use_warp_loss=False)
+    model = SLAMNetwork(conf, dataset=DS(), n_images=2000).to(device)
+    model.train()
+    model.engine = args.engine
+    if not args.param_grads:
+        for p in model.parameters():
+            p.requires_grad_(False)
+    return model, conf
+
+
+def synth_batch(gen, n_rays, device):
+    """SURVEY.md 8d synthetic inputs: 680x1200 image, K=(600,600,599.5,339.5), random pixels, U(0,1) colours."""
+    H, W = DS.img_res
+    idx = torch.randint(H * W, (1, n_rays), generator=gen, device=device)
+    uv = torch.stack([(idx % W).float(), (idx // W).float()], -1)
+    return uv, torch.rand(n_rays, 3, generator=gen, device=device)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from nicer_slam_amd.hashencoder import backend as be
+    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    model, conf = make_model(args, device)
+    K = torch.eye(4, device=device)
+    K[0, 0] = K[1, 1] = 600.0
+    K[0, 2], K[1, 2] = 599.5, 339.5
+    K = K[None]
+    gen = torch.Generator(device=device).manual_seed(1 + rank)
+    total = args.warmup + args.steps
+    batches = [synth_batch(gen, args.rays, device) for _ in range(total)]
+    cam = torch.tensor([1.0, 0, 0, 0, 0.1, 0.0, -0.2], device=device)
+    cam = (cam + 1e-3 * torch.randn(7, device=device, generator=gen)).requires_grad_(True)
+    if world > 1:
+        dist.broadcast(cam.data, 0)
+    opt = torch.optim.Adam([cam], lr=0.005)
+    ind = torch.zeros(1, dtype=torch.long, device=device)
+    red = torch.zeros(8, device=device)
+
+    def step(i):
+        uv, gt = batches[i]
+        pose = get_camera_from_tensor(cam).unsqueeze(0)
+        out = model({"intrinsics": K, "uv": uv, "pose": pose}, ind, {}, mode="tracking", frame_idx=1)
+        loss = (out["rgb_values"].reshape(-1, 3) - gt).abs().mean()
+        loss.backward()
+        if world > 1:   # mean over the global batch: one fused 8-float all-reduce (7 pose-grad + loss)
+            red[:7] = cam.grad
+            red[7] = loss.detach()
+            dist.all_reduce(red)
+            cam.grad.copy_(red[:7] / world)
+        opt.step()
+        opt.zero_grad(set_to_none=False)
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    be.PROFILE = []
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        last = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    prof, be.PROFILE = be.PROFILE, None
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        rays_total = args.rays * world * args.steps
+        # dominant kernel of OUR kernels over the timed region, from events on the launch stream
+        agg = {}
+        for name, nbytes, e0, e1 in prof:
+            a = agg.setdefault(name, [0.0, 0, 0])
+            a[0] += e0.elapsed_time(e1)
+            a[1] += nbytes
+            a[2] += 1
+        roof = None
+        if agg:
+            name, (tms, nbytes, n) = max(agg.items(), key=lambda kv: kv[1][0])
+            ach = nbytes / (tms * 1e-3) / 1e9
+            roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": n,
+                    "avg_launch_us": round(tms / n * 1e3, 2), "bytes_per_launch": nbytes // n,
+                    "share_of_step": round(tms / (dt * 1e3), 4)}
+        cpu = None if args.no_cpu_baseline else cpu_baseline(args, model, conf)
+        line = {
+            "metric": "rays/sec (fwd+bwd), one tracking iteration", "value": round(rays_total / dt, 1), "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Replica room0 tracking iteration, {args.rays} rays x {args.samples} samples "
+                                   f"(+640 sampler evaluations/ray), single MI355X fp32 [BASELINE configs[1]]",
+                       "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "sampler_evals_per_ray": 640,
+                       "global_rays": args.rays * world, "engine": model.last_engine, "param_grads": args.param_grads,
+                       "parallelism": f"ray-shard x{world}" if world > 1 else "single"},
+            "final_loss": round(float(last), 6),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, model, conf):
+    """The oracle (pure-PyTorch CPU restatement + C hash kernels = "port") timed on this box's host cores on a
+    bounded sample of the same workload: `--cpu-rays` rays x (640 + S) samples, fwd+bwd to the pose gradient."""
+    from oracle import render_ref as R
+    n = args.cpu_rays
+    torch.set_num_threads(os.cpu_count())
+    mk = R.make_grid_spec
+    cfg = R.RenderConfig(coarse=R.SdfNetSpec(mk(4, 8, 32, 32, 19), 2), fine=R.SdfNetSpec(mk(8, 4, 32, 128, 19), 4),
+                         colour_grid=mk(16, 2, 16, 2048, 24), n_samples=args.samples - 34, n_samples_eval=640,
+                         n_samples_extra=32)
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    H, W = DS.img_res
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 600.0
+    K[0, 2], K[1, 2] = 599.5, 339.5
+    vox = torch.zeros(64, 64, 64)
+    times = []
+    for it in range(5):
+        idx = torch.randint(H * W, (1, n), generator=g)
+        uv = torch.stack([(idx % W).float(), (idx // W).float()], -1)
+        gt = torch.rand(n, 3, generator=g)
+        draws = {"t_rand": torch.rand(n, 640, generator=g), "extra_idx": torch.randperm(640, generator=g)[:32],
+                 "eik_idx": torch.randint(args.samples, (n,), generator=g)}
+        cam = torch.tensor([1.0, 0, 0, 0, 0.1, 0.0, -0.2]).requires_grad_(True)
+        t0 = time.perf_counter()
+        out = R.render(params, cfg, uv, R.camera_from_tensor(cam).unsqueeze(0), K[None], vox, draws,
+                       mode="tracking", training=True)
+        R.rgb_l1(out, gt).backward()
+        times.append(time.perf_counter() - t0)
+    med = sorted(times[2:])[len(times[2:]) // 2]
+    return {"value": round(n / med, 1), "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} rays x (640 sampler + {args.samples} composite) samples, fwd+bwd to pose grad, "
+                      f"median of 3 after 2 warm-ups, torch {torch.get_num_threads()} threads + OpenMP C hash kernels"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+/*
+ * nicer_slam_amd.h -- C ABI of the MI355X-native NICER-SLAM render core (libnicer_slam_amd.so).
+ *
+ * Plain pointers and sizes only; every buffer is DEVICE memory owned by the caller unless the
+ * parameter name ends in `_host`.  Nothing is allocated or kept between calls.  All launches are
+ * asynchronous on `stream` (a hipStream_t; NULL = the legacy default stream, which is what the
+ * reference launches on).  Every entry point returns 0 (NSA_OK) or an NSA_E* code; the text the
+ * reference would have thrown for that condition is available from nsa_strerror().
+ *
+ * Section 1 replaces, one for one, the three functions of the reference's native module
+ * (reference: code/hashencoder/src/hashencoder.h:13-15, bound at code/hashencoder/src/bindings.cpp:5-7,
+ *  implemented at code/hashencoder/src/hashencoder.cu:758-854).  Differences from that interface:
+ *   - raw device pointers + an explicit stream instead of at::Tensor (the tensor checks of
+ *     hashencoder.cu:759-775 live in the thin binding, nicer_slam_amd/hashencoder/backend.py);
+ *   - `offsets_host` is a HOST copy of the int32 offsets tensor (the per-level geometry is derived
+ *     on the host and passed as kernel arguments, so the device never calls exp2f/ceil);
+ *   - float32 only (the reference also dispatches half/double; it never runs them);
+ *   - an int status instead of a C++ exception.
+ * Layouts are the reference's: inputs[B,D] in [0,1]; embeddings[rows,C]; outputs[L,B,C] (level-major);
+ * dy_dx[B,L,D,C]; grad[L,B,C]; grad_embeddings/grad2_embeddings[rows,C] are ACCUMULATED INTO with
+ * float atomics (caller pre-zeroes, as hashgrid.py:84-85,117-118 does); grad_inputs[B,D] and
+ * grad_grad[L,B,C] are overwritten.
+ */
+#ifndef NICER_SLAM_AMD_H
+#define NICER_SLAM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSA_OK 0
+#define NSA_EUNSUPPORTED_C 1   /* "GridEncoding: C must be 1, 2, 4, or 8." (hashencoder.cu:637,652,...) */
+#define NSA_ETOO_MANY_LEVELS 2 /* more than NSA_MAX_LEVELS levels */
+#define NSA_ELAUNCH 3          /* hipGetLastError() != hipSuccess after a launch */
+#define NSA_EBADARG 4          /* null pointer / inconsistent sizes */
+#define NSA_EUNSUPPORTED_NET 5 /* fused core: network shape outside the compiled set */
+
+#define NSA_MAX_LEVELS 32
+
+typedef void *nsa_stream_t; /* hipStream_t */
+
+const char *nsa_strerror(int code);
+int nsa_version(void);
+
+/* ---- Section 1: hash/dense multi-resolution grid encoder (reference hashencoder.h:13-15) ---- */
+
+/* replaces hash_encode_forward (hashencoder.cu:758-781 -> kernel_grid :131-283).
+ * dy_dx may be NULL when calc_grad_inputs == 0. */
+int nsa_hash_encode_forward(const float *inputs, const float *embeddings, const int32_t *offsets_host,
+                            float *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                            uint32_t H, int calc_grad_inputs, float *dy_dx, nsa_stream_t stream);
+
+/* replaces hash_encode_backward (hashencoder.cu:783-813 -> kernel_grid_backward :286-373 and
+ * kernel_input_backward :376-402).  grad_embeddings may be NULL to skip the table scatter
+ * (extension: used when the table does not require grad). */
+int nsa_hash_encode_backward(const float *grad, const float *inputs, const float *embeddings,
+                             const int32_t *offsets_host, float *grad_embeddings, uint32_t B, uint32_t D,
+                             uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs,
+                             const float *dy_dx, float *grad_inputs, nsa_stream_t stream);
+
+/* replaces hash_encode_second_backward (hashencoder.cu:816-854 -> kernel_grid_second_backward_grad
+ * :405-458 and kernel_grid_second_backward_embedding :461-625).  C == 1 is rejected like the
+ * reference (:708-714).  grad2_embeddings may be NULL to skip the table scatter (extension). */
+int nsa_hash_encode_second_backward(const float *grad, const float *inputs, const float *embeddings,
+                                    const int32_t *offsets_host, uint32_t B, uint32_t D, uint32_t C,
+                                    uint32_t L, float S, uint32_t H, int calc_grad_inputs,
+                                    const float *dy_dx, const float *grad_grad_inputs, float *grad_grad,
+                                    float *grad2_embeddings, nsa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NICER_SLAM_AMD_H */

@@ -1,0 +1,37 @@
+"""ctypes binding of libnicer_slam_amd.so (the C ABI in include/nicer_slam_amd.h).
+
+There is NO fallback: if the library is missing the import fails, so nothing above it can silently run
+without the HIP kernels.
+"""
+import ctypes
+import os
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnicer_slam_amd.so")
+
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        f"{_LIB_PATH} not found: the HIP extension has not been built.  Run "
+        "`python -m nicer_slam_amd.build` (needs hipcc; cross-compiles gfx950 without a GPU).")
+
+lib = ctypes.CDLL(_LIB_PATH)
+
+_p, _u32, _f32, _i = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_float, ctypes.c_int
+
+lib.nsa_strerror.restype = ctypes.c_char_p
+lib.nsa_strerror.argtypes = [_i]
+lib.nsa_version.restype = _i
+lib.nsa_hash_encode_forward.restype = _i
+lib.nsa_hash_encode_forward.argtypes = [_p, _p, _p, _p, _u32, _u32, _u32, _u32, _f32, _u32, _i, _p, _p]
+lib.nsa_hash_encode_backward.restype = _i
+lib.nsa_hash_encode_backward.argtypes = [_p, _p, _p, _p, _p, _u32, _u32, _u32, _u32, _f32, _u32, _i, _p, _p, _p]
+lib.nsa_hash_encode_second_backward.restype = _i
+lib.nsa_hash_encode_second_backward.argtypes = [_p, _p, _p, _p, _u32, _u32, _u32, _u32, _f32, _u32, _i, _p, _p,
+                                                _p, _p, _p]
+
+EXPORTS = ["nsa_strerror", "nsa_version", "nsa_hash_encode_forward", "nsa_hash_encode_backward",
+           "nsa_hash_encode_second_backward"]
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(lib.nsa_strerror(rc).decode())

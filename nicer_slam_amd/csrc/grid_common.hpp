@@ -1,0 +1,187 @@
+// grid_common.hpp -- level geometry + per-(point,level) cell location shared by every gfx950 kernel
+// that touches a multi-resolution grid.  Algorithm per reference code/hashencoder/src/hashencoder.cu
+// (index rule :35-73, geometry :179-181, cell split :188-195); the host derives everything that is
+// point-independent once per call and hands it to the kernels as kernel arguments (SGPR loads).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/nicer_slam_amd.h"
+
+namespace nsa {
+
+// flags
+constexpr uint32_t LV_HASHED = 1u;    // index = xor-prime hash of the cell
+constexpr uint32_t LV_POW2 = 2u;      // rows is a power of two: modulo == mask
+constexpr uint32_t LV_SUBONCE = 4u;   // dense and idx < 2*rows guaranteed: modulo == one conditional subtract
+
+struct LevelGeom {
+    float scale;     // exp2f(level*S)*H - 1   (float32, hashencoder.cu:180)
+    uint32_t rows;   // hashmap_size = offsets[l+1]-offsets[l]
+    uint32_t row0;   // offsets[l]
+    uint32_t s1;     // dense stride of dim 1 (= res, uint32)
+    uint32_t s2;     // dense stride of dim 2 (= res*res, uint32 wrap)
+    uint32_t flags;
+};
+
+struct GridGeom {
+    LevelGeom lv[NSA_MAX_LEVELS];
+};
+
+// Host: emulate get_grid_index's stride loop (hashencoder.cu:56-70) in uint32 to classify the level.
+inline int make_grid_geom(const int32_t* offsets_host, uint32_t L, uint32_t D, float S, uint32_t H, GridGeom* out) {
+    if (L > NSA_MAX_LEVELS) return NSA_ETOO_MANY_LEVELS;
+    for (uint32_t l = 0; l < L; ++l) {
+        LevelGeom g;
+        g.scale = exp2f((float)l * S) * (float)H - 1.0f;
+        const uint32_t res = (uint32_t)ceilf(g.scale) + 1u;
+        g.row0 = (uint32_t)offsets_host[l];
+        g.rows = (uint32_t)(offsets_host[l + 1] - offsets_host[l]);
+        if (g.rows == 0) return NSA_EBADARG;
+        uint32_t stride = 1u;
+        uint64_t max_idx = 0;     // exact (non-wrapping) bound of the dense index, to pick LV_SUBONCE
+        bool wrapped = false;
+        uint32_t d = 0;
+        for (; d < D && stride <= g.rows; ++d) {
+            max_idx += (uint64_t)res * stride;     // cell+1 <= res
+            uint64_t next = (uint64_t)stride * res;
+            if (next > 0xFFFFFFFFull) wrapped = true;
+            stride = (uint32_t)next;
+        }
+        g.s1 = res;
+        g.s2 = res * res;
+        g.flags = 0;
+        if (stride > g.rows) g.flags |= LV_HASHED;
+        if ((g.rows & (g.rows - 1)) == 0) g.flags |= LV_POW2;
+        else if (!(g.flags & LV_HASHED) && !wrapped && max_idx < 2ull * g.rows) g.flags |= LV_SUBONCE;
+        out->lv[l] = g;
+    }
+    return NSA_OK;
+}
+
+// ---- device side -------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ uint32_t level_row(const LevelGeom& g, const uint32_t (&q)[D]) {
+    uint32_t idx;
+    if (g.flags & LV_HASHED) {                        // wave-uniform branch (level is per block)
+        idx = q[0];                                   // prime[0] == 1
+        if (D > 1) idx ^= q[1] * 2654435761u;
+        if (D > 2) idx ^= q[2] * 805459861u;
+    } else {
+        idx = q[0];
+        if (D > 1) idx += q[1] * g.s1;
+        if (D > 2) idx += q[2] * g.s2;
+    }
+    if (g.flags & LV_POW2) return idx & (g.rows - 1u);
+    if (g.flags & LV_SUBONCE) return idx >= g.rows ? idx - g.rows : idx;
+    return idx % g.rows;
+}
+
+// Range test + cell/fraction split.  Returns false for a point outside [0,1]^D (NaN passes, as in the
+// reference's `<`/`>` tests).  w = smoothstep(t), dw = smoothstep'(t).
+template <int D>
+__device__ __forceinline__ bool locate(const float (&x)[D], float scale, uint32_t (&cell)[D], float (&w)[D], float (&dw)[D]) {
+    bool inside = true;
+#pragma unroll
+    for (int d = 0; d < D; ++d) inside = inside && !(x[d] < 0.0f || x[d] > 1.0f);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float p = x[d] * scale;
+        const float fl = floorf(p);
+        cell[d] = (uint32_t)fl;
+        const float t = p - (float)cell[d];
+        dw[d] = 6.0f * t * (1.0f - t);
+        w[d] = t * t * (3.0f - 2.0f * t);
+    }
+    return inside;
+}
+
+template <int C> struct VecOf;
+template <> struct VecOf<1> { using type = float; };
+template <> struct VecOf<2> { using type = float2; };
+template <> struct VecOf<4> { using type = float4; };
+
+// C contiguous floats starting at a C*4-byte aligned address -> registers (1 or 2 vector loads).
+template <int C>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&v)[C]) {
+    if constexpr (C == 8) {
+        const float4 a = reinterpret_cast<const float4*>(p)[0];
+        const float4 b = reinterpret_cast<const float4*>(p)[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else if constexpr (C == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    } else if constexpr (C == 2) {
+        const float2 a = *reinterpret_cast<const float2*>(p);
+        v[0] = a.x; v[1] = a.y;
+    } else {
+        v[0] = p[0];
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void store_row(float* __restrict__ p, const float (&v)[C]) {
+    if constexpr (C == 8) {
+        reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    } else if constexpr (C == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (C == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+    } else {
+        p[0] = v[0];
+    }
+}
+
+// Gather the 2^D corner rows of the cell into registers: corner bit d set <=> +1 along dim d.
+template <int D, int C>
+__device__ __forceinline__ void gather_corners(const float* __restrict__ table, const LevelGeom& g,
+                                               const uint32_t (&cell)[D], float (&v)[1 << D][C]) {
+#pragma unroll
+    for (int corner = 0; corner < (1 << D); ++corner) {
+        uint32_t q[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) q[d] = cell[d] + ((corner >> d) & 1);
+        load_row<C>(table + (size_t)(g.row0 + level_row<D>(g, q)) * C, v[corner]);
+    }
+}
+
+// Smoothstep-weighted multilinear blend, corner order/product order as kernel_grid (:203-229).
+template <int D, int C>
+__device__ __forceinline__ void blend(const float (&v)[1 << D][C], const float (&w)[D], float (&out)[C]) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) out[c] = 0.0f;
+#pragma unroll
+    for (int corner = 0; corner < (1 << D); ++corner) {
+        float wt = 1.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) wt *= ((corner >> d) & 1) ? w[d] : 1.0f - w[d];
+#pragma unroll
+        for (int c = 0; c < C; ++c) out[c] += wt * v[corner][c];
+    }
+}
+
+// Jacobian row d out/d x[gd] from the SAME corner values (kernel_grid :239-282 re-gathers them).
+template <int D, int C>
+__device__ __forceinline__ void jacobian_row(const float (&v)[1 << D][C], const float (&w)[D], const float (&dw)[D],
+                                             float scale, int gd, float (&j)[C]) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) j[c] = 0.0f;
+#pragma unroll
+    for (int face = 0; face < (1 << (D - 1)); ++face) {
+        float wt = scale;
+        int lo = 0;
+#pragma unroll
+        for (int nd = 0; nd < D - 1; ++nd) {
+            const int d = (nd >= gd) ? nd + 1 : nd;
+            if ((face >> nd) & 1) { wt *= w[d]; lo |= 1 << d; }
+            else                  { wt *= 1.0f - w[d]; }
+        }
+        const int hi = lo | (1 << gd);
+#pragma unroll
+        for (int c = 0; c < C; ++c) j[c] += wt * (v[hi][c] - v[lo][c]) * dw[gd];
+    }
+}
+
+}  // namespace nsa

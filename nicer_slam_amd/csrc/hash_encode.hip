@@ -1,0 +1,294 @@
+// hash_encode.hip -- gfx950 kernels behind Section 1 of include/nicer_slam_amd.h: the stand-alone
+// multi-resolution grid encoder with the reference's operator interface
+// (reference: code/hashencoder/src/hashencoder.cu; entry points :758-854).
+//
+// Mapping (all kernels): 1-D grid, 256-thread blocks (4 waves), block b works on level (b % L) and on the
+// point tile (b / L).  With the dispatcher's round-robin block->XCD placement this pins a level's table
+// to L2s of the XCDs {level % 8, ...}: each of the 8 private 4 MiB L2s caches 1/8th (L=8), 1/4 (L=16:
+// two levels) or a replicated quarter (L=4) of the grid instead of all of it.  One thread owns one
+// (point, level): it gathers the 2^D corner rows with 8/16/32-byte vector loads (C = 2/4/8), keeps them in
+// registers and derives both the blended feature and the D Jacobian rows from the same values.
+// Everything that does not depend on the point (scale, strides, hashed/dense, modulo form) arrives as
+// kernel arguments and is wave-uniform.
+#include "grid_common.hpp"
+
+namespace nsa {
+
+constexpr int TPB = 256;
+
+// ------------------------------------------------------------------------------------------ forward
+template <int D, int C, bool JAC>
+__global__ __launch_bounds__(TPB) void k_grid_forward(const float* __restrict__ inputs, const float* __restrict__ emb,
+                                                      float* __restrict__ outputs, float* __restrict__ dy_dx,
+                                                      uint32_t B, uint32_t L, GridGeom geom) {
+    const uint32_t level = blockIdx.x % L;
+    const uint32_t b = (blockIdx.x / L) * TPB + threadIdx.x;
+    if (b >= B) return;
+    const LevelGeom g = geom.lv[level];
+
+    float x[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = inputs[(size_t)b * D + d];
+    uint32_t cell[D];
+    float w[D], dw[D];
+    const bool inside = locate<D>(x, g.scale, cell, w, dw);
+
+    float out[C];
+    float* o = outputs + ((size_t)level * B + b) * C;
+    float* jrow = JAC ? dy_dx + (((size_t)b * L + level) * D) * C : nullptr;
+    if (!inside) {   // hashencoder.cu:161-177
+#pragma unroll
+        for (int c = 0; c < C; ++c) out[c] = 0.0f;
+        store_row<C>(o, out);
+        if (JAC) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) store_row<C>(jrow + d * C, out);
+        }
+        return;
+    }
+    float v[1 << D][C];
+    gather_corners<D, C>(emb, g, cell, v);
+    blend<D, C>(v, w, out);
+    store_row<C>(o, out);
+    if (JAC) {
+#pragma unroll
+        for (int gd = 0; gd < D; ++gd) {
+            float j[C];
+            jacobian_row<D, C>(v, w, dw, g.scale, gd, j);
+            store_row<C>(jrow + gd * C, j);
+        }
+    }
+}
+
+// -------------------------------------------------------------------- first backward: table scatter
+// grad_emb[row(corner), c] += w(corner) * grad[l,b,c]   (kernel_grid_backward :286-373)
+template <int D, int C>
+__global__ __launch_bounds__(TPB) void k_grid_scatter(const float* __restrict__ grad, const float* __restrict__ inputs,
+                                                      float* __restrict__ grad_emb, uint32_t B, uint32_t L, GridGeom geom) {
+    const uint32_t level = blockIdx.x % L;
+    const uint32_t b = (blockIdx.x / L) * TPB + threadIdx.x;
+    if (b >= B) return;
+    const LevelGeom g = geom.lv[level];
+    float x[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = inputs[(size_t)b * D + d];
+    uint32_t cell[D];
+    float w[D], dw[D];
+    if (!locate<D>(x, g.scale, cell, w, dw)) return;
+    float gy[C];
+    load_row<C>(grad + ((size_t)level * B + b) * C, gy);
+#pragma unroll
+    for (int corner = 0; corner < (1 << D); ++corner) {
+        float wt = 1.0f;
+        uint32_t q[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int bit = (corner >> d) & 1;
+            wt *= bit ? w[d] : 1.0f - w[d];
+            q[d] = cell[d] + bit;
+        }
+        float* dst = grad_emb + (size_t)(g.row0 + level_row<D>(g, q)) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) atomicAdd(dst + c, wt * gy[c]);   // -munsafe-fp-atomics: global_atomic_add_f32
+    }
+}
+
+// -------------------------------------------------------------- first backward: input gradient J^T g
+// grad_inputs[b,d] = sum_l sum_c grad[l,b,c] * dy_dx[b,l,d,c]   (kernel_input_backward :376-402)
+// One thread per point: its dy_dx row (L*D*C floats) is contiguous and read with 16-byte loads.
+template <int D, int C>
+__global__ __launch_bounds__(TPB) void k_input_backward(const float* __restrict__ grad, const float* __restrict__ dy_dx,
+                                                        float* __restrict__ grad_inputs, uint32_t B, uint32_t L) {
+    const uint32_t b = blockIdx.x * TPB + threadIdx.x;
+    if (b >= B) return;
+    float acc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = 0.0f;
+    const float* jrow = dy_dx + (size_t)b * L * D * C;
+    for (uint32_t l = 0; l < L; ++l) {
+        float gy[C];
+        load_row<C>(grad + ((size_t)l * B + b) * C, gy);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            float j[C];
+            load_row<C>(jrow + ((size_t)l * D + d) * C, j);
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[d] += gy[c] * j[c];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) grad_inputs[(size_t)b * D + d] = acc[d];
+}
+
+// ------------------------------------------------------------------------------- second backward
+// grad_grad[l,b,c] = sum_d ggi[b,d]*dy_dx[b,l,d,c]                 (:405-458)
+// grad2_emb[row(corner),c] += sum_gd +-scale*w_{-gd}*grad[l,b,c]*ggi[b,gd]*smoothstep'(t_gd)   (:461-625)
+// Fused into one pass over (point, level); the d/dx of J^T g is NOT produced (hashgrid.py:134).
+template <int D, int C, bool SCATTER>
+__global__ __launch_bounds__(TPB) void k_grid_second_backward(const float* __restrict__ grad, const float* __restrict__ inputs,
+                                                              const float* __restrict__ dy_dx, const float* __restrict__ ggi_,
+                                                              float* __restrict__ grad_grad, float* __restrict__ grad2_emb,
+                                                              uint32_t B, uint32_t L, GridGeom geom) {
+    const uint32_t level = blockIdx.x % L;
+    const uint32_t b = (blockIdx.x / L) * TPB + threadIdx.x;
+    if (b >= B) return;
+    const LevelGeom g = geom.lv[level];
+    float ggi[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) ggi[d] = ggi_[(size_t)b * D + d];
+    {
+        const float* jrow = dy_dx + (((size_t)b * L + level) * D) * C;
+        float r[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) r[c] = 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            float j[C];
+            load_row<C>(jrow + d * C, j);
+#pragma unroll
+            for (int c = 0; c < C; ++c) r[c] += ggi[d] * j[c];
+        }
+        store_row<C>(grad_grad + ((size_t)level * B + b) * C, r);
+    }
+    if (!SCATTER) return;
+    float x[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = inputs[(size_t)b * D + d];
+    uint32_t cell[D];
+    float w[D], dw[D];
+    if (!locate<D>(x, g.scale, cell, w, dw)) return;
+    float gy[C];
+    load_row<C>(grad + ((size_t)level * B + b) * C, gy);
+    // per-corner scalar coefficient k[corner] = sum_gd sign * scale * prod_{d != gd} w_d * ggi[gd] * dw[gd]
+    float k[1 << D];
+#pragma unroll
+    for (int corner = 0; corner < (1 << D); ++corner) k[corner] = 0.0f;
+#pragma unroll
+    for (int gd = 0; gd < D; ++gd) {
+#pragma unroll
+        for (int face = 0; face < (1 << (D - 1)); ++face) {
+            float wt = g.scale;
+            int lo = 0;
+#pragma unroll
+            for (int nd = 0; nd < D - 1; ++nd) {
+                const int d = (nd >= gd) ? nd + 1 : nd;
+                if ((face >> nd) & 1) { wt *= w[d]; lo |= 1 << d; }
+                else                  { wt *= 1.0f - w[d]; }
+            }
+            const float t = wt * ggi[gd] * dw[gd];
+            k[lo | (1 << gd)] += t;
+            k[lo] -= t;
+        }
+    }
+#pragma unroll
+    for (int corner = 0; corner < (1 << D); ++corner) {
+        uint32_t q[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) q[d] = cell[d] + ((corner >> d) & 1);
+        float* dst = grad2_emb + (size_t)(g.row0 + level_row<D>(g, q)) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) atomicAdd(dst + c, k[corner] * gy[c]);
+    }
+}
+
+static inline uint32_t tiles(uint32_t B) { return (B + TPB - 1) / TPB; }
+static inline int launch_status() { return hipGetLastError() == hipSuccess ? NSA_OK : NSA_ELAUNCH; }
+
+template <int D, int C>
+static int forward_dc(const float* in, const float* emb, float* out, float* dy_dx, uint32_t B, uint32_t L, bool jac,
+                      const GridGeom& geom, hipStream_t st) {
+    const dim3 grid(tiles(B) * L), block(TPB);
+    if (jac) hipLaunchKernelGGL((k_grid_forward<D, C, true>), grid, block, 0, st, in, emb, out, dy_dx, B, L, geom);
+    else     hipLaunchKernelGGL((k_grid_forward<D, C, false>), grid, block, 0, st, in, emb, out, dy_dx, B, L, geom);
+    return launch_status();
+}
+
+template <int D, int C>
+static int backward_dc(const float* grad, const float* in, float* gemb, uint32_t B, uint32_t L, bool gi, const float* dy_dx,
+                       float* gin, const GridGeom& geom, hipStream_t st) {
+    if (gemb) hipLaunchKernelGGL((k_grid_scatter<D, C>), dim3(tiles(B) * L), dim3(TPB), 0, st, grad, in, gemb, B, L, geom);
+    if (gi) hipLaunchKernelGGL((k_input_backward<D, C>), dim3(tiles(B)), dim3(TPB), 0, st, grad, dy_dx, gin, B, L);
+    return launch_status();
+}
+
+template <int D, int C>
+static int second_dc(const float* grad, const float* in, const float* dy_dx, const float* ggi, float* gg, float* g2emb,
+                     uint32_t B, uint32_t L, const GridGeom& geom, hipStream_t st) {
+    const dim3 grid(tiles(B) * L), block(TPB);
+    if (g2emb) hipLaunchKernelGGL((k_grid_second_backward<D, C, true>), grid, block, 0, st, grad, in, dy_dx, ggi, gg, g2emb, B, L, geom);
+    else       hipLaunchKernelGGL((k_grid_second_backward<D, C, false>), grid, block, 0, st, grad, in, dy_dx, ggi, gg, g2emb, B, L, geom);
+    return launch_status();
+}
+
+}  // namespace nsa
+
+#define NSA_DISPATCH_DC(D, C, CALL)                                                             \
+    do {                                                                                        \
+        if ((D) != 2 && (D) != 3) return NSA_EUNSUPPORTED_C; /* same text as the reference */   \
+        switch ((C) * 10 + (D)) {                                                               \
+            case 12: { constexpr int D_ = 2, C_ = 1; return CALL; }                             \
+            case 13: { constexpr int D_ = 3, C_ = 1; return CALL; }                             \
+            case 22: { constexpr int D_ = 2, C_ = 2; return CALL; }                             \
+            case 23: { constexpr int D_ = 3, C_ = 2; return CALL; }                             \
+            case 42: { constexpr int D_ = 2, C_ = 4; return CALL; }                             \
+            case 43: { constexpr int D_ = 3, C_ = 4; return CALL; }                             \
+            case 82: { constexpr int D_ = 2, C_ = 8; return CALL; }                             \
+            case 83: { constexpr int D_ = 3, C_ = 8; return CALL; }                             \
+            default: return NSA_EUNSUPPORTED_C;                                                 \
+        }                                                                                       \
+    } while (0)
+
+extern "C" {
+
+const char* nsa_strerror(int code) {
+    switch (code) {
+        case NSA_OK: return "ok";
+        case NSA_EUNSUPPORTED_C: return "GridEncoding: C must be 1, 2, 4, or 8.";
+        case NSA_ETOO_MANY_LEVELS: return "GridEncoding: more than NSA_MAX_LEVELS (32) levels";
+        case NSA_ELAUNCH: return "HIP kernel launch failed";
+        case NSA_EBADARG: return "bad argument (null pointer or inconsistent sizes)";
+        case NSA_EUNSUPPORTED_NET: return "fused render core: network shape outside the compiled set";
+        default: return "unknown error";
+    }
+}
+
+int nsa_version(void) { return 1; }
+
+int nsa_hash_encode_forward(const float* inputs, const float* embeddings, const int32_t* offsets_host, float* outputs,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs,
+                            float* dy_dx, nsa_stream_t stream) {
+    if (B == 0) return NSA_OK;
+    if (!inputs || !embeddings || !offsets_host || !outputs || (calc_grad_inputs && !dy_dx)) return NSA_EBADARG;
+    nsa::GridGeom geom;
+    if (int rc = nsa::make_grid_geom(offsets_host, L, D, S, H, &geom)) return rc;
+    NSA_DISPATCH_DC(D, C, (nsa::forward_dc<D_, C_>(inputs, embeddings, outputs, dy_dx, B, L, calc_grad_inputs != 0, geom,
+                                                   (hipStream_t)stream)));
+}
+
+int nsa_hash_encode_backward(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets_host,
+                             float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             int calc_grad_inputs, const float* dy_dx, float* grad_inputs, nsa_stream_t stream) {
+    (void)embeddings;
+    if (B == 0) return NSA_OK;
+    if (!grad || !inputs || !offsets_host || (calc_grad_inputs && (!dy_dx || !grad_inputs))) return NSA_EBADARG;
+    nsa::GridGeom geom;
+    if (int rc = nsa::make_grid_geom(offsets_host, L, D, S, H, &geom)) return rc;
+    NSA_DISPATCH_DC(D, C, (nsa::backward_dc<D_, C_>(grad, inputs, grad_embeddings, B, L, calc_grad_inputs != 0, dy_dx,
+                                                    grad_inputs, geom, (hipStream_t)stream)));
+}
+
+int nsa_hash_encode_second_backward(const float* grad, const float* inputs, const float* embeddings,
+                                    const int32_t* offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                    uint32_t H, int calc_grad_inputs, const float* dy_dx, const float* grad_grad_inputs,
+                                    float* grad_grad, float* grad2_embeddings, nsa_stream_t stream) {
+    (void)embeddings; (void)calc_grad_inputs;
+    if (C == 1) return NSA_EUNSUPPORTED_C;   // hashencoder.cu:708-714: the C=1 case is commented out
+    if (B == 0) return NSA_OK;
+    if (!grad || !inputs || !offsets_host || !dy_dx || !grad_grad_inputs || !grad_grad) return NSA_EBADARG;
+    nsa::GridGeom geom;
+    if (int rc = nsa::make_grid_geom(offsets_host, L, D, S, H, &geom)) return rc;
+    NSA_DISPATCH_DC(D, C, (nsa::second_dc<D_, C_>(grad, inputs, dy_dx, grad_grad_inputs, grad_grad, grad2_embeddings, B, L,
+                                                  geom, (hipStream_t)stream)));
+}
+
+}  // extern "C"

@@ -1,0 +1,148 @@
+"""Host-side mirror of the reference's hash-grid operator (code/hashencoder/hashgrid.py:13-215).
+
+Same public names and argument meaning -- ``hash_encode(inputs, embeddings, offsets, per_level_scale,
+base_resolution, calc_grad_inputs)``, ``HashEncoder(input_dim, num_levels, level_dim, per_level_scale,
+base_resolution, log2_hashmap_size, desired_resolution)`` with parameter ``embeddings`` and buffer
+``offsets`` (so reference checkpoints load) -- on top of the MI355X kernels.  The module attribute
+``_backend`` is the native seam, exactly as in the reference (hashgrid.py:11).
+
+Autograd semantics reproduced from the reference:
+  * first backward is itself a differentiable node (hashgrid.py:54-69 -> :79-134), so
+    ``autograd.grad(sdf, x, create_graph=True)`` followed by ``loss.backward()`` works;
+  * its backward yields d/d(grad) and d/d(table) only -- the derivative of J^T g w.r.t. the inputs
+    (grid Hessian) is NOT produced (hashgrid.py:134 returns None there);
+  * table gradients are dense ``[rows, C]`` tensors.
+Differences (all behaviour-preserving for the reference's callers): no ``custom_fwd(cast_inputs=half)``
+(the reference never enables autocast); the dense table-gradient buffers are only materialised when
+the table requires grad (the reference always zero-fills them: 1 GiB for the colour grid per call).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from .backend import _backend  # noqa: F401  (module attribute = native seam; tests may swap it)
+
+
+def _be():
+    return globals()["_backend"]
+
+
+class _hash_encode_second_backward(Function):
+    """First backward as a Function whose own backward is the "second backward" (hashgrid.py:79-134)."""
+
+    @staticmethod
+    def forward(ctx, grad, inputs, embeddings, offsets, B, D, C, L, S, H, calc_grad_inputs, dy_dx, need_table=True):
+        grad_inputs = torch.zeros_like(inputs)
+        grad_embeddings = torch.zeros_like(embeddings) if need_table else None
+        _be().hash_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H,
+                                   calc_grad_inputs, dy_dx, grad_inputs)
+        ctx.save_for_backward(grad, inputs, embeddings, offsets, dy_dx)
+        ctx.dims = (B, D, C, L, S, H)
+        ctx.calc_grad_inputs = calc_grad_inputs
+        return grad_inputs, grad_embeddings
+
+    @staticmethod
+    def backward(ctx, grad_grad_inputs, grad_grad_embeddings):
+        grad, inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H = ctx.dims
+        grad_grad = torch.zeros_like(grad)
+        grad2_embeddings = torch.zeros_like(embeddings) if ctx.needs_input_grad[2] else None
+        nones = (None,) * 10
+        if grad_grad_inputs is None:
+            return (grad_grad, None, grad2_embeddings) + nones
+        _be().hash_encode_second_backward(grad, inputs, embeddings, offsets, B, D, C, L, S, H,
+                                          ctx.calc_grad_inputs, dy_dx, grad_grad_inputs.contiguous(),
+                                          grad_grad, grad2_embeddings)
+        # no gradient w.r.t. `inputs` (hashgrid.py:134)
+        return (grad_grad, None, grad2_embeddings) + nones
+
+
+class _hash_encode(Function):
+    """hashgrid.py:13-69."""
+
+    @staticmethod
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False):
+        inputs = inputs.contiguous()
+        embeddings = embeddings.contiguous()
+        offsets = offsets.contiguous()
+        B, D = inputs.shape
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        S = np.log2(per_level_scale)
+        H = base_resolution
+        outputs = torch.empty(L, B, C, device=inputs.device, dtype=inputs.dtype)
+        if calc_grad_inputs:
+            dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=inputs.dtype)
+        else:
+            dy_dx = torch.empty(1, device=inputs.device, dtype=inputs.dtype)
+        _be().hash_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs, dy_dx)
+        outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
+        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
+        ctx.dims = (B, D, C, L, S, H)
+        ctx.calc_grad_inputs = calc_grad_inputs
+        return outputs
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H = ctx.dims
+        grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()
+        grad_inputs, grad_embeddings = _hash_encode_second_backward.apply(
+            grad, inputs, embeddings, offsets, B, D, C, L, S, H, ctx.calc_grad_inputs, dy_dx,
+            bool(ctx.needs_input_grad[1]))
+        return (grad_inputs if ctx.calc_grad_inputs else None), grad_embeddings, None, None, None, None
+
+
+hash_encode = _hash_encode.apply
+
+
+def level_layout(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size):
+    """Rows per level = min(2^log2_hashmap_size, ceil(base * scale^i)^D) (hashgrid.py:159-172)."""
+    cap = 2 ** log2_hashmap_size
+    offsets, total = [], 0
+    for i in range(num_levels):
+        res = int(np.ceil(base_resolution * per_level_scale ** i))
+        offsets.append(total)
+        total += min(cap, res ** input_dim)
+    offsets.append(total)
+    return np.array(offsets, dtype=np.int32)
+
+
+class HashEncoder(nn.Module):
+    """Multi-resolution grid feature encoder (hashgrid.py:140-215)."""
+
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16,
+                 log2_hashmap_size=19, desired_resolution=None):
+        super().__init__()
+        if desired_resolution is not None:   # overrides per_level_scale (hashgrid.py:144-146)
+            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+        self.input_dim = input_dim
+        self.num_levels = num_levels
+        self.level_dim = level_dim
+        self.per_level_scale = per_level_scale
+        self.log2_hashmap_size = log2_hashmap_size
+        self.base_resolution = base_resolution
+        self.output_dim = num_levels * level_dim
+        self.max_params = 2 ** log2_hashmap_size
+        offsets = level_layout(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size)
+        self.register_buffer("offsets", torch.from_numpy(offsets))
+        self.n_params = int(offsets[-1]) * level_dim
+        self.embeddings = nn.Parameter(torch.empty(int(offsets[-1]), level_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.embeddings.data.uniform_(-1e-4, 1e-4)   # hashgrid.py:180-182
+
+    def __repr__(self):
+        return (f"HashEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
+                f"base_resolution={self.base_resolution} per_level_scale={self.per_level_scale} "
+                f"params={tuple(self.embeddings.shape)}")
+
+    def forward(self, inputs, size=1):
+        inputs = (inputs + size) / (2 * size)   # [-size, size] -> [0, 1]
+        prefix_shape = list(inputs.shape[:-1])
+        inputs = inputs.view(-1, self.input_dim)
+        outputs = hash_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
+                              inputs.requires_grad)
+        return outputs.view(prefix_shape + [self.output_dim])

@@ -1,0 +1,192 @@
+"""SLAMNetwork -- the model plug-in (reference code/model/network.py:14-370).
+
+Select it with ``train.model_class = nicer_slam_amd.model.network.SLAMNetwork``: same constructor
+``(conf, dataset, n_images)``, same ``forward(input, indices, ground_truth, keyframe_list, frame_idx, mode, stage,
+color_stage, iter) -> dict`` keys, same sub-module / parameter names, same ``voxels`` / ``density.voxels``
+attributes, so code/training/volsdf_train.py drives it unchanged.
+
+Two engines produce the same numbers:
+  * ``fused``    -- hand-written gfx950 kernels for the whole per-frame core (rays -> sampler -> encoders/MLPs ->
+                    composite -> gradients), used whenever the configuration is in the compiled set;
+  * ``composed`` -- torch ops around the HIP hash-grid operator, covering every option of the module layer.
+Both require the HIP extension; there is no CPU path.
+"""
+import torch
+import torch.nn as nn
+
+from ..utils import rend_util
+from ..utils.conf import as_conf
+from ..utils.general import index_to_1d
+from .base_networks import ImplicitNetworkGrid_COMBINE, RenderingNetwork
+from .density import GridPredefineDensity, LaplaceDensity
+from .ray_sampler import ImportantSampler, transmittance_weights
+
+
+class SLAMNetwork(nn.Module):
+    def __init__(self, conf, dataset=None, n_images=2000, colour_grid=None):
+        super().__init__()
+        conf = as_conf(conf)
+        self.dataset = dataset
+        self.H, self.W = dataset.img_res if dataset is not None else (0, 0)
+        self.white_bkgd = conf.get_bool("white_bkgd", default=False)
+        self.feature_vector_size = conf.get_int("feature_vector_size")
+        self.use_warp_loss = conf.get_bool("use_warp_loss", default=False)
+        self.embedding_method = conf.get_string("embedding_method", default="nerf")
+        self.mapping_patchsizes = conf.get_list("mapping_patchsizes", default=[1, 5, 11])
+        self.tracking_patchsizes = conf.get_list("tracking_patchsizes", default=[1, 5, 11])
+        self.scene_bounding_sphere = conf.get_float("scene_bounding_sphere", default=1.0)
+        self.register_buffer("bg_color", torch.tensor(conf.get_list("bg_color", default=[1.0, 1.0, 1.0])).float(),
+                             persistent=False)
+        self.implicit_network = ImplicitNetworkGrid_COMBINE(
+            conf.get_config("implicit_network"), self.feature_vector_size,
+            0.0 if self.white_bkgd else self.scene_bounding_sphere)
+        self.rendering_network = RenderingNetwork(
+            self.feature_vector_size, n_images=n_images, embedding_method=self.embedding_method,
+            colour_grid=colour_grid, **conf.get_config("rendering_network"))
+        self.density_method = conf.get_string("density_method", default="volsdf_gridpredefined")
+        if self.density_method == "volsdf_laplace":
+            self.density = LaplaceDensity(**conf.get_config("density"))
+        elif self.density_method == "volsdf_gridpredefined":
+            self.density = GridPredefineDensity(**conf.get_config("gridpredefinedensity"))
+        else:
+            raise NotImplementedError(self.density_method)
+        self.sampling_method = conf.get_string("sampling_method", default="important")
+        if self.sampling_method != "important":
+            raise NotImplementedError(self.sampling_method)
+        self.ray_sampler = ImportantSampler(self.scene_bounding_sphere, **conf.get_config("ray_sampler"))
+        # visit counter (network.py:54-60): a plain tensor attribute, shared with the density module
+        self.voxel_res = conf.get_int("voxel_res", default=64)
+        self.voxels = torch.zeros((self.voxel_res,) * 3)
+        self.voxels_shape = self.voxels.shape
+        self._share_voxels()
+        self.draws = None          # optional dict of pre-drawn randoms (parity tests); else device generator
+        self._generator = None
+        self.engine = "auto"       # "auto" | "fused" | "composed"
+        self.last_engine = None    # which engine the most recent forward used
+
+    # ------------------------------------------------------------------ plumbing
+    def _share_voxels(self):
+        if "gridpredefined" in self.density_method:
+            self.density.voxels = self.voxels
+            self.density.voxel_res = self.voxel_res
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.voxels = fn(self.voxels)
+        self._share_voxels()
+        return out
+
+    def __setattr__(self, name, value):
+        super().__setattr__(name, value)
+        if name == "voxels" and "density" in self._modules and isinstance(value, torch.Tensor):
+            self._share_voxels()
+
+    def draw(self, kind, spec):
+        """Random draws of the render core; see model/ray_sampler.py.  ``self.draws[kind]`` wins when present."""
+        dev = self.voxels.device
+        if self.draws is not None and kind in self.draws:
+            return self.draws[kind].to(dev)
+        if self._generator is None or self._generator.device != dev:
+            self._generator = torch.Generator(device=dev)
+            self._generator.manual_seed(torch.initial_seed() & 0x7FFFFFFF)
+        g = self._generator
+        if kind in ("t_rand", "eik_jitter"):
+            return torch.rand(tuple(spec), device=dev, generator=g)
+        if kind == "extra_idx":
+            n, k = spec
+            return torch.randperm(n, device=dev, generator=g)[:k]
+        if kind == "eik_idx":
+            high, n = spec
+            return torch.randint(high, (n,), device=dev, generator=g)
+        if kind == "eik_uniform":
+            n, b = spec
+            return (torch.rand((n, 3), device=dev, generator=g) * 2 - 1) * b
+        raise KeyError(kind)
+
+    # ------------------------------------------------------------------ visit counter
+    def update_voxels(self, x):
+        """Count sample visits per 64^3 voxel, skipping |x_d| > 0.99 (network.py:62-76).  In place, so the
+        density module (which shares the storage) sees the new counts within the same forward."""
+        keep = ~(x.abs() > 0.99).any(dim=1)
+        idx = ((x[keep] + 1) / 2 * self.voxel_res).long()
+        flat = index_to_1d(idx, self.voxel_res)
+        self.voxels.view(-1).index_add_(0, flat, torch.ones_like(flat, dtype=self.voxels.dtype))
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input, indices, ground_truth, keyframe_list=None, frame_idx=-1, mode="vis", stage="fine",
+                color_stage="highfreq", iter=0):
+        if mode == "tracking":
+            self.patchsizes = self.tracking_patchsizes
+        elif mode == "mapping":
+            self.patchsizes = self.mapping_patchsizes
+        intrinsics, uv, pose = input["intrinsics"], input["uv"], input["pose"]
+        self.last_engine = "composed"
+        ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
+        eye = torch.eye(4, device=pose.device, dtype=pose.dtype)[None].repeat(pose.shape[0], 1, 1)
+        depth_scale = rend_util.get_camera_params(uv, eye, intrinsics)[0][:, :, 2:]   # network.py:99-102
+        bs, num_pixels, _ = ray_dirs.shape
+        cam_flat = cam_loc.unsqueeze(1).repeat(1, num_pixels, 1).reshape(-1, 3)
+        dirs = ray_dirs.reshape(-1, 3)
+
+        z_vals, z_samples_eik = self.ray_sampler.get_z_vals(dirs, cam_flat, self, frame_idx, keyframe_list, mode)
+        if self.draws is not None and "z_vals_override" in self.draws:   # parity tests only
+            z_vals = self.draws["z_vals_override"].to(z_vals.device)
+        N = z_vals.shape[1]
+        points_flat = (cam_flat.unsqueeze(1) + z_vals.unsqueeze(2) * dirs.unsqueeze(1)).reshape(-1, 3)
+        if mode == "mapping":
+            self.update_voxels(points_flat.detach())
+        dirs_flat = dirs.unsqueeze(1).repeat(1, N, 1).reshape(-1, 3)
+
+        sdf, feats, gradients = self.implicit_network.get_outputs(points_flat, stage=stage)
+        rgb = self.rendering_network(points_flat, gradients, dirs_flat, feats, indices,
+                                     color_stage=color_stage).reshape(-1, N, 3)
+        weights = self.volume_rendering(z_vals, sdf, points_flat)
+        rgb_values = torch.sum(weights.unsqueeze(-1) * rgb, 1)
+        depth = torch.sum(weights * z_vals, 1, keepdims=True) / (weights.sum(dim=1, keepdims=True) + 1e-8)
+
+        output = {}
+        if "edges" in ground_truth:   # optical-flow reprojection (network.py:153-165)
+            pts = (cam_flat.unsqueeze(1) + depth.unsqueeze(2) * dirs.unsqueeze(1)).reshape(bs, -1, 3).permute(0, 2, 1)
+            idii, idjj, _, _ = ground_truth["edges"]
+            w2c = torch.linalg.inv(pose[idjj])
+            cam_pts = w2c[:, :3, :3] @ pts[idii] + w2c[:, :3, 3:]
+            proj = (intrinsics[idjj][:, :3, :3] @ cam_pts).permute(0, 2, 1)
+            output["flow"] = proj[..., :2] / (proj[..., 2:] + 1e-8) - uv[idii]
+        if self.use_warp_loss and ("vis" not in mode) and ("tracking" not in mode):
+            from .warp import patch_warp
+            output["warp_output"] = patch_warp(self, uv, pose, intrinsics, depth.unsqueeze(2), ground_truth, bs)
+
+        depth_values = depth_scale * depth.reshape(bs, -1, 1)
+        if self.white_bkgd:
+            rgb_values = rgb_values + (1.0 - weights.sum(-1)[..., None]) * self.bg_color.unsqueeze(0)
+        output.update({
+            "rgb": rgb,
+            "rgb_values": rgb_values.reshape(bs, -1, 3),
+            "depth_values": depth_values,
+            "z_vals": z_vals,
+            "depth_vals": z_vals * depth_scale.reshape(-1, 1),
+            "sdf": sdf.reshape(z_vals.shape),
+            "weights": weights,
+            "entropy": (-weights * torch.log(weights + 1e-4)).sum(dim=-1).mean(),
+            "scene_bounding_sphere": self.scene_bounding_sphere,
+        })
+        if self.training and ("vis" not in mode) and ("mapping" in mode):   # eikonal samples (network.py:313-336)
+            n = bs * num_pixels
+            eik = self.draw("eik_uniform", (n * 10, self.scene_bounding_sphere))
+            with torch.no_grad():
+                near_surface = (cam_flat.unsqueeze(1) + z_samples_eik.unsqueeze(2) * dirs.unsqueeze(1)).reshape(-1, 3)
+            eik = torch.cat([eik, near_surface], 0)
+            eik = torch.cat([eik, eik + (self.draw("eik_jitter", eik.shape) - 0.5) * 0.01], 0)
+            grad_theta = self.implicit_network.gradient(eik, stage=stage)
+            half = grad_theta.shape[0] // 2
+            output["grad_theta"], output["grad_theta_nei"] = grad_theta[:half], grad_theta[half:]
+        normals = gradients / (gradients.norm(2, -1, keepdim=True) + 1e-6)
+        normal_map = torch.sum(weights.unsqueeze(-1) * normals.reshape(-1, N, 3), 1).reshape(bs, -1, 3)
+        output["normal_map"] = torch.einsum("bij,bni->bnj", pose[:, :3, :3], normal_map)
+        return output
+
+    def volume_rendering(self, z_vals, sdf, points_flat, rays_o=None, rays_d=None, gradients=None, frame_idx=1,
+                         mode=None):
+        """SDF -> density -> alpha/transmittance weights (network.py:349-370)."""
+        density = self.density(sdf, x=points_flat).reshape(-1, z_vals.shape[1])
+        return transmittance_weights(z_vals, density)

@@ -1,0 +1,112 @@
+"""Host logic of the product's model layer (nicer_slam_amd/model, composed engine) against the goldens captured from
+the reference -- on CPU, with the oracle injected at the native seam (``hashgrid._backend``), i.e. everything
+except the HIP kernels themselves: module structure, state_dict key compatibility, sampler, composite, RNG plumbing."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load, tt, params_of, draws_of, golden_objective, assert_close
+
+
+@pytest.fixture()
+def oracle_seam(monkeypatch):
+    from oracle import hashenc
+    from nicer_slam_amd.hashencoder import hashgrid
+    monkeypatch.setattr(hashgrid, "_backend", hashenc.OracleBackend())
+    return hashgrid
+
+
+def build_model(fx):
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    cg, fg, col = fx["meta_coarse_grid"], fx["meta_fine_grid"], fx["meta_colour_grid"]
+    ns, ne, nx = [int(v) for v in fx["meta_samples"]]
+    conf = replica_model_conf(ns, ne, nx, use_warp_loss=False)
+    for net, g in (("coarse", cg), ("fine", fg)):
+        conf["implicit_network"][net].update(base_size=int(g[0]), end_size=int(g[1]), logmap=int(g[2]),
+                                             num_levels=int(g[3]), level_dim=int(g[4]))
+
+    class DS:
+        img_res = (680, 1200)
+    model = SLAMNetwork(conf, dataset=DS(), n_images=4,
+                        colour_grid=dict(base_resolution=int(col[0]), desired_resolution=int(col[1]),
+                                         log2_hashmap_size=int(col[2])))
+    missing, unexpected = model.load_state_dict(params_of(fx), strict=True), None
+    return model
+
+
+@pytest.mark.parametrize("name", ["full_tracking", "full_mapping", "full_mapping_coarse_base", "full_vis_eval"])
+def test_model_layer_matches_reference(oracle_seam, name):
+    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    fx = load(name)
+    model = build_model(fx)
+    # state_dict names are the reference's (checkpoint compatibility, volsdf_train.py:226-253)
+    assert set(model.state_dict().keys()) == {k[len("param_"):] for k in fx if k.startswith("param_")}
+    mode, stage, cstage = str(fx["meta_mode"]), str(fx["meta_stage"]), str(fx["meta_color_stage"])
+    model.train(bool(fx["meta_training"]))
+    model.voxels = tt(fx["in_voxels"]).clone()
+    assert model.density.voxels is model.voxels
+    model.draws = draws_of(fx)
+    model.draws["z_vals_override"] = tt(fx["out_z_vals"])
+    cam = tt(fx["in_cam"]).requires_grad_(True)
+    pose = get_camera_from_tensor(cam)
+    assert_close(pose, fx["in_pose"], 1e-7, 1e-6, "pose")
+    out = model({"intrinsics": tt(fx["in_K"]), "uv": tt(fx["in_uv"]), "pose": pose}, torch.arange(pose.shape[0]), {},
+                mode=mode, stage=stage, color_stage=cstage, frame_idx=1)
+    for k in ("depth_vals", "sdf", "weights", "rgb", "rgb_values", "depth_values", "entropy", "normal_map",
+              "grad_theta", "grad_theta_nei"):
+        if "out_" + k in fx:
+            assert_close(out[k], fx["out_" + k], 1e-5, 1e-4, k)
+    assert_close(model.voxels, fx["out_voxels"], 0, 0, "voxels")
+    if not model.training:
+        return
+    loss = golden_objective(out, fx, mode)
+    loss.backward()
+    assert_close(cam.grad, fx["grad_cam"], 1e-6, 1e-3, "grad_cam")
+    for n, p in model.named_parameters():
+        ref = fx["grad_" + n]
+        if ref.size == 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0
+        else:
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            assert_close(g, ref, 1e-6 + 1e-4 * float(np.abs(ref).max()), 1e-3, "grad " + n)
+
+
+def test_sampler_free_running(oracle_seam):
+    """Sampler of the model layer without the z override: compare in CDF space (see test_oracle_golden)."""
+    from oracle import render_ref as R
+    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    fx = load("full_tracking")
+    model = build_model(fx)
+    model.train(True)
+    model.draws = draws_of(fx)
+    pose = get_camera_from_tensor(tt(fx["in_cam"]))
+    with torch.no_grad():
+        from nicer_slam_amd.utils import rend_util
+        d, o = rend_util.get_camera_params(tt(fx["in_uv"]), pose, tt(fx["in_K"]))
+        assert_close(d, fx["out_ray_dirs"], 1e-9, 1e-6, "dirs")
+        z, _ = model.ray_sampler.get_z_vals(d.reshape(-1, 3), o.repeat(d.shape[1], 1), model)
+    zr = tt(fx["out_z_vals"])
+    assert float(((z - zr).abs() <= 1e-5 + 1e-4 * zr.abs()).float().mean()) >= 0.97
+    assert bool((z[:, 1:] >= z[:, :-1]).all())
+
+
+def test_get_tensor_from_camera_roundtrip():
+    from nicer_slam_amd.utils.general import get_camera_from_tensor, get_tensor_from_camera
+    g = torch.Generator().manual_seed(0)
+    for _ in range(20):
+        q = torch.randn(4, generator=g)
+        q = q / q.norm()
+        if q[0] < 0:
+            q = -q
+        cam = torch.cat([q, torch.randn(3, generator=g)])
+        back = get_tensor_from_camera(get_camera_from_tensor(cam))
+        assert_close(back, cam, 1e-5, 1e-5, "roundtrip")
+
+
+def test_backend_rejects_cpu_tensors():
+    """No CPU fallback: the native seam refuses host tensors like the reference's CHECK_CUDA (hashencoder.cu:16)."""
+    from nicer_slam_amd.hashencoder.hashgrid import HashEncoder
+    enc = HashEncoder(num_levels=2, level_dim=2, base_resolution=4, desired_resolution=8, log2_hashmap_size=8)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        enc(torch.zeros(4, 3))

@@ -1,0 +1,46 @@
+"""The model plug-in (SLAMNetwork) on the GPU vs the goldens captured from the reference: forward dict, pose
+gradient and every parameter gradient, tracking and mapping, both stages."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load, tt, draws_of, golden_objective, assert_close
+from test_model_cpu import build_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("engine", ["composed"])
+@pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_mapping", "full_mapping_coarse_base",
+                                  "full_vis_eval"])
+def test_forward_and_grads_vs_reference_goldens(name, engine):
+    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    fx = load(name)
+    model = build_model(fx).cuda()
+    model.engine = engine
+    mode, stage, cstage = str(fx["meta_mode"]), str(fx["meta_stage"]), str(fx["meta_color_stage"])
+    model.train(bool(fx["meta_training"]))
+    model.voxels = tt(fx["in_voxels"]).cuda()
+    model.draws = draws_of(fx, "cuda")
+    model.draws["z_vals_override"] = tt(fx["out_z_vals"]).cuda()
+    cam = tt(fx["in_cam"]).cuda().requires_grad_(True)
+    pose = get_camera_from_tensor(cam)
+    out = model({"intrinsics": tt(fx["in_K"]).cuda(), "uv": tt(fx["in_uv"]).cuda(), "pose": pose},
+                torch.arange(pose.shape[0], device="cuda"), {}, mode=mode, stage=stage, color_stage=cstage, frame_idx=1)
+    for k in ("depth_vals", "sdf", "weights", "rgb", "rgb_values", "depth_values", "entropy", "normal_map",
+              "grad_theta", "grad_theta_nei"):
+        if "out_" + k in fx:
+            assert_close(out[k], fx["out_" + k], 2e-5, 1e-4, k)
+    assert_close(model.voxels, fx["out_voxels"], 0, 0, "voxels")
+    if not model.training:
+        return
+    loss = golden_objective(out, fx, mode)
+    loss.backward()
+    assert_close(cam.grad, fx["grad_cam"], 2e-6, 1e-3, "grad_cam")
+    for n, p in model.named_parameters():
+        ref = fx["grad_" + n]
+        if ref.size == 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0
+        else:
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            assert_close(g, ref, 1e-6 + 2e-4 * float(np.abs(ref).max()), 1e-3, "grad " + n)

@@ -174,7 +174,9 @@ def cpu_baseline(args, model, conf):
     bounded sample of the same workload: `--cpu-rays` rays x (640 + S) samples, fwd+bwd to the pose gradient."""
     from oracle import render_ref as R
     n = args.cpu_rays
-    torch.set_num_threads(os.cpu_count())
+    # torch intra-op pool capped at 32: beyond that the small [n*768, 64] GEMMs of this sample only get slower
+    # (256 threads measured 1 ray/s on the GPU box); the C hash kernels use min(16, cores) OpenMP threads.
+    torch.set_num_threads(min(32, os.cpu_count()))
     mk = R.make_grid_spec
     cfg = R.RenderConfig(coarse=R.SdfNetSpec(mk(4, 8, 32, 32, 19), 2), fine=R.SdfNetSpec(mk(8, 4, 32, 128, 19), 4),
                          colour_grid=mk(16, 2, 16, 2048, 24), n_samples=args.samples - 34, n_samples_eval=640,
@@ -200,7 +202,8 @@ def cpu_baseline(args, model, conf):
         R.rgb_l1(out, gt).backward()
         times.append(time.perf_counter() - t0)
     med = sorted(times[2:])[len(times[2:]) // 2]
-    return {"value": round(n / med, 1), "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": round(n / med, 1), "unit": "rays/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(),
+            "kind": "port",
             "sample": f"{n} rays x (640 sampler + {args.samples} composite) samples, fwd+bwd to pose grad, "
                       f"median of 3 after 2 warm-ups, torch {torch.get_num_threads()} threads + OpenMP C hash kernels"}
 

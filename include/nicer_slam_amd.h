@@ -69,6 +69,39 @@ int nsa_hash_encode_second_backward(const float *grad, const float *inputs, cons
                                     const float *dy_dx, const float *grad_grad_inputs, float *grad_grad,
                                     float *grad2_embeddings, nsa_stream_t stream);
 
+/* ---- Section 2: fused render core (no native counterpart in the reference: these replace the PyTorch-level
+ * functions named at each entry point; rays, samples and per-point quantities stay in HBM between them) ---- */
+
+/* One multi-resolution grid + the MLP that consumes it. */
+typedef struct nsa_grid {
+    const float *table;          /* embeddings[rows, C] (device)                                   */
+    const int32_t *offsets_host; /* [L+1] (host)                                                   */
+    uint32_t L, C;               /* levels, features per level                                     */
+    float S;                     /* log2(per_level_scale)                                          */
+    uint32_t H;                  /* base resolution                                                */
+    float divide_factor;         /* x is divided by this before the [-1,1] -> [0,1] map            */
+    uint32_t n_hidden;           /* hidden layers of the attached MLP (coarse 1, fine 3)           */
+} nsa_grid_t;
+
+/* Coarse sampler stage: stratified z on [near, cube exit], points, coarse+fine SDF at R*E points (no grad).
+ * replaces UniformSampler.get_z_vals (code/model/ray_sampler.py:37-61) + ImplicitNetworkGrid_COMBINE.get_sdf_vals
+ * (code/model/base_networks.py:27-32) as called from ImportantSampler.get_z_vals (ray_sampler.py:92-102).
+ * t_lin = linspace(0,1,E); t_rand = per-sample jitter in [0,1) or NULL (eval mode); packed_* = MLP parameters
+ * in MFMA fragment order (nicer_slam_amd/fused/pack.py).  Outputs z[R,E], sdf[R,E], far[R]. */
+int nsa_sampler_sdf(const float *rays_o, const float *rays_d, uint32_t R, uint32_t E, const float *t_lin,
+                    const float *t_rand, float near, float bound, float far_cap, const nsa_grid_t *coarse,
+                    const nsa_grid_t *fine, const float *packed_coarse, const float *packed_fine, float *z,
+                    float *sdf, float *far, nsa_stream_t stream);
+
+/* Per-ray importance stage: density -> weights -> cdf -> N inverse-CDF samples, merged with near, far and
+ * n_extra of the coarse samples, sorted.  replaces ImportantSampler.get_z_vals (ray_sampler.py:104-159) and
+ * GridPredefineDensity (code/model/density.py:37-67).  z_vals[R, N+2+n_extra]; z_eik[R] = z_vals[r, eik_idx[r]]
+ * (optional). */
+int nsa_sample_rays(const float *rays_o, const float *rays_d, const float *z, const float *sdf, const float *far,
+                    const float *voxels, uint32_t voxel_res, uint32_t R, uint32_t E, uint32_t N, const float *u_lin,
+                    const int32_t *extra_idx, uint32_t n_extra, float near, const int32_t *eik_idx, float *z_vals,
+                    float *z_eik, nsa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

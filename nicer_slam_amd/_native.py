@@ -35,3 +35,17 @@ EXPORTS = ["nsa_strerror", "nsa_version", "nsa_hash_encode_forward", "nsa_hash_e
 def check(rc):
     if rc != 0:
         raise RuntimeError(lib.nsa_strerror(rc).decode())
+
+
+class GridDesc(ctypes.Structure):
+    """nsa_grid_t"""
+    _fields_ = [("table", _p), ("offsets_host", _p), ("L", _u32), ("C", _u32), ("S", _f32), ("H", _u32),
+                ("divide_factor", _f32), ("n_hidden", _u32)]
+
+
+_gp = ctypes.POINTER(GridDesc)
+lib.nsa_sampler_sdf.restype = _i
+lib.nsa_sampler_sdf.argtypes = [_p, _p, _u32, _u32, _p, _p, _f32, _f32, _f32, _gp, _gp, _p, _p, _p, _p, _p, _p]
+lib.nsa_sample_rays.restype = _i
+lib.nsa_sample_rays.argtypes = [_p, _p, _p, _p, _p, _p, _u32, _u32, _u32, _u32, _p, _p, _u32, _f32, _p, _p, _p, _p]
+EXPORTS += ["nsa_sampler_sdf", "nsa_sample_rays"]

@@ -60,6 +60,11 @@ inline int make_grid_geom(const int32_t* offsets_host, uint32_t L, uint32_t D, f
     return NSA_OK;
 }
 
+// hipGetLastError() also reports stale non-errors left by OTHER runtime calls on this host thread (e.g. PyTorch's
+// hipEventQuery -> hipErrorNotReady), so every entry point clears it before launching and reads it after.
+inline void launch_begin() { (void)hipGetLastError(); }
+inline int launch_end() { return hipGetLastError() == hipSuccess ? NSA_OK : NSA_ELAUNCH; }
+
 // ---- device side -------------------------------------------------------------------------------
 template <int D>
 __device__ __forceinline__ uint32_t level_row(const LevelGeom& g, const uint32_t (&q)[D]) {

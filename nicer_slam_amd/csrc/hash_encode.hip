@@ -192,12 +192,13 @@ __global__ __launch_bounds__(TPB) void k_grid_second_backward(const float* __res
 }
 
 static inline uint32_t tiles(uint32_t B) { return (B + TPB - 1) / TPB; }
-static inline int launch_status() { return hipGetLastError() == hipSuccess ? NSA_OK : NSA_ELAUNCH; }
+static inline int launch_status() { return launch_end(); }
 
 template <int D, int C>
 static int forward_dc(const float* in, const float* emb, float* out, float* dy_dx, uint32_t B, uint32_t L, bool jac,
                       const GridGeom& geom, hipStream_t st) {
     const dim3 grid(tiles(B) * L), block(TPB);
+    launch_begin();
     if (jac) hipLaunchKernelGGL((k_grid_forward<D, C, true>), grid, block, 0, st, in, emb, out, dy_dx, B, L, geom);
     else     hipLaunchKernelGGL((k_grid_forward<D, C, false>), grid, block, 0, st, in, emb, out, dy_dx, B, L, geom);
     return launch_status();
@@ -206,6 +207,7 @@ static int forward_dc(const float* in, const float* emb, float* out, float* dy_d
 template <int D, int C>
 static int backward_dc(const float* grad, const float* in, float* gemb, uint32_t B, uint32_t L, bool gi, const float* dy_dx,
                        float* gin, const GridGeom& geom, hipStream_t st) {
+    launch_begin();
     if (gemb) hipLaunchKernelGGL((k_grid_scatter<D, C>), dim3(tiles(B) * L), dim3(TPB), 0, st, grad, in, gemb, B, L, geom);
     if (gi) hipLaunchKernelGGL((k_input_backward<D, C>), dim3(tiles(B)), dim3(TPB), 0, st, grad, dy_dx, gin, B, L);
     return launch_status();
@@ -215,6 +217,7 @@ template <int D, int C>
 static int second_dc(const float* grad, const float* in, const float* dy_dx, const float* ggi, float* gg, float* g2emb,
                      uint32_t B, uint32_t L, const GridGeom& geom, hipStream_t st) {
     const dim3 grid(tiles(B) * L), block(TPB);
+    launch_begin();
     if (g2emb) hipLaunchKernelGGL((k_grid_second_backward<D, C, true>), grid, block, 0, st, grad, in, dy_dx, ggi, gg, g2emb, B, L, geom);
     else       hipLaunchKernelGGL((k_grid_second_backward<D, C, false>), grid, block, 0, st, grad, in, dy_dx, ggi, gg, g2emb, B, L, geom);
     return launch_status();

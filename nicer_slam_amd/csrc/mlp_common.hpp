@@ -1,0 +1,140 @@
+// mlp_common.hpp -- register-resident batched MLP on fp32 MFMA for the fused render-core kernels.
+//
+// Tiling (wave64, v_mfma_f32_32x32x2_f32, exact fp32 = an fmaf chain):
+//   * a wave owns NT "point tiles" of 32 points; lane l works for point (l & 31) of each tile, and the two
+//     half-waves h = l >> 5 split every per-point job in two (half of the grid levels, half of the positional
+//     encoding pairs, half of every activation vector);
+//   * a layer is D[out, point] += W[out, k] * act[k, point]: the WEIGHTS are the MFMA "A" operand (M = output
+//     features, 32 per tile) and the ACTIVATIONS the "B" operand (N = points).  The MFMA result layout gives
+//     lane (p, h), register r of output tile t the feature  f = 32 t + (r & 3) + 8 (r >> 2) + 4 h  of point p.
+//     That register IS the B operand of k-step  s = 16 t + r  of the next layer (k-order inside a GEMM is free as
+//     long as A agrees), so layers chain in registers with no transposes, no LDS round trips and no barriers;
+//   * the weights are pre-packed on the host into that fragment order ("step-major, lane-minor", 4 k-steps per
+//     16-byte load) and read straight from global memory: every wave of the chip streams the same ~150 KB, which
+//     stays L1/L2 resident; a fragment costs one coalesced 1 KiB wave load per 4 MFMAs (256 cycles of matrix pipe).
+//
+// Packed "A" block layout for a GEMM with MT output tiles and KS k-steps:  float idx = ((mt*KS4 + s/4)*64 + lane)*4 + s%4
+// holding W[row(mt, lane & 31)][slot(s, lane >> 5)]  (zero for padded rows/slots);  KS4 = ceil(KS/4).
+// Packed per-feature vectors (biases, the sdf row) in activation layout:   idx = (t*2 + h)*16 + r.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nsa {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int HID = 64;        // hidden width of every MLP in the shipped configs
+constexpr int HS = 32;         // k-steps of a hidden activation (64 features / 2 half-waves)
+constexpr int SDF_IN_STEPS = 36;   // 71 inputs -> 36 slots per half-wave (one zero pad)
+constexpr int COL_IN_STEPS = 65;   // 129 inputs -> 65 slots per half-wave (one zero pad)
+
+__host__ __device__ constexpr int a_block_floats(int mt, int ks) { return mt * ((ks + 3) / 4) * 64 * 4; }
+
+// acc[mt] += sum_{s < KS} A(mt, s) * b[s]
+template <int KS, int MT>
+__device__ __forceinline__ void gemm_op(const float* __restrict__ wp, int lane, const float (&b)[KS], f32x16 (&acc)[MT]) {
+    constexpr int KS4 = (KS + 3) / 4;
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wp) + lane;
+#pragma unroll
+    for (int s4 = 0; s4 < KS4; ++s4) {
+        float4 a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = w4[(mt * KS4 + s4) * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (4 * s4 + q < KS) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float av = q == 0 ? a[mt].x : q == 1 ? a[mt].y : q == 2 ? a[mt].z : a[mt].w;
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[4 * s4 + q], acc[mt], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+// Two point tiles sharing each weight fragment (NT = 2).
+template <int KS, int MT>
+__device__ __forceinline__ void gemm_op2(const float* __restrict__ wp, int lane, const float (&b0)[KS], const float (&b1)[KS],
+                                         f32x16 (&acc0)[MT], f32x16 (&acc1)[MT]) {
+    constexpr int KS4 = (KS + 3) / 4;
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wp) + lane;
+#pragma unroll
+    for (int s4 = 0; s4 < KS4; ++s4) {
+        float4 a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = w4[(mt * KS4 + s4) * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (4 * s4 + q < KS) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float av = q == 0 ? a[mt].x : q == 1 ? a[mt].y : q == 2 ? a[mt].z : a[mt].w;
+                    acc0[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[4 * s4 + q], acc0[mt], 0, 0, 0);
+                    acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1[4 * s4 + q], acc1[mt], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+// Load a packed per-feature vector (bias) for MT tiles into accumulator layout.
+template <int MT>
+__device__ __forceinline__ void load_vec(const float* __restrict__ vp, int h, f32x16 (&acc)[MT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const float4* p = reinterpret_cast<const float4*>(vp + (mt * 2 + h) * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 v = p[i];
+            acc[mt][4 * i + 0] = v.x; acc[mt][4 * i + 1] = v.y; acc[mt][4 * i + 2] = v.z; acc[mt][4 * i + 3] = v.w;
+        }
+    }
+}
+
+__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
+
+// Softplus(beta = 100) with PyTorch's threshold 20 (base_networks.py:153), its derivative sigmoid(100 a) and the
+// second derivative 100 s (1 - s) (zero in the linear region, like torch's double backward).
+__device__ __forceinline__ float softplus100(float a) {
+    const float t = 100.0f * a;
+    return t > 20.0f ? a : 0.01f * __logf(1.0f + __expf(t));
+}
+__device__ __forceinline__ float softplus100_d1(float a) {
+    const float t = 100.0f * a;
+    const float e = __expf(t);
+    return t > 20.0f ? 1.0f : e / (e + 1.0f);
+}
+__device__ __forceinline__ void softplus100_all(float a, float& y, float& d1, float& d2) {
+    const float t = 100.0f * a;
+    const float e = __expf(t);
+    const bool lin = t > 20.0f;
+    const float s = e / (e + 1.0f);
+    y = lin ? a : 0.01f * __logf(1.0f + e);
+    d1 = lin ? 1.0f : s;
+    d2 = lin ? 0.0f : 100.0f * s * (1.0f - s);
+}
+
+// sin and cos of a (|a| <~ 1e3) sharing one Cody-Waite reduction to [-pi/4, pi/4]; ~1 ulp-class polynomials.
+__device__ __forceinline__ void sincos_f(float a, float& s, float& c) {
+    const float n = rintf(a * 0.63661977236758134f);          // a / (pi/2)
+    float r = fmaf(n, -1.5707963705062866f, a);                 // pi/2 = c1 + c2 + c3 (float32 parts)
+    r = fmaf(n, 4.371138828673793e-08f, r);
+    r = fmaf(n, 1.7763568394002505e-15f, r);
+    const float r2 = r * r;
+    float ps = fmaf(r2, 2.7557314297e-6f, -1.9841270114e-4f);   // sin r = r + r^3 * P(r^2)
+    ps = fmaf(ps, r2, 8.3333337680e-3f);
+    ps = fmaf(ps, r2, -1.6666667163e-1f);
+    const float sr = fmaf(ps * r2, r, r);
+    float pc = fmaf(r2, 2.4433157e-5f, -1.3887316255e-3f);      // cos r = 1 - r^2/2 + r^4 * Q(r^2)
+    pc = fmaf(pc, r2, 4.1666645683e-2f);
+    const float cr = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+    const int q = (int)n & 3;
+    const float s0 = (q & 1) ? cr : sr;
+    const float c0 = (q & 1) ? sr : cr;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+}  // namespace nsa

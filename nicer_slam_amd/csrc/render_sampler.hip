@@ -1,0 +1,328 @@
+// render_sampler.hip -- the hierarchical ray sampler of the render core.
+// Reference: UniformSampler.get_z_vals / near_far_from_cube (code/model/ray_sampler.py:23-61),
+//            ImportantSampler.get_z_vals (code/model/ray_sampler.py:90-166),
+//            GridPredefineDensity (code/model/density.py:37-67).
+//
+// k_sampler_sdf   one lane-pair per (ray, coarse sample): builds the stratified z, the point, both grid encodings,
+//                 the positional encoding and evaluates coarse+fine SDF MLPs on fp32 MFMA entirely in registers
+//                 (the reference's redundant second coarse evaluation, base_networks.py:31, is not repeated).
+// k_sample_rays   one wave per ray: SDF -> Laplace density (beta from the visit counter) -> alpha/transmittance
+//                 weights via a wave-shuffle scan -> pdf/cdf in LDS -> inverse-CDF samples by binary search ->
+//                 merge with near/far/extras -> in-LDS bitonic sort.
+#include "sdf_net.hpp"
+
+namespace nsa {
+
+struct SamplerArgs {
+    const float* rays_o;      // [R,3]
+    const float* rays_d;      // [R,3]
+    const float* t_lin;       // [E] = linspace(0,1,E)
+    const float* t_rand;      // [R,E] stratified jitter in [0,1) or nullptr (eval mode)
+    float* z;                 // [R,E] out
+    float* sdf;               // [R,E] out
+    float* far;               // [R] out
+    uint32_t R, E;
+    float near, bound, far_cap;
+    const float* table_c;
+    const float* table_f;
+    const float* wp_c;
+    const float* wp_f;
+    float df_c, df_f;
+};
+
+// far end of the ray inside the cube [-bound, bound]^3, clamped to far_cap (ray_sampler.py:23-35).
+__device__ __forceinline__ float cube_far(const float (&o)[3], const float (&d)[3], float bound, float far_cap, float near_clamp) {
+    float nearv = -INFINITY, farv = INFINITY;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float den = d[k] + 1e-15f;
+        const float t0 = (-bound - o[k]) / den;
+        const float t1 = (bound - o[k]) / den;
+        nearv = fmaxf(nearv, t0 < t1 ? t0 : t1);
+        farv = fminf(farv, t0 > t1 ? t0 : t1);
+    }
+    if (farv < nearv) farv = 1e9f;
+    (void)near_clamp;
+    return fminf(farv, far_cap);
+}
+
+template <int LC, int CC, int NHC, int LF, int CF, int NHF>
+__global__ __launch_bounds__(256) void k_sampler_sdf(SamplerArgs a, GridGeom16 gc, GridGeom16 gf) {
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t total = (uint64_t)a.R * a.E;
+    uint64_t pid = (uint64_t)wave * 32 + (lane & 31);
+    const bool live = pid < total;
+    if (!live) pid = total - 1;                 // keep the wave converged for the MFMAs; store is predicated
+    const uint32_t ray = (uint32_t)(pid / a.E);
+    const uint32_t i = (uint32_t)(pid - (uint64_t)ray * a.E);
+
+    float o[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o[k] = a.rays_o[ray * 3 + k]; d[k] = a.rays_d[ray * 3 + k]; }
+    const float farv = cube_far(o, d, a.bound, a.far_cap, a.near);
+    const float nearv = a.near;
+    // z_lin(i) = near (1 - t_i) + far t_i ; stratified: lower + (upper - lower) * rand   (ray_sampler.py:49-59)
+    const uint32_t E = a.E;
+    const float ti = a.t_lin[i];
+    float zi = nearv * (1.0f - ti) + farv * ti;
+    if (a.t_rand) {
+        const float tp = a.t_lin[i + 1 < E ? i + 1 : i], tm = a.t_lin[i > 0 ? i - 1 : 0];
+        const float zp = nearv * (1.0f - tp) + farv * tp;
+        const float zm = nearv * (1.0f - tm) + farv * tm;
+        const float upper = i + 1 < E ? 0.5f * (zp + zi) : zi;
+        const float lower = i > 0 ? 0.5f * (zi + zm) : zi;
+        zi = lower + (upper - lower) * a.t_rand[pid];
+    }
+    float x[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x[k] = o[k] + zi * d[k];
+
+    float in[SDF_IN_STEPS];
+    float sdf;
+    {
+        float jdummy[LC / 2][3][CC];
+        sdf_net_inputs<LC, CC, false>(x, a.df_c, a.table_c, gc, h, in, jdummy);
+        sdf = sdf_only<NHC>(a.wp_c, lane, h, in);
+    }
+    {
+        float jdummy[LF / 2][3][CF];
+        // the positional-encoding slots (0..19) are identical for both nets; only the grid slots change
+        float in_f[SDF_IN_STEPS];
+        sdf_net_inputs<LF, CF, false>(x, a.df_f, a.table_f, gf, h, in_f, jdummy);
+        sdf += sdf_only<NHF>(a.wp_f, lane, h, in_f);
+    }
+    if (live && h == 0) {
+        a.z[pid] = zi;
+        a.sdf[pid] = sdf;
+        if (i == 0) a.far[ray] = farv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ per-ray stage
+struct RaySampleArgs {
+    const float* rays_o;
+    const float* rays_d;
+    const float* z;         // [R,E] coarse samples
+    const float* sdf;       // [R,E]
+    const float* far;       // [R]
+    const float* voxels;    // [res^3] visit counter
+    const float* u_lin;     // [N] = linspace(0,1,N)
+    const int32_t* extra_idx;   // [n_extra] indices into the E coarse samples
+    const int32_t* eik_idx;     // [R] or nullptr
+    float* z_vals;          // [R,S] out, S = N + 2 + n_extra
+    float* z_eik;           // [R] out (may be nullptr)
+    uint32_t R, E, N, n_extra, voxel_res;
+    float near;
+};
+
+__device__ __forceinline__ float beta_of(const float* __restrict__ voxels, uint32_t res, const float (&x)[3]) {
+    // density.py:41-60
+    const bool outside = fabsf(x[0]) > 0.99f || fabsf(x[1]) > 0.99f || fabsf(x[2]) > 0.99f;
+    float count = 0.0f;
+    if (!outside) {
+        int idx[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int v = (int)((x[k] + 1.0f) / 2.0f * (float)res);   // .long() truncation
+            idx[k] = v < 0 ? 0 : (v >= (int)res ? (int)res - 1 : v);
+        }
+        count = voxels[((size_t)idx[0] * res + idx[1]) * res + idx[2]];
+    }
+    return 0.01207724805f * expf(-0.0116544676f * 0.0001f * count * 5.37538f) + 0.0023639156f;
+}
+
+__device__ __forceinline__ float laplace_density(float sdf, float beta) {
+    // alpha * (0.5 + 0.5 * sign(s) * expm1(-|s| / beta)), alpha = 1/beta   (density.py:37-39)
+    const float sg = sdf > 0.0f ? 1.0f : (sdf < 0.0f ? -1.0f : 0.0f);
+    return (1.0f / beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(sdf) / beta));
+}
+
+__device__ __forceinline__ float wave_excl_scan(float v, int lane, float& total) {
+    float incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float n = __shfl_up(incl, off);
+        if (lane >= off) incl += n;
+    }
+    total = __shfl(incl, 63);
+    return incl - v;
+}
+
+constexpr int MAX_S = 256;    // final samples per ray supported by the sort buffer
+
+__device__ __forceinline__ uint32_t next_pow2(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// One wave per ray, 4 rays per 256-thread workgroup; LDS per ray: pdf[E], cdf[E], z[E], sort[MAX_S].
+__global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const uint32_t E = a.E, N = a.N;
+    const uint32_t S = N + 2 + a.n_extra;
+    const uint32_t ray_raw = blockIdx.x * 4 + wv;
+    const bool live = ray_raw < a.R;
+    const uint32_t ray = live ? ray_raw : a.R - 1;        // dead waves shadow the last ray (no early exit: barriers)
+    float* pdf = smem + (size_t)wv * (3 * E + MAX_S);
+    float* cdf = pdf + E;
+    float* zb = cdf + E;
+    float* sb = zb + E;
+
+    float o[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o[k] = a.rays_o[ray * 3 + k]; d[k] = a.rays_d[ray * 3 + k]; }
+    const float* zr = a.z + (size_t)ray * E;
+    const float* sr = a.sdf + (size_t)ray * E;
+    const uint32_t per = (E + 63) / 64;
+    const uint32_t i0 = lane * per;
+
+    // free energy sigma_i * delta_i (last delta = 1e10)                       ray_sampler.py:105-108
+    float esum = 0.0f;
+    for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t i = i0 + k;
+        if (i < E) {
+            const float zi = zr[i];
+            float x[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x[c] = o[c] + zi * d[c];
+            const float sigma = laplace_density(sr[i], beta_of(a.voxels, a.voxel_res, x));
+            const float en = (i + 1 < E ? zr[i + 1] - zi : 1e10f) * sigma;
+            zb[i] = zi;
+            pdf[i] = en;
+            esum += en;
+        }
+    }
+    float tot;
+    float run = wave_excl_scan(esum, lane, tot);
+    // w_i = (1 - exp(-E_i)) exp(-sum_{j<i} E_j);  pdf_i = w_i + 1e-5 for i < E-1      :109-117
+    float psum = 0.0f;
+    for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t i = i0 + k;
+        if (i < E) {
+            const float en = pdf[i];
+            const float w = (1.0f - expf(-en)) * expf(-run);
+            run += en;
+            const float p = i + 1 < E ? w + 1e-5f : 0.0f;
+            pdf[i] = p;
+            psum += p;
+        }
+    }
+    float ptot;
+    (void)wave_excl_scan(psum, lane, ptot);
+    // cdf = [0, cumsum(pdf / sum)]                                                     :118-121
+    float nsum = 0.0f;
+    for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t i = i0 + k;
+        if (i + 1 < E) nsum += pdf[i] / ptot;
+    }
+    float ntot;
+    float nrun = wave_excl_scan(nsum, lane, ntot);
+    for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t i = i0 + k;
+        if (i + 1 < E) {
+            nrun += pdf[i] / ptot;
+            cdf[i + 1] = nrun;
+        }
+    }
+    if (lane == 0) cdf[0] = 0.0f;
+    __syncthreads();
+
+    // inverse CDF at u_j = linspace(0,1,N)_j: searchsorted(right=True)                 :124-139
+    for (uint32_t j = lane; j < N; j += 64) {
+        const float u = a.u_lin[j];
+        uint32_t lo = 0, hi = E;                     // first index with cdf > u
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const uint32_t below = lo > 0 ? lo - 1 : 0;
+        const uint32_t above = lo < E - 1 ? lo : E - 1;
+        const float c0 = cdf[below], c1 = cdf[above];
+        const float b0 = zb[below], b1 = zb[above];
+        float den = c1 - c0;
+        if (den < 1e-5f) den = 1.0f;
+        sb[j] = b0 + (u - c0) / den * (b1 - b0);
+    }
+    // extras: near, far, n_extra of the coarse samples                                  :146-153
+    const uint32_t P2 = next_pow2(S);
+    for (uint32_t j = N + lane; j < P2; j += 64) {
+        float v = INFINITY;
+        if (j == N) v = a.near;
+        else if (j == N + 1) v = a.far[ray];
+        else if (j < S) v = zb[a.extra_idx[j - N - 2]];
+        sb[j] = v;
+    }
+    __syncthreads();
+    // bitonic sort of P2 <= 256 keys in LDS                                             :155
+    for (uint32_t k = 2; k <= P2; k <<= 1) {
+        for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
+            for (uint32_t t = lane; t < P2 / 2; t += 64) {
+                const uint32_t i = 2 * t - (t & (jj - 1));      // index with bit jj clear
+                const uint32_t p = i + jj;
+                const bool up = (i & k) == 0;
+                const float x0 = sb[i], x1 = sb[p];
+                if ((x0 > x1) == up) { sb[i] = x1; sb[p] = x0; }
+            }
+            __syncthreads();
+        }
+    }
+    if (live) {
+        for (uint32_t j = lane; j < S; j += 64) a.z_vals[(size_t)ray * S + j] = sb[j];
+        if (a.z_eik && lane == 0) a.z_eik[ray] = sb[a.eik_idx[ray]];
+    }
+}
+
+}  // namespace nsa
+
+extern "C" {
+
+int nsa_sampler_sdf(const float* rays_o, const float* rays_d, uint32_t R, uint32_t E, const float* t_lin,
+                    const float* t_rand, float near, float bound, float far_cap, const nsa_grid_t* coarse,
+                    const nsa_grid_t* fine, const float* packed_coarse, const float* packed_fine, float* z, float* sdf,
+                    float* far, nsa_stream_t stream) {
+    using namespace nsa;
+    if (R == 0 || E == 0) return NSA_OK;
+    if (!rays_o || !rays_d || !t_lin || !coarse || !fine || !packed_coarse || !packed_fine || !z || !sdf || !far)
+        return NSA_EBADARG;
+    if (!(coarse->L == 4 && coarse->C == 8 && coarse->n_hidden == 1 && fine->L == 8 && fine->C == 4 && fine->n_hidden == 3))
+        return NSA_EUNSUPPORTED_NET;
+    GridGeom16 gc, gf;
+    if (int rc = make_grid_geom16(coarse->offsets_host, coarse->L, coarse->S, coarse->H, &gc)) return rc;
+    if (int rc = make_grid_geom16(fine->offsets_host, fine->L, fine->S, fine->H, &gf)) return rc;
+    SamplerArgs a{rays_o, rays_d, t_lin, t_rand, z, sdf, far, R, E, near, bound, far_cap,
+                  coarse->table, fine->table, packed_coarse, packed_fine, coarse->divide_factor, fine->divide_factor};
+    const uint64_t total = (uint64_t)R * E;
+    const uint32_t waves = (uint32_t)((total + 31) / 32);
+    const uint32_t blocks = (waves + 3) / 4;
+    launch_begin();
+    hipLaunchKernelGGL((k_sampler_sdf<4, 8, 1, 8, 4, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, gc, gf);
+    return launch_end();
+}
+
+int nsa_sample_rays(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const float* far,
+                    const float* voxels, uint32_t voxel_res, uint32_t R, uint32_t E, uint32_t N, const float* u_lin,
+                    const int32_t* extra_idx, uint32_t n_extra, float near, const int32_t* eik_idx, float* z_vals,
+                    float* z_eik, nsa_stream_t stream) {
+    using namespace nsa;
+    if (R == 0) return NSA_OK;
+    if (!rays_o || !rays_d || !z || !sdf || !far || !voxels || !u_lin || !z_vals || (n_extra && !extra_idx) ||
+        (z_eik && !eik_idx))
+        return NSA_EBADARG;
+    const uint32_t S = N + 2 + n_extra;
+    if (S > MAX_S || E < 2 || (3 * E + MAX_S) * 4 * 4 > 160 * 1024) return NSA_EBADARG;
+    RaySampleArgs a{rays_o, rays_d, z, sdf, far, voxels, u_lin, extra_idx, eik_idx, z_vals, z_eik, R, E, N, n_extra,
+                    voxel_res, near};
+    const size_t lds = (size_t)(3 * E + MAX_S) * 4 * sizeof(float);
+    launch_begin();
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_sample_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_sample_rays, dim3((R + 3) / 4), dim3(256), lds, (hipStream_t)stream, a);
+    return launch_end();
+}
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+// sdf_net.hpp -- the SDF networks (coarse: 71->64->65, fine: 71->64->64->64->65; Softplus(100)) evaluated per
+// wave on MFMA, fused with their grid encoders and positional encoding.
+// Reference: ImplicitNetworkGrid.forward / get_outputs (code/model/base_networks.py:155-221), HashEncoder.forward
+// (code/hashencoder/hashgrid.py:199-215), Embedder (code/model/embedder.py:5-37).
+//
+// Input-slot map of the first layer (36 slots per half-wave h; reference feature index in brackets):
+//   slot 0        : h=0 -> x0 [0]              h=1 -> x2 [2]
+//   slot 1        : h=0 -> x1 [1]              h=1 -> zero pad
+//   slot 2+2j,3+2j: sin, cos of 2^k x_d for the pair g = 2j+h, k = g/3, d = g%3   [3+6k+d], [6+6k+d]     (j < 9)
+//   slot 20+jl*C+c: channel c of grid level 2*jl+h   [39 + (2jl+h)*C + c]                               (jl < L/2)
+// (nicer_slam_amd/fused/pack.py builds the packed weights from exactly this table.)
+#pragma once
+#include "grid_common.hpp"
+#include "mlp_common.hpp"
+
+namespace nsa {
+
+struct GridGeom16 {
+    LevelGeom lv[16];
+};
+
+inline int make_grid_geom16(const int32_t* offsets_host, uint32_t L, float S, uint32_t H, GridGeom16* out) {
+    if (L > 16) return NSA_ETOO_MANY_LEVELS;
+    GridGeom g;
+    if (int rc = make_grid_geom(offsets_host, L, 3, S, H, &g)) return rc;
+    for (uint32_t l = 0; l < L; ++l) out->lv[l] = g.lv[l];
+    return NSA_OK;
+}
+
+// Offsets (in floats) inside one SDF net's packed parameter block; NH = number of hidden layers.
+template <int NH>
+struct SdfPack {
+    static constexpr int kW0 = 0;                                   // A[2 tiles][36 steps]
+    static constexpr int kB0 = kW0 + a_block_floats(2, SDF_IN_STEPS);
+    static constexpr int kWH = kB0 + 64;                            // (NH-1) x { A[2][32], bias[64] }
+    static constexpr int kWSDF = kWH + (NH - 1) * (4096 + 64);      // last-layer row 0 in activation layout
+    static constexpr int kBSDF = kWSDF + 64;                        // [0] = bias of the sdf output
+    static constexpr int kWFEAT = kBSDF + 64;                       // last-layer rows 1..64: A[2][32]
+    static constexpr int kBFEAT = kWFEAT + 4096;
+    static constexpr int kWHT = kBFEAT + 64;                        // transposed hidden layers, order k = NH-1 .. 1
+    static constexpr int kW0T = kWHT + (NH - 1) * 4096;             // A[3 tiles][32 steps]: rows = input slots
+    static constexpr int kWFEATT = kW0T + a_block_floats(3, HS);    // transposed feature rows
+    static constexpr int kTotal = kWFEATT + 4096;
+    __host__ __device__ static constexpr int wh(int k) { return kWH + (k - 1) * (4096 + 64); }       // k = 1..NH-1
+    __host__ __device__ static constexpr int bh(int k) { return wh(k) + 4096; }
+    __host__ __device__ static constexpr int wht(int k) { return kWHT + (NH - 1 - k) * 4096; }       // k = 1..NH-1
+};
+
+// First-layer inputs of one SDF net for one point, as seen by lane half h.  Optionally keeps the Jacobian rows of
+// this lane's levels (d feature / d u, u = (x/df + 1)/2) and the sin/cos values for the gradient pass.
+template <int L, int C, bool KEEP>
+__device__ __forceinline__ void sdf_net_inputs(const float (&x)[3], float divide_factor, const float* __restrict__ table,
+                                               const GridGeom16& geom, int h, float (&in)[SDF_IN_STEPS],
+                                               float (&jac)[L / 2][3][C]) {
+    in[0] = h ? x[2] : x[0];
+    in[1] = h ? 0.0f : x[1];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        constexpr int dummy = 0; (void)dummy;
+        const int g0 = 2 * j, g1 = 2 * j + 1;
+        const float xa = h ? x[g1 % 3] : x[g0 % 3];
+        const float sc = h ? (float)(1 << (g1 / 3)) : (float)(1 << (g0 / 3));
+        sincos_f(xa * sc, in[2 + 2 * j], in[3 + 2 * j]);
+    }
+    float u[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) u[d] = (x[d] / divide_factor + 1.0f) / 2.0f;   // hashgrid.py:203 (size = 1)
+#pragma unroll
+    for (int jl = 0; jl < L / 2; ++jl) {
+        const LevelGeom g = geom.lv[2 * jl + h];
+        uint32_t cell[3];
+        float w[3], dw[3];
+        const bool inside = locate<3>(u, g.scale, cell, w, dw);
+        float v[8][C];
+        gather_corners<3, C>(table, g, cell, v);
+        float f[C];
+        blend<3, C>(v, w, f);
+#pragma unroll
+        for (int c = 0; c < C; ++c) in[20 + jl * C + c] = inside ? f[c] : 0.0f;
+        if (KEEP) {
+#pragma unroll
+            for (int gd = 0; gd < 3; ++gd) {
+                float jr[C];
+                jacobian_row<3, C>(v, w, dw, g.scale, gd, jr);
+#pragma unroll
+                for (int c = 0; c < C; ++c) jac[jl][gd][c] = inside ? jr[c] : 0.0f;
+            }
+        }
+    }
+}
+
+// NOTE on out-of-range points: the table gather above still runs for them (addresses stay inside the level because
+// of the modulo), only the result is zeroed -- same values as kernel_grid's early-out (hashencoder.cu:161-177).
+// A point with NaN coordinates is "inside" for the reference's </> tests; cell then comes from (uint)NaN: keep the
+// gather in range by construction of level_row (mask / modulo), values are garbage-in garbage-out on both sides.
+
+// SDF value only (sampler pass): acc chain through the hidden layers, then the sdf row as a VALU dot.
+template <int NH>
+__device__ __forceinline__ float sdf_only(const float* __restrict__ wp, int lane, int h, const float (&in)[SDF_IN_STEPS]) {
+    using P = SdfPack<NH>;
+    f32x16 acc[2];
+    load_vec<2>(wp + P::kB0, h, acc);
+    gemm_op<SDF_IN_STEPS, 2>(wp + P::kW0, lane, in, acc);
+    float act[HS];
+#pragma unroll
+    for (int k = 1; k < NH; ++k) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) act[16 * t + r] = softplus100(acc[t][r]);
+        load_vec<2>(wp + P::bh(k), h, acc);
+        gemm_op<HS, 2>(wp + P::wh(k), lane, act, acc);
+    }
+    f32x16 ws[2];
+    load_vec<2>(wp + P::kWSDF, h, ws);
+    float part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part = fmaf(softplus100(acc[t][r]), ws[t][r], part);
+    return xhalf_sum(part) + wp[P::kBSDF];
+}
+
+}  // namespace nsa

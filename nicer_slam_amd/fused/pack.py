@@ -1,0 +1,151 @@
+"""Pack MLP parameters into MFMA fragment order for the fused kernels (layout: csrc/mlp_common.hpp, csrc/sdf_net.hpp).
+
+Every packed block is a pure gather of the flattened effective parameters (weight-norm applied:
+W = g * v / |v|_row, reference base_networks.py:148-149), so packing is ONE indexing op per network on the device;
+index maps are built once per network shape with numpy.
+"""
+import functools
+
+import numpy as np
+import torch
+
+SDF_IN_STEPS = 36
+COL_IN_STEPS = 65
+
+
+def F(r, h):
+    """MFMA 32x32 result row of register r in half-wave h."""
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def hid_feature(s, h):
+    """hidden feature held by k-step s of half-wave h."""
+    return 32 * (s >> 4) + F(s & 15, h)
+
+
+def sdf_in_feature(s, h, L, C):
+    """reference input-feature index (base_networks.py:155-164: [x, PE6(x), grid]) of first-layer slot (s, h)."""
+    if s == 0:
+        return 0 if h == 0 else 2
+    if s == 1:
+        return 1 if h == 0 else -1
+    if s < 20:
+        j, which = divmod(s - 2, 2)
+        g = 2 * j + h
+        k, d = divmod(g, 3)
+        return 3 + 6 * k + d + (3 if which else 0)
+    jl, c = divmod(s - 20, C)
+    return 39 + (2 * jl + h) * C + c
+
+
+def row_slot(mt, i):
+    """(slot, half) owned by output row i of tile mt in a GEMM whose OUTPUT is a slot list (transposed first layer)."""
+    hh = (i >> 2) & 1
+    r = (i & 3) + 4 * (i >> 3)
+    return 16 * mt + r, hh
+
+
+def a_block(MT, KS, elem):
+    """int64 index block [MT][KS4][64][4]; elem(mt, i, s, h) -> flat parameter index or -1 (zero)."""
+    KS4 = (KS + 3) // 4
+    out = np.full((MT, KS4, 64, 4), -1, dtype=np.int64)
+    for mt in range(MT):
+        for s4 in range(KS4):
+            for lane in range(64):
+                for q in range(4):
+                    s = 4 * s4 + q
+                    if s < KS:
+                        out[mt, s4, lane, q] = elem(mt, lane & 31, s, lane >> 5)
+    return out.reshape(-1)
+
+
+def vec_block(n_tiles, elem, pad_to=None):
+    """activation-layout vector [(t*2+h)*16 + r]; elem(feature) -> flat index."""
+    out = np.full(n_tiles * 32, -1, dtype=np.int64)
+    for t in range(n_tiles):
+        for h in range(2):
+            for r in range(16):
+                out[(t * 2 + h) * 16 + r] = elem(32 * t + F(r, h))
+    if pad_to:
+        out = np.concatenate([out, np.full(pad_to - out.size, -1, dtype=np.int64)])
+    return out
+
+
+@functools.lru_cache(maxsize=None)
+def sdf_net_index(NH, L, C):
+    """Index map of one SDF network's packed block (order = csrc/sdf_net.hpp::SdfPack<NH>) into
+    flat = cat[lin0.W(64x71), lin0.b, lin1.W, lin1.b, ..., lin{NH}.W(65x64), lin{NH}.b]."""
+    n_in = 39 + L * C
+    assert n_in == 71
+    offs, o = [], 0
+    shapes = [(64, n_in)] + [(64, 64)] * (NH - 1) + [(65, 64)]
+    for (a, b) in shapes:
+        offs.append((o, o + a * b))   # (W offset, bias offset)
+        o += a * b + a
+    Wo = lambda k: offs[k][0]
+    Bo = lambda k: offs[k][1]
+    n_cols = lambda k: shapes[k][1]
+    blocks = []
+    # W0, B0
+    blocks.append(a_block(2, SDF_IN_STEPS, lambda mt, i, s, h: (
+        Wo(0) + (32 * mt + i) * n_in + f if (f := sdf_in_feature(s, h, L, C)) >= 0 else -1)))
+    blocks.append(vec_block(2, lambda f: Bo(0) + f))
+    for k in range(1, NH):
+        blocks.append(a_block(2, 32, lambda mt, i, s, h, k=k: Wo(k) + (32 * mt + i) * 64 + hid_feature(s, h)))
+        blocks.append(vec_block(2, lambda f, k=k: Bo(k) + f))
+    # WSDF, BSDF
+    blocks.append(vec_block(2, lambda f: Wo(NH) + f))
+    bs = np.full(64, -1, dtype=np.int64)
+    bs[0] = Bo(NH)
+    blocks.append(bs)
+    # WFEAT, BFEAT (rows 1..64 of the last layer)
+    blocks.append(a_block(2, 32, lambda mt, i, s, h: Wo(NH) + (1 + 32 * mt + i) * 64 + hid_feature(s, h)))
+    blocks.append(vec_block(2, lambda f: Bo(NH) + 1 + f))
+    # transposed hidden layers, k = NH-1 .. 1:  A[row = in-feature][slot = out-feature]
+    for k in range(NH - 1, 0, -1):
+        blocks.append(a_block(2, 32, lambda mt, i, s, h, k=k: Wo(k) + hid_feature(s, h) * 64 + (32 * mt + i)))
+
+    def w0t(mt, i, s, h):
+        q, hh = row_slot(mt, i)
+        if q >= SDF_IN_STEPS:
+            return -1
+        f = sdf_in_feature(q, hh, L, C)
+        return Wo(0) + hid_feature(s, h) * n_in + f if f >= 0 else -1
+    blocks.append(a_block(3, 32, w0t))
+    # WFEATT: A[row = hidden in-feature][slot = feature output (1 + ...)]
+    blocks.append(a_block(2, 32, lambda mt, i, s, h: Wo(NH) + (1 + hid_feature(s, h)) * 64 + (32 * mt + i)))
+    idx = np.concatenate(blocks)
+    idx[idx < 0] = o            # index of the appended zero
+    return torch.from_numpy(idx), o
+
+
+def sdf_pack_size(NH):
+    return 4608 + 64 + (NH - 1) * 4160 + 64 + 64 + 4096 + 64 + (NH - 1) * 4096 + 6144 + 4096
+
+
+def effective_weight(lin):
+    """Weight of a (possibly legacy weight-normed) nn.Linear, recomputed from the live parameters."""
+    if hasattr(lin, "weight_g"):
+        return torch._weight_norm(lin.weight_v, lin.weight_g, 0)
+    return lin.weight
+
+
+def flat_params(net):
+    parts = []
+    for l in range(net.num_layers - 1):
+        lin = getattr(net, "lin" + str(l))
+        parts += [effective_weight(lin).reshape(-1), lin.bias.reshape(-1)]
+    parts.append(parts[0].new_zeros(1))
+    return torch.cat(parts)
+
+
+def pack_sdf_net(net):
+    """ImplicitNetworkGrid -> packed float32 device tensor (differentiable gather of the effective parameters)."""
+    NH = net.num_layers - 2
+    enc = net.encoding
+    idx, n = sdf_net_index(NH, enc.num_levels, enc.level_dim)
+    flat = flat_params(net)
+    assert flat.numel() == n + 1, (flat.numel(), n)
+    packed = flat[idx.to(flat.device)]
+    assert packed.numel() == sdf_pack_size(NH)
+    return packed

@@ -1,0 +1,130 @@
+"""Fused hierarchical sampler: thin wrapper over nsa_sampler_sdf + nsa_sample_rays (include/nicer_slam_amd.h,
+Section 2).  Replaces ImportantSampler.get_z_vals of the composed engine (reference code/model/ray_sampler.py:90-166)
+with two kernel launches; no gradient flows through the sampler (the reference runs it on detached rays under
+no_grad, ray_sampler.py:38-39,101-102)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from .._native import lib, check, GridDesc
+from ..hashencoder.backend import _offsets_host, _timed
+from . import pack
+
+_LIN = {}
+
+
+def _linspace(n, device):
+    key = (n, str(device))
+    if key not in _LIN:
+        _LIN[key] = torch.linspace(0.0, 1.0, steps=n, device=device)
+    return _LIN[key]
+
+
+def grid_desc(net_or_enc, divide_factor, n_hidden):
+    enc = net_or_enc
+    off = _offsets_host(enc.offsets)
+    d = GridDesc(enc.embeddings.data_ptr(), off.data_ptr(), enc.num_levels, enc.level_dim,
+                 float(np.log2(enc.per_level_scale)), enc.base_resolution, float(divide_factor), n_hidden)
+    return d, (off, enc.embeddings)
+
+
+def supported(model):
+    """Configurations the compiled kernels cover: the architecture shared by all 23 shipped run configs."""
+    imp = model.implicit_network
+    c, f = imp.coarse, imp.fine
+
+    def ok(net, L, C, nh):
+        e = net.encoding
+        return (e.num_levels == L and e.level_dim == C and e.input_dim == 3 and net.num_layers - 2 == nh
+                and net.multires == 6 and not net.skip_in and not net.clamp and net.use_grid_feature
+                and all(d == 64 for d in net.dims[1:-1]) and net.dims[-1] == 65
+                and net.encoding.embeddings.dtype == torch.float32)
+    return (ok(c, 4, 8, 1) and ok(f, 8, 4, 3) and model.density_method == "volsdf_gridpredefined"
+            and model.feature_vector_size == 64 and model.voxels.is_cuda)
+
+
+def packed_sdf(model, which, detach=True):
+    """Packed parameters of the coarse/fine SDF MLP, cached on the parameters' version counters."""
+    net = getattr(model.implicit_network, which)
+    params = net.mlp_parameters()
+    key = tuple((p.data_ptr(), p._version) for p in params)
+    cache = model.__dict__.setdefault("_fused_pack", {})
+    hit = cache.get(which)
+    if detach and hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.set_grad_enabled(not detach):
+        packed = pack.pack_sdf_net(net)
+    if detach:
+        cache[which] = (key, packed)
+    return packed
+
+
+def sampler_sdf(model, rays_o, rays_d, t_rand):
+    """-> z[R,E], sdf[R,E], far[R] (coarse stage)."""
+    samp = model.ray_sampler
+    us = samp.uniform_sampler
+    R, E = rays_o.shape[0], samp.N_samples_eval
+    dev = rays_o.device
+    imp = model.implicit_network
+    gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1)
+    gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3)
+    pc, pf = packed_sdf(model, "coarse"), packed_sdf(model, "fine")
+    z = torch.empty(R, E, device=dev)
+    sdf = torch.empty(R, E, device=dev)
+    far = torch.empty(R, device=dev)
+    t_lin = _linspace(E, dev)
+    rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
+    if t_rand is not None:
+        t_rand = t_rand.contiguous()
+        assert t_rand.shape == (R, E) and t_rand.dtype == torch.float32
+    # algorithmic bytes: both SDF grids, 2^3 corners x C x 4 B per level per point
+    with _timed("k_sampler_sdf", R * E * (4 * 8 * 8 * 4 + 8 * 8 * 4 * 4)):
+        check(lib.nsa_sampler_sdf(rays_o.data_ptr(), rays_d.data_ptr(), R, E, t_lin.data_ptr(),
+                                  t_rand.data_ptr() if t_rand is not None else None, float(us.near),
+                                  float(us.scene_bounding_sphere), float(us.far), ctypes.byref(gc), ctypes.byref(gf),
+                                  pc.data_ptr(), pf.data_ptr(), z.data_ptr(), sdf.data_ptr(), far.data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream))
+    return z, sdf, far
+
+
+def sample_rays(model, rays_o, rays_d, z, sdf, far, extra_idx, eik_idx):
+    """-> z_vals[R,S] sorted, z_eik[R,1] (importance stage)."""
+    samp = model.ray_sampler
+    R, E = z.shape
+    N = samp.N_samples
+    n_extra = 0 if extra_idx is None else int(extra_idx.numel())
+    S = N + 2 + n_extra
+    dev = z.device
+    z_vals = torch.empty(R, S, device=dev)
+    z_eik = torch.empty(R, device=dev)
+    u_lin = _linspace(N, dev)
+    ex = extra_idx.to(torch.int32).contiguous() if n_extra else None
+    ek = eik_idx.to(torch.int32).contiguous()
+    vox = model.voxels.contiguous()
+    with _timed("k_sample_rays", R * E * 8):
+        check(lib.nsa_sample_rays(rays_o.data_ptr(), rays_d.data_ptr(), z.data_ptr(), sdf.data_ptr(), far.data_ptr(),
+                                  vox.data_ptr(), model.voxel_res, R, E, N, u_lin.data_ptr(),
+                                  ex.data_ptr() if n_extra else None, n_extra, float(samp.near), ek.data_ptr(),
+                                  z_vals.data_ptr(), z_eik.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    return z_vals, z_eik.unsqueeze(-1)
+
+
+def get_z_vals(model, ray_dirs, cam_loc):
+    """Drop-in for ImportantSampler.get_z_vals (fused engine)."""
+    samp = model.ray_sampler
+    rays_d = ray_dirs.detach().contiguous()
+    rays_o = cam_loc.detach().contiguous()
+    R, E = rays_d.shape[0], samp.N_samples_eval
+    t_rand = model.draw("t_rand", (R, E)) if model.training else None
+    z, sdf, far = sampler_sdf(model, rays_o, rays_d, t_rand)
+    if samp.N_samples_extra > 0:
+        if model.training:
+            extra = model.draw("extra_idx", (E, samp.N_samples_extra))
+        else:
+            extra = torch.linspace(0, E - 1, samp.N_samples_extra, device=z.device).long()
+    else:
+        extra = None
+    S = samp.N_samples + 2 + (samp.N_samples_extra if extra is not None else 0)
+    eik_idx = model.draw("eik_idx", (S, R))
+    return sample_rays(model, rays_o, rays_d, z, sdf, far, extra, eik_idx)

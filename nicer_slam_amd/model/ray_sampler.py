@@ -63,6 +63,13 @@ class ImportantSampler:
                                               take_sphere_intersection=True)
 
     def get_z_vals(self, ray_dirs, cam_loc, model, frame_idx=None, keyframe_list=None, mode=None):
+        if getattr(model, "engine", "composed") != "composed":
+            from ..fused import sampler as fused_sampler
+            if fused_sampler.supported(model) and ray_dirs.is_cuda:
+                model.last_engine = "fused-sampler"
+                return fused_sampler.get_z_vals(model, ray_dirs, cam_loc)
+            if model.engine == "fused":
+                raise RuntimeError("engine='fused' requested but this configuration is outside the compiled set")
         z, near, far = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model)
         pts = (cam_loc.unsqueeze(1) + z.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
         with torch.no_grad():

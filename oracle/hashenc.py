@@ -38,6 +38,9 @@ def lib():
         build()
         _lib = ctypes.CDLL(_LIB_PATH)
         u32, f32, vp, i32 = ctypes.c_uint32, ctypes.c_float, ctypes.c_void_p, ctypes.c_int
+        _lib.nso_set_threads.restype = None
+        _lib.nso_set_threads.argtypes = [i32]
+        _lib.nso_set_threads(min(16, os.cpu_count() or 1))
         _lib.nso_fast_hash.restype = u32
         _lib.nso_fast_hash.argtypes = [vp, u32]
         _lib.nso_level_row.restype = u32

@@ -36,6 +36,9 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define NSO_MAX_D 3u
 #define NSO_MAX_C 8u
@@ -49,6 +52,15 @@ typedef struct {
 
 static const uint32_t nso_primes[7] = {1u, 2654435761u, 805459861u, 3674653429u,
                                        2097192037u, 1434869437u, 2165219737u};
+
+/* bound the OpenMP team (levels are the parallel axis: more threads than levels only adds spin-wait) */
+void nso_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n < 1 ? 1 : n);
+#else
+    (void)n;
+#endif
+}
 
 /* hashencoder.cu:35-51 */
 uint32_t nso_fast_hash(const uint32_t *cell, uint32_t D) {

@@ -1,0 +1,131 @@
+"""Host-side weight packing of the fused engine vs a plain torch evaluation, through a numpy emulation of the MFMA
+dataflow (tests/mfma_emu.py).  Catches slot-map / fragment-order mistakes without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+import mfma_emu as emu
+from nicer_slam_amd.fused import pack
+
+
+def softplus(a):
+    t = 100.0 * a
+    return np.where(t > 20, a, np.log1p(np.exp(np.minimum(t, 20))) / 100.0)
+
+
+def make_net(NH, L, C, seed):
+    from nicer_slam_amd.model.base_networks import ImplicitNetworkGrid
+    torch.manual_seed(seed)
+    net = ImplicitNetworkGrid(64, 1.0, d_in=3, d_out=1, dims=[64] * NH, geometric_init=True, bias=0.6, skip_in=[],
+                              weight_norm=True, multires=6, inside_outside=True, base_size=4, end_size=8, logmap=8,
+                              num_levels=L, level_dim=C, divide_factor=1.0)
+    g = torch.Generator().manual_seed(seed)
+    for p in net.parameters():   # move away from the structured geometric init
+        if p.dim() >= 1 and p.shape != net.encoding.embeddings.shape:
+            p.data += 0.05 * torch.randn(p.shape, generator=g)
+    return net
+
+
+def slots_from_features(feats71, L, C):
+    """[32 points][71] reference-ordered first-layer input -> B operand [64 lanes][36]."""
+    b = np.zeros((64, pack.SDF_IN_STEPS))
+    for lane in range(64):
+        p, h = lane & 31, lane >> 5
+        for s in range(pack.SDF_IN_STEPS):
+            f = pack.sdf_in_feature(s, h, L, C)
+            b[lane, s] = feats71[p, f] if f >= 0 else 0.0
+    return b
+
+
+@pytest.mark.parametrize("NH,L,C", [(1, 4, 8), (3, 8, 4)])
+def test_sdf_net_pack_forward_and_transposes(NH, L, C):
+    net = make_net(NH, L, C, seed=NH)
+    packed = pack.pack_sdf_net(net).detach().double().numpy()
+    assert packed.size == pack.sdf_pack_size(NH)
+    rng = np.random.default_rng(0)
+    h0 = rng.standard_normal((32, 71)) * 0.5
+    Ws = [pack.effective_weight(getattr(net, f"lin{l}")).detach().double().numpy() for l in range(NH + 1)]
+    bs = [getattr(net, f"lin{l}").bias.detach().double().numpy() for l in range(NH + 1)]
+    # plain evaluation
+    a = [h0 @ Ws[0].T + bs[0]]
+    for k in range(1, NH):
+        a.append(softplus(a[-1]) @ Ws[k].T + bs[k])
+    out = softplus(a[-1]) @ Ws[NH].T + bs[NH]
+    # emulated kernel dataflow (offsets as SdfPack<NH>)
+    o = 0
+    W0 = packed[o:o + 4608]; o += 4608
+    B0 = packed[o:o + 64]; o += 64
+    WH = []
+    for k in range(1, NH):
+        WH.append((packed[o:o + 4096], packed[o + 4096:o + 4160])); o += 4160
+    WSDF = packed[o:o + 64]; o += 64
+    BSDF = packed[o]; o += 64
+    WFEAT = packed[o:o + 4096]; o += 4096
+    BFEAT = packed[o:o + 64]; o += 64
+    WHT = {}
+    for k in range(NH - 1, 0, -1):
+        WHT[k] = packed[o:o + 4096]; o += 4096
+    W0T = packed[o:o + 6144]; o += 6144
+    WFEATT = packed[o:o + 4096]; o += 4096
+    assert o == packed.size
+    acc = emu.load_vec(B0, 2)
+    emu.gemm_op(W0, 2, 36, slots_from_features(h0, L, C), acc)
+    pre = [acc.copy()]
+    for k in range(1, NH):
+        nxt = emu.load_vec(WH[k - 1][1], 2)
+        emu.gemm_op(WH[k - 1][0], 2, 32, emu.act_to_b(softplus(acc)), nxt)
+        acc = nxt
+        pre.append(acc.copy())
+    act = softplus(acc)
+    sdf = emu.xhalf_sum((act * emu.load_vec(WSDF, 2)).reshape(64, -1).sum(1)) + BSDF
+    np.testing.assert_allclose(sdf[:32], out[:, 0], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(sdf[32:], out[:, 0], rtol=1e-9, atol=1e-9)
+    feat = emu.load_vec(BFEAT, 2)
+    emu.gemm_op(WFEAT, 2, 32, emu.act_to_b(act), feat)
+    for lane in range(64):
+        p, h = lane & 31, lane >> 5
+        for t in range(2):
+            for r in range(16):
+                assert abs(feat[lane, t, r] - out[p, 1 + 32 * t + pack.F(r, h)]) < 1e-9
+    # transposed blocks: y = W^T g for a random hidden-layout vector g
+    gvec = rng.standard_normal((32, 64))
+    g_b = np.zeros((64, 32))
+    for lane in range(64):
+        for s in range(32):
+            g_b[lane, s] = gvec[lane & 31, pack.hid_feature(s, lane >> 5)]
+    for k in range(1, NH):
+        acc = np.zeros((64, 2, 16))
+        emu.gemm_op(WHT[k], 2, 32, g_b, acc)
+        want = gvec @ Ws[k]            # [32, 64 in-features]
+        for lane in range(64):
+            for t in range(2):
+                for r in range(16):
+                    assert abs(acc[lane, t, r] - want[lane & 31, 32 * t + pack.F(r, lane >> 5)]) < 1e-9
+    acc = np.zeros((64, 3, 16))
+    emu.gemm_op(W0T, 3, 32, g_b, acc)
+    want = gvec @ Ws[0]                # [32, 71]
+    for lane in range(64):
+        p, h = lane & 31, lane >> 5
+        for q in range(48):
+            f = pack.sdf_in_feature(q, h, L, C) if q < 36 else -1
+            got = acc[lane, q // 16, q % 16]
+            assert abs(got - (want[p, f] if f >= 0 else 0.0)) < 1e-9, (lane, q)
+    acc = np.zeros((64, 2, 16))
+    emu.gemm_op(WFEATT, 2, 32, g_b, acc)
+    want = gvec @ Ws[NH][1:, :]        # feature rows only
+    for lane in range(64):
+        for t in range(2):
+            for r in range(16):
+                assert abs(acc[lane, t, r] - want[lane & 31, 32 * t + pack.F(r, lane >> 5)]) < 1e-9
+
+
+def test_every_input_feature_has_exactly_one_slot():
+    for (L, C) in [(4, 8), (8, 4)]:
+        seen = {}
+        for h in range(2):
+            for s in range(pack.SDF_IN_STEPS):
+                f = pack.sdf_in_feature(s, h, L, C)
+                if f >= 0:
+                    assert f not in seen
+                    seen[f] = (s, h)
+        assert sorted(seen) == list(range(71))

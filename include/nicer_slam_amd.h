@@ -83,6 +83,66 @@ typedef struct nsa_grid {
     uint32_t n_hidden;           /* hidden layers of the attached MLP (coarse 1, fine 3)           */
 } nsa_grid_t;
 
+/* Where the points of a per-point kernel come from: sample (pid % S) of ray (pid / S), x = o + z d -- or, when
+ * `points` is non-NULL, an explicit list (eikonal samples). */
+typedef struct nsa_points {
+    const float *rays_o;  /* [R,3] */
+    const float *rays_d;  /* [R,3] */
+    const float *z_vals;  /* [R,S] */
+    const float *points;  /* [P,3] or NULL */
+    uint32_t P, S;        /* P = R*S in ray mode */
+} nsa_points_t;
+
+/* Per-point feature vectors travel in "HL" layout (the MFMA register image): float index ((tile*32+q)*64+lane),
+ * tile = point/32, sized ceil(P/32)*2048 floats; see csrc/mlp_common.hpp. */
+
+/* One SDF network (coarse or fine) at P points: sdf, grad sdf (reverse pass, kept differentiable by
+ * nsa_sdfnet_backward) and the 64-feature vector.  accumulate != 0 adds to sdf/grad/feat (the fine network on
+ * top of the coarse one).  replaces ImplicitNetworkGrid.get_outputs / ImplicitNetworkGrid_COMBINE.get_outputs
+ * (code/model/base_networks.py:34-40,208-221) incl. HashEncoder.forward and the positional encoding. */
+int nsa_sdfnet_forward(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, int accumulate,
+                       float *sdf, float *grad, float *feat_hl, nsa_stream_t stream);
+
+/* Backward of the above for the DATA path: given d/d(sdf)[P], d/d(feat) (HL), d/d(grad sdf)[P,3] (any may be
+ * NULL = zero) produce d/dx [P,3] -- value path + double backward through the reverse pass, with exactly the terms
+ * of the reference graph (the grid-Hessian term is dropped, code/hashencoder/hashgrid.py:134). */
+int nsa_sdfnet_backward(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, const float *g_sdf,
+                        const float *g_feat_hl, const float *g_grad, int accumulate, float *g_x,
+                        nsa_stream_t stream);
+
+/* Colour network at the composite points: rgb = sigmoid(MLP([x, PE4(view dir), grad sdf, feature, colour grid])).
+ * replaces RenderingNetwork.forward, mode "idr" (code/model/base_networks.py:333-395).  `save` (optional,
+ * ceil(P/32)*4096 floats) receives what the backward needs from the 1 GiB colour table (features + Jacobian). */
+int nsa_colour_forward(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, const float *grad,
+                       const float *feat_hl, float *rgb, float *save, nsa_stream_t stream);
+
+/* Data-path backward of the colour network: d/d(rgb)[P,3] -> d/d(feat) (HL, overwritten), d/d(grad sdf)[P,3]
+ * (ADDED into g_grad), d/dx [P,3] and d/d(view dir) [P,3] (overwritten).  grid_grad = 0 reproduces
+ * color_stage == "base" (grid feature detached, base_networks.py:337-339). */
+int nsa_colour_backward(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, const float *grad,
+                        const float *feat_hl, const float *save, const float *g_rgb, int grid_grad,
+                        float *g_feat_hl, float *g_grad, float *g_x, float *g_dir, nsa_stream_t stream);
+
+/* Per-ray SDF -> density -> alpha compositing.  replaces SLAMNetwork.volume_rendering (code/model/network.py:349-370)
+ * + the composite sums of SLAMNetwork.forward (:147-151, 298, 338-342) + GridPredefineDensity (density.py:37-67).
+ * Outputs weights[R,S], rgb_values[R,3], depth[R] (= sum w z / (sum w + 1e-8), before depth_scale),
+ * nmap[R,3] (= sum w grad/(|grad|+1e-6), before the rotation by the pose), entropy[R] (= sum -w log(w+1e-4)). */
+int nsa_composite_forward(const float *rays_o, const float *rays_d, const float *z_vals, const float *sdf,
+                          const float *rgb, const float *grad, const float *voxels, uint32_t voxel_res, uint32_t R,
+                          uint32_t S, float *weights, float *rgb_values, float *depth, float *nmap, float *entropy,
+                          nsa_stream_t stream);
+
+/* Backward of the above: per-ray cotangents (any may be NULL) -> d/d(sdf)[R,S], d/d(rgb)[R,S,3], d/d(grad)[R,S,3]. */
+int nsa_composite_backward(const float *rays_o, const float *rays_d, const float *z_vals, const float *sdf,
+                           const float *rgb, const float *grad, const float *voxels, uint32_t voxel_res, uint32_t R,
+                           uint32_t S, const float *g_rgb_values, const float *g_depth, const float *g_nmap,
+                           const float *g_entropy, const float *g_weights, float *g_sdf, float *g_rgb, float *g_grad,
+                           nsa_stream_t stream);
+
+/* x = o + z d, view dir = d:  d/d(rays_o)[R,3] = sum_i g_x ;  d/d(rays_d)[R,3] = sum_i z_i g_x + sum_i g_dir. */
+int nsa_rays_backward(const float *z_vals, const float *g_x, const float *g_dir, uint32_t R, uint32_t S,
+                      float *g_rays_o, float *g_rays_d, nsa_stream_t stream);
+
 /* Coarse sampler stage: stratified z on [near, cube exit], points, coarse+fine SDF at R*E points (no grad).
  * replaces UniformSampler.get_z_vals (code/model/ray_sampler.py:37-61) + ImplicitNetworkGrid_COMBINE.get_sdf_vals
  * (code/model/base_networks.py:27-32) as called from ImportantSampler.get_z_vals (ray_sampler.py:92-102).

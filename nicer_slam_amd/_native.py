@@ -6,6 +6,12 @@ without the HIP kernels.
 import ctypes
 import os
 
+# PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7 -- the same
+# SONAME as /opt/rocm's).  Whichever is loaded first serves the whole process, so torch must come first: our kernels
+# then launch on the very runtime that owns torch's allocations and streams.  (Loading this library first made
+# every launch fail on the GPU box.)
+import torch  # noqa: F401  (must precede the CDLL below)
+
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnicer_slam_amd.so")
 
 if not os.path.exists(_LIB_PATH):
@@ -49,3 +55,27 @@ lib.nsa_sampler_sdf.argtypes = [_p, _p, _u32, _u32, _p, _p, _f32, _f32, _f32, _g
 lib.nsa_sample_rays.restype = _i
 lib.nsa_sample_rays.argtypes = [_p, _p, _p, _p, _p, _p, _u32, _u32, _u32, _u32, _p, _p, _u32, _f32, _p, _p, _p, _p]
 EXPORTS += ["nsa_sampler_sdf", "nsa_sample_rays"]
+
+
+class PointsDesc(ctypes.Structure):
+    """nsa_points_t"""
+    _fields_ = [("rays_o", _p), ("rays_d", _p), ("z_vals", _p), ("points", _p), ("P", _u32), ("S", _u32)]
+
+
+_pp = ctypes.POINTER(PointsDesc)
+lib.nsa_sdfnet_forward.restype = _i
+lib.nsa_sdfnet_forward.argtypes = [_pp, _gp, _p, _i, _p, _p, _p, _p]
+lib.nsa_sdfnet_backward.restype = _i
+lib.nsa_sdfnet_backward.argtypes = [_pp, _gp, _p, _p, _p, _p, _i, _p, _p]
+lib.nsa_colour_forward.restype = _i
+lib.nsa_colour_forward.argtypes = [_pp, _gp, _p, _p, _p, _p, _p, _p]
+lib.nsa_colour_backward.restype = _i
+lib.nsa_colour_backward.argtypes = [_pp, _gp, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]
+lib.nsa_composite_forward.restype = _i
+lib.nsa_composite_forward.argtypes = [_p, _p, _p, _p, _p, _p, _p, _u32, _u32, _u32, _p, _p, _p, _p, _p, _p]
+lib.nsa_composite_backward.restype = _i
+lib.nsa_composite_backward.argtypes = [_p, _p, _p, _p, _p, _p, _p, _u32, _u32, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p]
+lib.nsa_rays_backward.restype = _i
+lib.nsa_rays_backward.argtypes = [_p, _p, _p, _u32, _u32, _p, _p, _p]
+EXPORTS += ["nsa_sdfnet_forward", "nsa_sdfnet_backward", "nsa_colour_forward", "nsa_colour_backward",
+            "nsa_composite_forward", "nsa_composite_backward", "nsa_rays_backward"]

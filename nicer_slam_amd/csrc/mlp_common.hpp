@@ -36,6 +36,9 @@ template <int KS, int MT>
 __device__ __forceinline__ void gemm_op(const float* __restrict__ wp, int lane, const float (&b)[KS], f32x16 (&acc)[MT]) {
     constexpr int KS4 = (KS + 3) / 4;
     const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wp) + lane;
+    // Fence the scheduler at GEMM boundaries: without it hipcc hoists the fragment loads of LATER layers above this
+    // one (it has a 512-register budget at one wave per SIMD) and the kernel spills.
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s4 = 0; s4 < KS4; ++s4) {
         float4 a[MT];
@@ -52,6 +55,7 @@ __device__ __forceinline__ void gemm_op(const float* __restrict__ wp, int lane, 
             }
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // Two point tiles sharing each weight fragment (NT = 2).

@@ -1,0 +1,314 @@
+// render_colour.hip -- the colour network of the composite pass.
+// Reference: RenderingNetwork.forward, mode "idr" with the colour hash grid (code/model/base_networks.py:333-395):
+//   rgb = sigmoid(MLP_relu([x(3), PE4(view dir)(27), grad sdf(3), feature(64), colour-grid feature(32)]))   129 -> 64 -> 64 -> 3
+// The colour grid is the 1 GiB, HBM-resident table (16 levels x 2 features, 7 hashed levels of 2^24 rows): each
+// lane gathers 8 of the 16 levels (level 2*jl + h) with 8-byte loads, all 64 gathers of a lane in flight at once.
+// The forward pass keeps what the backward needs from the table (the 16 features and 48 Jacobian entries of the
+// lane's levels) in a per-lane save area, so the backward never touches the table again.
+//
+// Input-slot map (65 slots per half-wave h; reference column of rendering_input in brackets):
+//   0..31          feature vector, HL order                                   [33 + f]
+//   32             h0: x0 [0]        h1: x1 [1]
+//   33             h0: x2 [2]        h1: d0 [3]
+//   34             h0: d1 [4]        h1: d2 [5]
+//   35             h0: grad0 [30]    h1: grad1 [31]
+//   36             h0: grad2 [32]    h1: pad
+//   37+2j, 38+2j   sin, cos of 2^k d_dd, pair g = 2j+h, k = g/3, dd = g%3    [6+6k+dd], [9+6k+dd]      (j < 6)
+//   49+2jl+c       colour-grid level 2jl+h, channel c                         [97 + 2(2jl+h) + c]       (jl < 8)
+#include "sdf_net.hpp"
+
+namespace nsa {
+
+constexpr int CL = 16, CC = 2;   // colour grid shape (hard-coded in the reference, base_networks.py:265-284)
+
+struct ColPack {
+    static constexpr int kW0 = 0;                                        // A[2][65]
+    static constexpr int kB0 = kW0 + a_block_floats(2, COL_IN_STEPS);    // 8704
+    static constexpr int kW1 = kB0 + 64;
+    static constexpr int kB1 = kW1 + 4096;
+    static constexpr int kW2V = kB1 + 64;                                // 3 output rows in activation layout
+    static constexpr int kB2 = kW2V + 3 * 64;                            // [0..2]
+    static constexpr int kW1T = kB2 + 64;
+    static constexpr int kW0T = kW1T + 4096;                             // A[5][32]: rows = input slots
+    static constexpr int kTotal = kW0T + a_block_floats(5, HS);
+};
+
+struct ColourArgs {
+    PointSrc src;
+    const float* table;
+    const float* wp;
+    float divide_factor;
+    const float* grad;      // [P,3] grad sdf (input "normals")
+    const float* feat;      // HL
+    float* rgb;             // [P,3] out
+    float* save;            // per-lane save area [tiles][64 floats][64 lanes] or nullptr (16 features + 48 Jacobian)
+    // backward
+    const float* g_rgb;     // [P,3]
+    float* g_feat;          // HL out
+    float* g_grad;          // [P,3] in/out: += colour part
+    float* g_x;             // [P,3] out (overwrite)
+    float* g_dir;           // [P,3] out (overwrite)
+    int grid_grad;          // 0: colour-grid feature detached (color_stage "base"), 1: propagate through it
+};
+
+__device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeom16& geom, uint32_t tile, uint32_t pid, int lane,
+                                              int h, const float (&x)[3], const float (&dir)[3], float (&in)[COL_IN_STEPS],
+                                              bool from_save) {
+    const float* fsrc = a.feat + (size_t)tile * 32 * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < HS; ++q) in[q] = fsrc[q * 64];
+    float gr[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) gr[d] = a.grad[(size_t)pid * 3 + d];
+    in[32] = h ? x[1] : x[0];
+    in[33] = h ? dir[0] : x[2];
+    in[34] = h ? dir[2] : dir[1];
+    in[35] = h ? gr[1] : gr[0];
+    in[36] = h ? 0.0f : gr[2];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int g0 = 2 * j, g1 = 2 * j + 1;
+        const float da = h ? dir[g1 % 3] : dir[g0 % 3];
+        const float sc = h ? (float)(1 << (g1 / 3)) : (float)(1 << (g0 / 3));
+        sincos_f(da * sc, in[37 + 2 * j], in[38 + 2 * j]);
+    }
+    if (from_save) {
+        const float* sv = a.save + (size_t)tile * 64 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) in[49 + q] = sv[q * 64];
+        return;
+    }
+    float u[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) u[d] = (x[d] / a.divide_factor + 1.0f) / 2.0f;
+    float* sv = a.save ? a.save + (size_t)tile * 64 * 64 + lane : nullptr;
+#pragma unroll
+    for (int jl = 0; jl < CL / 2; ++jl) {
+        const LevelGeom lg = geom.lv[2 * jl + h];
+        uint32_t cell[3];
+        float w[3], dw[3];
+        const bool inside = locate<3>(u, lg.scale, cell, w, dw);
+        float v[8][CC];
+        gather_corners<3, CC>(a.table, lg, cell, v);
+        float f[CC];
+        blend<3, CC>(v, w, f);
+#pragma unroll
+        for (int c = 0; c < CC; ++c) in[49 + jl * CC + c] = inside ? f[c] : 0.0f;
+        if (sv) {
+#pragma unroll
+            for (int c = 0; c < CC; ++c) sv[(jl * CC + c) * 64] = in[49 + jl * CC + c];
+#pragma unroll
+            for (int gd = 0; gd < 3; ++gd) {
+                float jr[CC];
+                jacobian_row<3, CC>(v, w, dw, lg.scale, gd, jr);
+#pragma unroll
+                for (int c = 0; c < CC; ++c) sv[(16 + (jl * 3 + gd) * CC + c) * 64] = inside ? jr[c] : 0.0f;
+            }
+        }
+    }
+}
+
+// hidden activations: returns pre-activations a1, a2 (masks for the backward) and the 3 sigmoid outputs
+__device__ __forceinline__ void colour_mlp(const float* __restrict__ wp, int lane, int h, const float (&in)[COL_IN_STEPS],
+                                           f32x16 (&a1)[2], f32x16 (&a2)[2], float (&rgb)[3]) {
+    load_vec<2>(wp + ColPack::kB0, h, a1);
+    gemm_op<COL_IN_STEPS, 2>(wp + ColPack::kW0, lane, in, a1);
+    float h1[HS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h1[16 * t + r] = fmaxf(a1[t][r], 0.0f);
+    load_vec<2>(wp + ColPack::kB1, h, a2);
+    gemm_op<HS, 2>(wp + ColPack::kW1, lane, h1, a2);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        f32x16 wv[2];
+        load_vec<2>(wp + ColPack::kW2V + 64 * j, h, wv);
+        float part = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part = fmaf(fmaxf(a2[t][r], 0.0f), wv[t][r], part);
+        const float o = xhalf_sum(part) + wp[ColPack::kB2 + j];
+        rgb[j] = 1.0f / (1.0f + expf(-o));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_colour_fwd(ColourArgs a, GridGeom16 geom) {
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile * 32 >= a.src.P) return;
+    uint32_t pid = tile * 32 + (lane & 31);
+    const bool live = pid < a.src.P;
+    if (!live) pid = a.src.P - 1;
+    float x[3], z, dir[3];
+    uint32_t ray;
+    load_point(a.src, pid, x, ray, z);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) dir[d] = a.src.rays_d[ray * 3 + d];
+    float in[COL_IN_STEPS];
+    colour_inputs(a, geom, tile, pid, lane, h, x, dir, in, false);
+    f32x16 a1[2], a2[2];
+    float rgb[3];
+    colour_mlp(a.wp, lane, h, in, a1, a2, rgb);
+    if (live && h == 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a.rgb[(size_t)pid * 3 + j] = rgb[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_colour_bwd(ColourArgs a, GridGeom16 geom) {
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile * 32 >= a.src.P) return;
+    uint32_t pid = tile * 32 + (lane & 31);
+    const bool live = pid < a.src.P;
+    if (!live) pid = a.src.P - 1;
+    float x[3], z, dir[3];
+    uint32_t ray;
+    load_point(a.src, pid, x, ray, z);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) dir[d] = a.src.rays_d[ray * 3 + d];
+    float in[COL_IN_STEPS];
+    colour_inputs(a, geom, tile, pid, lane, h, x, dir, in, true);
+    f32x16 a1[2], a2[2];
+    float rgb[3];
+    colour_mlp(a.wp, lane, h, in, a1, a2, rgb);
+    // d/d(pre-sigmoid), d/d h2 = sum_j ob_j W2[j,:], relu masks (torch: grad * (a > 0))
+    float ab[HS];
+    {
+        float ob[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ob[j] = a.g_rgb[(size_t)pid * 3 + j] * rgb[j] * (1.0f - rgb[j]);
+#pragma unroll
+        for (int q = 0; q < HS; ++q) ab[q] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            f32x16 wv[2];
+            load_vec<2>(a.wp + ColPack::kW2V + 64 * j, h, wv);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ab[16 * t + r] = fmaf(ob[j], wv[t][r], ab[16 * t + r]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ab[16 * t + r] = a2[t][r] > 0.0f ? ab[16 * t + r] : 0.0f;
+    }
+    {
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        gemm_op<HS, 2>(a.wp + ColPack::kW1T, lane, ab, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ab[16 * t + r] = a1[t][r] > 0.0f ? acc[t][r] : 0.0f;
+    }
+    float ib[80];
+    {
+        f32x16 a5[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a5[t][r] = 0.0f;
+        gemm_op<HS, 5>(a.wp + ColPack::kW0T, lane, ab, a5);
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ib[16 * t + r] = a5[t][r];
+    }
+    // feature cotangent -> HL
+    float* fdst = a.g_feat + (size_t)tile * 32 * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < HS; ++q) fdst[q * 64] = ib[q];
+    // scalar slots
+    float gx[3], gd[3], gg[3];
+    gx[0] = h ? 0.0f : ib[32];   gx[1] = h ? ib[32] : 0.0f;   gx[2] = h ? 0.0f : ib[33];
+    gd[0] = h ? ib[33] : 0.0f;   gd[1] = h ? 0.0f : ib[34];   gd[2] = h ? ib[34] : 0.0f;
+    gg[0] = h ? 0.0f : ib[35];   gg[1] = h ? ib[35] : 0.0f;   gg[2] = h ? 0.0f : ib[36];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int g0 = 2 * j, g1 = 2 * j + 1;
+        const float sc = h ? (float)(1 << (g1 / 3)) : (float)(1 << (g0 / 3));
+        const float t = sc * (in[38 + 2 * j] * ib[37 + 2 * j] - in[37 + 2 * j] * ib[38 + 2 * j]);
+        gd[g0 % 3] += h ? 0.0f : t;
+        gd[g1 % 3] += h ? t : 0.0f;
+    }
+    if (a.grid_grad) {   // x += J^T fbar / (2 df) with the Jacobian saved by the forward pass
+        const float* sv = a.save + (size_t)tile * 64 * 64 + lane;
+        const float chain = 1.0f / (2.0f * a.divide_factor);
+#pragma unroll
+        for (int jl = 0; jl < CL / 2; ++jl)
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int c = 0; c < CC; ++c)
+                    gx[d] = fmaf(sv[(16 + (jl * 3 + d) * CC + c) * 64] * chain, ib[49 + jl * CC + c], gx[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gx[d] = xhalf_sum(gx[d]); gd[d] = xhalf_sum(gd[d]); gg[d] = xhalf_sum(gg[d]); }
+    if (live && h == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            a.g_x[(size_t)pid * 3 + d] = gx[d];
+            a.g_dir[(size_t)pid * 3 + d] = gd[d];
+            a.g_grad[(size_t)pid * 3 + d] += gg[d];
+        }
+    }
+}
+
+}  // namespace nsa
+
+extern "C" {
+
+static int colour_common(const nsa_points_t* pts, const nsa_grid_t* grid, nsa::ColourArgs* a, nsa::GridGeom16* geom) {
+    using namespace nsa;
+    if (!pts || !grid) return NSA_EBADARG;
+    if (pts->points || !pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0) return NSA_EBADARG;   // needs view dirs
+    if (!(grid->L == 16 && grid->C == 2)) return NSA_EUNSUPPORTED_NET;
+    if (int rc = make_grid_geom16(grid->offsets_host, grid->L, grid->S, grid->H, geom)) return rc;
+    a->src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, nullptr, pts->P, pts->S};
+    a->table = grid->table;
+    a->divide_factor = grid->divide_factor;
+    return NSA_OK;
+}
+
+int nsa_colour_forward(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad,
+                       const float* feat_hl, float* rgb, float* save, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!packed || !grad || !feat_hl || !rgb) return NSA_EBADARG;
+    ColourArgs a{};
+    GridGeom16 geom;
+    if (int rc = colour_common(pts, grid, &a, &geom)) return rc;
+    if (pts->P == 0) return NSA_OK;
+    a.wp = packed; a.grad = grad; a.feat = feat_hl; a.rgb = rgb; a.save = save;
+    const uint32_t tiles = (pts->P + 31) / 32;
+    launch_begin();
+    hipLaunchKernelGGL(k_colour_fwd, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
+    return launch_end();
+}
+
+int nsa_colour_backward(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad,
+                        const float* feat_hl, const float* save, const float* g_rgb, int grid_grad, float* g_feat_hl,
+                        float* g_grad, float* g_x, float* g_dir, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!packed || !grad || !feat_hl || !save || !g_rgb || !g_feat_hl || !g_grad || !g_x || !g_dir) return NSA_EBADARG;
+    ColourArgs a{};
+    GridGeom16 geom;
+    if (int rc = colour_common(pts, grid, &a, &geom)) return rc;
+    if (pts->P == 0) return NSA_OK;
+    a.wp = packed; a.grad = grad; a.feat = feat_hl; a.save = const_cast<float*>(save); a.g_rgb = g_rgb;
+    a.g_feat = g_feat_hl; a.g_grad = g_grad; a.g_x = g_x; a.g_dir = g_dir; a.grid_grad = grid_grad;
+    const uint32_t tiles = (pts->P + 31) / 32;
+    launch_begin();
+    hipLaunchKernelGGL(k_colour_bwd, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
+    return launch_end();
+}
+
+}  // extern "C"

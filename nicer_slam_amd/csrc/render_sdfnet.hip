@@ -1,0 +1,334 @@
+// render_sdfnet.hip -- per-point SDF network kernels of the composite pass:
+//   k_sdfnet_fwd   sdf, feature vector and grad sdf (the reverse pass of base_networks.py:214-219) of one network
+//   k_sdfnet_bwd   its hand-derived backward: value path + the double-backward through the reverse pass,
+//                  with exactly the terms the reference graph has (hash-grid Hessian dropped, hashgrid.py:134)
+// Reference: ImplicitNetworkGrid.get_outputs/gradient (code/model/base_networks.py:195-221),
+//            ImplicitNetworkGrid_COMBINE (:7-47): the coarse and fine networks are run as two launches that
+//            accumulate into the same sdf / grad / feature buffers.
+//
+// One wave = 32 points (lane pair per point), everything in registers, weights streamed from L2 in fragment
+// order (mlp_common.hpp).  Per-point feature vectors travel between kernels in "HL" layout: float index
+// ((tile*32 + q)*64 + lane), q = 16 t + r -- i.e. exactly the register image of the MFMA result, so the consumer's
+// B operand is a coalesced 256-byte load per register.
+//
+// Notation (per network, NH hidden layers): h0 = first-layer input slots, a_k = W_{k-1} h_{k-1} + b, h_k = sp(a_k),
+// out = W_NH h_NH + b = [sdf, feat];   reverse pass: dh_NH = W_NH[0,:], da_k = sp'(a_k) * dh_k,
+// dh_{k-1} = W_{k-1}^T da_k, grad sdf = G(x, dh_0).
+// Backward, given (sbar, fbar, nbar) = cotangents of (sdf, feat, grad sdf):
+//   tangent sweep   t_0 = dG/d(dh_0)^T nbar ;  ta_k = W_{k-1} th_{k-1} ;  e_k = sp''(a_k) dh_k ta_k ;  th_k = sp'(a_k) ta_k
+//   reverse sweep   hb_NH = sbar W_NH[0,:] + Wfeat^T fbar ;  ab_k = sp'(a_k) hb_k + e_k ;  hb_{k-1} = W_{k-1}^T ab_k
+//   xbar            = G(x, hb_0) + nbar * (PE second-derivative term)           [no grid-Hessian term]
+#include "sdf_net.hpp"
+
+namespace nsa {
+
+struct SdfNetArgs {
+    PointSrc src;
+    const float* table;
+    const float* wp;
+    float divide_factor;
+    int accumulate;        // 0: overwrite outputs, 1: add to them (second network of the COMBINE)
+    // forward outputs
+    float* sdf;            // [P]
+    float* grad;           // [P,3]
+    float* feat;           // HL [tiles*32*64]
+    // backward inputs / outputs
+    const float* g_sdf;    // [P]
+    const float* g_feat;   // HL
+    const float* g_grad;   // [P,3]
+    float* g_x;            // [P,3]
+};
+
+template <int NH>
+__device__ __forceinline__ void hidden_forward(const float* __restrict__ wp, int lane, int h, const float (&in)[SDF_IN_STEPS],
+                                               float (&sg)[NH][HS], float (&hlast)[HS]) {
+    using P = SdfPack<NH>;
+    f32x16 acc[2];
+    load_vec<2>(wp + P::kB0, h, acc);
+    gemm_op<SDF_IN_STEPS, 2>(wp + P::kW0, lane, in, acc);
+#pragma unroll
+    for (int k = 1; k <= NH; ++k) {
+        float d2;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) softplus100_all(acc[t][r], hlast[16 * t + r], sg[k - 1][16 * t + r], d2);
+        if (k < NH) {
+            load_vec<2>(wp + P::bh(k), h, acc);
+            gemm_op<HS, 2>(wp + P::wh(k), lane, hlast, acc);
+        }
+    }
+}
+
+// reverse pass from the sdf output: fills dh[k-1] = dh_k for k = 1..NH-1 (dh_NH is the packed sdf row) and dl = dh_0.
+template <int NH>
+__device__ __forceinline__ void reverse_pass(const float* __restrict__ wp, int lane, int h, const float (&sg)[NH][HS],
+                                             float (&dh)[NH > 1 ? NH - 1 : 1][HS], float (&dl)[48]) {
+    using P = SdfPack<NH>;
+    f32x16 ws[2];
+    load_vec<2>(wp + P::kWSDF, h, ws);
+    float da[HS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) da[16 * t + r] = sg[NH - 1][16 * t + r] * ws[t][r];
+#pragma unroll
+    for (int k = NH - 1; k >= 1; --k) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        gemm_op<HS, 2>(wp + P::wht(k), lane, da, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dh[k - 1][16 * t + r] = acc[t][r];
+                da[16 * t + r] = sg[k - 1][16 * t + r] * acc[t][r];
+            }
+    }
+    f32x16 a3[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a3[t][r] = 0.0f;
+    gemm_op<HS, 3>(wp + P::kW0T, lane, da, a3);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dl[16 * t + r] = a3[t][r];
+}
+
+template <int L, int C, int NH>
+__global__ __launch_bounds__(256) void k_sdfnet_fwd(SdfNetArgs a, GridGeom16 geom) {
+    using P = SdfPack<NH>;
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile * 32 >= a.src.P) return;                       // whole wave
+    uint32_t pid = tile * 32 + (lane & 31);
+    const bool live = pid < a.src.P;
+    if (!live) pid = a.src.P - 1;
+    float x[3], z;
+    uint32_t ray;
+    load_point(a.src, pid, x, ray, z);
+
+    float in[SDF_IN_STEPS];
+    {
+        float jd[L / 2][3][C];
+        sdf_net_inputs<L, C, false>(x, a.divide_factor, a.table, geom, h, in, jd);
+    }
+    float sg[NH][HS], hl[HS];
+    hidden_forward<NH>(a.wp, lane, h, in, sg, hl);
+    // outputs: sdf (row 0, VALU dot) and the 64 features (rows 1..64)
+    f32x16 ws[2], fo[2];
+    load_vec<2>(a.wp + P::kWSDF, h, ws);
+    float part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part = fmaf(hl[16 * t + r], ws[t][r], part);
+    float sdf = xhalf_sum(part) + a.wp[P::kBSDF];
+    load_vec<2>(a.wp + P::kBFEAT, h, fo);
+    gemm_op<HS, 2>(a.wp + P::kWFEAT, lane, hl, fo);
+    float* fdst = a.feat + (size_t)tile * 32 * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = fo[t][r];
+            if (a.accumulate) v += fdst[(16 * t + r) * 64];
+            fdst[(16 * t + r) * 64] = v;
+        }
+    // grad sdf
+    float dh[NH > 1 ? NH - 1 : 1][HS], dl[48], g[3];
+    reverse_pass<NH>(a.wp, lane, h, sg, dh, dl);
+    slots_to_x<L, C>(x, a.divide_factor, a.table, geom, h, in, dl, g);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) g[d] = xhalf_sum(g[d]);
+    if (live && h == 0) {
+        if (a.accumulate) {
+            sdf += a.sdf[pid];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) g[d] += a.grad[(size_t)pid * 3 + d];
+        }
+        a.sdf[pid] = sdf;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) a.grad[(size_t)pid * 3 + d] = g[d];
+    }
+}
+
+template <int L, int C, int NH>
+__global__ __launch_bounds__(256) void k_sdfnet_bwd(SdfNetArgs a, GridGeom16 geom) {
+    using P = SdfPack<NH>;
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile * 32 >= a.src.P) return;
+    uint32_t pid = tile * 32 + (lane & 31);
+    const bool live = pid < a.src.P;
+    if (!live) pid = a.src.P - 1;
+    float x[3], z;
+    uint32_t ray;
+    load_point(a.src, pid, x, ray, z);
+    float in[SDF_IN_STEPS];
+    {
+        float jd[L / 2][3][C];
+        sdf_net_inputs<L, C, false>(x, a.divide_factor, a.table, geom, h, in, jd);
+    }
+    float sg[NH][HS], hl[HS];
+    hidden_forward<NH>(a.wp, lane, h, in, sg, hl);
+    float dh[NH > 1 ? NH - 1 : 1][HS], dl[48];
+    reverse_pass<NH>(a.wp, lane, h, sg, dh, dl);
+
+    float nbar[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) nbar[d] = a.g_grad ? a.g_grad[(size_t)pid * 3 + d] : 0.0f;
+    const float sbar = a.g_sdf ? a.g_sdf[pid] : 0.0f;
+
+    // ---- tangent sweep: e_k = sp''(a_k) dh_k ta_k (kept in e[k-1]) ----
+    float e[NH][HS];
+    float xb2[3];
+    {
+        float tin[SDF_IN_STEPS];
+        x_to_slots_tangent<L, C>(x, a.divide_factor, a.table, geom, h, in, nbar, dl, tin, xb2);
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        gemm_op<SDF_IN_STEPS, 2>(a.wp + P::kW0, lane, tin, acc);
+        f32x16 ws[2];
+        load_vec<2>(a.wp + P::kWSDF, h, ws);
+        float th[HS];
+#pragma unroll
+        for (int k = 1; k <= NH; ++k) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = 16 * t + r;
+                    const float s1 = sg[k - 1][q];
+                    const float s2 = 100.0f * s1 * (1.0f - s1);          // 0 in the linear region (s1 == 1)
+                    const float dhk = (k == NH) ? ws[t][r] : dh[k - 1][q];
+                    e[k - 1][q] = s2 * dhk * acc[t][r];
+                    th[q] = s1 * acc[t][r];
+                }
+            if (k < NH) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+                gemm_op<HS, 2>(a.wp + P::wh(k), lane, th, acc);
+            }
+        }
+    }
+    // ---- reverse sweep ----
+    float ab[HS];
+    {
+        float fb[HS];
+        const float* fsrc = a.g_feat ? a.g_feat + (size_t)tile * 32 * 64 + lane : nullptr;
+#pragma unroll
+        for (int q = 0; q < HS; ++q) fb[q] = fsrc ? fsrc[q * 64] : 0.0f;
+        f32x16 acc[2], ws[2];
+        load_vec<2>(a.wp + P::kWSDF, h, ws);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = sbar * ws[t][r];
+        gemm_op<HS, 2>(a.wp + P::kWFEATT, lane, fb, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ab[16 * t + r] = sg[NH - 1][16 * t + r] * acc[t][r] + e[NH - 1][16 * t + r];
+    }
+#pragma unroll
+    for (int k = NH - 1; k >= 1; --k) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        gemm_op<HS, 2>(a.wp + P::wht(k), lane, ab, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ab[16 * t + r] = sg[k - 1][16 * t + r] * acc[t][r] + e[k - 1][16 * t + r];
+    }
+    float hb0[48];
+    {
+        f32x16 a3[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a3[t][r] = 0.0f;
+        gemm_op<HS, 3>(a.wp + P::kW0T, lane, ab, a3);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hb0[16 * t + r] = a3[t][r];
+    }
+    float gx[3];
+    slots_to_x<L, C>(x, a.divide_factor, a.table, geom, h, in, hb0, gx);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) gx[d] = xhalf_sum(gx[d] + xb2[d]);
+    if (live && h == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float v = gx[d];
+            if (a.accumulate) v += a.g_x[(size_t)pid * 3 + d];
+            a.g_x[(size_t)pid * 3 + d] = v;
+        }
+    }
+}
+
+static int launch_sdfnet(bool bwd, const nsa_grid_t* grid, const SdfNetArgs& a, hipStream_t st) {
+    GridGeom16 geom;
+    if (int rc = make_grid_geom16(grid->offsets_host, grid->L, grid->S, grid->H, &geom)) return rc;
+    const uint32_t tiles = (a.src.P + 31) / 32;
+    const dim3 g((tiles + 3) / 4), b(256);
+    launch_begin();
+    if (grid->L == 4 && grid->C == 8 && grid->n_hidden == 1) {
+        if (bwd) hipLaunchKernelGGL((k_sdfnet_bwd<4, 8, 1>), g, b, 0, st, a, geom);
+        else     hipLaunchKernelGGL((k_sdfnet_fwd<4, 8, 1>), g, b, 0, st, a, geom);
+    } else if (grid->L == 8 && grid->C == 4 && grid->n_hidden == 3) {
+        if (bwd) hipLaunchKernelGGL((k_sdfnet_bwd<8, 4, 3>), g, b, 0, st, a, geom);
+        else     hipLaunchKernelGGL((k_sdfnet_fwd<8, 4, 3>), g, b, 0, st, a, geom);
+    } else {
+        return NSA_EUNSUPPORTED_NET;
+    }
+    return launch_end();
+}
+
+}  // namespace nsa
+
+extern "C" {
+
+int nsa_sdfnet_forward(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, int accumulate, float* sdf,
+                       float* grad, float* feat_hl, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!pts || !grid || !packed || !sdf || !grad || !feat_hl) return NSA_EBADARG;
+    if (pts->P == 0) return NSA_OK;
+    if (!pts->points && (!pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0)) return NSA_EBADARG;
+    SdfNetArgs a{};
+    a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S};
+    a.table = grid->table; a.wp = packed; a.divide_factor = grid->divide_factor; a.accumulate = accumulate;
+    a.sdf = sdf; a.grad = grad; a.feat = feat_hl;
+    return launch_sdfnet(false, grid, a, (hipStream_t)stream);
+}
+
+int nsa_sdfnet_backward(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* g_sdf,
+                        const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!pts || !grid || !packed || !g_x) return NSA_EBADARG;
+    if (pts->P == 0) return NSA_OK;
+    if (!pts->points && (!pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0)) return NSA_EBADARG;
+    SdfNetArgs a{};
+    a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S};
+    a.table = grid->table; a.wp = packed; a.divide_factor = grid->divide_factor; a.accumulate = accumulate;
+    a.g_sdf = g_sdf; a.g_feat = g_feat_hl; a.g_grad = g_grad; a.g_x = g_x;
+    return launch_sdfnet(true, grid, a, (hipStream_t)stream);
+}
+
+}  // extern "C"

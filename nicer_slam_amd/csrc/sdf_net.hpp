@@ -122,3 +122,158 @@ __device__ __forceinline__ float sdf_only(const float* __restrict__ wp, int lane
 }
 
 }  // namespace nsa
+
+namespace nsa {
+
+// ------------------------------------------------------------------------------------------------------------------
+// Contraction of a per-slot cotangent with d(first-layer input)/dx for THIS lane's share of the slots:
+//   g[d] = sum_slots dl[slot] * d in[slot] / d x_d     (x slots, sin/cos pairs, grid levels 2*jl+h through J/(2 df)).
+// Used for grad sdf (dl = reverse pass from the sdf output, base_networks.py:214-219) and for the value-path input
+// gradient (dl = d loss / d h0).  The grid Jacobian is not stored: the corner rows are gathered again (L2-resident
+// SDF tables) and contracted as  sum_faces w_face * (p_hi - p_lo),  p_corner = <dl_level, row_corner>.
+// Caller adds the two half-waves (xhalf_sum).
+template <int L, int C>
+__device__ __forceinline__ void slots_to_x(const float (&x)[3], float divide_factor, const float* __restrict__ table,
+                                           const GridGeom16& geom, int h, const float (&in)[SDF_IN_STEPS],
+                                           const float (&dl)[3 * 16], float (&g)[3]) {
+    g[0] = h ? 0.0f : dl[0];
+    g[1] = h ? 0.0f : dl[1];
+    g[2] = h ? dl[0] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        constexpr int unused = 0; (void)unused;
+        const int g0 = 2 * j, g1 = 2 * j + 1;
+        const float sc = h ? (float)(1 << (g1 / 3)) : (float)(1 << (g0 / 3));
+        const float t = sc * (in[3 + 2 * j] * dl[2 + 2 * j] - in[2 + 2 * j] * dl[3 + 2 * j]);   // 2^k (cos d_sin - sin d_cos)
+        g[g0 % 3] += h ? 0.0f : t;
+        g[g1 % 3] += h ? t : 0.0f;
+    }
+    float u[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) u[d] = (x[d] / divide_factor + 1.0f) / 2.0f;
+    const float chain = 1.0f / (2.0f * divide_factor);
+#pragma unroll
+    for (int jl = 0; jl < L / 2; ++jl) {
+        const LevelGeom lg = geom.lv[2 * jl + h];
+        uint32_t cell[3];
+        float w[3], dw[3];
+        const bool inside = locate<3>(u, lg.scale, cell, w, dw);
+        float v[8][C];
+        gather_corners<3, C>(table, lg, cell, v);
+        float p[8];
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            p[corner] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) p[corner] = fmaf(dl[20 + jl * C + c], v[corner][c], p[corner]);
+        }
+#pragma unroll
+        for (int gd = 0; gd < 3; ++gd) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int face = 0; face < 4; ++face) {
+                float wt = lg.scale;
+                int lo = 0;
+#pragma unroll
+                for (int nd = 0; nd < 2; ++nd) {
+                    const int d = (nd >= gd) ? nd + 1 : nd;
+                    if ((face >> nd) & 1) { wt *= w[d]; lo |= 1 << d; }
+                    else                  { wt *= 1.0f - w[d]; }
+                }
+                acc = fmaf(wt, p[lo | (1 << gd)] - p[lo], acc);
+            }
+            g[gd] += inside ? acc * dw[gd] * chain : 0.0f;
+        }
+    }
+}
+
+// Tangent of the first-layer input along n (a cotangent of grad sdf): dn_in[slot] = sum_d (d in[slot]/d x_d) n_d.
+// This is the reverse of the grad-sdf assembly w.r.t. the reverse-pass vector; the grid Hessian term is NOT part of
+// it (hashgrid.py:134).  Also returns the positional-encoding second-derivative term
+//   xbar_d += n_d * sum_k -(4^k) (sin * dl_sin + cos * dl_cos)      (dl = reverse-pass vector of this point).
+template <int L, int C>
+__device__ __forceinline__ void x_to_slots_tangent(const float (&x)[3], float divide_factor, const float* __restrict__ table,
+                                                   const GridGeom16& geom, int h, const float (&in)[SDF_IN_STEPS],
+                                                   const float (&n)[3], const float (&dl)[3 * 16],
+                                                   float (&tin)[SDF_IN_STEPS], float (&xbar)[3]) {
+    tin[0] = h ? n[2] : n[0];
+    tin[1] = h ? 0.0f : n[1];
+    xbar[0] = xbar[1] = xbar[2] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int g0 = 2 * j, g1 = 2 * j + 1;
+        const float sc = h ? (float)(1 << (g1 / 3)) : (float)(1 << (g0 / 3));
+        const float nd = h ? n[g1 % 3] : n[g0 % 3];
+        const float s = in[2 + 2 * j], c = in[3 + 2 * j];
+        tin[2 + 2 * j] = sc * c * nd;
+        tin[3 + 2 * j] = -sc * s * nd;
+        const float t = -sc * sc * (s * dl[2 + 2 * j] + c * dl[3 + 2 * j]) * nd;
+        xbar[g0 % 3] += h ? 0.0f : t;
+        xbar[g1 % 3] += h ? t : 0.0f;
+    }
+    float u[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) u[d] = (x[d] / divide_factor + 1.0f) / 2.0f;
+    const float chain = 1.0f / (2.0f * divide_factor);
+#pragma unroll
+    for (int jl = 0; jl < L / 2; ++jl) {
+        const LevelGeom lg = geom.lv[2 * jl + h];
+        uint32_t cell[3];
+        float w[3], dw[3];
+        const bool inside = locate<3>(u, lg.scale, cell, w, dw);
+        float v[8][C];
+        gather_corners<3, C>(table, lg, cell, v);
+        float k[8];
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) k[corner] = 0.0f;
+#pragma unroll
+        for (int gd = 0; gd < 3; ++gd) {
+#pragma unroll
+            for (int face = 0; face < 4; ++face) {
+                float wt = lg.scale;
+                int lo = 0;
+#pragma unroll
+                for (int nd = 0; nd < 2; ++nd) {
+                    const int d = (nd >= gd) ? nd + 1 : nd;
+                    if ((face >> nd) & 1) { wt *= w[d]; lo |= 1 << d; }
+                    else                  { wt *= 1.0f - w[d]; }
+                }
+                const float t = wt * dw[gd] * n[gd] * chain;
+                k[lo | (1 << gd)] += t;
+                k[lo] -= t;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) acc = fmaf(k[corner], v[corner][c], acc);
+            tin[20 + jl * C + c] = inside ? acc : 0.0f;
+        }
+    }
+}
+
+// Where a point comes from: sample `pid % S` of ray `pid / S` (x = o + z d), or an explicit point list.
+struct PointSrc {
+    const float* rays_o;   // [R,3]
+    const float* rays_d;   // [R,3]
+    const float* z_vals;   // [R,S]
+    const float* points;   // [P,3] or nullptr
+    uint32_t P, S;
+};
+
+__device__ __forceinline__ void load_point(const PointSrc& ps, uint32_t pid, float (&x)[3], uint32_t& ray, float& z) {
+    if (ps.points) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x[k] = ps.points[(size_t)pid * 3 + k];
+        ray = 0;
+        z = 0.0f;
+        return;
+    }
+    ray = pid / ps.S;
+    z = ps.z_vals[pid];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x[k] = ps.rays_o[ray * 3 + k] + z * ps.rays_d[ray * 3 + k];
+}
+
+}  // namespace nsa

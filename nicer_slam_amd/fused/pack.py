@@ -149,3 +149,78 @@ def pack_sdf_net(net):
     packed = flat[idx.to(flat.device)]
     assert packed.numel() == sdf_pack_size(NH)
     return packed
+
+
+# ------------------------------------------------------------------------------------------------ colour network
+def col_in_feature(s, h):
+    """reference column of rendering_input (base_networks.py:346: [x, PE4(view), normals, features, grid]) of
+    first-layer slot (s, h); table in csrc/render_colour.hip."""
+    if s < 32:
+        return 33 + hid_feature(s, h)
+    if s == 32:
+        return 0 if h == 0 else 1
+    if s == 33:
+        return 2 if h == 0 else 3
+    if s == 34:
+        return 4 if h == 0 else 5
+    if s == 35:
+        return 30 if h == 0 else 31
+    if s == 36:
+        return 32 if h == 0 else -1
+    if s < 49:
+        j, which = divmod(s - 37, 2)
+        g = 2 * j + h
+        k, dd = divmod(g, 3)
+        return 6 + 6 * k + dd + (3 if which else 0)
+    jl, c = divmod(s - 49, 2)
+    return 97 + (2 * jl + h) * 2 + c
+
+
+@functools.lru_cache(maxsize=None)
+def colour_net_index():
+    """Index map of the colour network's packed block (order = csrc/render_colour.hip::ColPack) into
+    flat = cat[lin0.W(64x129), lin0.b, lin1.W(64x64), lin1.b, lin2.W(3x64), lin2.b]."""
+    n_in = 129
+    W0o, B0o = 0, 64 * n_in
+    W1o = B0o + 64
+    B1o = W1o + 64 * 64
+    W2o = B1o + 64
+    B2o = W2o + 3 * 64
+    total = B2o + 3
+    blocks = [
+        a_block(2, COL_IN_STEPS, lambda mt, i, s, h: (
+            W0o + (32 * mt + i) * n_in + f if (f := col_in_feature(s, h)) >= 0 else -1)),
+        vec_block(2, lambda f: B0o + f),
+        a_block(2, 32, lambda mt, i, s, h: W1o + (32 * mt + i) * 64 + hid_feature(s, h)),
+        vec_block(2, lambda f: B1o + f),
+    ]
+    for j in range(3):
+        blocks.append(vec_block(2, lambda f, j=j: W2o + j * 64 + f))
+    b2 = np.full(64, -1, dtype=np.int64)
+    b2[:3] = [B2o, B2o + 1, B2o + 2]
+    blocks.append(b2)
+    blocks.append(a_block(2, 32, lambda mt, i, s, h: W1o + hid_feature(s, h) * 64 + (32 * mt + i)))
+
+    def w0t(mt, i, s, h):
+        q, hh = row_slot(mt, i)
+        if q >= COL_IN_STEPS:
+            return -1
+        f = col_in_feature(q, hh)
+        return W0o + hid_feature(s, h) * n_in + f if f >= 0 else -1
+    blocks.append(a_block(5, 32, w0t))
+    idx = np.concatenate(blocks)
+    idx[idx < 0] = total
+    return torch.from_numpy(idx), total
+
+
+COL_PACK_SIZE = 8704 + 64 + 4096 + 64 + 192 + 64 + 4096 + 10240
+
+
+def pack_colour_net(net):
+    """RenderingNetwork (mode idr, 129->64->64->3) -> packed float32 device tensor."""
+    idx, n = colour_net_index()
+    flat = flat_params(net)
+    assert flat.numel() == n + 1, (flat.numel(), n)
+    packed = flat[idx.to(flat.device)]
+    assert packed.numel() == COL_PACK_SIZE
+    return packed

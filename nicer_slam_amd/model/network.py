@@ -112,6 +112,20 @@ class SLAMNetwork(nn.Module):
         flat = index_to_1d(idx, self.voxel_res)
         self.voxels.view(-1).index_add_(0, flat, torch.ones_like(flat, dtype=self.voxels.dtype))
 
+    def _fused_composite_ok(self, mode, ground_truth):
+        """The fused composite kernels cover the data path (pose gradient).  Parameter gradients, the eikonal
+        samples of mapping mode and the flow/warp blocks still run on the composed engine."""
+        if self.engine == "composed" or not self.voxels.is_cuda:
+            return False
+        from ..fused import render as fused_render
+        needs_params = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        ok = (fused_render.supported(self) and not needs_params and "edges" not in ground_truth
+              and not (self.training and "mapping" in mode and "vis" not in mode))
+        if not ok and self.engine == "fused":
+            raise RuntimeError("engine='fused' requested but this call is outside the fused engine's coverage "
+                               "(parameter gradients / mapping-mode extras / unsupported configuration)")
+        return ok
+
     # ------------------------------------------------------------------ forward
     def forward(self, input, indices, ground_truth, keyframe_list=None, frame_idx=-1, mode="vis", stage="fine",
                 color_stage="highfreq", iter=0):
@@ -137,12 +151,19 @@ class SLAMNetwork(nn.Module):
             self.update_voxels(points_flat.detach())
         dirs_flat = dirs.unsqueeze(1).repeat(1, N, 1).reshape(-1, 3)
 
-        sdf, feats, gradients = self.implicit_network.get_outputs(points_flat, stage=stage)
-        rgb = self.rendering_network(points_flat, gradients, dirs_flat, feats, indices,
-                                     color_stage=color_stage).reshape(-1, N, 3)
-        weights = self.volume_rendering(z_vals, sdf, points_flat)
-        rgb_values = torch.sum(weights.unsqueeze(-1) * rgb, 1)
-        depth = torch.sum(weights * z_vals, 1, keepdims=True) / (weights.sum(dim=1, keepdims=True) + 1e-8)
+        fused = self._fused_composite_ok(mode, ground_truth)
+        if fused:
+            from ..fused import render as fused_render
+            self.last_engine = "fused"
+            rgb_values, depth, nmap_w, weights, ent_ray, sdf, rgb, gradients = fused_render.composite(
+                self, cam_flat, dirs, z_vals, stage, color_stage)
+        else:
+            sdf, feats, gradients = self.implicit_network.get_outputs(points_flat, stage=stage)
+            rgb = self.rendering_network(points_flat, gradients, dirs_flat, feats, indices,
+                                         color_stage=color_stage).reshape(-1, N, 3)
+            weights = self.volume_rendering(z_vals, sdf, points_flat)
+            rgb_values = torch.sum(weights.unsqueeze(-1) * rgb, 1)
+            depth = torch.sum(weights * z_vals, 1, keepdims=True) / (weights.sum(dim=1, keepdims=True) + 1e-8)
 
         output = {}
         if "edges" in ground_truth:   # optical-flow reprojection (network.py:153-165)
@@ -167,7 +188,7 @@ class SLAMNetwork(nn.Module):
             "depth_vals": z_vals * depth_scale.reshape(-1, 1),
             "sdf": sdf.reshape(z_vals.shape),
             "weights": weights,
-            "entropy": (-weights * torch.log(weights + 1e-4)).sum(dim=-1).mean(),
+            "entropy": ent_ray.mean() if fused else (-weights * torch.log(weights + 1e-4)).sum(dim=-1).mean(),
             "scene_bounding_sphere": self.scene_bounding_sphere,
         })
         if self.training and ("vis" not in mode) and ("mapping" in mode):   # eikonal samples (network.py:313-336)
@@ -180,8 +201,11 @@ class SLAMNetwork(nn.Module):
             grad_theta = self.implicit_network.gradient(eik, stage=stage)
             half = grad_theta.shape[0] // 2
             output["grad_theta"], output["grad_theta_nei"] = grad_theta[:half], grad_theta[half:]
-        normals = gradients / (gradients.norm(2, -1, keepdim=True) + 1e-6)
-        normal_map = torch.sum(weights.unsqueeze(-1) * normals.reshape(-1, N, 3), 1).reshape(bs, -1, 3)
+        if fused:
+            normal_map = nmap_w.reshape(bs, -1, 3)
+        else:
+            normals = gradients / (gradients.norm(2, -1, keepdim=True) + 1e-6)
+            normal_map = torch.sum(weights.unsqueeze(-1) * normals.reshape(-1, N, 3), 1).reshape(bs, -1, 3)
         output["normal_map"] = torch.einsum("bij,bni->bnj", pose[:, :3, :3], normal_map)
         return output
 

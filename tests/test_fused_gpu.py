@@ -1,0 +1,188 @@
+"""Fused composite kernels (SDF networks, colour network, compositing; forward and hand-derived backward) vs the
+goldens captured from the reference and vs the CPU oracle.  Needs an MI355X.
+
+Tolerances: forward tensors abs 2e-5 / rel 1e-4 (fp32); gradients rel 1e-3 of the tensor's max."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import load, tt, params_of, oracle_config, draws_of, golden_objective, assert_close
+from test_model_cpu import build_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(name):
+    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    from nicer_slam_amd.utils import rend_util
+    fx = load(name)
+    model = build_model(fx).cuda()
+    model.train(bool(fx["meta_training"]))
+    model.voxels = tt(fx["in_voxels"]).cuda()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    cam = tt(fx["in_cam"]).cuda().requires_grad_(True)
+    pose = get_camera_from_tensor(cam)
+    d, o = rend_util.get_camera_params(tt(fx["in_uv"]).cuda(), pose, tt(fx["in_K"]).cuda())
+    bs, n, _ = d.shape
+    rays_d = d.reshape(-1, 3)
+    rays_o = o.unsqueeze(1).repeat(1, n, 1).reshape(-1, 3)
+    return fx, model, cam, pose, rays_o, rays_d
+
+
+@pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_vis_eval"])
+def test_stage_by_stage_forward(name):
+    """sdf / grad sdf / feature / rgb / weights of the fused kernels at the reference's own sample positions."""
+    from oracle import render_ref as R
+    from nicer_slam_amd.fused import render as fr
+    fx, model, cam, pose, rays_o, rays_d = _setup(name)
+    z = tt(fx["out_z_vals"]).cuda()
+    with torch.no_grad():
+        rgbv, depth, nmap, w, ent, sdf, rgb, grad = fr.composite(model, rays_o.detach(), rays_d.detach(), z, "fine",
+                                                               "highfreq")
+    assert_close(sdf, fx["out_sdf"], 2e-5, 1e-4, "sdf")
+    assert_close(rgb, fx["out_rgb"], 2e-5, 1e-4, "rgb per sample")
+    assert_close(w, fx["out_weights"], 2e-5, 1e-4, "weights")
+    assert_close(rgbv, fx["out_rgb_values"].reshape(-1, 3), 2e-5, 1e-4, "rgb_values")
+    # grad sdf and the normal map vs the oracle (the goldens hold only the rotated normal map)
+    cfg, params = oracle_config(fx), params_of(fx)
+    pts = (rays_o.detach().cpu().unsqueeze(1) + z.cpu().unsqueeze(2) * rays_d.detach().cpu().unsqueeze(1)).reshape(-1, 3)
+    s_o, f_o, g_o = R.sdf_outputs(params, cfg, pts.clone(), "fine")
+    assert_close(grad, g_o, 2e-5 * float(g_o.abs().max()), 1e-4, "grad sdf")
+    nm = torch.einsum("bij,bni->bnj", pose[:, :3, :3].detach(), nmap.reshape(pose.shape[0], -1, 3))
+    assert_close(nm, fx["out_normal_map"], 2e-5, 1e-4, "normal_map")
+    assert_close(ent.mean(), fx["out_entropy"], 2e-5, 1e-4, "entropy")
+
+
+def test_feature_vector_hl_layout():
+    from oracle import render_ref as R
+    from nicer_slam_amd.fused import render as fr, sampler as fs
+    from nicer_slam_amd._native import lib, check
+    import ctypes
+    fx, model, cam, pose, rays_o, rays_d = _setup("full_tracking")
+    z = tt(fx["out_z_vals"]).cuda()
+    P = z.numel()
+    ro, rd = rays_o.detach().contiguous(), rays_d.detach().contiguous()
+    pts = fr._pts(ro, rd, z)
+    sdf, grad = torch.empty(P, device="cuda"), torch.empty(P, 3, device="cuda")
+    feat = torch.empty(fr.hl_size(P), device="cuda")
+    imp = model.implicit_network
+    for which, acc, nh in (("coarse", 0, 1), ("fine", 1, 3)):
+        net = getattr(imp, which)
+        g, keep = fs.grid_desc(net.encoding, net.divide_factor, nh)
+        check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(g), fs.packed_sdf(model, which).data_ptr(), acc,
+                                     sdf.data_ptr(), grad.data_ptr(), feat.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    dense = feat[fr.hl_index(P, "cuda")]
+    cfg, params = oracle_config(fx), params_of(fx)
+    x = (ro.cpu().unsqueeze(1) + z.cpu().unsqueeze(2) * rd.cpu().unsqueeze(1)).reshape(-1, 3)
+    s_o, f_o, g_o = R.sdf_outputs(params, cfg, x.clone(), "fine")
+    assert_close(dense, f_o, 2e-5 * float(f_o.abs().max()), 1e-4, "feature vector")
+
+
+@pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson"])
+def test_model_fused_engine_vs_reference_goldens(name):
+    """SLAMNetwork with engine='fused': output dict and the pose gradient of the tracking objective."""
+    fx, model, cam, pose, _, _ = _setup(name)
+    model.engine = "fused"
+    model.draws = draws_of(fx, "cuda")
+    model.draws["z_vals_override"] = tt(fx["out_z_vals"]).cuda()
+    out = model({"intrinsics": tt(fx["in_K"]).cuda(), "uv": tt(fx["in_uv"]).cuda(), "pose": pose},
+                torch.arange(pose.shape[0], device="cuda"), {}, mode="tracking", frame_idx=1)
+    assert model.last_engine == "fused"
+    for k in ("depth_vals", "sdf", "weights", "rgb", "rgb_values", "depth_values", "entropy", "normal_map"):
+        assert_close(out[k], fx["out_" + k], 2e-5, 1e-4, k)
+    loss = golden_objective(out, fx, "tracking")
+    assert_close(loss, fx["out_loss"], 1e-6, 1e-5, "loss")
+    loss.backward()
+    assert_close(cam.grad, fx["grad_cam"], 1e-3 * float(np.abs(fx["grad_cam"]).max()), 1e-3, "grad_cam")
+
+
+@pytest.mark.parametrize("name,stage,cstage", [("full_tracking", "fine", "highfreq"), ("full_tracking_poisson", "fine", "base"),
+                                               ("full_mapping", "coarse", "highfreq")])
+def test_backward_all_cotangents_vs_oracle(name, stage, cstage):
+    """Every differentiable output (rgb, depth, normal map, entropy, weights) pulled back to the pose and compared
+    with the CPU oracle (torch autograd over the restated reference graph) -- both stages / colour stages."""
+    from oracle import render_ref as R
+    fx, model, cam, pose, _, _ = _setup(name)
+    model.train(True)
+    model.engine = "fused"
+    d = draws_of(fx, "cuda")
+    d["z_vals_override"] = tt(fx["out_z_vals"]).cuda()
+    model.draws = d
+    g = torch.Generator().manual_seed(11)
+    n_ray = fx["out_z_vals"].shape[0]
+    t_rgb, t_dep = torch.rand(n_ray, 3, generator=g), torch.rand(n_ray, 1, generator=g) * 2
+    t_nrm = F.normalize(torch.randn(n_ray, 3, generator=g), dim=-1)
+    t_w = torch.rand(fx["out_z_vals"].shape, generator=g)
+
+    def objective(out, dev):
+        loss = (out["rgb_values"].reshape(-1, 3) - t_rgb.to(dev)).abs().mean()
+        loss = loss + 0.3 * (out["depth_values"].reshape(-1, 1) - t_dep.to(dev)).abs().mean()
+        n = F.normalize(out["normal_map"].reshape(-1, 3), p=2, dim=-1)
+        loss = loss + 0.2 * (n - t_nrm.to(dev)).abs().sum(-1).mean() + 0.05 * out["entropy"]
+        return loss + 0.1 * (out["weights"] * t_w.to(dev)).sum(-1).mean()
+
+    out = model({"intrinsics": tt(fx["in_K"]).cuda(), "uv": tt(fx["in_uv"]).cuda(), "pose": pose},
+                torch.arange(pose.shape[0], device="cuda"), {}, mode="tracking", stage=stage, color_stage=cstage, frame_idx=1)
+    assert model.last_engine == "fused"
+    objective(out, "cuda").backward()
+    cfg, params = oracle_config(fx), params_of(fx)
+    cam_c = tt(fx["in_cam"]).requires_grad_(True)
+    dc = draws_of(fx)
+    dc["z_vals_override"] = tt(fx["out_z_vals"])
+    ref = R.render(params, cfg, tt(fx["in_uv"]), R.camera_from_tensor(cam_c), tt(fx["in_K"]), tt(fx["in_voxels"]), dc,
+                   mode="tracking", stage=stage, color_stage=cstage, training=True)
+    for k in ("rgb_values", "depth_values", "normal_map", "weights", "entropy"):
+        assert_close(out[k], ref[k], 2e-5, 1e-4, k)
+    objective(ref, "cpu").backward()
+    assert_close(cam.grad, cam_c.grad, 1e-3 * float(cam_c.grad.abs().max()), 1e-3, "grad_cam")
+
+
+def test_bench_size_fused_vs_composed_engine():
+    """BASELINE size (1024 rays x 128 samples, shipped SDF grids, 2^19-capped colour grid to keep the test light):
+    the fused engine and the composed engine (torch autograd around the HIP hash operator) agree on the rendered
+    colours and on the pose gradient from the same sample positions."""
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    from nicer_slam_amd.utils.general import get_camera_from_tensor
+
+    class DS:
+        img_res = (680, 1200)
+    torch.manual_seed(0)
+    conf = replica_model_conf(94, 640, 32, use_warp_loss=False)
+    model = SLAMNetwork(conf, dataset=DS(), n_images=1,
+                        colour_grid=dict(base_resolution=16, desired_resolution=2048, log2_hashmap_size=19)).cuda()
+    model.train()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for enc, s in ((model.implicit_network.coarse.encoding, 0.02), (model.implicit_network.fine.encoding, 0.02),
+                   (model.rendering_network.encoding, 0.3)):
+        enc.embeddings.data = (torch.rand(enc.embeddings.shape, device="cuda", generator=g) * 2 - 1) * s
+    for p in model.parameters():
+        p.requires_grad_(False)
+    R = 1024
+    idx = torch.randint(680 * 1200, (1, R), device="cuda", generator=g)
+    uv = torch.stack([(idx % 1200).float(), (idx // 1200).float()], -1)
+    K = torch.eye(4, device="cuda")
+    K[0, 0] = K[1, 1] = 600.0
+    K[0, 2], K[1, 2] = 599.5, 339.5
+    gt = torch.rand(R, 3, device="cuda", generator=g)
+    t_rand = torch.rand(R, 640, device="cuda", generator=g)
+    res = {}
+    zfix = None
+    for engine in ("fused", "composed"):
+        model.engine = engine
+        model.draws = {"t_rand": t_rand, "extra_idx": torch.arange(0, 640, 20, device="cuda"),
+                       "eik_idx": torch.zeros(R, dtype=torch.long, device="cuda")}
+        if zfix is not None:
+            model.draws["z_vals_override"] = zfix
+        cam = torch.tensor([1.0, 0.01, -0.02, 0.015, 0.1, 0.0, -0.2], device="cuda", requires_grad=True)
+        out = model({"intrinsics": K[None], "uv": uv, "pose": get_camera_from_tensor(cam).unsqueeze(0)},
+                    torch.zeros(1, dtype=torch.long, device="cuda"), {}, mode="tracking", frame_idx=1)
+        zfix = out["z_vals"].detach()
+        (out["rgb_values"].reshape(-1, 3) - gt).abs().mean().backward()
+        res[engine] = (out["rgb_values"].detach(), cam.grad.clone(), out["weights"].detach(), model.last_engine)
+    assert res["fused"][3] == "fused" and res["composed"][3] == "composed"
+    assert_close(res["fused"][2], res["composed"][2], 2e-5, 1e-4, "weights")
+    assert_close(res["fused"][0], res["composed"][0], 2e-5, 1e-4, "rgb_values")
+    assert_close(res["fused"][1], res["composed"][1], 2e-3 * float(res["composed"][1].abs().max()), 2e-3, "grad_cam")

@@ -129,3 +129,69 @@ def test_every_input_feature_has_exactly_one_slot():
                     assert f not in seen
                     seen[f] = (s, h)
         assert sorted(seen) == list(range(71))
+
+
+def test_colour_net_pack():
+    from nicer_slam_amd.model.base_networks import RenderingNetwork
+    torch.manual_seed(5)
+    net = RenderingNetwork(64, mode="idr", d_in=9, d_out=3, dims=[64, 64], weight_norm=True, multires_view=4,
+                           use_grid_feature=True,
+                           colour_grid=dict(base_resolution=4, desired_resolution=8, log2_hashmap_size=6))
+    packed = pack.pack_colour_net(net).detach().double().numpy()
+    assert packed.size == pack.COL_PACK_SIZE
+    seen = {}
+    for h in range(2):
+        for s in range(pack.COL_IN_STEPS):
+            f = pack.col_in_feature(s, h)
+            if f >= 0:
+                assert f not in seen
+                seen[f] = (s, h)
+    assert sorted(seen) == list(range(129))
+    Ws = [pack.effective_weight(getattr(net, f"lin{l}")).detach().double().numpy() for l in range(3)]
+    bs = [getattr(net, f"lin{l}").bias.detach().double().numpy() for l in range(3)]
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((32, 129))
+    a1 = x @ Ws[0].T + bs[0]
+    a2 = np.maximum(a1, 0) @ Ws[1].T + bs[1]
+    o = np.maximum(a2, 0) @ Ws[2].T + bs[2]
+    b = np.zeros((64, 65))
+    for lane in range(64):
+        for s in range(65):
+            f = pack.col_in_feature(s, lane >> 5)
+            b[lane, s] = x[lane & 31, f] if f >= 0 else 0.0
+    off = 0
+    W0 = packed[off:off + 8704]; off += 8704
+    B0 = packed[off:off + 64]; off += 64
+    W1 = packed[off:off + 4096]; off += 4096
+    B1 = packed[off:off + 64]; off += 64
+    W2V = packed[off:off + 192]; off += 192
+    B2 = packed[off:off + 64]; off += 64
+    W1T = packed[off:off + 4096]; off += 4096
+    W0T = packed[off:off + 10240]; off += 10240
+    assert off == packed.size
+    acc1 = emu.load_vec(B0, 2)
+    emu.gemm_op(W0, 2, 65, b, acc1)
+    acc2 = emu.load_vec(B1, 2)
+    emu.gemm_op(W1, 2, 32, emu.act_to_b(np.maximum(acc1, 0)), acc2)
+    for j in range(3):
+        oj = emu.xhalf_sum((np.maximum(acc2, 0) * emu.load_vec(W2V[64 * j:64 * j + 64], 2)).reshape(64, -1).sum(1)) + B2[j]
+        np.testing.assert_allclose(oj[:32], o[:, j], rtol=1e-9, atol=1e-9)
+    g = rng.standard_normal((32, 64))
+    g_b = np.zeros((64, 32))
+    for lane in range(64):
+        for s in range(32):
+            g_b[lane, s] = g[lane & 31, pack.hid_feature(s, lane >> 5)]
+    acc = np.zeros((64, 2, 16))
+    emu.gemm_op(W1T, 2, 32, g_b, acc)
+    want = g @ Ws[1]
+    for lane in range(64):
+        for t in range(2):
+            for r in range(16):
+                assert abs(acc[lane, t, r] - want[lane & 31, 32 * t + pack.F(r, lane >> 5)]) < 1e-9
+    acc = np.zeros((64, 5, 16))
+    emu.gemm_op(W0T, 5, 32, g_b, acc)
+    want = g @ Ws[0]
+    for lane in range(64):
+        for q in range(80):
+            f = pack.col_in_feature(q, lane >> 5) if q < 65 else -1
+            assert abs(acc[lane, q // 16, q % 16] - (want[lane & 31, f] if f >= 0 else 0.0)) < 1e-9

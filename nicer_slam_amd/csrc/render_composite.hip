@@ -41,7 +41,10 @@ __device__ __forceinline__ float wave_excl(float v, int lane, float& total) {
         if (lane >= off) incl += n;
     }
     total = __shfl(incl, 63);
-    return incl - v;
+    // exclusive = inclusive of the previous lane (NOT incl - v: the last sample's free energy is ~1e10 * sigma and
+    // the subtraction would cancel the whole prefix)
+    const float prev = __shfl_up(incl, 1);
+    return lane == 0 ? 0.0f : prev;
 }
 
 struct CompositeArgs {

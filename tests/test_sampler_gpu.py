@@ -103,3 +103,18 @@ def test_bench_shape_sampler_properties():
     assert float(z_vals.min()) == 0.0                      # near is always a sample
     assert bool((z_vals.max(dim=1)[0] >= far - 1e-6).all())   # far is always a sample
     assert bool(torch.isfinite(z_vals).all())
+    # full-length rays (E = 640: ten samples per lane, the last lane holds the 1e10 interval) vs the oracle, CDF space
+    from oracle import render_ref as Rr
+    n = 48
+    mk = Rr.make_grid_spec
+    cfg = Rr.RenderConfig(coarse=Rr.SdfNetSpec(mk(4, 8, 32, 32, 19), 2), fine=Rr.SdfNetSpec(mk(8, 4, 32, 128, 19), 4),
+                          colour_grid=mk(16, 2, 16, 64, 12), n_samples=94, n_samples_eval=640, n_samples_extra=32)
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    extra = torch.arange(0, 640, 20)
+    model.draws = {"t_rand": t_rand[:n], "extra_idx": extra.cuda(), "eik_idx": torch.zeros(n, dtype=torch.long).cuda()}
+    z_gpu, _ = model.ray_sampler.get_z_vals(d[:n], o[:n], model)
+    aux = {}
+    z_cpu, _ = Rr.importance_z(params, cfg, d[:n].cpu(), o[:n].cpu(), torch.zeros(64, 64, 64), True,
+                               {"t_rand": t_rand[:n].cpu(), "extra_idx": extra, "eik_idx": torch.zeros(n, dtype=torch.long)},
+                               aux=aux)
+    check_samples(z_gpu.cpu(), z_cpu, aux["bins"], aux["cdf"], u_tol=5e-5)

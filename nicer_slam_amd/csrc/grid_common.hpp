@@ -65,6 +65,15 @@ inline int make_grid_geom(const int32_t* offsets_host, uint32_t L, uint32_t D, f
 inline void launch_begin() { (void)hipGetLastError(); }
 inline int launch_end() { return hipGetLastError() == hipSuccess ? NSA_OK : NSA_ELAUNCH; }
 
+// a*b rounded on its own (never contracted into an FMA): sample positions are built as o + z*d by two separate torch
+// kernels in the reference (network.py:112-114, ray_sampler.py:97); with the `far` sample sitting exactly on the cube
+// face by construction, a fused multiply-add can flip that point's in-range test (hashencoder.cu:155-159).
+__device__ __forceinline__ float mul_rn(float a, float b) {
+    float r;
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // ---- device side -------------------------------------------------------------------------------
 template <int D>
 __device__ __forceinline__ uint32_t level_row(const LevelGeom& g, const uint32_t (&q)[D]) {

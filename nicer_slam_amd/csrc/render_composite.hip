@@ -98,7 +98,7 @@ __device__ __forceinline__ int ray_forward(const CompositeArgs& a, uint32_t ray,
             s.sdf = sr[i];
             float x[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) x[c] = o[c] + s.z * d[c];
+            for (int c = 0; c < 3; ++c) x[c] = o[c] + mul_rn(s.z, d[c]);
             s.beta = beta_at(a.voxels, a.voxel_res, x);
             const float sg = s.sdf > 0.0f ? 1.0f : (s.sdf < 0.0f ? -1.0f : 0.0f);
             s.sigma = (1.0f / s.beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(s.sdf) / s.beta));

@@ -66,18 +66,19 @@ __global__ __launch_bounds__(256) void k_sampler_sdf(SamplerArgs a, GridGeom16 g
     // z_lin(i) = near (1 - t_i) + far t_i ; stratified: lower + (upper - lower) * rand   (ray_sampler.py:49-59)
     const uint32_t E = a.E;
     const float ti = a.t_lin[i];
-    float zi = nearv * (1.0f - ti) + farv * ti;
+    // every product rounded separately, as the reference's elementwise torch ops do (see mul_rn)
+    float zi = mul_rn(nearv, 1.0f - ti) + mul_rn(farv, ti);
     if (a.t_rand) {
         const float tp = a.t_lin[i + 1 < E ? i + 1 : i], tm = a.t_lin[i > 0 ? i - 1 : 0];
-        const float zp = nearv * (1.0f - tp) + farv * tp;
-        const float zm = nearv * (1.0f - tm) + farv * tm;
+        const float zp = mul_rn(nearv, 1.0f - tp) + mul_rn(farv, tp);
+        const float zm = mul_rn(nearv, 1.0f - tm) + mul_rn(farv, tm);
         const float upper = i + 1 < E ? 0.5f * (zp + zi) : zi;
         const float lower = i > 0 ? 0.5f * (zi + zm) : zi;
-        zi = lower + (upper - lower) * a.t_rand[pid];
+        zi = lower + mul_rn(upper - lower, a.t_rand[pid]);
     }
     float x[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) x[k] = o[k] + zi * d[k];
+    for (int k = 0; k < 3; ++k) x[k] = o[k] + mul_rn(zi, d[k]);
 
     float in[SDF_IN_STEPS];
     float sdf;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
             const float zi = zr[i];
             float x[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) x[c] = o[c] + zi * d[c];
+            for (int c = 0; c < 3; ++c) x[c] = o[c] + mul_rn(zi, d[c]);
             const float sigma = laplace_density(sr[i], beta_of(a.voxels, a.voxel_res, x));
             const float en = (i + 1 < E ? zr[i + 1] - zi : 1e10f) * sigma;
             zb[i] = zi;
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
         const float b0 = zb[below], b1 = zb[above];
         float den = c1 - c0;
         if (den < 1e-5f) den = 1.0f;
-        sb[j] = b0 + (u - c0) / den * (b1 - b0);
+        sb[j] = b0 + mul_rn((u - c0) / den, b1 - b0);
     }
     // extras: near, far, n_extra of the coarse samples                                  :146-153
     const uint32_t P2 = next_pow2(S);

@@ -273,7 +273,7 @@ __device__ __forceinline__ void load_point(const PointSrc& ps, uint32_t pid, flo
     ray = pid / ps.S;
     z = ps.z_vals[pid];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) x[k] = ps.rays_o[ray * 3 + k] + z * ps.rays_d[ray * 3 + k];
+    for (int k = 0; k < 3; ++k) x[k] = ps.rays_o[ray * 3 + k] + mul_rn(z, ps.rays_d[ray * 3 + k]);
 }
 
 }  // namespace nsa

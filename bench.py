@@ -6,7 +6,7 @@ sampler (E=640 SDF evaluations/ray) -> S=128 composite samples/ray through the t
 -> SDF->density composite -> L1(rgb) -> backward to the pose gradient -> Adam step on the camera.  Real shipped
 network/grid sizes (1 GiB colour table), fp32, synthetic inputs already resident in HBM when the clock starts.
 N > 1: every rank renders its own 1024-ray shard (rays are independent given replicated parameters) and the only
-exchange is one RCCL all-reduce of the 7-float pose gradient + loss per step  ->  "scaling": "weak".
+exchange is one fused 9-float RCCL all-reduce (pose gradient, loss, ray count) per step  ->  "scaling": "weak".
 
     python bench.py [--gpus N --steps K --warmup W]       (N>1: launched by torch.distributed.run)
 Prints ONE JSON line on rank 0.
@@ -96,7 +96,7 @@ def main():
         dist.broadcast(cam.data, 0)
     opt = torch.optim.Adam([cam], lr=0.005)
     ind = torch.zeros(1, dtype=torch.long, device=device)
-    red = torch.zeros(8, device=device)
+    from nicer_slam_amd.dist import allreduce_pose_grad
 
     def step(i):
         uv, gt = batches[i]
@@ -104,11 +104,9 @@ def main():
         out = model({"intrinsics": K, "uv": uv, "pose": pose}, ind, {}, mode="tracking", frame_idx=1)
         loss = (out["rgb_values"].reshape(-1, 3) - gt).abs().mean()
         loss.backward()
-        if world > 1:   # mean over the global batch: one fused 8-float all-reduce (7 pose-grad + loss)
-            red[:7] = cam.grad
-            red[7] = loss.detach()
-            dist.all_reduce(red)
-            cam.grad.copy_(red[:7] / world)
+        if world > 1:   # mean over the global ray batch: ONE fused 9-float RCCL all-reduce (pose grad, loss, count)
+            g, loss = allreduce_pose_grad(cam.grad, loss, args.rays)
+            cam.grad.copy_(g)
         opt.step()
         opt.zero_grad(set_to_none=False)
         return loss

@@ -110,6 +110,16 @@ int nsa_sdfnet_backward(const nsa_points_t *pts, const nsa_grid_t *grid, const f
                         const float *g_feat_hl, const float *g_grad, int accumulate, float *g_x,
                         nsa_stream_t stream);
 
+/* Pixels -> rays for b images x n pixels: rays_o[b*n,3] = pose[:3,3], rays_d = (p - o)/|p - o|^2 (NOT unit length),
+ * depth_scale[b*n] = z of the identity-pose direction.  replaces rend_util.get_camera_params + lift
+ * (code/utils/rend_util.py:68-93,107-129), both calls of code/model/network.py:98-102. */
+int nsa_rays_forward(const float *uv, const float *pose, const float *K, uint32_t b, uint32_t n, float *rays_o,
+                     float *rays_d, float *depth_scale, nsa_stream_t stream);
+
+/* Backward of the above to the camera-to-world matrices: g_pose[b,4,4] (overwritten; bottom row zero). */
+int nsa_rays_pose_backward(const float *uv, const float *pose, const float *K, uint32_t b, uint32_t n,
+                           const float *g_rays_o, const float *g_rays_d, float *g_pose, nsa_stream_t stream);
+
 /* Colour network at the composite points: rgb = sigmoid(MLP([x, PE4(view dir), grad sdf, feature, colour grid])).
  * replaces RenderingNetwork.forward, mode "idr" (code/model/base_networks.py:333-395).  `save` (optional,
  * ceil(P/32)*4096 floats) receives what the backward needs from the 1 GiB colour table (features + Jacobian). */

@@ -79,3 +79,9 @@ lib.nsa_rays_backward.restype = _i
 lib.nsa_rays_backward.argtypes = [_p, _p, _p, _u32, _u32, _p, _p, _p]
 EXPORTS += ["nsa_sdfnet_forward", "nsa_sdfnet_backward", "nsa_colour_forward", "nsa_colour_backward",
             "nsa_composite_forward", "nsa_composite_backward", "nsa_rays_backward"]
+
+lib.nsa_rays_forward.restype = _i
+lib.nsa_rays_forward.argtypes = [_p, _p, _p, _u32, _u32, _p, _p, _p, _p]
+lib.nsa_rays_pose_backward.restype = _i
+lib.nsa_rays_pose_backward.argtypes = [_p, _p, _p, _u32, _u32, _p, _p, _p, _p]
+EXPORTS += ["nsa_rays_forward", "nsa_rays_pose_backward"]

@@ -1,0 +1,120 @@
+// render_rays.hip -- pixel -> ray lifting and its backward to the camera-to-world matrix.
+// Reference: rend_util.get_camera_params + lift (code/utils/rend_util.py:68-93,107-129) and the identity-pose second
+// call that yields depth_scale (code/model/network.py:99-102).  One thread per ray; the backward reduces
+// d/d(pose[:3,:3]) = sum_rays vbar c^T and d/d(pose[:3,3]) = sum_rays obar with wave reductions + 12 atomics per wave.
+#include "grid_common.hpp"
+
+namespace nsa {
+
+struct RaysArgs {
+    const float* uv;     // [b,n,2]
+    const float* pose;   // [b,4,4] camera-to-world
+    const float* K;      // [b,4,4]
+    uint32_t b, n;
+    float* rays_o;       // [b*n,3]
+    float* rays_d;       // [b*n,3]   (p - o) / |p - o|^2  -- NOT unit length (rend_util.py:92)
+    float* depth_scale;  // [b*n]     z component of the identity-pose ray
+    const float* g_o;    // [b*n,3]
+    const float* g_d;    // [b*n,3]
+    float* g_pose;       // [b,4,4] pre-zeroed
+};
+
+__device__ __forceinline__ void lift_pixel(const float* __restrict__ K, float u, float v, float (&c)[3]) {
+    const float fx = K[0], sk = K[1], cx = K[2], fy = K[5], cy = K[6];
+    c[0] = (u - cx + cy * sk / fy - sk * v / fy) / fx;       // rend_util.py:117-125 (z = 1)
+    c[1] = (v - cy) / fy;
+    c[2] = 1.0f;
+}
+
+__global__ __launch_bounds__(256) void k_rays_fwd(RaysArgs a) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.b * a.n) return;
+    const uint32_t bi = r / a.n;
+    const float* P = a.pose + bi * 16;
+    float c[3];
+    lift_pixel(a.K + bi * 16, a.uv[2 * r], a.uv[2 * r + 1], c);
+    float v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float w = P[4 * k] * c[0] + P[4 * k + 1] * c[1] + P[4 * k + 2] * c[2] + P[4 * k + 3];   // bmm with [x,y,1,1]
+        v[k] = w - P[4 * k + 3];                                                                       // - cam_loc
+        a.rays_o[3 * r + k] = P[4 * k + 3];
+    }
+    const float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.rays_d[3 * r + k] = v[k] / s;
+    a.depth_scale[r] = c[2] / (c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+}
+
+__global__ __launch_bounds__(256) void k_rays_pose_bwd(RaysArgs a) {
+    const uint32_t r0 = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t total = a.b * a.n;
+    const bool live = r0 < total;
+    const uint32_t r = live ? r0 : total - 1;
+    const uint32_t bi = r / a.n;
+    const float* P = a.pose + bi * 16;
+    float c[3];
+    lift_pixel(a.K + bi * 16, a.uv[2 * r], a.uv[2 * r + 1], c);
+    float v[3], gd[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float w = P[4 * k] * c[0] + P[4 * k + 1] * c[1] + P[4 * k + 2] * c[2] + P[4 * k + 3];
+        v[k] = w - P[4 * k + 3];
+        gd[k] = live ? a.g_d[3 * r + k] : 0.0f;
+    }
+    const float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const float vg = v[0] * gd[0] + v[1] * gd[1] + v[2] * gd[2];
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float vb = gd[k] / s - 2.0f * v[k] * vg / (s * s);     // d = v / (v.v)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[4 * k + j] = vb * c[j];
+        acc[4 * k + 3] = live ? a.g_o[3 * r + k] : 0.0f;             // cam_loc = pose[:3,3]; (w - cam_loc) cancels
+    }
+    // all rays of a wave belong to one image when n % 64 == 0; otherwise fall back to per-lane atomics
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t first = __shfl(bi, 0), last = __shfl(bi, 63);
+    if (first == last) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            float x = acc[q];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if (lane == 0) atomicAdd(a.g_pose + bi * 16 + q, x);
+        }
+    } else if (live) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) atomicAdd(a.g_pose + bi * 16 + q, acc[q]);
+    }
+}
+
+}  // namespace nsa
+
+extern "C" {
+
+int nsa_rays_forward(const float* uv, const float* pose, const float* K, uint32_t b, uint32_t n, float* rays_o, float* rays_d,
+                     float* depth_scale, nsa_stream_t stream) {
+    using namespace nsa;
+    if (b * n == 0) return NSA_OK;
+    if (!uv || !pose || !K || !rays_o || !rays_d || !depth_scale) return NSA_EBADARG;
+    RaysArgs a{uv, pose, K, b, n, rays_o, rays_d, depth_scale, nullptr, nullptr, nullptr};
+    launch_begin();
+    hipLaunchKernelGGL(k_rays_fwd, dim3((b * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_end();
+}
+
+int nsa_rays_pose_backward(const float* uv, const float* pose, const float* K, uint32_t b, uint32_t n, const float* g_rays_o,
+                           const float* g_rays_d, float* g_pose, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!g_pose) return NSA_EBADARG;
+    launch_begin();
+    if (hipMemsetAsync(g_pose, 0, sizeof(float) * 16 * b, (hipStream_t)stream) != hipSuccess) return NSA_ELAUNCH;
+    if (b * n == 0) return NSA_OK;
+    if (!uv || !pose || !K || !g_rays_o || !g_rays_d) return NSA_EBADARG;
+    RaysArgs a{uv, pose, K, b, n, nullptr, nullptr, nullptr, g_rays_o, g_rays_d, g_pose};
+    hipLaunchKernelGGL(k_rays_pose_bwd, dim3((b * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_end();
+}
+
+}  // extern "C"

@@ -157,3 +157,36 @@ class FusedComposite(torch.autograd.Function):
 
 def composite(model, rays_o, rays_d, z_vals, stage, color_stage):
     return FusedComposite.apply(rays_o, rays_d, z_vals, model, stage, color_stage)
+
+
+class FusedRays(torch.autograd.Function):
+    """pose[b,4,4] (+ uv, K) -> rays_o[b*n,3], rays_d[b*n,3], depth_scale[b*n]; backward to the pose only."""
+
+    @staticmethod
+    def forward(ctx, pose, uv, K):
+        pose, uv, K = pose.contiguous(), uv.contiguous(), K.contiguous()
+        b, n, _ = uv.shape
+        dev = uv.device
+        rays_o = torch.empty(b * n, 3, device=dev)
+        rays_d = torch.empty(b * n, 3, device=dev)
+        depth_scale = torch.empty(b * n, device=dev)
+        check(lib.nsa_rays_forward(uv.data_ptr(), pose.data_ptr(), K.data_ptr(), b, n, rays_o.data_ptr(),
+                                   rays_d.data_ptr(), depth_scale.data_ptr(), _stream()))
+        ctx.save_for_backward(pose, uv, K)
+        ctx.mark_non_differentiable(depth_scale)
+        return rays_o, rays_d, depth_scale
+
+    @staticmethod
+    def backward(ctx, g_o, g_d, _g_ds):
+        pose, uv, K = ctx.saved_tensors
+        b, n, _ = uv.shape
+        zero = lambda g: torch.zeros(b * n, 3, device=uv.device) if g is None else g.contiguous()
+        g_o, g_d = zero(g_o), zero(g_d)
+        g_pose = torch.empty(b, 4, 4, device=uv.device)
+        check(lib.nsa_rays_pose_backward(uv.data_ptr(), pose.data_ptr(), K.data_ptr(), b, n, g_o.data_ptr(),
+                                         g_d.data_ptr(), g_pose.data_ptr(), _stream()))
+        return g_pose, None, None
+
+
+def rays(pose, uv, K):
+    return FusedRays.apply(pose, uv, K)

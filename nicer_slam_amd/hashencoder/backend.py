@@ -12,19 +12,20 @@ from .._native import lib, check
 
 __all__ = ["_backend"]
 
-_host_offsets = {}
-
-
 def _offsets_host(offsets):
-    """Host copy of the (constant) int32 offsets tensor; one D2H per distinct tensor."""
-    key = (offsets.data_ptr(), offsets.numel(), str(offsets.device))
-    hit = _host_offsets.get(key)
-    if hit is None:
-        if len(_host_offsets) > 256:
-            _host_offsets.clear()
-        hit = offsets.detach().to("cpu", copy=True).contiguous()
-        _host_offsets[key] = hit
-    return hit
+    """Host copy of the (constant) int32 offsets tensor.  Cached ON the tensor object (one D2H copy per tensor):
+    a cache keyed by data_ptr would go stale when the allocator hands a freed offsets buffer to another encoder --
+    wrong level geometry -> out-of-bounds gathers."""
+    if not offsets.is_cuda:
+        return offsets.contiguous()
+    host = getattr(offsets, "_nsa_host", None)
+    if host is None:
+        host = offsets.detach().to("cpu", copy=True).contiguous()
+        try:
+            offsets._nsa_host = host
+        except AttributeError:
+            pass
+    return host
 
 
 def _dev(t, name):

@@ -60,7 +60,6 @@ class SLAMNetwork(nn.Module):
         self.voxels_shape = self.voxels.shape
         self._share_voxels()
         self.draws = None          # optional dict of pre-drawn randoms (parity tests); else device generator
-        self._generator = None
         self.engine = "auto"       # "auto" | "fused" | "composed"
         self.last_engine = None    # which engine the most recent forward used
 
@@ -86,21 +85,18 @@ class SLAMNetwork(nn.Module):
         dev = self.voxels.device
         if self.draws is not None and kind in self.draws:
             return self.draws[kind].to(dev)
-        if self._generator is None or self._generator.device != dev:
-            self._generator = torch.Generator(device=dev)
-            self._generator.manual_seed(torch.initial_seed() & 0x7FFFFFFF)
-        g = self._generator
+        # default device generator: graph-capture safe (philox offsets are advanced per replay)
         if kind in ("t_rand", "eik_jitter"):
-            return torch.rand(tuple(spec), device=dev, generator=g)
-        if kind == "extra_idx":
+            return torch.rand(tuple(spec), device=dev)
+        if kind == "extra_idx":      # k distinct indices of n, uniformly: first k of a random permutation
             n, k = spec
-            return torch.randperm(n, device=dev, generator=g)[:k]
+            return torch.rand(n, device=dev).argsort()[:k]
         if kind == "eik_idx":
             high, n = spec
-            return torch.randint(high, (n,), device=dev, generator=g)
+            return torch.randint(high, (n,), device=dev)
         if kind == "eik_uniform":
             n, b = spec
-            return (torch.rand((n, 3), device=dev, generator=g) * 2 - 1) * b
+            return (torch.rand((n, 3), device=dev) * 2 - 1) * b
         raise KeyError(kind)
 
     # ------------------------------------------------------------------ visit counter
@@ -135,29 +131,35 @@ class SLAMNetwork(nn.Module):
             self.patchsizes = self.mapping_patchsizes
         intrinsics, uv, pose = input["intrinsics"], input["uv"], input["pose"]
         self.last_engine = "composed"
-        ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
-        eye = torch.eye(4, device=pose.device, dtype=pose.dtype)[None].repeat(pose.shape[0], 1, 1)
-        depth_scale = rend_util.get_camera_params(uv, eye, intrinsics)[0][:, :, 2:]   # network.py:99-102
-        bs, num_pixels, _ = ray_dirs.shape
-        cam_flat = cam_loc.unsqueeze(1).repeat(1, num_pixels, 1).reshape(-1, 3)
-        dirs = ray_dirs.reshape(-1, 3)
+        bs, num_pixels, _ = uv.shape
+        fused = self._fused_composite_ok(mode, ground_truth)
+        if fused and pose.shape[1] == 4 and uv.dtype == torch.float32:
+            from ..fused import render as fused_render
+            cam_flat, dirs, ds_flat = fused_render.rays(pose, uv, intrinsics.to(uv.device))
+            depth_scale = ds_flat.reshape(bs, num_pixels, 1)
+        else:
+            ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
+            eye = torch.eye(4, device=pose.device, dtype=pose.dtype)[None].repeat(pose.shape[0], 1, 1)
+            depth_scale = rend_util.get_camera_params(uv, eye, intrinsics)[0][:, :, 2:]   # network.py:99-102
+            cam_flat = cam_loc.unsqueeze(1).repeat(1, num_pixels, 1).reshape(-1, 3)
+            dirs = ray_dirs.reshape(-1, 3)
 
         z_vals, z_samples_eik = self.ray_sampler.get_z_vals(dirs, cam_flat, self, frame_idx, keyframe_list, mode)
         if self.draws is not None and "z_vals_override" in self.draws:   # parity tests only
             z_vals = self.draws["z_vals_override"].to(z_vals.device)
         N = z_vals.shape[1]
-        points_flat = (cam_flat.unsqueeze(1) + z_vals.unsqueeze(2) * dirs.unsqueeze(1)).reshape(-1, 3)
+        if not fused or mode == "mapping":
+            points_flat = (cam_flat.unsqueeze(1) + z_vals.unsqueeze(2) * dirs.unsqueeze(1)).reshape(-1, 3)
         if mode == "mapping":
             self.update_voxels(points_flat.detach())
-        dirs_flat = dirs.unsqueeze(1).repeat(1, N, 1).reshape(-1, 3)
 
-        fused = self._fused_composite_ok(mode, ground_truth)
         if fused:
             from ..fused import render as fused_render
             self.last_engine = "fused"
             rgb_values, depth, nmap_w, weights, ent_ray, sdf, rgb, gradients = fused_render.composite(
                 self, cam_flat, dirs, z_vals, stage, color_stage)
         else:
+            dirs_flat = dirs.unsqueeze(1).repeat(1, N, 1).reshape(-1, 3)
             sdf, feats, gradients = self.implicit_network.get_outputs(points_flat, stage=stage)
             rgb = self.rendering_network(points_flat, gradients, dirs_flat, feats, indices,
                                          color_stage=color_stage).reshape(-1, N, 3)

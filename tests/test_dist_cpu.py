@@ -1,0 +1,83 @@
+"""N > 1 path on CPU: world_size-2 gloo, ray-sharded tracking step, fused 9-float all-reduce of the pose gradient.
+The sharded result must equal the single-process gradient captured from the reference (goldens)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import load, tt, draws_of
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from oracle import hashenc
+    from nicer_slam_amd.hashencoder import hashgrid
+    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    from nicer_slam_amd import dist as nd
+    from test_model_cpu import build_model
+    hashgrid._backend = hashenc.OracleBackend()       # CPU stand-in at the native seam (tests only)
+    fx = load("full_tracking")
+    model = build_model(fx)
+    model.train(True)
+    n = fx["in_uv"].shape[1]
+    lo, hi = nd.shard_rays(n, rank, world)
+    d = draws_of(fx)
+    model.draws = {"t_rand": d["t_rand"][lo:hi], "extra_idx": d["extra_idx"], "eik_idx": d["eik_idx"][lo:hi],
+                   "z_vals_override": tt(fx["out_z_vals"])[lo:hi]}
+    cam = tt(fx["in_cam"]).requires_grad_(True)
+    out = model({"intrinsics": tt(fx["in_K"]), "uv": tt(fx["in_uv"])[:, lo:hi], "pose": get_camera_from_tensor(cam)},
+                torch.arange(1), {}, mode="tracking", frame_idx=1)
+    loss = (out["rgb_values"].reshape(-1, 3) - tt(fx["gt_rgb"])[lo:hi]).abs().mean()
+    loss.backward()
+    g, l = nd.allreduce_pose_grad(cam.grad.reshape(-1), loss, hi - lo)
+    out_q.put((rank, g.numpy().copy(), float(l)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_rays_balanced():
+    from nicer_slam_amd.dist import shard_rays
+    for n, w in [(1024, 8), (1000, 3), (7, 2), (5, 8)]:
+        spans = [shard_rays(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_tracking_step_matches_reference_gradient():
+    fx = load("full_tracking")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda t: t[0])
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=0)          # identical on every rank
+    ref = fx["grad_cam"].reshape(-1)
+    np.testing.assert_allclose(res[0][1], ref, rtol=1e-3, atol=1e-6 + 1e-4 * np.abs(ref).max())
+    assert abs(res[0][2] - float(fx["out_loss"])) < 1e-5

@@ -186,3 +186,35 @@ def test_bench_size_fused_vs_composed_engine():
     assert_close(res["fused"][2], res["composed"][2], 2e-5, 1e-4, "weights")
     assert_close(res["fused"][0], res["composed"][0], 2e-5, 1e-4, "rgb_values")
     assert_close(res["fused"][1], res["composed"][1], 2e-3 * float(res["composed"][1].abs().max()), 2e-3, "grad_cam")
+
+
+def test_fused_rays_vs_torch_path():
+    """nsa_rays_forward / nsa_rays_pose_backward vs the torch restatement of rend_util.get_camera_params (batch of 2
+    poses, skewed intrinsics, ragged pixel count)."""
+    from nicer_slam_amd.fused import render as fr
+    from nicer_slam_amd.utils import rend_util
+    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    g = torch.Generator().manual_seed(2)
+    b, n = 2, 203
+    uv = torch.stack([torch.randint(1200, (b, n), generator=g).float(), torch.randint(680, (b, n), generator=g).float()], -1).cuda()
+    K = torch.eye(4)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[0, 1] = 600.0, 590.0, 599.5, 339.5, 0.3
+    K = K[None].repeat(b, 1, 1).cuda()
+    cam = torch.tensor([[1.0, 0.02, -0.01, 0.03, 0.1, 0.0, -0.2], [0.9, -0.1, 0.05, 0.2, -0.3, 0.2, 0.1]]).cuda()
+    w_o, w_d = torch.randn(b * n, 3, generator=g).cuda(), torch.randn(b * n, 3, generator=g).cuda()
+    res = []
+    for fused in (True, False):
+        c = cam.clone().requires_grad_(True)
+        pose = get_camera_from_tensor(c)
+        if fused:
+            o, d, ds = fr.rays(pose, uv, K)
+        else:
+            dd, oo = rend_util.get_camera_params(uv, pose, K)
+            d, o = dd.reshape(-1, 3), oo.unsqueeze(1).repeat(1, n, 1).reshape(-1, 3)
+            eye = torch.eye(4, device="cuda")[None].repeat(b, 1, 1)
+            ds = rend_util.get_camera_params(uv, eye, K)[0][:, :, 2].reshape(-1)
+        ((o * w_o).sum() + (d * w_d).sum()).backward()
+        res.append((o.detach(), d.detach(), ds.detach(), c.grad.clone()))
+    for i, what in enumerate(("rays_o", "rays_d", "depth_scale")):
+        assert_close(res[0][i], res[1][i], 1e-7, 2e-6, what)
+    assert_close(res[0][3], res[1][3], 1e-4 * float(res[1][3].abs().max()), 1e-4, "camera-tensor gradient")

@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--engine", default="auto", choices=["auto", "fused", "composed"])
     ap.add_argument("--param-grads", action="store_true",
                     help="also produce (and discard) table/MLP gradients like the reference's tracking loop")
+    ap.add_argument("--no-graph", action="store_true", help="launch every op eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=64)
     return ap.parse_args()
@@ -91,25 +92,16 @@ def main():
     total = args.warmup + args.steps
     batches = [synth_batch(gen, args.rays, device) for _ in range(total)]
     cam = torch.tensor([1.0, 0, 0, 0, 0.1, 0.0, -0.2], device=device)
-    cam = (cam + 1e-3 * torch.randn(7, device=device, generator=gen)).requires_grad_(True)
+    cam = cam + 1e-3 * torch.randn(7, device=device, generator=gen)
     if world > 1:
-        dist.broadcast(cam.data, 0)
-    opt = torch.optim.Adam([cam], lr=0.005)
-    ind = torch.zeros(1, dtype=torch.long, device=device)
-    from nicer_slam_amd.dist import allreduce_pose_grad
+        dist.broadcast(cam, 0)
+    from nicer_slam_amd.tracking import TrackingStepper
+    use_graph = not args.no_graph and not args.param_grads
+    stepper = TrackingStepper(model, K, args.rays, cam, lr=0.005, use_graph=use_graph, world=world)
 
     def step(i):
         uv, gt = batches[i]
-        pose = get_camera_from_tensor(cam).unsqueeze(0)
-        out = model({"intrinsics": K, "uv": uv, "pose": pose}, ind, {}, mode="tracking", frame_idx=1)
-        loss = (out["rgb_values"].reshape(-1, 3) - gt).abs().mean()
-        loss.backward()
-        if world > 1:   # mean over the global ray batch: ONE fused 9-float RCCL all-reduce (pose grad, loss, count)
-            g, loss = allreduce_pose_grad(cam.grad, loss, args.rays)
-            cam.grad.copy_(g)
-        opt.step()
-        opt.zero_grad(set_to_none=False)
-        return loss
+        return stepper.step(uv, gt)
 
     def fence():
         if world > 1:
@@ -119,12 +111,20 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    be.PROFILE = []
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         last = step(i)
     fence()
     dt = time.perf_counter() - t0
+    last = float(last)
+    # Per-kernel durations: graph nodes cannot be bracketed by events, so the same K batches are run once more,
+    # eagerly, right after the timed region with an event pair around every launch of ours (on the launch stream).
+    eager = stepper if not use_graph else TrackingStepper(model, K, args.rays, stepper.cam.detach(), lr=0.005,
+                                                          use_graph=False, world=1)
+    be.PROFILE = []
+    for i in range(args.warmup, total):
+        eager.step(*batches[i])
+    torch.cuda.synchronize()
     prof, be.PROFILE = be.PROFILE, None
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
@@ -148,7 +148,8 @@ def main():
             roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": n,
                     "avg_launch_us": round(tms / n * 1e3, 2), "bytes_per_launch": nbytes // n,
-                    "share_of_step": round(tms / (dt * 1e3), 4)}
+                    "share_of_step": round(tms / n / ms, 4),
+                    "all_kernels_us": {k: round(v[0] / v[2] * 1e3, 1) for k, v in sorted(agg.items())}}
         cpu = None if args.no_cpu_baseline else cpu_baseline(args, model, conf)
         line = {
             "metric": "rays/sec (fwd+bwd), one tracking iteration", "value": round(rays_total / dt, 1), "unit": "rays/s",
@@ -158,8 +159,9 @@ def main():
                                    f"(+640 sampler evaluations/ray), single MI355X fp32 [BASELINE configs[1]]",
                        "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "sampler_evals_per_ray": 640,
                        "global_rays": args.rays * world, "engine": model.last_engine, "param_grads": args.param_grads,
+                       "hip_graph": bool(use_graph),
                        "parallelism": f"ray-shard x{world}" if world > 1 else "single"},
-            "final_loss": round(float(last), 6),
+            "final_loss": round(last, 6),
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

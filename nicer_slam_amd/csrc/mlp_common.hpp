@@ -31,19 +31,41 @@ constexpr int COL_IN_STEPS = 65;   // 129 inputs -> 65 slots per half-wave (one 
 
 __host__ __device__ constexpr int a_block_floats(int mt, int ks) { return mt * ((ks + 3) / 4) * 64 * 4; }
 
-// acc[mt] += sum_{s < KS} A(mt, s) * b[s]
+// Two k-step groups (8 MFMAs per tile) of "A" fragments in flight ahead of the matrix pipe: the fragments are L2 hits
+// (~200-300 cycles), one group of MFMAs is 256*MT cycles, so the wave never waits on them once the pipeline is primed.
+// gemm_preload() can be issued BEFORE the elementwise epilogue of the previous layer so that the first groups
+// arrive under the softplus / gather code.
+template <int MT>
+struct AFrag {
+    float4 g0[MT], g1[MT];
+};
+
 template <int KS, int MT>
-__device__ __forceinline__ void gemm_op(const float* __restrict__ wp, int lane, const float (&b)[KS], f32x16 (&acc)[MT]) {
+__device__ __forceinline__ void gemm_preload(const float* __restrict__ wp, int lane, AFrag<MT>& f) {
     constexpr int KS4 = (KS + 3) / 4;
     const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wp) + lane;
-    // Fence the scheduler at GEMM boundaries: without it hipcc hoists the fragment loads of LATER layers above this
-    // one (it has a 512-register budget at one wave per SIMD) and the kernel spills.
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        f.g0[mt] = w4[(mt * KS4 + 0) * 64];
+        f.g1[mt] = w4[(mt * KS4 + (KS4 > 1 ? 1 : 0)) * 64];
+    }
+}
+
+// acc[mt] += sum_{s < KS} A(mt, s) * b[s]   (fragments of groups 0 and 1 already requested into f)
+template <int KS, int MT>
+__device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane, AFrag<MT>& f, const float (&b)[KS],
+                                         f32x16 (&acc)[MT]) {
+    constexpr int KS4 = (KS + 3) / 4;
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wp) + lane;
 #pragma unroll
     for (int s4 = 0; s4 < KS4; ++s4) {
         float4 a[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = w4[(mt * KS4 + s4) * 64];
+        for (int mt = 0; mt < MT; ++mt) {
+            a[mt] = f.g0[mt];
+            f.g0[mt] = f.g1[mt];
+            if (s4 + 2 < KS4) f.g1[mt] = w4[(mt * KS4 + s4 + 2) * 64];
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (4 * s4 + q < KS) {
@@ -55,32 +77,15 @@ __device__ __forceinline__ void gemm_op(const float* __restrict__ wp, int lane, 
             }
         }
     }
+    // keep later layers' loads from being hoisted above this GEMM (register pressure)
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Two point tiles sharing each weight fragment (NT = 2).
 template <int KS, int MT>
-__device__ __forceinline__ void gemm_op2(const float* __restrict__ wp, int lane, const float (&b0)[KS], const float (&b1)[KS],
-                                         f32x16 (&acc0)[MT], f32x16 (&acc1)[MT]) {
-    constexpr int KS4 = (KS + 3) / 4;
-    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wp) + lane;
-#pragma unroll
-    for (int s4 = 0; s4 < KS4; ++s4) {
-        float4 a[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = w4[(mt * KS4 + s4) * 64];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (4 * s4 + q < KS) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const float av = q == 0 ? a[mt].x : q == 1 ? a[mt].y : q == 2 ? a[mt].z : a[mt].w;
-                    acc0[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[4 * s4 + q], acc0[mt], 0, 0, 0);
-                    acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1[4 * s4 + q], acc1[mt], 0, 0, 0);
-                }
-            }
-        }
-    }
+__device__ __forceinline__ void gemm_op(const float* __restrict__ wp, int lane, const float (&b)[KS], f32x16 (&acc)[MT]) {
+    AFrag<MT> f;
+    gemm_preload<KS, MT>(wp, lane, f);
+    gemm_run<KS, MT>(wp, lane, f, b, acc);
 }
 
 // Load a packed per-feature vector (bias) for MT tiles into accumulator layout.
@@ -108,13 +113,13 @@ __device__ __forceinline__ float softplus100(float a) {
 __device__ __forceinline__ float softplus100_d1(float a) {
     const float t = 100.0f * a;
     const float e = __expf(t);
-    return t > 20.0f ? 1.0f : e / (e + 1.0f);
+    return t > 20.0f ? 1.0f : e * __frcp_rn(e + 1.0f);
 }
 __device__ __forceinline__ void softplus100_all(float a, float& y, float& d1, float& d2) {
     const float t = 100.0f * a;
     const float e = __expf(t);
     const bool lin = t > 20.0f;
-    const float s = e / (e + 1.0f);
+    const float s = e * __frcp_rn(e + 1.0f);
     y = lin ? a : 0.01f * __logf(1.0f + e);
     d1 = lin ? 1.0f : s;
     d2 = lin ? 0.0f : 100.0f * s * (1.0f - s);

@@ -218,3 +218,23 @@ def test_fused_rays_vs_torch_path():
     for i, what in enumerate(("rays_o", "rays_d", "depth_scale")):
         assert_close(res[0][i], res[1][i], 1e-7, 2e-6, what)
     assert_close(res[0][3], res[1][3], 1e-4 * float(res[1][3].abs().max()), 1e-4, "camera-tensor gradient")
+
+
+def test_graph_captured_tracking_step_matches_eager():
+    """TrackingStepper: the hipGraph-captured iteration (forward + backward + Adam in one replay) follows exactly the
+    same camera trajectory as the eager iteration when both see the same pre-drawn randoms."""
+    from nicer_slam_amd.tracking import TrackingStepper
+    fx, model, cam, pose, _, _ = _setup("full_tracking")
+    model.train(True)
+    model.engine = "fused"
+    model.draws = draws_of(fx, "cuda")
+    K, uv, gt = tt(fx["in_K"]).cuda(), tt(fx["in_uv"]).cuda(), tt(fx["gt_rgb"]).cuda()
+    cam0 = tt(fx["in_cam"]).reshape(-1)
+    out = {}
+    for use_graph in (False, True):
+        st = TrackingStepper(model, K, uv.shape[1], cam0, lr=0.005, use_graph=use_graph)
+        losses = [float(st.step(uv, gt)) for _ in range(4)]
+        out[use_graph] = (st.cam.detach().clone(), losses)
+    assert_close(out[True][0], out[False][0], 1e-6, 1e-5, "camera after 4 steps")
+    assert abs(out[True][1][0] - float(fx["out_loss"])) < 5e-5      # first-iteration loss = the reference's
+    assert out[True][1][-1] < out[True][1][0]                        # and tracking actually descends

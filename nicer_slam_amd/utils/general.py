@@ -23,7 +23,8 @@ def get_camera_from_tensor(inputs):
         inputs = inputs.unsqueeze(0)
     R = quad2rotation(inputs[:, :4])
     top = torch.cat([R, inputs[:, 4:, None]], 2)
-    bottom = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=top.dtype, device=top.device).expand(top.shape[0], 1, 4)
+    bottom = top.new_zeros(top.shape[0], 1, 4)      # built on the device: no H2D copy (hipGraph-capture safe)
+    bottom[:, :, 3] = 1.0
     RT = torch.cat([top, bottom], 1)
     return RT[0] if single else RT
 

@@ -40,6 +40,7 @@ class TrackingStepper:
         return loss
 
     def _capture(self):
+        cam0 = self.cam.detach().clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -49,6 +50,13 @@ class TrackingStepper:
                 if self.graph_all:
                     self.opt.step()
         torch.cuda.current_stream().wait_stream(side)
+        # undo the warm-up: same camera and a fresh optimizer state (zeroed IN PLACE: the graph captures these tensors)
+        with torch.no_grad():
+            self.cam.copy_(cam0)
+            for st in self.opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
         self.cam.grad = None
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):

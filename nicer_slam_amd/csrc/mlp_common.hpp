@@ -102,6 +102,17 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ vp, int h, f3
     }
 }
 
+// Two waves share a SIMD's matrix pipe and VALU issue port.  Running the same program from the same start they stay
+// in lock-step (both in a VALU phase, then both in an MFMA phase) and the two pipes never overlap -- measured:
+// MFMA-busy + VALU-active cycles == wave cycles.  Giving the co-resident waves different static priorities makes the
+// favoured wave run ahead; the other fills the slots it leaves and the phases become complementary (matrix beside
+// VALU).  The wave slot id (HW_REG_HW_ID[3:0]) differs between the waves of one SIMD.
+__device__ __forceinline__ void desync_simd_partners() {
+    const unsigned slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);   // hwreg(HW_REG_HW_ID, 0, 4) = WAVE_ID
+    if (slot & 1u) __builtin_amdgcn_s_setprio(1);
+    else           __builtin_amdgcn_s_setprio(0);
+}
+
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
 
 // Softplus(beta = 100) with PyTorch's threshold 20 (base_networks.py:153), its derivative sigmoid(100 a) and the

@@ -134,7 +134,8 @@ __device__ __forceinline__ void colour_mlp(const float* __restrict__ wp, int lan
     }
 }
 
-__global__ __launch_bounds__(256) void k_colour_fwd(ColourArgs a, GridGeom16 geom) {
+__global__ __launch_bounds__(256, 2) void k_colour_fwd(ColourArgs a, GridGeom16 geom) {
+    desync_simd_partners();
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
     const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -158,7 +159,8 @@ __global__ __launch_bounds__(256) void k_colour_fwd(ColourArgs a, GridGeom16 geo
     }
 }
 
-__global__ __launch_bounds__(256) void k_colour_bwd(ColourArgs a, GridGeom16 geom) {
+__global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 geom) {
+    desync_simd_partners();
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
     const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -47,7 +47,8 @@ __device__ __forceinline__ float cube_far(const float (&o)[3], const float (&d)[
 }
 
 template <int LC, int CC, int NHC, int LF, int CF, int NHF>
-__global__ __launch_bounds__(256) void k_sampler_sdf(SamplerArgs a, GridGeom16 gc, GridGeom16 gf) {
+__global__ __launch_bounds__(256, 2) void k_sampler_sdf(SamplerArgs a, GridGeom16 gc, GridGeom16 gf) {
+    desync_simd_partners();
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -81,19 +82,11 @@ __global__ __launch_bounds__(256) void k_sampler_sdf(SamplerArgs a, GridGeom16 g
     for (int k = 0; k < 3; ++k) x[k] = o[k] + mul_rn(zi, d[k]);
 
     float in[SDF_IN_STEPS];
-    float sdf;
-    {
-        float jdummy[LC / 2][3][CC];
-        sdf_net_inputs<LC, CC, false>(x, a.df_c, a.table_c, gc, h, in, jdummy);
-        sdf = sdf_only<NHC>(a.wp_c, lane, h, in);
-    }
-    {
-        float jdummy[LF / 2][3][CF];
-        // the positional-encoding slots (0..19) are identical for both nets; only the grid slots change
-        float in_f[SDF_IN_STEPS];
-        sdf_net_inputs<LF, CF, false>(x, a.df_f, a.table_f, gf, h, in_f, jdummy);
-        sdf += sdf_only<NHF>(a.wp_f, lane, h, in_f);
-    }
+    pe_slots(x, h, in);                         // shared by both networks
+    grid_slots<LC, CC>(x, a.df_c, a.table_c, gc, h, in);
+    float sdf = sdf_only<NHC>(a.wp_c, lane, h, in);
+    grid_slots<LF, CF>(x, a.df_f, a.table_f, gf, h, in);
+    sdf += sdf_only<NHF>(a.wp_f, lane, h, in);
     if (live && h == 0) {
         a.z[pid] = zi;
         a.sdf[pid] = sdf;

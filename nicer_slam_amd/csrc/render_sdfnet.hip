@@ -101,8 +101,9 @@ __device__ __forceinline__ void reverse_pass(const float* __restrict__ wp, int l
 }
 
 template <int L, int C, int NH>
-__global__ __launch_bounds__(256) void k_sdfnet_fwd(SdfNetArgs a, GridGeom16 geom) {
+__global__ __launch_bounds__(256, 2) void k_sdfnet_fwd(SdfNetArgs a, GridGeom16 geom) {
     using P = SdfPack<NH>;
+    desync_simd_partners();
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
     const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -159,9 +160,11 @@ __global__ __launch_bounds__(256) void k_sdfnet_fwd(SdfNetArgs a, GridGeom16 geo
     }
 }
 
+// NH == 1 fits two waves per SIMD (a few spilled dwords); NH == 3 needs the whole register file (one wave per SIMD).
 template <int L, int C, int NH>
-__global__ __launch_bounds__(256) void k_sdfnet_bwd(SdfNetArgs a, GridGeom16 geom) {
+__global__ __launch_bounds__(256, (NH == 1 ? 2 : 1)) void k_sdfnet_bwd(SdfNetArgs a, GridGeom16 geom) {
     using P = SdfPack<NH>;
+    desync_simd_partners();
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
     const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -46,22 +46,23 @@ struct SdfPack {
     __host__ __device__ static constexpr int wht(int k) { return kWHT + (NH - 1 - k) * 4096; }       // k = 1..NH-1
 };
 
-// First-layer inputs of one SDF net for one point, as seen by lane half h.  Optionally keeps the Jacobian rows of
-// this lane's levels (d feature / d u, u = (x/df + 1)/2) and the sin/cos values for the gradient pass.
-template <int L, int C, bool KEEP>
-__device__ __forceinline__ void sdf_net_inputs(const float (&x)[3], float divide_factor, const float* __restrict__ table,
-                                               const GridGeom16& geom, int h, float (&in)[SDF_IN_STEPS],
-                                               float (&jac)[L / 2][3][C]) {
+// Position + positional-encoding slots 0..19 (identical for the coarse and the fine network).
+__device__ __forceinline__ void pe_slots(const float (&x)[3], int h, float (&in)[SDF_IN_STEPS]) {
     in[0] = h ? x[2] : x[0];
     in[1] = h ? 0.0f : x[1];
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-        constexpr int dummy = 0; (void)dummy;
         const int g0 = 2 * j, g1 = 2 * j + 1;
         const float xa = h ? x[g1 % 3] : x[g0 % 3];
         const float sc = h ? (float)(1 << (g1 / 3)) : (float)(1 << (g0 / 3));
         sincos_f(xa * sc, in[2 + 2 * j], in[3 + 2 * j]);
     }
+}
+
+// Grid-feature slots 20..35: the L/2 levels (2*jl + h) of this lane, C channels each.
+template <int L, int C>
+__device__ __forceinline__ void grid_slots(const float (&x)[3], float divide_factor, const float* __restrict__ table,
+                                           const GridGeom16& geom, int h, float (&in)[SDF_IN_STEPS]) {
     float u[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) u[d] = (x[d] / divide_factor + 1.0f) / 2.0f;   // hashgrid.py:203 (size = 1)
@@ -77,16 +78,17 @@ __device__ __forceinline__ void sdf_net_inputs(const float (&x)[3], float divide
         blend<3, C>(v, w, f);
 #pragma unroll
         for (int c = 0; c < C; ++c) in[20 + jl * C + c] = inside ? f[c] : 0.0f;
-        if (KEEP) {
-#pragma unroll
-            for (int gd = 0; gd < 3; ++gd) {
-                float jr[C];
-                jacobian_row<3, C>(v, w, dw, g.scale, gd, jr);
-#pragma unroll
-                for (int c = 0; c < C; ++c) jac[jl][gd][c] = inside ? jr[c] : 0.0f;
-            }
-        }
     }
+}
+
+// First-layer inputs of one SDF net for one point, as seen by lane half h.
+template <int L, int C, bool KEEP>
+__device__ __forceinline__ void sdf_net_inputs(const float (&x)[3], float divide_factor, const float* __restrict__ table,
+                                               const GridGeom16& geom, int h, float (&in)[SDF_IN_STEPS],
+                                               float (&jac)[L / 2][3][C]) {
+    (void)jac;
+    pe_slots(x, h, in);
+    grid_slots<L, C>(x, divide_factor, table, geom, h, in);
 }
 
 // NOTE on out-of-range points: the table gather above still runs for them (addresses stay inside the level because

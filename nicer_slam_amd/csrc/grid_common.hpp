@@ -15,6 +15,7 @@ namespace nsa {
 constexpr uint32_t LV_HASHED = 1u;    // index = xor-prime hash of the cell
 constexpr uint32_t LV_POW2 = 2u;      // rows is a power of two: modulo == mask
 constexpr uint32_t LV_SUBONCE = 4u;   // dense and idx < 2*rows guaranteed: modulo == one conditional subtract
+constexpr uint32_t LV_GENERIC = 8u;   // neither: needs a true uint32 modulo (never the case for the shipped grids)
 
 struct LevelGeom {
     float scale;     // exp2f(level*S)*H - 1   (float32, hashencoder.cu:180)
@@ -23,6 +24,8 @@ struct LevelGeom {
     uint32_t s1;     // dense stride of dim 1 (= res, uint32)
     uint32_t s2;     // dense stride of dim 2 (= res*res, uint32 wrap)
     uint32_t flags;
+    uint32_t mask;   // rows-1 when rows is a power of two, else 0xFFFFFFFF (so `idx & mask` is always legal)
+    uint32_t pad;
 };
 
 struct GridGeom {
@@ -55,9 +58,18 @@ inline int make_grid_geom(const int32_t* offsets_host, uint32_t L, uint32_t D, f
         if (stride > g.rows) g.flags |= LV_HASHED;
         if ((g.rows & (g.rows - 1)) == 0) g.flags |= LV_POW2;
         else if (!(g.flags & LV_HASHED) && !wrapped && max_idx < 2ull * g.rows) g.flags |= LV_SUBONCE;
+        else g.flags |= LV_GENERIC;
+        g.mask = (g.flags & LV_POW2) ? g.rows - 1u : 0xFFFFFFFFu;
+        g.pad = 0;
         out->lv[l] = g;
     }
     return NSA_OK;
+}
+
+inline bool has_generic_level(const LevelGeom* lv, uint32_t L) {
+    for (uint32_t l = 0; l < L; ++l)
+        if (lv[l].flags & LV_GENERIC) return true;
+    return false;
 }
 
 // hipGetLastError() also reports stale non-errors left by OTHER runtime calls on this host thread (e.g. PyTorch's
@@ -149,15 +161,43 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&v
 }
 
 // Gather the 2^D corner rows of the cell into registers: corner bit d set <=> +1 along dim d.
-template <int D, int C>
+// Branch-free (the level, hence hashed/dense, differs between the two half-waves): per dimension the two candidate
+// index terms (cell, cell+1) are formed once -- (q * prime) for hashed levels, (q * stride) for dense ones -- and the
+// 2^D corners combine them with xor resp. add; `& mask` and one conditional subtract implement the modulo for every
+// level class except LV_GENERIC, which only a pathological geometry produces: the stand-alone operator compiles the
+// slow path in (GENERIC = true), the fused kernels refuse such a grid on the host (has_generic_level).
+template <int D, int C, bool GENERIC = false>
 __device__ __forceinline__ void gather_corners(const float* __restrict__ table, const LevelGeom& g,
                                                const uint32_t (&cell)[D], float (&v)[1 << D][C]) {
+    const bool hashed = (g.flags & LV_HASHED) != 0;
+    uint32_t term[D][2];
+    term[0][0] = cell[0];
+    term[0][1] = cell[0] + 1u;
+    if (D > 1) {
+        const uint32_t m1 = hashed ? 2654435761u : g.s1;
+        term[1][0] = cell[1] * m1;
+        term[1][1] = term[1][0] + m1;
+    }
+    if (D > 2) {
+        const uint32_t m2 = hashed ? 805459861u : g.s2;
+        term[2][0] = cell[2] * m2;
+        term[2][1] = term[2][0] + m2;
+    }
 #pragma unroll
     for (int corner = 0; corner < (1 << D); ++corner) {
-        uint32_t q[D];
+        uint32_t x = term[0][corner & 1], a = x;
 #pragma unroll
-        for (int d = 0; d < D; ++d) q[d] = cell[d] + ((corner >> d) & 1);
-        load_row<C>(table + (size_t)(g.row0 + level_row<D>(g, q)) * C, v[corner]);
+        for (int d = 1; d < D; ++d) {
+            const uint32_t t = term[d][(corner >> d) & 1];
+            x ^= t;
+            a += t;
+        }
+        uint32_t idx = (hashed ? x : a) & g.mask;
+        idx = idx >= g.rows ? idx - g.rows : idx;
+        if (GENERIC) {
+            if ((g.flags & LV_GENERIC) != 0) idx = (hashed ? x : a) % g.rows;
+        }
+        load_row<C>(table + (size_t)(g.row0 + idx) * C, v[corner]);
     }
 }
 

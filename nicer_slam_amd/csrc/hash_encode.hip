@@ -47,7 +47,7 @@ __global__ __launch_bounds__(TPB) void k_grid_forward(const float* __restrict__ 
         return;
     }
     float v[1 << D][C];
-    gather_corners<D, C>(emb, g, cell, v);
+    gather_corners<D, C, true>(emb, g, cell, v);
     blend<D, C>(v, w, out);
     store_row<C>(o, out);
     if (JAC) {

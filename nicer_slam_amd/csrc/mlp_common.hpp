@@ -117,21 +117,29 @@ __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 3
 
 // Softplus(beta = 100) with PyTorch's threshold 20 (base_networks.py:153), its derivative sigmoid(100 a) and the
 // second derivative 100 s (1 - s) (zero in the linear region, like torch's double backward).
+// Softplus(beta = 100) with PyTorch's threshold 20 (base_networks.py:153), its derivative sigmoid(100 a) and the second
+// derivative 100 s (1 - s) (zero in the linear region, like torch's double backward).  exp / log go through the raw
+// base-2 v_exp_f32 / v_log_f32 with the constants folded in: arguments stay in [.., 2^29] resp. [1, 2^29], so the library
+// wrappers' denormal fix-ups (v_ldexp + compares) would be dead weight.
+constexpr float SP_K = 100.0f * 1.4426950408889634f;       // beta * log2(e)
+constexpr float SP_LIN = 20.0f * 1.4426950408889634f;      // threshold in the same units
+constexpr float SP_OUT = 0.01f * 0.6931471805599453f;      // ln(2) / beta
+
 __device__ __forceinline__ float softplus100(float a) {
-    const float t = 100.0f * a;
-    return t > 20.0f ? a : 0.01f * __logf(1.0f + __expf(t));
+    const float t = SP_K * a;
+    return t > SP_LIN ? a : SP_OUT * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(t));
 }
 __device__ __forceinline__ float softplus100_d1(float a) {
-    const float t = 100.0f * a;
-    const float e = __expf(t);
-    return t > 20.0f ? 1.0f : e * __frcp_rn(e + 1.0f);
+    const float t = SP_K * a;
+    const float e = __builtin_amdgcn_exp2f(t);
+    return t > SP_LIN ? 1.0f : e * __frcp_rn(e + 1.0f);
 }
 __device__ __forceinline__ void softplus100_all(float a, float& y, float& d1, float& d2) {
-    const float t = 100.0f * a;
-    const float e = __expf(t);
-    const bool lin = t > 20.0f;
+    const float t = SP_K * a;
+    const float e = __builtin_amdgcn_exp2f(t);
+    const bool lin = t > SP_LIN;
     const float s = e * __frcp_rn(e + 1.0f);
-    y = lin ? a : 0.01f * __logf(1.0f + e);
+    y = lin ? a : SP_OUT * __builtin_amdgcn_logf(1.0f + e);
     d1 = lin ? 1.0f : s;
     d2 = lin ? 0.0f : 100.0f * s * (1.0f - s);
 }

@@ -24,6 +24,7 @@ inline int make_grid_geom16(const int32_t* offsets_host, uint32_t L, float S, ui
     GridGeom g;
     if (int rc = make_grid_geom(offsets_host, L, 3, S, H, &g)) return rc;
     for (uint32_t l = 0; l < L; ++l) out->lv[l] = g.lv[l];
+    if (has_generic_level(out->lv, L)) return NSA_EUNSUPPORTED_NET;   // fused kernels carry no generic-modulo path
     return NSA_OK;
 }
 

@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--param-grads", action="store_true",
                     help="also produce (and discard) table/MLP gradients like the reference's tracking loop")
     ap.add_argument("--no-graph", action="store_true", help="launch every op eagerly instead of replaying a hipGraph")
+    ap.add_argument("--autograd", action="store_true",
+                    help="drive the model through torch autograd (TrackingStepper) instead of the kernel sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=64)
     return ap.parse_args()
@@ -95,9 +97,10 @@ def main():
     cam = cam + 1e-3 * torch.randn(7, device=device, generator=gen)
     if world > 1:
         dist.broadcast(cam, 0)
-    from nicer_slam_amd.tracking import TrackingStepper
+    from nicer_slam_amd.tracking import TrackingStepper, KernelTracker
     use_graph = not args.no_graph and not args.param_grads
-    stepper = TrackingStepper(model, K, args.rays, cam, lr=0.005, use_graph=use_graph, world=world)
+    Stepper = TrackingStepper if (args.autograd or args.param_grads) else KernelTracker
+    stepper = Stepper(model, K, args.rays, cam, lr=0.005, use_graph=use_graph, world=world)
 
     def step(i):
         uv, gt = batches[i]
@@ -119,8 +122,8 @@ def main():
     last = float(last)
     # Per-kernel durations: graph nodes cannot be bracketed by events, so the same K batches are run once more,
     # eagerly, right after the timed region with an event pair around every launch of ours (on the launch stream).
-    eager = stepper if not use_graph else TrackingStepper(model, K, args.rays, stepper.cam.detach(), lr=0.005,
-                                                          use_graph=False, world=1)
+    eager = stepper if not use_graph else Stepper(model, K, args.rays, stepper.cam.detach(), lr=0.005,
+                                                  use_graph=False, world=1)
     be.PROFILE = []
     for i in range(args.warmup, total):
         eager.step(*batches[i])
@@ -159,7 +162,7 @@ def main():
                                    f"(+640 sampler evaluations/ray), single MI355X fp32 [BASELINE configs[1]]",
                        "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "sampler_evals_per_ray": 640,
                        "global_rays": args.rays * world, "engine": model.last_engine, "param_grads": args.param_grads,
-                       "hip_graph": bool(use_graph),
+                       "hip_graph": bool(use_graph), "driver": Stepper.__name__,
                        "parallelism": f"ray-shard x{world}" if world > 1 else "single"},
             "final_loss": round(last, 6),
             "roofline": roof, "cpu_baseline": cpu,

@@ -172,6 +172,24 @@ int nsa_sample_rays(const float *rays_o, const float *rays_d, const float *z, co
                     const int32_t *extra_idx, uint32_t n_extra, float near, const int32_t *eik_idx, float *z_vals,
                     float *z_eik, nsa_stream_t stream);
 
+/* ---- Section 3: scalar head/tail of a tracking iteration (so a whole iteration is a fixed kernel sequence) ---- */
+
+/* cam[b,7] = (qw,qx,qy,qz,tx,ty,tz) -> pose[b,4,4].  replaces quad2rotation / get_camera_from_tensor
+ * (code/utils/general.py:52-100); nsa_pose_grad_to_cam is its backward (g_pose[b,4,4] -> g_cam[b,7]). */
+int nsa_cam_to_pose(const float *cam, uint32_t b, float *pose, nsa_stream_t stream);
+int nsa_pose_grad_to_cam(const float *cam, const float *g_pose, uint32_t b, float *g_cam, nsa_stream_t stream);
+
+/* loss[0] = mean |pred - target| over n scalars, g_pred = sign(pred - target)/n.  replaces SLAMLoss.get_rgb_loss with
+ * torch.nn.L1Loss(reduction="mean") (code/model/loss.py:57-65,131) and its backward. */
+int nsa_l1_loss(const float *pred, const float *target, uint32_t n, float *loss, float *g_pred, nsa_stream_t stream);
+
+/* torch.optim.Adam step (no weight decay / amsgrad) on n <= 256 parameters; `step` is a device scalar that is
+ * incremented; lr_step > 0 applies StepLR(lr_step, lr_gamma).  replaces optimizer_camera.step() +
+ * scheduler_camera.step() (code/training/volsdf_train.py:396-399,425-427). */
+int nsa_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, uint32_t n,
+                  float lr, float beta1, float beta2, float eps, uint32_t lr_step, float lr_gamma,
+                  nsa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,3 +85,13 @@ lib.nsa_rays_forward.argtypes = [_p, _p, _p, _u32, _u32, _p, _p, _p, _p]
 lib.nsa_rays_pose_backward.restype = _i
 lib.nsa_rays_pose_backward.argtypes = [_p, _p, _p, _u32, _u32, _p, _p, _p, _p]
 EXPORTS += ["nsa_rays_forward", "nsa_rays_pose_backward"]
+
+lib.nsa_cam_to_pose.restype = _i
+lib.nsa_cam_to_pose.argtypes = [_p, _u32, _p, _p]
+lib.nsa_pose_grad_to_cam.restype = _i
+lib.nsa_pose_grad_to_cam.argtypes = [_p, _p, _u32, _p, _p]
+lib.nsa_l1_loss.restype = _i
+lib.nsa_l1_loss.argtypes = [_p, _p, _u32, _p, _p, _p]
+lib.nsa_adam_step.restype = _i
+lib.nsa_adam_step.argtypes = [_p, _p, _p, _p, _p, _u32, _f32, _f32, _f32, _f32, _u32, _f32, _p]
+EXPORTS += ["nsa_cam_to_pose", "nsa_pose_grad_to_cam", "nsa_l1_loss", "nsa_adam_step"]

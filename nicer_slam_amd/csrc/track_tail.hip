@@ -1,0 +1,144 @@
+// track_tail.hip -- the scalar head and tail of a camera-tracking iteration, so that a whole iteration is a fixed
+// sequence of our kernels with no autograd bookkeeping in between (SURVEY 8a rows a16, a17 + the camera optimizer):
+//   k_cam_to_pose        7-vector (qw,qx,qy,qz,tx,ty,tz) -> 4x4 camera-to-world, two_s = 2/|q|^2
+//                        (code/utils/general.py:52-100: quad2rotation / get_camera_from_tensor)
+//   k_l1_loss            loss = mean |rgb - gt| and d loss / d rgb = sign(rgb - gt) / N
+//                        (code/model/loss.py:57-65,131 with rgb_loss = torch.nn.L1Loss, the tracking objective)
+//   k_pose_grad_to_cam   backward of k_cam_to_pose
+//   k_adam               torch.optim.Adam update of the (tiny) camera vector, optional StepLR schedule
+//                        (code/training/volsdf_train.py:396-399,425-427)
+#include "grid_common.hpp"
+
+namespace nsa {
+
+__global__ void k_cam_to_pose(const float* __restrict__ cam, float* __restrict__ pose, uint32_t b) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= b) return;
+    const float* q = cam + 7 * n;
+    float* P = pose + 16 * n;
+    const float r = q[0], i = q[1], j = q[2], k = q[3];
+    const float s = 2.0f / (r * r + i * i + j * j + k * k);
+    P[0] = -s * (j * j + k * k) + 1.0f;  P[1] = s * (i * j - k * r);          P[2] = s * (i * k + j * r);           P[3] = q[4];
+    P[4] = s * (i * j + k * r);          P[5] = -s * (i * i + k * k) + 1.0f;  P[6] = s * (j * k - i * r);           P[7] = q[5];
+    P[8] = s * (i * k - j * r);          P[9] = s * (j * k + i * r);          P[10] = -s * (i * i + j * j) + 1.0f;  P[11] = q[6];
+    P[12] = 0.0f; P[13] = 0.0f; P[14] = 0.0f; P[15] = 1.0f;
+}
+
+// out[0..6] = d loss / d cam of image n (n < b), from g_pose[b,4,4]
+__global__ void k_pose_grad_to_cam(const float* __restrict__ cam, const float* __restrict__ g_pose, float* __restrict__ g_cam,
+                                   uint32_t b) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= b) return;
+    const float* q = cam + 7 * n;
+    const float* G = g_pose + 16 * n;
+    const float r = q[0], i = q[1], j = q[2], k = q[3];
+    const float nn = r * r + i * i + j * j + k * k;
+    const float s = 2.0f / nn;
+    const float N[9] = {-(j * j + k * k), i * j - k * r, i * k + j * r, i * j + k * r, -(i * i + k * k), j * k - i * r,
+                        i * k - j * r, j * k + i * r, -(i * i + j * j)};
+    float A = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) A += G[4 * a + c] * N[3 * a + c];
+#define GG(a, c) G[4 * (a) + (c)]
+    const float dr = -k * GG(0, 1) + j * GG(0, 2) + k * GG(1, 0) - i * GG(1, 2) - j * GG(2, 0) + i * GG(2, 1);
+    const float di = j * GG(0, 1) + k * GG(0, 2) + j * GG(1, 0) - 2 * i * GG(1, 1) - r * GG(1, 2) + k * GG(2, 0) + r * GG(2, 1) - 2 * i * GG(2, 2);
+    const float dj = -2 * j * GG(0, 0) + i * GG(0, 1) + r * GG(0, 2) + i * GG(1, 0) + k * GG(1, 2) - r * GG(2, 0) + k * GG(2, 1) - 2 * j * GG(2, 2);
+    const float dk = -2 * k * GG(0, 0) - r * GG(0, 1) + i * GG(0, 2) + r * GG(1, 0) - 2 * k * GG(1, 1) + j * GG(1, 2) + i * GG(2, 0) + j * GG(2, 1);
+    float* o = g_cam + 7 * n;
+    o[0] = -s * s * r * A + s * dr;
+    o[1] = -s * s * i * A + s * di;
+    o[2] = -s * s * j * A + s * dj;
+    o[3] = -s * s * k * A + s * dk;
+    o[4] = GG(0, 3); o[5] = GG(1, 3); o[6] = GG(2, 3);
+#undef GG
+}
+
+// single block; n = number of scalars (3 R)
+__global__ __launch_bounds__(256) void k_l1_loss(const float* __restrict__ pred, const float* __restrict__ target, float* __restrict__ loss,
+                                                 float* __restrict__ g_pred, uint32_t n) {
+    __shared__ float part[4];
+    const float inv = 1.0f / (float)n;
+    float acc = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const float d = pred[i] - target[i];
+        acc += fabsf(d);
+        g_pred[i] = d > 0.0f ? inv : (d < 0.0f ? -inv : 0.0f);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (part[0] + part[1] + part[2] + part[3]) * inv;
+}
+
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v; float* step;   // step: device scalar, incremented here
+    uint32_t n;
+    float lr, beta1, beta2, eps, lr_gamma;
+    uint32_t lr_step;                                            // 0 = constant lr
+};
+
+__global__ void k_adam(AdamArgs a) {
+    const uint32_t i = threadIdx.x;
+    const float t = a.step[0] + 1.0f;
+    if (i < a.n) {
+        const float g = a.g[i];
+        const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
+        a.m[i] = m;
+        a.v[i] = v;
+        const double bc1 = 1.0 - pow((double)a.beta1, (double)t);
+        const double bc2 = 1.0 - pow((double)a.beta2, (double)t);
+        float lr = a.lr;
+        if (a.lr_step) lr *= (float)pow((double)a.lr_gamma, floor(((double)t - 1.0) / (double)a.lr_step));
+        const float step_size = (float)((double)lr / bc1);
+        const float denom = sqrtf(v) / (float)sqrt(bc2) + a.eps;
+        a.p[i] -= step_size * m / denom;
+    }
+    __syncthreads();
+    if (i == 0) a.step[0] = t;
+}
+
+}  // namespace nsa
+
+extern "C" {
+
+int nsa_cam_to_pose(const float* cam, uint32_t b, float* pose, nsa_stream_t stream) {
+    using namespace nsa;
+    if (b == 0) return NSA_OK;
+    if (!cam || !pose) return NSA_EBADARG;
+    launch_begin();
+    hipLaunchKernelGGL(k_cam_to_pose, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, cam, pose, b);
+    return launch_end();
+}
+
+int nsa_pose_grad_to_cam(const float* cam, const float* g_pose, uint32_t b, float* g_cam, nsa_stream_t stream) {
+    using namespace nsa;
+    if (b == 0) return NSA_OK;
+    if (!cam || !g_pose || !g_cam) return NSA_EBADARG;
+    launch_begin();
+    hipLaunchKernelGGL(k_pose_grad_to_cam, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, cam, g_pose, g_cam, b);
+    return launch_end();
+}
+
+int nsa_l1_loss(const float* pred, const float* target, uint32_t n, float* loss, float* g_pred, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!pred || !target || !loss || !g_pred || n == 0) return NSA_EBADARG;
+    launch_begin();
+    hipLaunchKernelGGL(k_l1_loss, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, target, loss, g_pred, n);
+    return launch_end();
+}
+
+int nsa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, uint32_t n, float lr,
+                  float beta1, float beta2, float eps, uint32_t lr_step, float lr_gamma, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step || n == 0 || n > 256) return NSA_EBADARG;
+    AdamArgs a{param, grad, exp_avg, exp_avg_sq, step, n, lr, beta1, beta2, eps, lr_gamma, lr_step};
+    launch_begin();
+    hipLaunchKernelGGL(k_adam, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_end();
+}
+
+}  // extern "C"

@@ -60,98 +60,105 @@ def _pts(rays_o, rays_d, z_vals):
     return PointsDesc(rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(), None, R * S, S)
 
 
+def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd):
+    """Launch the forward kernels of the composite pass.  Returns a dict of device buffers."""
+    R, S = z_vals.shape
+    P = R * S
+    dev = z_vals.device
+    imp = model.implicit_network
+    gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1)
+    gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3)
+    gr, keep_r = grid_desc(model.rendering_network.encoding, model.rendering_network.divide_factor, 2)
+    pc, pf, pr = packed_sdf(model, "coarse"), packed_sdf(model, "fine"), packed_colour(model)
+    pts = _pts(rays_o, rays_d, z_vals)
+    b = dict(sdf=torch.empty(P, device=dev), grad=torch.empty(P, 3, device=dev), feat=torch.empty(hl_size(P), device=dev),
+             rgb=torch.empty(P, 3, device=dev), save=torch.empty(hl_size(P) * 2, device=dev) if need_bwd else None,
+             weights=torch.empty(R, S, device=dev), rgb_values=torch.empty(R, 3, device=dev),
+             depth=torch.empty(R, device=dev), nmap=torch.empty(R, 3, device=dev), entropy=torch.empty(R, device=dev),
+             vox=model.voxels.contiguous(), packs=(pc, pf, pr), keep=(keep_c, keep_f, keep_r))
+    st = _stream()
+    with _timed("k_sdfnet_fwd<coarse>", P * 4 * 8 * 8 * 4):
+        check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), 0, b["sdf"].data_ptr(),
+                                     b["grad"].data_ptr(), b["feat"].data_ptr(), st))
+    if stage != "coarse":
+        with _timed("k_sdfnet_fwd<fine>", P * 8 * 8 * 4 * 4):
+            check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), 1, b["sdf"].data_ptr(),
+                                         b["grad"].data_ptr(), b["feat"].data_ptr(), st))
+    with _timed("k_colour_fwd", P * 16 * 8 * 2 * 4):
+        check(lib.nsa_colour_forward(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
+                                     b["feat"].data_ptr(), b["rgb"].data_ptr(),
+                                     b["save"].data_ptr() if need_bwd else None, st))
+    with _timed("k_composite_fwd", P * 32):
+        check(lib.nsa_composite_forward(rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(), b["sdf"].data_ptr(),
+                                        b["rgb"].data_ptr(), b["grad"].data_ptr(), b["vox"].data_ptr(), model.voxel_res,
+                                        R, S, b["weights"].data_ptr(), b["rgb_values"].data_ptr(), b["depth"].data_ptr(),
+                                        b["nmap"].data_ptr(), b["entropy"].data_ptr(), st))
+    return b
+
+
+def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage, g_rgbv=None, g_depth=None, g_nmap=None,
+                           g_ent=None, g_w=None):
+    """Launch the backward kernels.  Returns (g_rays_o[R,3], g_rays_d[R,3])."""
+    R, S = z_vals.shape
+    P = R * S
+    dev = z_vals.device
+    imp = model.implicit_network
+    gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1)
+    gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3)
+    gr, keep_r = grid_desc(model.rendering_network.encoding, model.rendering_network.divide_factor, 2)
+    pc, pf, pr = b["packs"]
+    pts = _pts(rays_o, rays_d, z_vals)
+    st = _stream()
+    ptr = lambda t: None if t is None else t.data_ptr()
+    gs = [None if g is None else g.contiguous() for g in (g_rgbv, g_depth, g_nmap, g_ent, g_w)]
+    g_sdf = torch.empty(P, device=dev)
+    g_rgb = torch.empty(P, 3, device=dev)
+    g_grad = torch.empty(P, 3, device=dev)
+    with _timed("k_composite_bwd", P * 60):
+        check(lib.nsa_composite_backward(rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(), b["sdf"].data_ptr(),
+                                         b["rgb"].data_ptr(), b["grad"].data_ptr(), b["vox"].data_ptr(), model.voxel_res,
+                                         R, S, ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gs[4]),
+                                         g_sdf.data_ptr(), g_rgb.data_ptr(), g_grad.data_ptr(), st))
+    g_feat = torch.empty(hl_size(P), device=dev)
+    g_x = torch.empty(P, 3, device=dev)
+    g_dir = torch.empty(P, 3, device=dev)
+    with _timed("k_colour_bwd", P * 512):
+        check(lib.nsa_colour_backward(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
+                                      b["feat"].data_ptr(), b["save"].data_ptr(), g_rgb.data_ptr(),
+                                      1 if color_stage != "base" else 0, g_feat.data_ptr(), g_grad.data_ptr(),
+                                      g_x.data_ptr(), g_dir.data_ptr(), st))
+    with _timed("k_sdfnet_bwd<coarse>", P * 3 * 4 * 8 * 8 * 4):
+        check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), g_sdf.data_ptr(),
+                                      g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))
+    if stage != "coarse":
+        with _timed("k_sdfnet_bwd<fine>", P * 3 * 8 * 8 * 4 * 4):
+            check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), g_sdf.data_ptr(),
+                                          g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))
+    g_o = torch.empty(R, 3, device=dev)
+    g_d = torch.empty(R, 3, device=dev)
+    check(lib.nsa_rays_backward(z_vals.data_ptr(), g_x.data_ptr(), g_dir.data_ptr(), R, S, g_o.data_ptr(),
+                                g_d.data_ptr(), st))
+    return g_o, g_d
+
+
 class FusedComposite(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, z_vals, model, stage, color_stage):
         rays_o, rays_d, z_vals = rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous()
         R, S = z_vals.shape
-        P = R * S
-        dev = z_vals.device
-        imp = model.implicit_network
-        gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1)
-        gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3)
-        gr, keep_r = grid_desc(model.rendering_network.encoding, model.rendering_network.divide_factor, 2)
-        pc, pf, pr = packed_sdf(model, "coarse"), packed_sdf(model, "fine"), packed_colour(model)
-        pts = _pts(rays_o, rays_d, z_vals)
-        sdf = torch.empty(P, device=dev)
-        grad = torch.empty(P, 3, device=dev)
-        feat = torch.empty(hl_size(P), device=dev)
-        rgb = torch.empty(P, 3, device=dev)
-        need_bwd = any(ctx.needs_input_grad[:2])
-        save = torch.empty(hl_size(P) * 2, device=dev) if need_bwd else None
-        st = _stream()
-        with _timed("k_sdfnet_fwd<coarse>", P * 4 * 8 * 8 * 4):
-            check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), 0, sdf.data_ptr(),
-                                         grad.data_ptr(), feat.data_ptr(), st))
-        if stage != "coarse":
-            with _timed("k_sdfnet_fwd<fine>", P * 8 * 8 * 4 * 4):
-                check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), 1, sdf.data_ptr(),
-                                             grad.data_ptr(), feat.data_ptr(), st))
-        with _timed("k_colour_fwd", P * 16 * 8 * 2 * 4):
-            check(lib.nsa_colour_forward(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), grad.data_ptr(),
-                                         feat.data_ptr(), rgb.data_ptr(), save.data_ptr() if save is not None else None, st))
-        weights = torch.empty(R, S, device=dev)
-        rgb_values = torch.empty(R, 3, device=dev)
-        depth = torch.empty(R, device=dev)
-        nmap = torch.empty(R, 3, device=dev)
-        entropy = torch.empty(R, device=dev)
-        vox = model.voxels.contiguous()
-        with _timed("k_composite_fwd", P * 32):
-            check(lib.nsa_composite_forward(rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(), sdf.data_ptr(),
-                                            rgb.data_ptr(), grad.data_ptr(), vox.data_ptr(), model.voxel_res, R, S,
-                                            weights.data_ptr(), rgb_values.data_ptr(), depth.data_ptr(), nmap.data_ptr(),
-                                            entropy.data_ptr(), st))
-        ctx.save_for_backward(rays_o, rays_d, z_vals, sdf, grad, feat, rgb, save, vox)
-        ctx.model, ctx.stage, ctx.color_stage = model, stage, color_stage
-        ctx.packs = (pc, pf, pr)
-        ctx.keep = (keep_c, keep_f, keep_r)
-        sdf_o, rgb_o, grad_o = sdf.view(R, S), rgb.view(R, S, 3), grad
+        b = composite_forward_raw(model, rays_o, rays_d, z_vals, stage, any(ctx.needs_input_grad[:2]))
+        ctx.save_for_backward(rays_o, rays_d, z_vals)
+        ctx.bufs, ctx.model, ctx.stage, ctx.color_stage = b, model, stage, color_stage
+        sdf_o, rgb_o, grad_o = b["sdf"].view(R, S), b["rgb"].view(R, S, 3), b["grad"]
         ctx.mark_non_differentiable(sdf_o, rgb_o, grad_o)
-        return rgb_values, depth.unsqueeze(-1), nmap, weights, entropy, sdf_o, rgb_o, grad_o
+        return b["rgb_values"], b["depth"].unsqueeze(-1), b["nmap"], b["weights"], b["entropy"], sdf_o, rgb_o, grad_o
 
     @staticmethod
     def backward(ctx, g_rgbv, g_depth, g_nmap, g_w, g_ent, *_unused):
-        rays_o, rays_d, z_vals, sdf, grad, feat, rgb, save, vox = ctx.saved_tensors
-        model = ctx.model
-        R, S = z_vals.shape
-        P = R * S
-        dev = z_vals.device
-        imp = model.implicit_network
-        gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1)
-        gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3)
-        gr, keep_r = grid_desc(model.rendering_network.encoding, model.rendering_network.divide_factor, 2)
-        pc, pf, pr = ctx.packs
-        pts = _pts(rays_o, rays_d, z_vals)
-        st = _stream()
-        ptr = lambda t: None if t is None else t.contiguous().data_ptr()
-        gs = [None if g is None else g.contiguous() for g in (g_rgbv, g_depth, g_nmap, g_ent, g_w)]
-        g_sdf = torch.empty(P, device=dev)
-        g_rgb = torch.empty(P, 3, device=dev)
-        g_grad = torch.empty(P, 3, device=dev)
-        with _timed("k_composite_bwd", P * 60):
-            check(lib.nsa_composite_backward(rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(), sdf.data_ptr(),
-                                             rgb.data_ptr(), grad.data_ptr(), vox.data_ptr(), model.voxel_res, R, S,
-                                             ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gs[4]),
-                                             g_sdf.data_ptr(), g_rgb.data_ptr(), g_grad.data_ptr(), st))
-        g_feat = torch.empty(hl_size(P), device=dev)
-        g_x = torch.empty(P, 3, device=dev)
-        g_dir = torch.empty(P, 3, device=dev)
-        with _timed("k_colour_bwd", P * 512):
-            check(lib.nsa_colour_backward(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), grad.data_ptr(),
-                                          feat.data_ptr(), save.data_ptr(), g_rgb.data_ptr(),
-                                          1 if ctx.color_stage != "base" else 0, g_feat.data_ptr(), g_grad.data_ptr(),
-                                          g_x.data_ptr(), g_dir.data_ptr(), st))
-        with _timed("k_sdfnet_bwd<coarse>", P * 3 * 4 * 8 * 8 * 4):
-            check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), g_sdf.data_ptr(),
-                                          g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))
-        if ctx.stage != "coarse":
-            with _timed("k_sdfnet_bwd<fine>", P * 3 * 8 * 8 * 4 * 4):
-                check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), g_sdf.data_ptr(),
-                                              g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))
-        g_o = torch.empty(R, 3, device=dev)
-        g_d = torch.empty(R, 3, device=dev)
-        check(lib.nsa_rays_backward(z_vals.data_ptr(), g_x.data_ptr(), g_dir.data_ptr(), R, S, g_o.data_ptr(),
-                                    g_d.data_ptr(), st))
+        rays_o, rays_d, z_vals = ctx.saved_tensors
+        g_o, g_d = composite_backward_raw(ctx.model, rays_o, rays_d, z_vals, ctx.bufs, ctx.stage, ctx.color_stage,
+                                          g_rgbv, g_depth, g_nmap, g_ent, g_w)
+        ctx.bufs = None
         return g_o, g_d, None, None, None, None
 
 

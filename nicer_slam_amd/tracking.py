@@ -11,6 +11,98 @@ from .dist import allreduce_pose_grad
 from .utils.general import get_camera_from_tensor
 
 
+class KernelTracker:
+    """The same iteration with NO autograd in the loop: a fixed sequence of our kernels --
+    cam->pose, rays, sampler (2), SDF nets (2), colour, composite, L1, composite-bwd, colour-bwd, SDF-net-bwd (2),
+    ray reduction, pose-bwd, cam-bwd, [all-reduce], Adam -- launched through the C ABI; optionally one hipGraph.
+    Only tracking (pose gradient) is covered; it needs a configuration in the fused engine's compiled set."""
+
+    def __init__(self, model, intrinsics, n_rays, cam_init, lr=0.005, betas=(0.9, 0.999), eps=1e-8, lr_step=0,
+                 lr_gamma=1.0, use_graph=True, world=1, stage="fine", color_stage="highfreq"):
+        from .fused import render as fr, sampler as fs
+        if not fr.supported(model):
+            raise RuntimeError("KernelTracker: configuration outside the fused engine's compiled set")
+        dev = model.voxels.device
+        self.fr, self.fs = fr, fs
+        self.model, self.world, self.R = model, world, n_rays
+        self.K = intrinsics.contiguous()
+        self.stage, self.color_stage = stage, color_stage
+        self.hyper = (float(lr), float(betas[0]), float(betas[1]), float(eps), int(lr_step), float(lr_gamma))
+        self.cam = cam_init.detach().clone().to(dev).float().contiguous()
+        self.uv = torch.zeros(1, n_rays, 2, device=dev)
+        self.gt = torch.zeros(n_rays, 3, device=dev)
+        z = lambda *s: torch.zeros(*s, device=dev)
+        self.pose, self.g_pose, self.red = z(1, 4, 4), z(1, 4, 4), z(9)     # red = [g_cam(7), loss, n_rays]
+        self.m, self.v, self.t = z(7), z(7), z(1)
+        self.rays_o, self.rays_d, self.ds = z(n_rays, 3), z(n_rays, 3), z(n_rays)
+        self.g_rgbv = z(n_rays, 3)
+        self.graph = None
+        if use_graph:
+            self._capture()
+
+    @property
+    def loss(self):
+        return self.red[7]
+
+    def _iteration(self):
+        from ._native import lib, check
+        fr, fs, model = self.fr, self.fs, self.model
+        st = torch.cuda.current_stream().cuda_stream
+        R = self.R
+        check(lib.nsa_cam_to_pose(self.cam.data_ptr(), 1, self.pose.data_ptr(), st))
+        check(lib.nsa_rays_forward(self.uv.data_ptr(), self.pose.data_ptr(), self.K.data_ptr(), 1, R,
+                                   self.rays_o.data_ptr(), self.rays_d.data_ptr(), self.ds.data_ptr(), st))
+        z_vals, _ = fs.get_z_vals(model, self.rays_d, self.rays_o)
+        b = fr.composite_forward_raw(model, self.rays_o, self.rays_d, z_vals, self.stage, True)
+        check(lib.nsa_l1_loss(b["rgb_values"].data_ptr(), self.gt.data_ptr(), 3 * R, self.red[7:8].data_ptr(),
+                              self.g_rgbv.data_ptr(), st))
+        g_o, g_d = fr.composite_backward_raw(model, self.rays_o, self.rays_d, z_vals, b, self.stage, self.color_stage,
+                                             g_rgbv=self.g_rgbv)
+        check(lib.nsa_rays_pose_backward(self.uv.data_ptr(), self.pose.data_ptr(), self.K.data_ptr(), 1, R,
+                                         g_o.data_ptr(), g_d.data_ptr(), self.g_pose.data_ptr(), st))
+        check(lib.nsa_pose_grad_to_cam(self.cam.data_ptr(), self.g_pose.data_ptr(), 1, self.red.data_ptr(), st))
+
+    def _update(self):
+        from ._native import lib, check
+        lr, b1, b2, eps, lr_step, lr_gamma = self.hyper
+        check(lib.nsa_adam_step(self.cam.data_ptr(), self.red.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                self.t.data_ptr(), 7, lr, b1, b2, eps, lr_step, lr_gamma,
+                                torch.cuda.current_stream().cuda_stream))
+
+    def _capture(self):
+        cam0 = self.cam.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                self._iteration()
+        torch.cuda.current_stream().wait_stream(side)
+        self.cam.copy_(cam0)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self._iteration()
+            if self.world == 1:
+                self._update()
+
+    def step(self, uv, gt):
+        self.uv.copy_(uv)
+        self.gt.copy_(gt)
+        with torch.no_grad():
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._iteration()
+            if self.world > 1:      # weighted mean over the global ray batch: one 9-float all-reduce
+                import torch.distributed as dist
+                self.red[:8] *= float(self.R)
+                self.red[8] = float(self.R)
+                dist.all_reduce(self.red)
+                self.red[:8] /= self.red[8]
+            if self.graph is None or self.world > 1:
+                self._update()
+        return self.red[7]
+
+
 class TrackingStepper:
     def __init__(self, model, intrinsics, n_rays, cam_init, lr=0.005, use_graph=True, world=1):
         dev = model.voxels.device

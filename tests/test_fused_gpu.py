@@ -238,3 +238,23 @@ def test_graph_captured_tracking_step_matches_eager():
     assert_close(out[True][0], out[False][0], 1e-6, 1e-5, "camera after 4 steps")
     assert abs(out[True][1][0] - float(fx["out_loss"])) < 5e-5      # first-iteration loss = the reference's
     assert out[True][1][-1] < out[True][1][0]                        # and tracking actually descends
+
+
+def test_kernel_tracker_matches_autograd_stepper():
+    """KernelTracker (no autograd: cam->pose, L1, Adam and all backward steps as our kernels) follows the same camera
+    trajectory as the autograd-driven TrackingStepper, eagerly and as a hipGraph."""
+    from nicer_slam_amd.tracking import TrackingStepper, KernelTracker
+    fx, model, cam, pose, _, _ = _setup("full_tracking")
+    model.train(True)
+    model.engine = "fused"
+    model.draws = draws_of(fx, "cuda")
+    K, uv, gt = tt(fx["in_K"]).cuda(), tt(fx["in_uv"]).cuda(), tt(fx["gt_rgb"]).cuda()
+    cam0 = tt(fx["in_cam"]).reshape(-1)
+    ref = TrackingStepper(model, K, uv.shape[1], cam0, lr=0.005, use_graph=False)
+    ref_l = [float(ref.step(uv, gt)) for _ in range(5)]
+    for use_graph in (False, True):
+        kt = KernelTracker(model, K, uv.shape[1], cam0, lr=0.005, use_graph=use_graph)
+        ls = [float(kt.step(uv, gt)) for _ in range(5)]
+        assert_close(torch.tensor(ls), torch.tensor(ref_l), 2e-6, 1e-5, f"losses (graph={use_graph})")
+        assert_close(kt.cam, ref.cam.detach(), 2e-6, 1e-4, f"camera after 5 steps (graph={use_graph})")
+    assert abs(ref_l[0] - float(fx["out_loss"])) < 5e-5

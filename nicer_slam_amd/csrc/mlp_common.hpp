@@ -13,8 +13,7 @@
 //     16-byte load) and read straight from global memory: every wave of the chip streams the same ~150 KB, which
 //     stays L1/L2 resident; a fragment costs one coalesced 1 KiB wave load per 4 MFMAs (256 cycles of matrix pipe).
 //
-// Packed "A" block layout for a GEMM with MT output tiles and KS k-steps:  float idx = ((mt*KS4 + s/4)*64 + lane)*4 + s%4
-// holding W[row(mt, lane & 31)][slot(s, lane >> 5)]  (zero for padded rows/slots);  KS4 = ceil(KS/4).
+// The packed "A" (weight) block layout is described at the GEMM primitive below.
 // Packed per-feature vectors (biases, the sdf row) in activation layout:   idx = (t*2 + h)*16 + r.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -29,12 +28,110 @@ constexpr int HS = 32;         // k-steps of a hidden activation (64 features / 
 constexpr int SDF_IN_STEPS = 36;   // 71 inputs -> 36 slots per half-wave (one zero pad)
 constexpr int COL_IN_STEPS = 65;   // 129 inputs -> 65 slots per half-wave (one zero pad)
 
+// ---------------------------------------------------------------------------------------------------------------
+// GEMM primitive.  acc[mt] (32 output features x 32 points, fp32) += sum_slots A(mt, slot) * b[slot].
+//
+// NSA_BF16X3 = 1 (default): fp32-faithful products on the bf16 matrix cores.  Every fp32 operand is split exactly into
+// three bf16 pieces (8 + 8 + 8 significand bits: x = hi + mid + lo), and the six cross products whose weight is
+// >= 2^-16 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16:
+//     a*b ~= a_lo b_hi + a_hi b_lo + a_mid b_mid + a_mid b_hi + a_hi b_mid + a_hi b_hi          (error <= ~2^-23 |a b|)
+// Each bf16 product is exact in fp32, so the result is fp32-class (measured against float64 it is no worse than an fp32
+// fmaf chain).  Why: the fp32-input MFMA runs at the fp32 VECTOR rate and -- measured, SQ_VALU_MFMA_COEXEC_CYCLES = 0 and
+// MFMA-busy + VALU-active == busy cycles -- does not overlap with VALU work at all, while one 32x32x16 bf16 MFMA does 8x
+// the MACs in half the cycles: 6 of them replace 8 fp32 MFMAs (2.7x fewer matrix cycles) and run beside the VALU.
+// Weights are split on the host (fused/pack.py); activations are split here with 2 ANDs + 2 SUBs + 1.5 PERMs per value.
+//
+// NSA_BF16X3 = 0: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain), kept for A/B comparison.
+//
+// Packed "A" block (weights), KS8 = ceil(KS/8) slot groups:   [mt][group][piece hi/mid/lo][lane][8 bf16]
+//   lane l = (row i = l & 31, half h = l >> 5) holds W[row(mt,i)][slot(8g+e, h)], e = 0..7  -- the 8 k-values that the
+//   MFMA takes from that lane; the activation fragment of lane (p, h) is its own slots 8g..8g+7.
+#ifndef NSA_BF16X3
+#define NSA_BF16X3 1
+#endif
+
+#if NSA_BF16X3
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+
+__host__ __device__ constexpr int a_block_floats(int mt, int ks) { return mt * ((ks + 7) / 8) * 3 * 64 * 4; }
+
+struct BFrag {
+    uint4 p[3];   // hi, mid, lo: 8 bf16 each
+};
+
+__device__ __forceinline__ bf16x8_t as_bf16x8(const uint4& v) {
+    bf16x8_t r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
+
+// exact 3-way split of 8 fp32 values into packed bf16 fragments (truncation split: every piece is the top 16 bits)
+__device__ __forceinline__ void split8(const float (&x)[8], BFrag& f) {
+    unsigned u0[8], u1[8], u2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        u0[e] = __float_as_uint(x[e]);
+        const float r1 = x[e] - __uint_as_float(u0[e] & 0xFFFF0000u);
+        u1[e] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u1[e] & 0xFFFF0000u);
+        u2[e] = __float_as_uint(r2);
+    }
+#define NSA_PK(u, d) __builtin_amdgcn_perm(u[2 * d + 1], u[2 * d], 0x07060302u)
+    f.p[0] = make_uint4(NSA_PK(u0, 0), NSA_PK(u0, 1), NSA_PK(u0, 2), NSA_PK(u0, 3));
+    f.p[1] = make_uint4(NSA_PK(u1, 0), NSA_PK(u1, 1), NSA_PK(u1, 2), NSA_PK(u1, 3));
+    f.p[2] = make_uint4(NSA_PK(u2, 0), NSA_PK(u2, 1), NSA_PK(u2, 2), NSA_PK(u2, 3));
+#undef NSA_PK
+}
+
+template <int MT>
+struct AFrag {
+    uint4 g[MT][3];   // the next slot group's weight pieces
+};
+
+template <int KS, int MT>
+__device__ __forceinline__ void gemm_preload(const float* __restrict__ wp, int lane, AFrag<MT>& f) {
+    const uint4* __restrict__ w4 = reinterpret_cast<const uint4*>(wp) + lane;
+    constexpr int KS8 = (KS + 7) / 8;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) f.g[mt][pc] = w4[((mt * KS8 + 0) * 3 + pc) * 64];
+}
+
+template <int KS, int MT>
+__device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane, AFrag<MT>& f, const float (&b)[KS],
+                                         f32x16 (&acc)[MT]) {
+    constexpr int KS8 = (KS + 7) / 8;
+    const uint4* __restrict__ w4 = reinterpret_cast<const uint4*>(wp) + lane;
+#pragma unroll
+    for (int g = 0; g < KS8; ++g) {
+        uint4 a[MT][3];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                a[mt][pc] = f.g[mt][pc];
+                if (g + 1 < KS8) f.g[mt][pc] = w4[((mt * KS8 + g + 1) * 3 + pc) * 64];
+            }
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? b[8 * g + e] : 0.0f;
+        BFrag bf;
+        split8(x, bf);
+        const bf16x8_t bh = as_bf16x8(bf.p[0]), bm = as_bf16x8(bf.p[1]), bl = as_bf16x8(bf.p[2]);
+        // smallest terms first; the MT accumulators alternate so no MFMA waits on its predecessor
+#define NSA_MM(AP, BV)                                                                                   \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                \
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[mt][AP]), BV, acc[mt], 0, 0, 0);
+        NSA_MM(2, bh) NSA_MM(0, bl) NSA_MM(1, bm) NSA_MM(1, bh) NSA_MM(0, bm) NSA_MM(0, bh)
+#undef NSA_MM
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep later layers' loads from being hoisted above this GEMM
+}
+
+#else   // ------------------------------------------------------------------ fp32-input MFMA variant
 __host__ __device__ constexpr int a_block_floats(int mt, int ks) { return mt * ((ks + 3) / 4) * 64 * 4; }
 
-// Two k-step groups (8 MFMAs per tile) of "A" fragments in flight ahead of the matrix pipe: the fragments are L2 hits
-// (~200-300 cycles), one group of MFMAs is 256*MT cycles, so the wave never waits on them once the pipeline is primed.
-// gemm_preload() can be issued BEFORE the elementwise epilogue of the previous layer so that the first groups
-// arrive under the softplus / gather code.
 template <int MT>
 struct AFrag {
     float4 g0[MT], g1[MT];
@@ -51,7 +148,6 @@ __device__ __forceinline__ void gemm_preload(const float* __restrict__ wp, int l
     }
 }
 
-// acc[mt] += sum_{s < KS} A(mt, s) * b[s]   (fragments of groups 0 and 1 already requested into f)
 template <int KS, int MT>
 __device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane, AFrag<MT>& f, const float (&b)[KS],
                                          f32x16 (&acc)[MT]) {
@@ -77,9 +173,9 @@ __device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane,
             }
         }
     }
-    // keep later layers' loads from being hoisted above this GEMM (register pressure)
     __builtin_amdgcn_sched_barrier(0);
 }
+#endif
 
 template <int KS, int MT>
 __device__ __forceinline__ void gemm_op(const float* __restrict__ wp, int lane, const float (&b)[KS], f32x16 (&acc)[MT]) {

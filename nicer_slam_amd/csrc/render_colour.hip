@@ -22,14 +22,15 @@ namespace nsa {
 constexpr int CL = 16, CC = 2;   // colour grid shape (hard-coded in the reference, base_networks.py:265-284)
 
 struct ColPack {
-    static constexpr int kW0 = 0;                                        // A[2][65]
-    static constexpr int kB0 = kW0 + a_block_floats(2, COL_IN_STEPS);    // 8704
+    static constexpr int kHH = a_block_floats(2, HS);
+    static constexpr int kW0 = 0;                                        // A[2][65 slots]
+    static constexpr int kB0 = kW0 + a_block_floats(2, COL_IN_STEPS);
     static constexpr int kW1 = kB0 + 64;
-    static constexpr int kB1 = kW1 + 4096;
+    static constexpr int kB1 = kW1 + kHH;
     static constexpr int kW2V = kB1 + 64;                                // 3 output rows in activation layout
     static constexpr int kB2 = kW2V + 3 * 64;                            // [0..2]
     static constexpr int kW1T = kB2 + 64;
-    static constexpr int kW0T = kW1T + 4096;                             // A[5][32]: rows = input slots
+    static constexpr int kW0T = kW1T + kHH;                              // A[5][32]: rows = input slots
     static constexpr int kTotal = kW0T + a_block_floats(5, HS);
 };
 

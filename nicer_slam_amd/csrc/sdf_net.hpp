@@ -31,20 +31,21 @@ inline int make_grid_geom16(const int32_t* offsets_host, uint32_t L, float S, ui
 // Offsets (in floats) inside one SDF net's packed parameter block; NH = number of hidden layers.
 template <int NH>
 struct SdfPack {
-    static constexpr int kW0 = 0;                                   // A[2 tiles][36 steps]
+    static constexpr int kHH = a_block_floats(2, HS);                // one 64x64 hidden block
+    static constexpr int kW0 = 0;                                   // A[2 tiles][36 slots]
     static constexpr int kB0 = kW0 + a_block_floats(2, SDF_IN_STEPS);
     static constexpr int kWH = kB0 + 64;                            // (NH-1) x { A[2][32], bias[64] }
-    static constexpr int kWSDF = kWH + (NH - 1) * (4096 + 64);      // last-layer row 0 in activation layout
+    static constexpr int kWSDF = kWH + (NH - 1) * (kHH + 64);       // last-layer row 0 in activation layout
     static constexpr int kBSDF = kWSDF + 64;                        // [0] = bias of the sdf output
     static constexpr int kWFEAT = kBSDF + 64;                       // last-layer rows 1..64: A[2][32]
-    static constexpr int kBFEAT = kWFEAT + 4096;
+    static constexpr int kBFEAT = kWFEAT + kHH;
     static constexpr int kWHT = kBFEAT + 64;                        // transposed hidden layers, order k = NH-1 .. 1
-    static constexpr int kW0T = kWHT + (NH - 1) * 4096;             // A[3 tiles][32 steps]: rows = input slots
+    static constexpr int kW0T = kWHT + (NH - 1) * kHH;              // A[3 tiles][32 slots]: rows = input slots
     static constexpr int kWFEATT = kW0T + a_block_floats(3, HS);    // transposed feature rows
-    static constexpr int kTotal = kWFEATT + 4096;
-    __host__ __device__ static constexpr int wh(int k) { return kWH + (k - 1) * (4096 + 64); }       // k = 1..NH-1
-    __host__ __device__ static constexpr int bh(int k) { return wh(k) + 4096; }
-    __host__ __device__ static constexpr int wht(int k) { return kWHT + (NH - 1 - k) * 4096; }       // k = 1..NH-1
+    static constexpr int kTotal = kWFEATT + kHH;
+    __host__ __device__ static constexpr int wh(int k) { return kWH + (k - 1) * (kHH + 64); }       // k = 1..NH-1
+    __host__ __device__ static constexpr int bh(int k) { return wh(k) + kHH; }
+    __host__ __device__ static constexpr int wht(int k) { return kWHT + (NH - 1 - k) * kHH; }       // k = 1..NH-1
 };
 
 // Position + positional-encoding slots 0..19 (identical for the coarse and the fine network).

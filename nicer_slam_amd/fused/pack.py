@@ -1,8 +1,9 @@
 """Pack MLP parameters into MFMA fragment order for the fused kernels (layout: csrc/mlp_common.hpp, csrc/sdf_net.hpp).
 
-Every packed block is a pure gather of the flattened effective parameters (weight-norm applied:
-W = g * v / |v|_row, reference base_networks.py:148-149), so packing is ONE indexing op per network on the device;
-index maps are built once per network shape with numpy.
+Every packed block is a gather of the flattened effective parameters (weight-norm applied: W = g * v / |v|_row,
+reference base_networks.py:148-149); weight blocks are additionally split exactly into three bfloat16 pieces
+(hi + mid + lo = the fp32 weight) for the split-bf16 GEMM.  Index maps are built once per network shape with numpy;
+packing runs on the device and is cached on the parameters' version counters.
 """
 import functools
 
@@ -46,17 +47,18 @@ def row_slot(mt, i):
 
 
 def a_block(MT, KS, elem):
-    """int64 index block [MT][KS4][64][4]; elem(mt, i, s, h) -> flat parameter index or -1 (zero)."""
-    KS4 = (KS + 3) // 4
-    out = np.full((MT, KS4, 64, 4), -1, dtype=np.int64)
+    """int64 index block [MT][KS8][64 lanes][8]; elem(mt, i, s, h) -> flat parameter index or -1 (zero).
+    (One index per fp32 weight; pack_blocks() splits the gathered values into the three bf16 pieces.)"""
+    KS8 = (KS + 7) // 8
+    out = np.full((MT, KS8, 64, 8), -1, dtype=np.int64)
     for mt in range(MT):
-        for s4 in range(KS4):
+        for g in range(KS8):
             for lane in range(64):
-                for q in range(4):
-                    s = 4 * s4 + q
+                for e in range(8):
+                    s = 8 * g + e
                     if s < KS:
-                        out[mt, s4, lane, q] = elem(mt, lane & 31, s, lane >> 5)
-    return out.reshape(-1)
+                        out[mt, g, lane, e] = elem(mt, lane & 31, s, lane >> 5)
+    return ("A", out.reshape(-1))
 
 
 def vec_block(n_tiles, elem, pad_to=None):
@@ -68,7 +70,29 @@ def vec_block(n_tiles, elem, pad_to=None):
                 out[(t * 2 + h) * 16 + r] = elem(32 * t + F(r, h))
     if pad_to:
         out = np.concatenate([out, np.full(pad_to - out.size, -1, dtype=np.int64)])
-    return out
+    return ("V", out)
+
+
+def split_bf16x3(x):
+    """exact 3-way split x = hi + mid + lo into bfloat16 pieces (8+8+8 significand bits)."""
+    hi = x.to(torch.bfloat16)
+    r = x - hi.float()
+    mid = r.to(torch.bfloat16)
+    lo = (r - mid.float()).to(torch.bfloat16)
+    return hi, mid, lo
+
+
+def pack_blocks(flat, blocks):
+    """Gather every block from the flat parameter vector; 'A' blocks become [group][piece][lane][8 bf16] (viewed as
+    float32 words), 'V' blocks stay fp32.  Layout: csrc/mlp_common.hpp (NSA_BF16X3)."""
+    out = []
+    for kind, idx in blocks:
+        g = flat[idx.to(flat.device)]
+        if kind == "A":
+            hi, mid, lo = split_bf16x3(g.view(-1, 64, 8))
+            g = torch.stack([hi, mid, lo], 1).contiguous().view(torch.float32).reshape(-1)
+        out.append(g)
+    return torch.cat(out)
 
 
 @functools.lru_cache(maxsize=None)
@@ -97,7 +121,7 @@ def sdf_net_index(NH, L, C):
     blocks.append(vec_block(2, lambda f: Wo(NH) + f))
     bs = np.full(64, -1, dtype=np.int64)
     bs[0] = Bo(NH)
-    blocks.append(bs)
+    blocks.append(("V", bs))
     # WFEAT, BFEAT (rows 1..64 of the last layer)
     blocks.append(a_block(2, 32, lambda mt, i, s, h: Wo(NH) + (1 + 32 * mt + i) * 64 + hid_feature(s, h)))
     blocks.append(vec_block(2, lambda f: Bo(NH) + 1 + f))
@@ -114,13 +138,26 @@ def sdf_net_index(NH, L, C):
     blocks.append(a_block(3, 32, w0t))
     # WFEATT: A[row = hidden in-feature][slot = feature output (1 + ...)]
     blocks.append(a_block(2, 32, lambda mt, i, s, h: Wo(NH) + (1 + hid_feature(s, h)) * 64 + (32 * mt + i)))
-    idx = np.concatenate(blocks)
-    idx[idx < 0] = o            # index of the appended zero
-    return torch.from_numpy(idx), o
+    return _finish(blocks, o), o
+
+
+def _finish(blocks, zero_index):
+    out = []
+    for kind, idx in blocks:
+        idx = idx.copy()
+        idx[idx < 0] = zero_index            # index of the appended zero
+        out.append((kind, torch.from_numpy(idx)))
+    return tuple(out)
+
+
+def a_floats(MT, KS):
+    return MT * ((KS + 7) // 8) * 3 * 64 * 4
 
 
 def sdf_pack_size(NH):
-    return 4608 + 64 + (NH - 1) * 4160 + 64 + 64 + 4096 + 64 + (NH - 1) * 4096 + 6144 + 4096
+    hh = a_floats(2, 32)
+    return (a_floats(2, SDF_IN_STEPS) + 64 + (NH - 1) * (hh + 64) + 64 + 64 + hh + 64 + (NH - 1) * hh
+            + a_floats(3, 32) + hh)
 
 
 def effective_weight(lin):
@@ -143,10 +180,10 @@ def pack_sdf_net(net):
     """ImplicitNetworkGrid -> packed float32 device tensor (differentiable gather of the effective parameters)."""
     NH = net.num_layers - 2
     enc = net.encoding
-    idx, n = sdf_net_index(NH, enc.num_levels, enc.level_dim)
+    blocks, n = sdf_net_index(NH, enc.num_levels, enc.level_dim)
     flat = flat_params(net)
     assert flat.numel() == n + 1, (flat.numel(), n)
-    packed = flat[idx.to(flat.device)]
+    packed = pack_blocks(flat, blocks)
     assert packed.numel() == sdf_pack_size(NH)
     return packed
 
@@ -198,7 +235,7 @@ def colour_net_index():
         blocks.append(vec_block(2, lambda f, j=j: W2o + j * 64 + f))
     b2 = np.full(64, -1, dtype=np.int64)
     b2[:3] = [B2o, B2o + 1, B2o + 2]
-    blocks.append(b2)
+    blocks.append(("V", b2))
     blocks.append(a_block(2, 32, lambda mt, i, s, h: W1o + hid_feature(s, h) * 64 + (32 * mt + i)))
 
     def w0t(mt, i, s, h):
@@ -208,19 +245,17 @@ def colour_net_index():
         f = col_in_feature(q, hh)
         return W0o + hid_feature(s, h) * n_in + f if f >= 0 else -1
     blocks.append(a_block(5, 32, w0t))
-    idx = np.concatenate(blocks)
-    idx[idx < 0] = total
-    return torch.from_numpy(idx), total
+    return _finish(blocks, total), total
 
 
-COL_PACK_SIZE = 8704 + 64 + 4096 + 64 + 192 + 64 + 4096 + 10240
+COL_PACK_SIZE = a_floats(2, COL_IN_STEPS) + 64 + a_floats(2, 32) + 64 + 192 + 64 + a_floats(2, 32) + a_floats(5, 32)
 
 
 def pack_colour_net(net):
     """RenderingNetwork (mode idr, 129->64->64->3) -> packed float32 device tensor."""
-    idx, n = colour_net_index()
+    blocks, n = colour_net_index()
     flat = flat_params(net)
     assert flat.numel() == n + 1, (flat.numel(), n)
-    packed = flat[idx.to(flat.device)]
+    packed = pack_blocks(flat, blocks)
     assert packed.numel() == COL_PACK_SIZE
     return packed

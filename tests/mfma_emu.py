@@ -1,24 +1,36 @@
 """numpy emulation of the fused kernels' MFMA dataflow (csrc/mlp_common.hpp) -- lets the CPU suite verify the
 host-side weight packing and slot maps against a plain torch MLP without a GPU.
 
-v_mfma_f32_32x32x2_f32 semantics: D[i][j] += sum_{k<2} A[i][k] B[k][j];  lane l supplies A[l&31][l>>5] and
-B[l>>5][l&31];  D[i][j] lands in lane (j + 32 hh), register r with i = (r&3) + 8(r>>2) + 4hh."""
+32x32 MFMA result layout: D[i][j] lands in lane (j + 32 hh), register r with i = (r&3) + 8(r>>2) + 4hh."""
 import numpy as np
 
 from nicer_slam_amd.fused.pack import F
 
 
+def _bf16_words_to_f64(words):
+    """float32 words each holding two bf16 values (low half first) -> float64 array of twice the length."""
+    u = np.ascontiguousarray(words, dtype=np.float32).view(np.uint32)
+    lo = ((u & 0xFFFF).astype(np.uint32) << 16).view(np.float32)
+    hi = (u & 0xFFFF0000).astype(np.uint32).view(np.float32)
+    return np.stack([lo, hi], -1).reshape(-1).astype(np.float64)
+
+
 def gemm_op(block, MT, KS, b, acc):
-    """block: packed floats [MT][KS4][64][4]; b: [64 lanes][KS]; acc: [64][MT][16] (updated in place)."""
-    KS4 = (KS + 3) // 4
-    blk = np.asarray(block, dtype=np.float64).reshape(MT, KS4, 64, 4)
+    """block: packed weights [MT][KS8][3 pieces][64 lanes][8 bf16] as float32 words; b: [64 lanes][KS] (fp32 slots);
+    acc: [64][MT][16] (updated in place).  v_mfma_f32_32x32x16_bf16: lane l supplies A[l&31][8(l>>5)+e] and
+    B[8(l>>5)+e][l&31], e < 8; the three pieces of each operand sum back to the fp32 value, so the emulation works
+    on the reassembled values (the kernel's six-product expansion differs from that only at the 2^-23 level)."""
+    KS8 = (KS + 7) // 8
+    blk = _bf16_words_to_f64(np.asarray(block, dtype=np.float32)).reshape(MT, KS8, 3, 64, 8).sum(2)   # [mt][g][lane][e]
+    bp = np.zeros((64, KS8 * 8))
+    bp[:, :KS] = b[:, :KS]
     for mt in range(MT):
         D = np.zeros((32, 32))
-        for s in range(KS):
-            a_l = blk[mt, s // 4, :, s % 4]            # per lane
-            A = np.stack([a_l[:32], a_l[32:]], 1)      # [i][k]
-            B = np.stack([b[:32, s], b[32:, s]], 0)    # [k][j]
-            D += A @ B
+        for g in range(KS8):
+            for h in range(2):
+                A = blk[mt, g, 32 * h:32 * h + 32, :]             # [i][e]
+                B = bp[32 * h:32 * h + 32, 8 * g:8 * g + 8].T      # [e][j]
+                D += A @ B
         for lane in range(64):
             j, hh = lane & 31, lane >> 5
             for r in range(16):

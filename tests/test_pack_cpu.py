@@ -40,7 +40,7 @@ def slots_from_features(feats71, L, C):
 @pytest.mark.parametrize("NH,L,C", [(1, 4, 8), (3, 8, 4)])
 def test_sdf_net_pack_forward_and_transposes(NH, L, C):
     net = make_net(NH, L, C, seed=NH)
-    packed = pack.pack_sdf_net(net).detach().double().numpy()
+    packed = pack.pack_sdf_net(net).detach().float().numpy()
     assert packed.size == pack.sdf_pack_size(NH)
     rng = np.random.default_rng(0)
     h0 = rng.standard_normal((32, 71)) * 0.5
@@ -53,20 +53,21 @@ def test_sdf_net_pack_forward_and_transposes(NH, L, C):
     out = softplus(a[-1]) @ Ws[NH].T + bs[NH]
     # emulated kernel dataflow (offsets as SdfPack<NH>)
     o = 0
-    W0 = packed[o:o + 4608]; o += 4608
+    hh, n0, n0t = pack.a_floats(2, 32), pack.a_floats(2, 36), pack.a_floats(3, 32)
+    W0 = packed[o:o + n0]; o += n0
     B0 = packed[o:o + 64]; o += 64
     WH = []
     for k in range(1, NH):
-        WH.append((packed[o:o + 4096], packed[o + 4096:o + 4160])); o += 4160
+        WH.append((packed[o:o + hh], packed[o + hh:o + hh + 64])); o += hh + 64
     WSDF = packed[o:o + 64]; o += 64
     BSDF = packed[o]; o += 64
-    WFEAT = packed[o:o + 4096]; o += 4096
+    WFEAT = packed[o:o + hh]; o += hh
     BFEAT = packed[o:o + 64]; o += 64
     WHT = {}
     for k in range(NH - 1, 0, -1):
-        WHT[k] = packed[o:o + 4096]; o += 4096
-    W0T = packed[o:o + 6144]; o += 6144
-    WFEATT = packed[o:o + 4096]; o += 4096
+        WHT[k] = packed[o:o + hh]; o += hh
+    W0T = packed[o:o + n0t]; o += n0t
+    WFEATT = packed[o:o + hh]; o += hh
     assert o == packed.size
     acc = emu.load_vec(B0, 2)
     emu.gemm_op(W0, 2, 36, slots_from_features(h0, L, C), acc)
@@ -78,15 +79,15 @@ def test_sdf_net_pack_forward_and_transposes(NH, L, C):
         pre.append(acc.copy())
     act = softplus(acc)
     sdf = emu.xhalf_sum((act * emu.load_vec(WSDF, 2)).reshape(64, -1).sum(1)) + BSDF
-    np.testing.assert_allclose(sdf[:32], out[:, 0], rtol=1e-9, atol=1e-9)
-    np.testing.assert_allclose(sdf[32:], out[:, 0], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(sdf[:32], out[:, 0], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(sdf[32:], out[:, 0], rtol=2e-6, atol=2e-6)
     feat = emu.load_vec(BFEAT, 2)
     emu.gemm_op(WFEAT, 2, 32, emu.act_to_b(act), feat)
     for lane in range(64):
         p, h = lane & 31, lane >> 5
         for t in range(2):
             for r in range(16):
-                assert abs(feat[lane, t, r] - out[p, 1 + 32 * t + pack.F(r, h)]) < 1e-9
+                assert abs(feat[lane, t, r] - out[p, 1 + 32 * t + pack.F(r, h)]) < 2e-6
     # transposed blocks: y = W^T g for a random hidden-layout vector g
     gvec = rng.standard_normal((32, 64))
     g_b = np.zeros((64, 32))
@@ -100,7 +101,7 @@ def test_sdf_net_pack_forward_and_transposes(NH, L, C):
         for lane in range(64):
             for t in range(2):
                 for r in range(16):
-                    assert abs(acc[lane, t, r] - want[lane & 31, 32 * t + pack.F(r, lane >> 5)]) < 1e-9
+                    assert abs(acc[lane, t, r] - want[lane & 31, 32 * t + pack.F(r, lane >> 5)]) < 2e-6
     acc = np.zeros((64, 3, 16))
     emu.gemm_op(W0T, 3, 32, g_b, acc)
     want = gvec @ Ws[0]                # [32, 71]
@@ -109,14 +110,14 @@ def test_sdf_net_pack_forward_and_transposes(NH, L, C):
         for q in range(48):
             f = pack.sdf_in_feature(q, h, L, C) if q < 36 else -1
             got = acc[lane, q // 16, q % 16]
-            assert abs(got - (want[p, f] if f >= 0 else 0.0)) < 1e-9, (lane, q)
+            assert abs(got - (want[p, f] if f >= 0 else 0.0)) < 2e-6, (lane, q)
     acc = np.zeros((64, 2, 16))
     emu.gemm_op(WFEATT, 2, 32, g_b, acc)
     want = gvec @ Ws[NH][1:, :]        # feature rows only
     for lane in range(64):
         for t in range(2):
             for r in range(16):
-                assert abs(acc[lane, t, r] - want[lane & 31, 32 * t + pack.F(r, lane >> 5)]) < 1e-9
+                assert abs(acc[lane, t, r] - want[lane & 31, 32 * t + pack.F(r, lane >> 5)]) < 2e-6
 
 
 def test_every_input_feature_has_exactly_one_slot():
@@ -137,7 +138,7 @@ def test_colour_net_pack():
     net = RenderingNetwork(64, mode="idr", d_in=9, d_out=3, dims=[64, 64], weight_norm=True, multires_view=4,
                            use_grid_feature=True,
                            colour_grid=dict(base_resolution=4, desired_resolution=8, log2_hashmap_size=6))
-    packed = pack.pack_colour_net(net).detach().double().numpy()
+    packed = pack.pack_colour_net(net).detach().float().numpy()
     assert packed.size == pack.COL_PACK_SIZE
     seen = {}
     for h in range(2):
@@ -160,14 +161,15 @@ def test_colour_net_pack():
             f = pack.col_in_feature(s, lane >> 5)
             b[lane, s] = x[lane & 31, f] if f >= 0 else 0.0
     off = 0
-    W0 = packed[off:off + 8704]; off += 8704
+    hh, n0, n0t = pack.a_floats(2, 32), pack.a_floats(2, 65), pack.a_floats(5, 32)
+    W0 = packed[off:off + n0]; off += n0
     B0 = packed[off:off + 64]; off += 64
-    W1 = packed[off:off + 4096]; off += 4096
+    W1 = packed[off:off + hh]; off += hh
     B1 = packed[off:off + 64]; off += 64
     W2V = packed[off:off + 192]; off += 192
     B2 = packed[off:off + 64]; off += 64
-    W1T = packed[off:off + 4096]; off += 4096
-    W0T = packed[off:off + 10240]; off += 10240
+    W1T = packed[off:off + hh]; off += hh
+    W0T = packed[off:off + n0t]; off += n0t
     assert off == packed.size
     acc1 = emu.load_vec(B0, 2)
     emu.gemm_op(W0, 2, 65, b, acc1)
@@ -175,7 +177,7 @@ def test_colour_net_pack():
     emu.gemm_op(W1, 2, 32, emu.act_to_b(np.maximum(acc1, 0)), acc2)
     for j in range(3):
         oj = emu.xhalf_sum((np.maximum(acc2, 0) * emu.load_vec(W2V[64 * j:64 * j + 64], 2)).reshape(64, -1).sum(1)) + B2[j]
-        np.testing.assert_allclose(oj[:32], o[:, j], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(oj[:32], o[:, j], rtol=2e-6, atol=2e-6)
     g = rng.standard_normal((32, 64))
     g_b = np.zeros((64, 32))
     for lane in range(64):
@@ -187,11 +189,11 @@ def test_colour_net_pack():
     for lane in range(64):
         for t in range(2):
             for r in range(16):
-                assert abs(acc[lane, t, r] - want[lane & 31, 32 * t + pack.F(r, lane >> 5)]) < 1e-9
+                assert abs(acc[lane, t, r] - want[lane & 31, 32 * t + pack.F(r, lane >> 5)]) < 2e-6
     acc = np.zeros((64, 5, 16))
     emu.gemm_op(W0T, 5, 32, g_b, acc)
     want = g @ Ws[0]
     for lane in range(64):
         for q in range(80):
             f = pack.col_in_feature(q, lane >> 5) if q < 65 else -1
-            assert abs(acc[lane, q // 16, q % 16] - (want[lane & 31, f] if f >= 0 else 0.0)) < 1e-9
+            assert abs(acc[lane, q // 16, q % 16] - (want[lane & 31, f] if f >= 0 else 0.0)) < 2e-6

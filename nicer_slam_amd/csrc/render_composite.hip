@@ -214,19 +214,26 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeArgs a) {
             }
         }
     }
-    // E_bar_k = wbar_k T_{k+1} - sum_{i>k} wbar_i w_i   (w_i = T_i - T_{i+1});  suffix sum via an exclusive scan
-    float tot;
-    float before = wave_excl(ww, lane, tot);       // sum over earlier lanes
-    float run = before;
+    // E_bar_k = wbar_k T_{k+1} - sum_{i>k} wbar_i w_i   (w_i = T_i - T_{i+1}).  The suffix sum is formed as a true
+    // suffix scan (later lanes, then later samples of this lane), NOT as total - prefix: sigma_bar = E_bar * delta and
+    // the last delta is 1e10, so a 1e-9 rounding residue in "total - prefix" would come out as a spurious gradient where
+    // the reference's is exactly zero (the last sample has no later samples: the sum is empty).
+    float later = ww;                                  // inclusive suffix over lanes
 #pragma unroll
-    for (int k = 0; k < MAX_PER; ++k) {
+    for (int off = 1; off < 64; off <<= 1) {
+        const float n2 = __shfl_down(later, off);
+        if (lane + off < 64) later += n2;
+    }
+    float suffix = __shfl_down(later, 1);              // exclusive: lanes after this one
+    if (lane == 63) suffix = 0.0f;
+#pragma unroll
+    for (int k = MAX_PER - 1; k >= 0; --k) {
         if (k < n) {
             const size_t i = (size_t)ray * S + lane * per + k;
             const Sample& s = sm[k];
-            run += wbar[k] * s.w;                                       // inclusive prefix
-            const float suffix = tot - run;
             const float Tn = s.T * expf(-s.en);                         // T_{k+1}
             const float eb = wbar[k] * Tn - suffix;
+            suffix += wbar[k] * s.w;
             const float sb = eb * s.dist;                               // sigma_bar
             const float sg = s.sdf > 0.0f ? 1.0f : (s.sdf < 0.0f ? -1.0f : 0.0f);
             const float dsig = -0.5f * sg * sg * expf(-fabsf(s.sdf) / s.beta) / (s.beta * s.beta);

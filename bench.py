@@ -24,7 +24,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured streaming copy)
-MFMA_F32_PEAK_TFLOPS = 157.3
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak = the peak for this config's dtype (MI355X_MICROARCH.md)
+
+# Algorithmic multiply-accumulates per point of each per-point kernel (true layer sizes, no padding):
+#   SDF nets 71->64(->64->64)->65 Softplus, colour net 129->64->64->3; forward kernels include the reverse pass that
+#   yields grad sdf, backward kernels include the recomputation + tangent sweep + reverse sweep.
+ALGO_MAC = {
+    "k_sampler_sdf": 17408,            # coarse (4544+64) + fine (4544+2*4096+64): sdf rows only
+    "k_sdfnet_fwd<coarse>": 13248, "k_sdfnet_fwd<fine>": 29632,
+    "k_sdfnet_bwd<coarse>": 22400, "k_sdfnet_bwd<fine>": 55168,
+    "k_colour_fwd": 12544, "k_colour_bwd": 25088,
+}
 
 
 def parse():
@@ -147,12 +157,24 @@ def main():
         roof = None
         if agg:
             name, (tms, nbytes, n) = max(agg.items(), key=lambda kv: kv[1][0])
-            ach = nbytes / (tms * 1e-3) / 1e9
-            roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": n,
-                    "avg_launch_us": round(tms / n * 1e3, 2), "bytes_per_launch": nbytes // n,
-                    "share_of_step": round(tms / n / ms, 4),
-                    "all_kernels_us": {k: round(v[0] / v[2] * 1e3, 1) for k, v in sorted(agg.items())}}
+            pts = args.rays * (640 if name == "k_sampler_sdf" else args.samples)
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")   # FETCH_SIZE/WRITE_SIZE of the same command
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(name)
+            if name in ALGO_MAC:     # per-point MLP kernels: bounded by the matrix pipe
+                flops = 2.0 * ALGO_MAC[name] * pts
+                ach = flops / (tms / n * 1e-3) / 1e12
+                roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                        "flops_per_launch": flops, "mfma_path": "fp32 products as 6 bf16 MFMAs on 3-way split operands "
+                        "(fp32-faithful); achieved counts algorithmic fp32 flops once"}
+            else:
+                ach = nbytes / (tms * 1e-3) / 1e9
+                roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "bytes_per_launch": nbytes // n}
+            roof.update({"launches": n, "avg_launch_us": round(tms / n * 1e3, 2), "share_of_step": round(tms / n / ms, 4),
+                         "all_kernels_us": {k: round(v[0] / v[2] * 1e3, 1) for k, v in sorted(agg.items())}})
         cpu = None if args.no_cpu_baseline else cpu_baseline(args, model, conf)
         line = {
             "metric": "rays/sec (fwd+bwd), one tracking iteration", "value": round(rays_total / dt, 1), "unit": "rays/s",

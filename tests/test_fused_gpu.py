@@ -258,3 +258,37 @@ def test_kernel_tracker_matches_autograd_stepper():
         assert_close(torch.tensor(ls), torch.tensor(ref_l), 2e-6, 1e-5, f"losses (graph={use_graph})")
         assert_close(kt.cam, ref.cam.detach(), 2e-6, 1e-4, f"camera after 5 steps (graph={use_graph})")
     assert abs(ref_l[0] - float(fx["out_loss"])) < 5e-5
+
+
+def test_composite_backward_exact_zero_on_saturated_last_interval():
+    """Regression: the last interval is 1e10 long, so d(weights)/d(sdf_last) is exactly 0 whenever sigma_last * 1e10
+    saturates alpha (the usual case) -- a 'total minus prefix' suffix sum leaks a rounding residue times 1e10 there.
+    Compared per sample with torch autograd over the oracle's volume_weights."""
+    import ctypes
+    from oracle import render_ref as R
+    from nicer_slam_amd.fused import render as fr
+    from nicer_slam_amd._native import lib, check
+    fx, model, cam, pose, rays_o, rays_d = _setup("full_tracking_poisson")
+    z = tt(fx["out_z_vals"]).cuda()
+    ro, rd = rays_o.detach().contiguous(), rays_d.detach().contiguous()
+    b = fr.composite_forward_raw(model, ro, rd, z, "fine", True)
+    n_ray, S = z.shape
+    g = torch.Generator().manual_seed(0)
+    g_rgbv = (torch.rand(n_ray, 3, generator=g) - 0.5).cuda().contiguous()
+    P = n_ray * S
+    g_sdf, g_rgb, g_grad = (torch.empty(P, device="cuda"), torch.empty(P, 3, device="cuda"), torch.empty(P, 3, device="cuda"))
+    check(lib.nsa_composite_backward(ro.data_ptr(), rd.data_ptr(), z.data_ptr(), b["sdf"].data_ptr(), b["rgb"].data_ptr(),
+                                     b["grad"].data_ptr(), b["vox"].data_ptr(), 64, n_ray, S, g_rgbv.data_ptr(), None, None,
+                                     None, None, g_sdf.data_ptr(), g_rgb.data_ptr(), g_grad.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream))
+    sdf = b["sdf"].detach().cpu().reshape(-1, 1).requires_grad_(True)
+    pts = (ro.cpu().unsqueeze(1) + z.cpu().unsqueeze(2) * rd.cpu().unsqueeze(1)).reshape(-1, 3)
+    w = R.volume_weights(z.cpu(), sdf, pts, tt(fx["in_voxels"]), 64)
+    rgbv = (w.unsqueeze(-1) * b["rgb"].detach().cpu().reshape(n_ray, S, 3)).sum(1)
+    (rgbv * g_rgbv.cpu()).sum().backward()
+    ref = sdf.grad.reshape(n_ray, S)
+    got = g_sdf.cpu().reshape(n_ray, S)
+    assert_close(got, ref, 1e-6 * float(ref.abs().max()), 2e-3, "d/d sdf")
+    sat = ref[:, -1] == 0
+    assert bool(sat.any())
+    assert bool((got[:, -1][sat] == 0).all())

@@ -16,7 +16,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libnicer_slam_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + os.environ.get("NSA_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _stale(target, deps):

@@ -100,8 +100,17 @@ __device__ __forceinline__ void reverse_pass(const float* __restrict__ wp, int l
         for (int r = 0; r < 16; ++r) dl[16 * t + r] = a3[t][r];
 }
 
+#ifndef NSA_OCC_FWD_FINE
+#define NSA_OCC_FWD_FINE 2
+#endif
+#ifndef NSA_OCC_BWD_FINE
+#define NSA_OCC_BWD_FINE 1
+#endif
+#ifndef NSA_OCC_BWD_COARSE
+#define NSA_OCC_BWD_COARSE 2
+#endif
 template <int L, int C, int NH>
-__global__ __launch_bounds__(256, 2) void k_sdfnet_fwd(SdfNetArgs a, GridGeom16 geom) {
+__global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfnet_fwd(SdfNetArgs a, GridGeom16 geom) {
     using P = SdfPack<NH>;
     desync_simd_partners();
     const int lane = threadIdx.x & 63;
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void k_sdfnet_fwd(SdfNetArgs a, GridGeom16 
 
 // NH == 1 fits two waves per SIMD (a few spilled dwords); NH == 3 needs the whole register file (one wave per SIMD).
 template <int L, int C, int NH>
-__global__ __launch_bounds__(256, (NH == 1 ? 2 : 1)) void k_sdfnet_bwd(SdfNetArgs a, GridGeom16 geom) {
+__global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FINE)) void k_sdfnet_bwd(SdfNetArgs a, GridGeom16 geom) {
     using P = SdfPack<NH>;
     desync_simd_partners();
     const int lane = threadIdx.x & 63;

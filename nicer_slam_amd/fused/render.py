@@ -75,17 +75,15 @@ def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd):
              rgb=torch.empty(P, 3, device=dev), save=torch.empty(hl_size(P) * 2, device=dev) if need_bwd else None,
              weights=torch.empty(R, S, device=dev), rgb_values=torch.empty(R, 3, device=dev),
              depth=torch.empty(R, device=dev), nmap=torch.empty(R, 3, device=dev), entropy=torch.empty(R, device=dev),
-             vox=model.voxels.contiguous(), packs=(pc, pf, pr), keep=(keep_c, keep_f, keep_r),
-             save_c=torch.empty(lib.nsa_sdfnet_save_floats(P, 1), device=dev),
-             save_f=torch.empty(lib.nsa_sdfnet_save_floats(P, 3), device=dev) if stage != "coarse" else None)
+             vox=model.voxels.contiguous(), packs=(pc, pf, pr), keep=(keep_c, keep_f, keep_r))
     st = _stream()
     with _timed("k_sdfnet_fwd<coarse>", P * 4 * 8 * 8 * 4):
         check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), 0, b["sdf"].data_ptr(),
-                                     b["grad"].data_ptr(), b["feat"].data_ptr(), b["save_c"].data_ptr(), st))
+                                     b["grad"].data_ptr(), b["feat"].data_ptr(), st))
     if stage != "coarse":
         with _timed("k_sdfnet_fwd<fine>", P * 8 * 8 * 4 * 4):
             check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), 1, b["sdf"].data_ptr(),
-                                         b["grad"].data_ptr(), b["feat"].data_ptr(), b["save_f"].data_ptr(), st))
+                                         b["grad"].data_ptr(), b["feat"].data_ptr(), st))
     with _timed("k_colour_fwd", P * 16 * 8 * 2 * 4):
         check(lib.nsa_colour_forward(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
                                      b["feat"].data_ptr(), b["rgb"].data_ptr(),
@@ -130,12 +128,12 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
                                       1 if color_stage != "base" else 0, g_feat.data_ptr(), g_grad.data_ptr(),
                                       g_x.data_ptr(), g_dir.data_ptr(), st))
     with _timed("k_sdfnet_bwd<coarse>", P * 3 * 4 * 8 * 8 * 4):
-        check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), b["save_c"].data_ptr(),
-                                      g_sdf.data_ptr(), g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))
+        check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), g_sdf.data_ptr(),
+                                      g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))
     if stage != "coarse":
         with _timed("k_sdfnet_bwd<fine>", P * 3 * 8 * 8 * 4 * 4):
-            check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), b["save_f"].data_ptr(),
-                                          g_sdf.data_ptr(), g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))
+            check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), g_sdf.data_ptr(),
+                                          g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))
     g_o = torch.empty(R, 3, device=dev)
     g_d = torch.empty(R, 3, device=dev)
     check(lib.nsa_rays_backward(z_vals.data_ptr(), g_x.data_ptr(), g_dir.data_ptr(), R, S, g_o.data_ptr(),

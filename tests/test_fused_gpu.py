@@ -71,10 +71,8 @@ def test_feature_vector_hl_layout():
     for which, acc, nh in (("coarse", 0, 1), ("fine", 1, 3)):
         net = getattr(imp, which)
         g, keep = fs.grid_desc(net.encoding, net.divide_factor, nh)
-        save = torch.empty(lib.nsa_sdfnet_save_floats(P, nh), device="cuda")
         check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(g), fs.packed_sdf(model, which).data_ptr(), acc,
-                                     sdf.data_ptr(), grad.data_ptr(), feat.data_ptr(), save.data_ptr(),
-                                     torch.cuda.current_stream().cuda_stream))
+                                     sdf.data_ptr(), grad.data_ptr(), feat.data_ptr(), torch.cuda.current_stream().cuda_stream))
     dense = feat[fr.hl_index(P, "cuda")]
     cfg, params = oracle_config(fx), params_of(fx)
     x = (ro.cpu().unsqueeze(1) + z.cpu().unsqueeze(2) * rd.cpu().unsqueeze(1)).reshape(-1, 3)

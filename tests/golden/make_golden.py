@@ -66,15 +66,15 @@ def capture_draws(log):
 
 
 # ------------------------------------------------------------------ configs
-def model_conf(coarse_grid, fine_grid, n_samples, n_eval, n_extra):
+def model_conf(coarse_grid, fine_grid, n_samples, n_eval, n_extra, warp=False):
     def sdf(dims, g):
         return dict(d_in=3, d_out=1, dims=dims, geometric_init=True, bias=0.6, skip_in=[],
                     weight_norm=True, multires=6, inside_outside=True, use_grid_feature=True,
                     base_size=g[0], end_size=g[1], logmap=g[2], num_levels=g[3], level_dim=g[4],
                     divide_factor=1.0, embedding_method="nerf")
     return ref_shims.Conf(
-        feature_vector_size=64, scene_bounding_sphere=1.0, use_warp_loss=False,
-        mapping_patchsizes=[1], tracking_patchsizes=[1], sampling_method="important",
+        feature_vector_size=64, scene_bounding_sphere=1.0, use_warp_loss=bool(warp),
+        mapping_patchsizes=[1, 5] if warp else [1], tracking_patchsizes=[1], sampling_method="important",
         density_method="volsdf_gridpredefined",
         implicit_network=dict(coarse=sdf([64], coarse_grid), fine=sdf([64, 64, 64], fine_grid)),
         rendering_network=dict(mode="idr", d_in=9, d_out=3, dims=[64, 64], weight_norm=True,
@@ -88,12 +88,12 @@ class _DS:
     img_res = (680, 1200)
 
 
-def build_model(seed, coarse_grid, fine_grid, colour_grid, n_samples, n_eval, n_extra, emb_scale):
+def build_model(seed, coarse_grid, fine_grid, colour_grid, n_samples, n_eval, n_extra, emb_scale, warp=False, ds=None):
     """Reference SLAMNetwork with reduced-size tables.  The colour encoder is hard-coded to a
     1 GiB table (base_networks.py:265-284); it is swapped for the reference's own HashEncoder
     class with a small geometry that keeps 16 levels x 2 features."""
     torch.manual_seed(seed)
-    conf = model_conf(coarse_grid, fine_grid, n_samples, n_eval, n_extra)
+    conf = model_conf(coarse_grid, fine_grid, n_samples, n_eval, n_extra, warp)
     # build with a throw-away tiny colour grid to avoid allocating 1 GiB: patch the class default
     RN = ref_shims.import_ref("model.base_networks").RenderingNetwork
     HE = hg.HashEncoder
@@ -108,7 +108,7 @@ def build_model(seed, coarse_grid, fine_grid, colour_grid, n_samples, n_eval, n_
 
     HE.__init__ = small_init
     try:
-        model = ref_network.SLAMNetwork(conf, dataset=_DS(), n_images=4)
+        model = ref_network.SLAMNetwork(conf, dataset=ds or _DS(), n_images=4)
     finally:
         HE.__init__ = orig
     g = torch.Generator().manual_seed(seed + 100)
@@ -327,7 +327,67 @@ def sparse_colour_case(name, seed, n_pts):
     print(name, len(rows), "rows touched of", tot)
 
 
+class _SmallDS:
+    img_res = (40, 60)
+
+
+def warp_case(name, seed, bs=2, n_pix=6):
+    """Mapping mode with the patch-warp block (network.py:167-279) on 40x60 images, patch sizes 1 and 5."""
+    coarse_grid, fine_grid, colour_grid = (4, 4, 8, 4, 8), (4, 32, 10, 8, 4), (4, 64, 10)
+    samples = (10, 32, 6)
+    model, conf = build_model(seed, coarse_grid, fine_grid, colour_grid, *samples, emb_scale=(0.05, 0.05, 0.5),
+                              warp=True, ds=_SmallDS())
+    model.train(True)
+    H, W = _SmallDS.img_res
+    g = torch.Generator().manual_seed(seed + 1)
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 30.0
+    K[0, 2], K[1, 2] = 29.5, 19.5
+    idx = torch.randint(H * W, (bs, n_pix), generator=g)
+    uv = torch.stack([(idx % W).float(), (idx // W).float()], -1)
+    uv[0, 0] = torch.tensor([1.0, 1.0])          # patch partly outside the image
+    cam = torch.zeros(bs, 7)
+    cam[:, 0] = 1.0
+    cam[:, :4] += 0.03 * torch.randn(bs, 4, generator=g)
+    cam[:, 4:] = torch.tensor([0.1, 0.0, -0.2]) + 0.03 * torch.randn(bs, 3, generator=g)
+    cam = cam.requires_grad_(True)
+    pose = ref_general.get_camera_from_tensor(cam)
+    Kb = K[None].repeat(bs, 1, 1)
+    full_rgb = torch.rand(bs, H * W, 3, generator=g)
+    full_depth = 1.0 + 0.02 * torch.rand(bs, H * W, 1, generator=g)
+    full_depth[:, : H * W // 3] += torch.rand(bs, H * W // 3, 1, generator=g)    # a non-flat region
+    gt_rgb = torch.rand(bs * n_pix, 3, generator=g)
+    log = DrawLog()
+    torch.manual_seed(seed + 3)
+    with capture_draws(log):
+        out = model({"intrinsics": Kb, "uv": uv, "pose": pose}, torch.arange(bs),
+                    {"full_rgb": full_rgb, "full_depth": full_depth}, mode="mapping", stage="fine",
+                    color_stage="highfreq", frame_idx=1)
+    rec = {"in_uv": uv, "in_cam": cam, "in_K": Kb, "in_pose": pose, "in_voxels": torch.zeros(64, 64, 64),
+           "in_full_rgb": full_rgb, "in_full_depth": full_depth, "gt_rgb": gt_rgb,
+           "meta_mode": "mapping", "meta_stage": "fine", "meta_color_stage": "highfreq", "meta_training": 1,
+           "meta_samples": np.array(samples), "meta_coarse_grid": np.array(coarse_grid),
+           "meta_fine_grid": np.array(fine_grid), "meta_colour_grid": np.array(colour_grid),
+           "meta_img_res": np.array([H, W])}
+    rec["draw_t_rand"], rec["draw_extra_idx"] = log.draws[0][1], log.draws[1][1][: samples[2]]
+    rec["draw_eik_idx"], rec["draw_eik_uniform"], rec["draw_eik_jitter"] = log.draws[2][1], log.draws[3][1], log.draws[4][1]
+    for k, v in model.state_dict().items():
+        rec["param_" + k] = v
+    loss = (out["rgb_values"].reshape(-1, 3) - gt_rgb).abs().mean()
+    for ps, (gt_w, samp, mask, ray_mask) in out["warp_output"].items():
+        rec[f"out_warp{ps}_gt"], rec[f"out_warp{ps}_sampled"], rec[f"out_warp{ps}_mask"] = gt_w, samp, mask
+        if ray_mask is not None:
+            rec[f"out_warp{ps}_raymask"] = ray_mask
+        loss = loss + 0.5 * ((gt_w - samp).abs().sum(-1) * mask.float()).sum() / (mask.float().sum() + 1)
+    loss.backward()
+    rec["out_loss"], rec["grad_cam"] = loss, cam.grad
+    rec["out_z_vals"], rec["out_rgb_values"], rec["out_depth_values"] = out["z_vals"], out["rgb_values"], out["depth_values"]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **t2n(rec))
+    print(name, float(loss), {k: tuple(v.shape) for k, v in rec.items() if k.startswith("out_warp")})
+
+
 if __name__ == "__main__":
+    warp_case("full_mapping_warp", 15)
     encoder_case("enc_coarse", 1, L=4, C=8, base=8, end=8, logmap=19, n_pts=64)
     encoder_case("enc_fine", 2, L=8, C=4, base=4, end=40, logmap=10, n_pts=64)
     encoder_case("enc_colour", 3, L=16, C=2, base=4, end=128, logmap=11, n_pts=64)

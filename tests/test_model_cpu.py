@@ -21,13 +21,16 @@ def build_model(fx):
     from nicer_slam_amd.utils.conf import replica_model_conf
     cg, fg, col = fx["meta_coarse_grid"], fx["meta_fine_grid"], fx["meta_colour_grid"]
     ns, ne, nx = [int(v) for v in fx["meta_samples"]]
-    conf = replica_model_conf(ns, ne, nx, use_warp_loss=False)
+    warp = "meta_img_res" in fx
+    conf = replica_model_conf(ns, ne, nx, use_warp_loss=warp)
+    if warp:
+        conf["mapping_patchsizes"] = [1, 5]
     for net, g in (("coarse", cg), ("fine", fg)):
         conf["implicit_network"][net].update(base_size=int(g[0]), end_size=int(g[1]), logmap=int(g[2]),
                                              num_levels=int(g[3]), level_dim=int(g[4]))
 
     class DS:
-        img_res = (680, 1200)
+        img_res = tuple(int(v) for v in fx["meta_img_res"]) if warp else (680, 1200)
     model = SLAMNetwork(conf, dataset=DS(), n_images=4,
                         colour_grid=dict(base_resolution=int(col[0]), desired_resolution=int(col[1]),
                                          log2_hashmap_size=int(col[2])))
@@ -70,6 +73,37 @@ def test_model_layer_matches_reference(oracle_seam, name):
         else:
             g = p.grad if p.grad is not None else torch.zeros_like(p)
             assert_close(g, ref, 1e-6 + 1e-4 * float(np.abs(ref).max()), 1e-3, "grad " + n)
+
+
+def test_patch_warp_block_matches_reference(oracle_seam):
+    """Mapping mode with use_warp_loss (all shipped configs enable it): the warp gather's four outputs per patch size
+    and the pose gradient of an objective that runs through it (reference network.py:167-279)."""
+    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    fx = load("full_mapping_warp")
+    model = build_model(fx)
+    model.train(True)
+    model.voxels = tt(fx["in_voxels"]).clone()
+    model.draws = draws_of(fx)
+    model.draws["z_vals_override"] = tt(fx["out_z_vals"])
+    cam = tt(fx["in_cam"]).requires_grad_(True)
+    out = model({"intrinsics": tt(fx["in_K"]), "uv": tt(fx["in_uv"]), "pose": get_camera_from_tensor(cam)},
+                torch.arange(2), {"full_rgb": tt(fx["in_full_rgb"]), "full_depth": tt(fx["in_full_depth"])},
+                mode="mapping", stage="fine", color_stage="highfreq", frame_idx=1)
+    assert_close(out["rgb_values"], fx["out_rgb_values"], 1e-5, 1e-4, "rgb_values")
+    loss = (out["rgb_values"].reshape(-1, 3) - tt(fx["gt_rgb"])).abs().mean()
+    assert sorted(out["warp_output"]) == [1, 5]
+    for ps, (gt_w, samp, mask, ray_mask) in out["warp_output"].items():
+        assert_close(gt_w, fx[f"out_warp{ps}_gt"], 0, 0, f"gt patch {ps}")
+        assert bool((mask == tt(fx[f"out_warp{ps}_mask"])).all()), f"mask {ps}"
+        assert_close(samp, fx[f"out_warp{ps}_sampled"], 2e-5, 1e-4, f"sampled {ps}")
+        if ps > 1:
+            assert bool((ray_mask == tt(fx[f"out_warp{ps}_raymask"])).all())
+        else:
+            assert ray_mask is None
+        loss = loss + 0.5 * ((gt_w - samp).abs().sum(-1) * mask.float()).sum() / (mask.float().sum() + 1)
+    assert_close(loss, fx["out_loss"], 1e-6, 1e-5, "loss")
+    loss.backward()
+    assert_close(cam.grad, fx["grad_cam"], 1e-4 * float(np.abs(fx["grad_cam"]).max()), 1e-3, "grad_cam")
 
 
 def test_sampler_free_running(oracle_seam):

@@ -60,6 +60,35 @@ __global__ __launch_bounds__(TPB) void k_grid_forward(const float* __restrict__ 
     }
 }
 
+// Run-merged atomic scatter.  Float atomics reach L2 one address at a time (measured ~7 G atomics/s on MI355X, the whole
+// cost of a mapping iteration's table gradients), while the points of a wave are consecutive samples of a ray and walk
+// through each cell of a coarse level in RUNS of equal row index.  The lanes of a run are summed with a segmented
+// shuffle scan and only the run's last lane issues the atomics: 64 atomics per wave and corner become one per run.
+// `key` = destination row or 0xFFFFFFFF for lanes with nothing to add (they never merge into a run).
+template <int C>
+__device__ __forceinline__ void scatter_runs(float* __restrict__ table_level, uint32_t key, float (&val)[C], int lane) {
+    const uint32_t prev = __shfl_up(key, 1);
+    const bool head = lane == 0 || prev != key || key == 0xFFFFFFFFu;
+    const unsigned long long hm = __ballot(head);
+    const int seg = __popcll(hm & ((2ull << lane) - 1ull));            // inclusive count of heads = segment id
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int oseg = __shfl_up(seg, off);
+        const bool take = lane >= off && oseg == seg;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float o = __shfl_up(val[c], off);
+            if (take) val[c] += o;
+        }
+    }
+    const bool tail = lane == 63 || ((hm >> (lane + 1)) & 1ull);
+    if (tail && key != 0xFFFFFFFFu) {
+        float* dst = table_level + (size_t)key * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) atomicAdd(dst + c, val[c]);        // -munsafe-fp-atomics: global_atomic_add_f32
+    }
+}
+
 // -------------------------------------------------------------------- first backward: table scatter
 // grad_emb[row(corner), c] += w(corner) * grad[l,b,c]   (kernel_grid_backward :286-373)
 template <int D, int C>
@@ -67,16 +96,20 @@ __global__ __launch_bounds__(TPB) void k_grid_scatter(const float* __restrict__ 
                                                       float* __restrict__ grad_emb, uint32_t B, uint32_t L, GridGeom geom) {
     const uint32_t level = blockIdx.x % L;
     const uint32_t b = (blockIdx.x / L) * TPB + threadIdx.x;
-    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
     const LevelGeom g = geom.lv[level];
+    const bool have = b < B;                       // no early exit: every lane takes part in the run merge
     float x[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) x[d] = inputs[(size_t)b * D + d];
+    for (int d = 0; d < D; ++d) x[d] = have ? inputs[(size_t)b * D + d] : -1.0f;
     uint32_t cell[D];
     float w[D], dw[D];
-    if (!locate<D>(x, g.scale, cell, w, dw)) return;
+    const bool active = have && locate<D>(x, g.scale, cell, w, dw);     // out-of-range points add nothing (:313-317)
     float gy[C];
-    load_row<C>(grad + ((size_t)level * B + b) * C, gy);
+#pragma unroll
+    for (int c = 0; c < C; ++c) gy[c] = 0.0f;
+    if (active) load_row<C>(grad + ((size_t)level * B + b) * C, gy);
+    float* tl = grad_emb + (size_t)g.row0 * C;
 #pragma unroll
     for (int corner = 0; corner < (1 << D); ++corner) {
         float wt = 1.0f;
@@ -87,9 +120,11 @@ __global__ __launch_bounds__(TPB) void k_grid_scatter(const float* __restrict__ 
             wt *= bit ? w[d] : 1.0f - w[d];
             q[d] = cell[d] + bit;
         }
-        float* dst = grad_emb + (size_t)(g.row0 + level_row<D>(g, q)) * C;
+        const uint32_t key = active ? level_row<D>(g, q) : 0xFFFFFFFFu;
+        float v[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) atomicAdd(dst + c, wt * gy[c]);   // -munsafe-fp-atomics: global_atomic_add_f32
+        for (int c = 0; c < C; ++c) v[c] = wt * gy[c];
+        scatter_runs<C>(tl, key, v, lane);
     }
 }
 
@@ -131,12 +166,13 @@ __global__ __launch_bounds__(TPB) void k_grid_second_backward(const float* __res
                                                               uint32_t B, uint32_t L, GridGeom geom) {
     const uint32_t level = blockIdx.x % L;
     const uint32_t b = (blockIdx.x / L) * TPB + threadIdx.x;
-    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const bool have = b < B;
     const LevelGeom g = geom.lv[level];
     float ggi[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) ggi[d] = ggi_[(size_t)b * D + d];
-    {
+    for (int d = 0; d < D; ++d) ggi[d] = have ? ggi_[(size_t)b * D + d] : 0.0f;
+    if (have) {
         const float* jrow = dy_dx + (((size_t)b * L + level) * D) * C;
         float r[C];
 #pragma unroll
@@ -153,12 +189,14 @@ __global__ __launch_bounds__(TPB) void k_grid_second_backward(const float* __res
     if (!SCATTER) return;
     float x[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) x[d] = inputs[(size_t)b * D + d];
+    for (int d = 0; d < D; ++d) x[d] = have ? inputs[(size_t)b * D + d] : -1.0f;
     uint32_t cell[D];
     float w[D], dw[D];
-    if (!locate<D>(x, g.scale, cell, w, dw)) return;
+    const bool active = have && locate<D>(x, g.scale, cell, w, dw);
     float gy[C];
-    load_row<C>(grad + ((size_t)level * B + b) * C, gy);
+#pragma unroll
+    for (int c = 0; c < C; ++c) gy[c] = 0.0f;
+    if (active) load_row<C>(grad + ((size_t)level * B + b) * C, gy);
     // per-corner scalar coefficient k[corner] = sum_gd sign * scale * prod_{d != gd} w_d * ggi[gd] * dw[gd]
     float k[1 << D];
 #pragma unroll
@@ -180,14 +218,17 @@ __global__ __launch_bounds__(TPB) void k_grid_second_backward(const float* __res
             k[lo] -= t;
         }
     }
+    float* tl = grad2_emb + (size_t)g.row0 * C;
 #pragma unroll
     for (int corner = 0; corner < (1 << D); ++corner) {
         uint32_t q[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) q[d] = cell[d] + ((corner >> d) & 1);
-        float* dst = grad2_emb + (size_t)(g.row0 + level_row<D>(g, q)) * C;
+        const uint32_t key = active ? level_row<D>(g, q) : 0xFFFFFFFFu;
+        float v[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) atomicAdd(dst + c, k[corner] * gy[c]);
+        for (int c = 0; c < C; ++c) v[c] = k[corner] * gy[c];
+        scatter_runs<C>(tl, key, v, lane);
     }
 }
 

@@ -133,6 +133,26 @@ int nsa_colour_backward(const nsa_points_t *pts, const nsa_grid_t *grid, const f
                         const float *feat_hl, const float *save, const float *g_rgb, int grid_grad,
                         float *g_feat_hl, float *g_grad, float *g_x, float *g_dir, nsa_stream_t stream);
 
+/* Mapping-mode backward (parameter gradients): the same kernels as nsa_sdfnet_backward / nsa_colour_backward with two
+ * more outputs.  replaces, for a mapping iteration, what torch.autograd does through ImplicitNetworkGrid /
+ * RenderingNetwork / _hash_encode.backward / _hash_encode_second_backward (code/model/base_networks.py:195-221,
+ * 333-395; code/hashencoder/hashgrid.py:64-141) for the trainable parameters of volsdf_train.py:150-173:
+ *   g_table  gradient of the grid table (same shape as grid->table), ATOMICALLY ACCUMULATED (caller zeroes it):
+ *            value path + (SDF grids) the table's share of the double backward through grad sdf; may be NULL.
+ *   emit     [nsa_*_emit_rows()][emit_ld] per-point vectors, column = point index (emit_ld >= ceil(P/32)*32, columns
+ *            of padding points are written as 0).  The weight gradients are GEMMs over these rows (row map: the
+ *            SE_* / CE_* enums in csrc/render_sdfnet.hip, csrc/render_colour.hip; host side fused/mapping.py).
+ *            SDF: coarse network (one hidden layer) only -- the fine MLP is frozen in the reference; may be NULL. */
+int nsa_sdfnet_backward_params(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, const float *g_sdf,
+                               const float *g_feat_hl, const float *g_grad, int accumulate, float *g_x, float *g_table,
+                               float *emit, uint32_t emit_ld, nsa_stream_t stream);
+int nsa_colour_backward_params(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, const float *grad,
+                               const float *feat_hl, const float *save, const float *g_rgb, int grid_grad,
+                               float *g_feat_hl, float *g_grad, float *g_x, float *g_dir, float *g_table, float *emit,
+                               uint32_t emit_ld, nsa_stream_t stream);
+int nsa_sdfnet_emit_rows(void);
+int nsa_colour_emit_rows(void);
+
 /* Per-ray SDF -> density -> alpha compositing.  replaces SLAMNetwork.volume_rendering (code/model/network.py:349-370)
  * + the composite sums of SLAMNetwork.forward (:147-151, 298, 338-342) + GridPredefineDensity (density.py:37-67).
  * Outputs weights[R,S], rgb_values[R,3], depth[R] (= sum w z / (sum w + 1e-8), before depth_scale),

@@ -77,6 +77,15 @@ lib.nsa_composite_backward.restype = _i
 lib.nsa_composite_backward.argtypes = [_p, _p, _p, _p, _p, _p, _p, _u32, _u32, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p]
 lib.nsa_rays_backward.restype = _i
 lib.nsa_rays_backward.argtypes = [_p, _p, _p, _u32, _u32, _p, _p, _p]
+lib.nsa_sdfnet_backward_params.restype = _i
+lib.nsa_sdfnet_backward_params.argtypes = [_pp, _gp, _p, _p, _p, _p, _i, _p, _p, _p, _u32, _p]
+lib.nsa_colour_backward_params.restype = _i
+lib.nsa_colour_backward_params.argtypes = [_pp, _gp, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _u32, _p]
+lib.nsa_sdfnet_emit_rows.restype = _i
+lib.nsa_sdfnet_emit_rows.argtypes = []
+lib.nsa_colour_emit_rows.restype = _i
+lib.nsa_colour_emit_rows.argtypes = []
+EXPORTS += ["nsa_sdfnet_backward_params", "nsa_colour_backward_params", "nsa_sdfnet_emit_rows", "nsa_colour_emit_rows"]
 EXPORTS += ["nsa_sdfnet_forward", "nsa_sdfnet_backward", "nsa_colour_forward", "nsa_colour_backward",
             "nsa_composite_forward", "nsa_composite_backward", "nsa_rays_backward"]
 

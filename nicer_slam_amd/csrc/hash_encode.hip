@@ -60,35 +60,6 @@ __global__ __launch_bounds__(TPB) void k_grid_forward(const float* __restrict__ 
     }
 }
 
-// Run-merged atomic scatter.  Float atomics reach L2 one address at a time (measured ~7 G atomics/s on MI355X, the whole
-// cost of a mapping iteration's table gradients), while the points of a wave are consecutive samples of a ray and walk
-// through each cell of a coarse level in RUNS of equal row index.  The lanes of a run are summed with a segmented
-// shuffle scan and only the run's last lane issues the atomics: 64 atomics per wave and corner become one per run.
-// `key` = destination row or 0xFFFFFFFF for lanes with nothing to add (they never merge into a run).
-template <int C>
-__device__ __forceinline__ void scatter_runs(float* __restrict__ table_level, uint32_t key, float (&val)[C], int lane) {
-    const uint32_t prev = __shfl_up(key, 1);
-    const bool head = lane == 0 || prev != key || key == 0xFFFFFFFFu;
-    const unsigned long long hm = __ballot(head);
-    const int seg = __popcll(hm & ((2ull << lane) - 1ull));            // inclusive count of heads = segment id
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int oseg = __shfl_up(seg, off);
-        const bool take = lane >= off && oseg == seg;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const float o = __shfl_up(val[c], off);
-            if (take) val[c] += o;
-        }
-    }
-    const bool tail = lane == 63 || ((hm >> (lane + 1)) & 1ull);
-    if (tail && key != 0xFFFFFFFFu) {
-        float* dst = table_level + (size_t)key * C;
-#pragma unroll
-        for (int c = 0; c < C; ++c) atomicAdd(dst + c, val[c]);        // -munsafe-fp-atomics: global_atomic_add_f32
-    }
-}
-
 // -------------------------------------------------------------------- first backward: table scatter
 // grad_emb[row(corner), c] += w(corner) * grad[l,b,c]   (kernel_grid_backward :286-373)
 template <int D, int C>

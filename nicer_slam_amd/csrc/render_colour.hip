@@ -50,6 +50,28 @@ struct ColourArgs {
     float* g_x;             // [P,3] out (overwrite)
     float* g_dir;           // [P,3] out (overwrite)
     int grid_grad;          // 0: colour-grid feature detached (color_stage "base"), 1: propagate through it
+    // mapping (parameter gradients)
+    float* g_table;         // colour-table gradient (atomically accumulated) or nullptr
+    float* emit;            // per-point vectors for the weight-gradient GEMMs, [CE_ROWS][emit_ld] or nullptr
+    uint32_t emit_ld;
+};
+
+// Rows of the emission buffer; column = tile*32 + point-in-tile.
+//   dW0 = AB1 IN^T, db0 = sum AB1, dW1 = AB2 H1^T, db1 = sum AB2, dW2 = OB H2^T, db2 = sum OB
+// IN rows are input slots (row = 2*slot + half), the others hidden features in reference order.
+enum : int { CE_IN = 0, CE_AB1 = 130, CE_H1 = 194, CE_AB2 = 258, CE_H2 = 322, CE_OB = 386, CE_ROWS = 389 };
+
+struct ColEmitter {
+    float* base;
+    uint32_t ld;
+    bool live;
+    __device__ __forceinline__ void slot(int region, int s, int h, float v) const {
+        base[(size_t)(region + 2 * s + h) * ld] = live ? v : 0.0f;
+    }
+    __device__ __forceinline__ void hid(int region, int q, int h, float v) const {
+        const int f = 32 * (q >> 4) + (q & 3) + 8 * ((q & 15) >> 2) + 4 * h;
+        base[(size_t)(region + f) * ld] = live ? v : 0.0f;
+    }
 };
 
 __device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeom16& geom, uint32_t tile, uint32_t pid, int lane,
@@ -160,6 +182,7 @@ __global__ __launch_bounds__(256, 2) void k_colour_fwd(ColourArgs a, GridGeom16 
     }
 }
 
+template <bool MAP>
 __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 geom) {
     desync_simd_partners();
     const int lane = threadIdx.x & 63;
@@ -179,12 +202,27 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
     f32x16 a1[2], a2[2];
     float rgb[3];
     colour_mlp(a.wp, lane, h, in, a1, a2, rgb);
+    const bool emit = MAP && a.emit != nullptr;
+    const ColEmitter em{emit ? a.emit + (size_t)tile * 32 + (lane & 31) : nullptr, a.emit_ld, live};
+    if (emit) {
+#pragma unroll
+        for (int s = 0; s < COL_IN_STEPS; ++s) em.slot(CE_IN, s, h, in[s]);
+#pragma unroll
+        for (int q = 0; q < HS; ++q) {
+            em.hid(CE_H1, q, h, fmaxf(a1[q >> 4][q & 15], 0.0f));
+            em.hid(CE_H2, q, h, fmaxf(a2[q >> 4][q & 15], 0.0f));
+        }
+    }
     // d/d(pre-sigmoid), d/d h2 = sum_j ob_j W2[j,:], relu masks (torch: grad * (a > 0))
     float ab[HS];
     {
         float ob[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) ob[j] = a.g_rgb[(size_t)pid * 3 + j] * rgb[j] * (1.0f - rgb[j]);
+        if (emit && h == 0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) em.base[(size_t)(CE_OB + j) * em.ld] = live ? ob[j] : 0.0f;
+        }
 #pragma unroll
         for (int q = 0; q < HS; ++q) ab[q] = 0.0f;
 #pragma unroll
@@ -201,6 +239,10 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
 #pragma unroll
             for (int r = 0; r < 16; ++r) ab[16 * t + r] = a2[t][r] > 0.0f ? ab[16 * t + r] : 0.0f;
     }
+    if (emit) {
+#pragma unroll
+        for (int q = 0; q < HS; ++q) em.hid(CE_AB2, q, h, ab[q]);
+    }
     {
         f32x16 acc[2];
 #pragma unroll
@@ -212,6 +254,10 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) ab[16 * t + r] = a1[t][r] > 0.0f ? acc[t][r] : 0.0f;
+    }
+    if (emit) {
+#pragma unroll
+        for (int q = 0; q < HS; ++q) em.hid(CE_AB1, q, h, ab[q]);
     }
     float ib[80];
     {
@@ -253,6 +299,34 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
 #pragma unroll
                 for (int c = 0; c < CC; ++c)
                     gx[d] = fmaf(sv[(16 + (jl * 3 + d) * CC + c) * 64] * chain, ib[49 + jl * CC + c], gx[d]);
+    }
+    if (MAP && a.grid_grad && a.g_table) {   // colour-table gradient: w_corner * fbar, run-merged (kernel_grid_backward)
+        float u[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) u[d] = (x[d] / a.divide_factor + 1.0f) / 2.0f;
+#pragma unroll
+        for (int jl = 0; jl < CL / 2; ++jl) {
+            const LevelGeom lg = geom.lv[2 * jl + h];
+            uint32_t cell[3];
+            float w[3], dw[3];
+            const bool active = locate<3>(u, lg.scale, cell, w, dw) && live;
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                float wt = 1.0f;
+                uint32_t q[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int bit = (corner >> d) & 1;
+                    wt *= bit ? w[d] : 1.0f - w[d];
+                    q[d] = cell[d] + bit;
+                }
+                const uint32_t key = active ? lg.row0 + level_row<3>(lg, q) : 0xFFFFFFFFu;
+                float v[CC];
+#pragma unroll
+                for (int c = 0; c < CC; ++c) v[c] = wt * ib[49 + jl * CC + c];
+                scatter_runs<CC>(a.g_table, key, v, lane);
+            }
+        }
     }
 #pragma unroll
     for (int d = 0; d < 3; ++d) { gx[d] = xhalf_sum(gx[d]); gd[d] = xhalf_sum(gd[d]); gg[d] = xhalf_sum(gg[d]); }
@@ -310,8 +384,31 @@ int nsa_colour_backward(const nsa_points_t* pts, const nsa_grid_t* grid, const f
     a.g_feat = g_feat_hl; a.g_grad = g_grad; a.g_x = g_x; a.g_dir = g_dir; a.grid_grad = grid_grad;
     const uint32_t tiles = (pts->P + 31) / 32;
     launch_begin();
-    hipLaunchKernelGGL(k_colour_bwd, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
+    hipLaunchKernelGGL(k_colour_bwd<false>, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
     return launch_end();
 }
+
+int nsa_colour_backward_params(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad,
+                               const float* feat_hl, const float* save, const float* g_rgb, int grid_grad,
+                               float* g_feat_hl, float* g_grad, float* g_x, float* g_dir, float* g_table, float* emit,
+                               uint32_t emit_ld, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!packed || !grad || !feat_hl || !save || !g_rgb || !g_feat_hl || !g_grad || !g_x || !g_dir) return NSA_EBADARG;
+    if (!g_table && !emit) return NSA_EBADARG;
+    ColourArgs a{};
+    GridGeom16 geom;
+    if (int rc = colour_common(pts, grid, &a, &geom)) return rc;
+    if (pts->P == 0) return NSA_OK;
+    if (emit && emit_ld < ((pts->P + 31) / 32) * 32) return NSA_EBADARG;
+    a.wp = packed; a.grad = grad; a.feat = feat_hl; a.save = const_cast<float*>(save); a.g_rgb = g_rgb;
+    a.g_feat = g_feat_hl; a.g_grad = g_grad; a.g_x = g_x; a.g_dir = g_dir; a.grid_grad = grid_grad;
+    a.g_table = g_table; a.emit = emit; a.emit_ld = emit_ld;
+    const uint32_t tiles = (pts->P + 31) / 32;
+    launch_begin();
+    hipLaunchKernelGGL(k_colour_bwd<true>, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
+    return launch_end();
+}
+
+int nsa_colour_emit_rows(void) { return nsa::CE_ROWS; }
 
 }  // extern "C"

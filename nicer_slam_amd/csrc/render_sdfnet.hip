@@ -37,6 +37,28 @@ struct SdfNetArgs {
     const float* g_feat;   // HL
     const float* g_grad;   // [P,3]
     float* g_x;            // [P,3]
+    // mapping (parameter gradients)
+    float* g_table;        // table gradient, same shape as `table` (atomically accumulated) or nullptr
+    float* emit;           // per-point vectors for the weight-gradient GEMMs, [SE_ROWS][emit_ld] or nullptr
+    uint32_t emit_ld;
+};
+
+// Rows of the emission buffer of a one-hidden-layer (coarse) network; column = tile*32 + point-in-tile.
+//   dW0 = AB1 H0^T + DA1 TIN^T,  db0 = sum AB1,  dW1[0] = sum sbar H1 + TH1,  dW1[1:] = FB H1^T,  db1 = [sum sbar, sum FB]
+// H0/TIN rows are first-layer slots (row = 2*slot + half), the others are hidden features in reference order.
+enum : int { SE_H0 = 0, SE_TIN = 72, SE_AB1 = 144, SE_DA1 = 208, SE_H1 = 272, SE_TH1 = 336, SE_FB = 400, SE_ROWS = 464 };
+
+struct Emitter {
+    float* base;
+    uint32_t ld;
+    bool live;
+    __device__ __forceinline__ void slot(int region, int s, int h, float v) const {
+        base[(size_t)(region + 2 * s + h) * ld] = live ? v : 0.0f;
+    }
+    __device__ __forceinline__ void hid(int region, int q, int h, float v) const {      // q = 16 t + r
+        const int f = 32 * (q >> 4) + (q & 3) + 8 * ((q & 15) >> 2) + 4 * h;
+        base[(size_t)(region + f) * ld] = live ? v : 0.0f;
+    }
 };
 
 template <int NH>
@@ -170,7 +192,9 @@ __global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfne
 }
 
 // Occupancy per variant was chosen by A/B timing on MI355X (profiles/): forward fine 2 waves/SIMD, both backward kernels 1.
-template <int L, int C, int NH>
+// MAP = true adds the mapping outputs: table gradient (run-merged atomics) and, for the coarse network, the per-point
+// vectors of the weight-gradient GEMMs (the fine MLP is frozen in the reference, volsdf_train.py:150-173).
+template <int L, int C, int NH, bool MAP>
 __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FINE)) void k_sdfnet_bwd(SdfNetArgs a, GridGeom16 geom) {
     using P = SdfPack<NH>;
     desync_simd_partners();
@@ -193,6 +217,19 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
     hidden_forward<NH>(a.wp, lane, h, in, sg, hl);
     float dh[NH > 1 ? NH - 1 : 1][HS], dl[48];
     reverse_pass<NH>(a.wp, lane, h, sg, dh, dl);
+    const bool emit = MAP && NH == 1 && a.emit != nullptr;
+    const Emitter em{emit ? a.emit + (size_t)tile * 32 + (lane & 31) : nullptr, a.emit_ld, live};
+    if (emit) {
+        f32x16 ws[2];
+        load_vec<2>(a.wp + P::kWSDF, h, ws);
+#pragma unroll
+        for (int s = 0; s < SDF_IN_STEPS; ++s) em.slot(SE_H0, s, h, in[s]);
+#pragma unroll
+        for (int q = 0; q < HS; ++q) {
+            em.hid(SE_H1, q, h, hl[q]);
+            em.hid(SE_DA1, q, h, sg[NH - 1][q] * ws[q >> 4][q & 15]);
+        }
+    }
 
     float nbar[3];
 #pragma unroll
@@ -205,6 +242,10 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
     {
         float tin[SDF_IN_STEPS];
         x_to_slots_tangent<L, C>(x, a.divide_factor, a.table, geom, h, in, nbar, dl, tin, xb2);
+        if (emit) {
+#pragma unroll
+            for (int s = 0; s < SDF_IN_STEPS; ++s) em.slot(SE_TIN, s, h, tin[s]);
+        }
         f32x16 acc[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -226,6 +267,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
                     const float dhk = (k == NH) ? ws[t][r] : dh[k - 1][q];
                     e[k - 1][q] = s2 * dhk * acc[t][r];
                     th[q] = s1 * acc[t][r];
+                    if (emit) em.hid(SE_TH1, q, h, th[q]);
                 }
             if (k < NH) {
 #pragma unroll
@@ -243,6 +285,10 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
         const float* fsrc = a.g_feat ? a.g_feat + (size_t)tile * 32 * 64 + lane : nullptr;
 #pragma unroll
         for (int q = 0; q < HS; ++q) fb[q] = fsrc ? fsrc[q * 64] : 0.0f;
+        if (emit) {
+#pragma unroll
+            for (int q = 0; q < HS; ++q) em.hid(SE_FB, q, h, fb[q]);
+        }
         f32x16 acc[2], ws[2];
         load_vec<2>(a.wp + P::kWSDF, h, ws);
 #pragma unroll
@@ -268,6 +314,10 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
 #pragma unroll
             for (int r = 0; r < 16; ++r) ab[16 * t + r] = sg[k - 1][16 * t + r] * acc[t][r] + e[k - 1][16 * t + r];
     }
+    if (emit) {
+#pragma unroll
+        for (int q = 0; q < HS; ++q) em.hid(SE_AB1, q, h, ab[q]);
+    }
     float hb0[48];
     {
         f32x16 a3[3];
@@ -283,6 +333,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
     }
     float gx[3];
     slots_to_x<L, C>(x, a.divide_factor, a.table, geom, h, in, hb0, gx);
+    if (MAP && a.g_table) table_grad_scatter<L, C>(x, a.divide_factor, geom, h, lane, live, hb0, dl, nbar, a.g_table);
 #pragma unroll
     for (int d = 0; d < 3; ++d) gx[d] = xhalf_sum(gx[d] + xb2[d]);
     if (live && h == 0) {
@@ -296,16 +347,20 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
 }
 
 static int launch_sdfnet(bool bwd, const nsa_grid_t* grid, const SdfNetArgs& a, hipStream_t st) {
+    const bool map = a.g_table != nullptr || a.emit != nullptr;
     GridGeom16 geom;
     if (int rc = make_grid_geom16(grid->offsets_host, grid->L, grid->S, grid->H, &geom)) return rc;
     const uint32_t tiles = (a.src.P + 31) / 32;
     const dim3 g((tiles + 3) / 4), b(256);
     launch_begin();
     if (grid->L == 4 && grid->C == 8 && grid->n_hidden == 1) {
-        if (bwd) hipLaunchKernelGGL((k_sdfnet_bwd<4, 8, 1>), g, b, 0, st, a, geom);
+        if (bwd && map) hipLaunchKernelGGL((k_sdfnet_bwd<4, 8, 1, true>), g, b, 0, st, a, geom);
+        else if (bwd)   hipLaunchKernelGGL((k_sdfnet_bwd<4, 8, 1, false>), g, b, 0, st, a, geom);
         else     hipLaunchKernelGGL((k_sdfnet_fwd<4, 8, 1>), g, b, 0, st, a, geom);
     } else if (grid->L == 8 && grid->C == 4 && grid->n_hidden == 3) {
-        if (bwd) hipLaunchKernelGGL((k_sdfnet_bwd<8, 4, 3>), g, b, 0, st, a, geom);
+        if (bwd && map && a.emit) return NSA_EUNSUPPORTED_NET;      // weight-gradient vectors: coarse network only
+        if (bwd && map) hipLaunchKernelGGL((k_sdfnet_bwd<8, 4, 3, true>), g, b, 0, st, a, geom);
+        else if (bwd)   hipLaunchKernelGGL((k_sdfnet_bwd<8, 4, 3, false>), g, b, 0, st, a, geom);
         else     hipLaunchKernelGGL((k_sdfnet_fwd<8, 4, 3>), g, b, 0, st, a, geom);
     } else {
         return NSA_EUNSUPPORTED_NET;
@@ -342,5 +397,23 @@ int nsa_sdfnet_backward(const nsa_points_t* pts, const nsa_grid_t* grid, const f
     a.g_sdf = g_sdf; a.g_feat = g_feat_hl; a.g_grad = g_grad; a.g_x = g_x;
     return launch_sdfnet(true, grid, a, (hipStream_t)stream);
 }
+
+int nsa_sdfnet_backward_params(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* g_sdf,
+                               const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x, float* g_table,
+                               float* emit, uint32_t emit_ld, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!pts || !grid || !packed || !g_x || (!g_table && !emit)) return NSA_EBADARG;
+    if (emit && emit_ld < ((pts->P + 31) / 32) * 32) return NSA_EBADARG;
+    if (pts->P == 0) return NSA_OK;
+    if (!pts->points && (!pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0)) return NSA_EBADARG;
+    SdfNetArgs a{};
+    a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S};
+    a.table = grid->table; a.wp = packed; a.divide_factor = grid->divide_factor; a.accumulate = accumulate;
+    a.g_sdf = g_sdf; a.g_feat = g_feat_hl; a.g_grad = g_grad; a.g_x = g_x;
+    a.g_table = g_table; a.emit = emit; a.emit_ld = emit_ld;
+    return launch_sdfnet(true, grid, a, (hipStream_t)stream);
+}
+
+int nsa_sdfnet_emit_rows(void) { return nsa::SE_ROWS; }
 
 }  // extern "C"

@@ -257,6 +257,66 @@ __device__ __forceinline__ void x_to_slots_tangent(const float (&x)[3], float di
     }
 }
 
+// Table gradient of one SDF grid for THIS lane's levels (mapping): per corner row,
+//   gT[row, c] += w_corner * hb[c]  +  k_corner * dl[c]
+// first term = value path (hb = cotangent of the grid features, kernel_grid_backward hashencoder.cu:286-373), second =
+// the table's share of the double backward through grad sdf (k_corner = sum_d n_d d w_corner/d x_d, dl = reverse-pass
+// vector; kernel_grad2_embeddings :461-625).  Consecutive samples of a ray share cells on the coarse levels, so the
+// atomics are run-merged across the half-wave (grid_common.hpp::scatter_runs; keys are table-global rows, which keeps
+// the two halves -- different levels -- apart).
+template <int L, int C>
+__device__ __forceinline__ void table_grad_scatter(const float (&x)[3], float divide_factor, const GridGeom16& geom, int h,
+                                                   int lane, bool live, const float (&hb)[3 * 16], const float (&dl)[3 * 16],
+                                                   const float (&n)[3], float* __restrict__ g_table) {
+    float u[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) u[d] = (x[d] / divide_factor + 1.0f) / 2.0f;
+    const float chain = 1.0f / (2.0f * divide_factor);
+#pragma unroll
+    for (int jl = 0; jl < L / 2; ++jl) {
+        const LevelGeom lg = geom.lv[2 * jl + h];
+        uint32_t cell[3];
+        float w[3], dw[3];
+        const bool active = locate<3>(u, lg.scale, cell, w, dw) && live;
+        float k[8];
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) k[corner] = 0.0f;
+#pragma unroll
+        for (int gd = 0; gd < 3; ++gd) {
+#pragma unroll
+            for (int face = 0; face < 4; ++face) {
+                float wt = lg.scale;
+                int lo = 0;
+#pragma unroll
+                for (int nd = 0; nd < 2; ++nd) {
+                    const int d = (nd >= gd) ? nd + 1 : nd;
+                    if ((face >> nd) & 1) { wt *= w[d]; lo |= 1 << d; }
+                    else                  { wt *= 1.0f - w[d]; }
+                }
+                const float t = wt * dw[gd] * n[gd] * chain;
+                k[lo | (1 << gd)] += t;
+                k[lo] -= t;
+            }
+        }
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            float wt = 1.0f;
+            uint32_t q[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int bit = (corner >> d) & 1;
+                wt *= bit ? w[d] : 1.0f - w[d];
+                q[d] = cell[d] + bit;
+            }
+            const uint32_t key = active ? lg.row0 + level_row<3>(lg, q) : 0xFFFFFFFFu;
+            float v[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) v[c] = fmaf(wt, hb[20 + jl * C + c], k[corner] * dl[20 + jl * C + c]);
+            scatter_runs<C>(g_table, key, v, lane);
+        }
+    }
+}
+
 // Where a point comes from: sample `pid % S` of ray `pid / S` (x = o + z d), or an explicit point list.
 struct PointSrc {
     const float* rays_o;   // [R,3]

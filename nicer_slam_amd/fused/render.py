@@ -97,8 +97,10 @@ def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd):
 
 
 def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage, g_rgbv=None, g_depth=None, g_nmap=None,
-                           g_ent=None, g_w=None):
-    """Launch the backward kernels.  Returns (g_rays_o[R,3], g_rays_d[R,3])."""
+                           g_ent=None, g_w=None, params=None):
+    """Launch the backward kernels.  Returns (g_rays_o[R,3], g_rays_d[R,3]); with ``params`` (dict of wanted parameter
+    gradients: flat_c, flat_r, tab_c, tab_f, tab_r -- see fused/mapping.py) the MAP kernels run instead and a third
+    value, the dict of those gradients, is returned."""
     R, S = z_vals.shape
     P = R * S
     dev = z_vals.device
@@ -122,22 +124,62 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
     g_feat = torch.empty(hl_size(P), device=dev)
     g_x = torch.empty(P, 3, device=dev)
     g_dir = torch.empty(P, 3, device=dev)
-    with _timed("k_colour_bwd", P * 512):
-        check(lib.nsa_colour_backward(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
-                                      b["feat"].data_ptr(), b["save"].data_ptr(), g_rgb.data_ptr(),
-                                      1 if color_stage != "base" else 0, g_feat.data_ptr(), g_grad.data_ptr(),
-                                      g_x.data_ptr(), g_dir.data_ptr(), st))
-    with _timed("k_sdfnet_bwd<coarse>", P * 3 * 4 * 8 * 8 * 4):
-        check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), g_sdf.data_ptr(),
-                                      g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))
-    if stage != "coarse":
-        with _timed("k_sdfnet_bwd<fine>", P * 3 * 8 * 8 * 4 * 4):
-            check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), g_sdf.data_ptr(),
+    grid_grad = 1 if color_stage != "base" else 0
+    pg = {}
+    want = params or {}
+    if want.get("flat_r") or want.get("tab_r"):
+        from . import mapping
+        emit = mapping.new_emit(mapping.CE["ROWS"], P, dev) if want.get("flat_r") else None
+        gt = torch.zeros_like(model.rendering_network.encoding.embeddings) if want.get("tab_r") else None
+        with _timed("k_colour_bwd<map>", P * 512):
+            check(lib.nsa_colour_backward_params(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
+                                                 b["feat"].data_ptr(), b["save"].data_ptr(), g_rgb.data_ptr(), grid_grad,
+                                                 g_feat.data_ptr(), g_grad.data_ptr(), g_x.data_ptr(), g_dir.data_ptr(),
+                                                 ptr(gt), ptr(emit), 0 if emit is None else emit.shape[1], st))
+        if emit is not None:
+            pg["flat_r"] = mapping.colour_flat_grad(emit)
+            del emit
+        pg["tab_r"] = gt
+    else:
+        with _timed("k_colour_bwd", P * 512):
+            check(lib.nsa_colour_backward(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
+                                          b["feat"].data_ptr(), b["save"].data_ptr(), g_rgb.data_ptr(), grid_grad,
+                                          g_feat.data_ptr(), g_grad.data_ptr(), g_x.data_ptr(), g_dir.data_ptr(), st))
+    if want.get("flat_c") or want.get("tab_c"):
+        from . import mapping
+        enc = imp.coarse.encoding
+        emit = mapping.new_emit(mapping.SE["ROWS"], P, dev) if want.get("flat_c") else None
+        gt = torch.zeros_like(enc.embeddings) if want.get("tab_c") else None
+        with _timed("k_sdfnet_bwd<coarse,map>", P * 3 * 4 * 8 * 8 * 4):
+            check(lib.nsa_sdfnet_backward_params(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), g_sdf.data_ptr(),
+                                                 g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), ptr(gt),
+                                                 ptr(emit), 0 if emit is None else emit.shape[1], st))
+        if emit is not None:
+            pg["flat_c"] = mapping.sdf_flat_grad(emit, g_sdf, P, enc.num_levels, enc.level_dim)
+            del emit
+        pg["tab_c"] = gt
+    else:
+        with _timed("k_sdfnet_bwd<coarse>", P * 3 * 4 * 8 * 8 * 4):
+            check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), g_sdf.data_ptr(),
                                           g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))
+    if stage != "coarse":
+        if want.get("tab_f"):
+            gt = torch.zeros_like(imp.fine.encoding.embeddings)
+            with _timed("k_sdfnet_bwd<fine,map>", P * 3 * 8 * 8 * 4 * 4):
+                check(lib.nsa_sdfnet_backward_params(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), g_sdf.data_ptr(),
+                                                     g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(),
+                                                     gt.data_ptr(), None, 0, st))
+            pg["tab_f"] = gt
+        else:
+            with _timed("k_sdfnet_bwd<fine>", P * 3 * 8 * 8 * 4 * 4):
+                check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), g_sdf.data_ptr(),
+                                              g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))
     g_o = torch.empty(R, 3, device=dev)
     g_d = torch.empty(R, 3, device=dev)
     check(lib.nsa_rays_backward(z_vals.data_ptr(), g_x.data_ptr(), g_dir.data_ptr(), R, S, g_o.data_ptr(),
                                 g_d.data_ptr(), st))
+    if params is not None:
+        return g_o, g_d, pg
     return g_o, g_d
 
 

@@ -108,19 +108,32 @@ class SLAMNetwork(nn.Module):
         flat = index_to_1d(idx, self.voxel_res)
         self.voxels.view(-1).index_add_(0, flat, torch.ones_like(flat, dtype=self.voxels.dtype))
 
+    def freeze_fine_mlp(self):
+        """The fine SDF MLP is pretrained and never handed to the optimizer (volsdf_train.py:143-173); marking it
+        so lets the fused mapping engine skip its weight gradients."""
+        for p in self.implicit_network.fine.mlp_parameters():
+            p.requires_grad_(False)
+        return self
+
     def _fused_composite_ok(self, mode, ground_truth):
-        """The fused composite kernels cover the data path (pose gradient).  Parameter gradients, the eikonal
-        samples of mapping mode and the flow/warp blocks still run on the composed engine."""
+        """Which engine renders this call.  Returns None (composed), "data" (fused kernels, pose gradient only) or
+        "params" (fused kernels with parameter gradients: mapping).  The fused engine does not produce gradients for
+        the fine SDF MLP; while those parameters require grad, "auto" stays on the composed engine."""
         if self.engine == "composed" or not self.voxels.is_cuda:
-            return False
-        from ..fused import render as fused_render
+            return None
+        from ..fused import render as fused_render, mapping as fused_mapping
         needs_params = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        ok = (fused_render.supported(self) and not needs_params and "edges" not in ground_truth
-              and not (self.training and "mapping" in mode and "vis" not in mode))
-        if not ok and self.engine == "fused":
+        kind = None
+        if fused_render.supported(self):
+            if not needs_params:
+                kind = "data"
+            elif fused_mapping.params_supported(self):
+                kind = "params"
+        if kind is None and self.engine == "fused":
             raise RuntimeError("engine='fused' requested but this call is outside the fused engine's coverage "
-                               "(parameter gradients / mapping-mode extras / unsupported configuration)")
-        return ok
+                               "(unsupported configuration, or parameters outside the reference's optimizer list "
+                               "require grad -- see SLAMNetwork.freeze_fine_mlp)")
+        return kind
 
     # ------------------------------------------------------------------ forward
     def forward(self, input, indices, ground_truth, keyframe_list=None, frame_idx=-1, mode="vis", stage="fine",
@@ -132,7 +145,8 @@ class SLAMNetwork(nn.Module):
         intrinsics, uv, pose = input["intrinsics"], input["uv"], input["pose"]
         self.last_engine = "composed"
         bs, num_pixels, _ = uv.shape
-        fused = self._fused_composite_ok(mode, ground_truth)
+        fused_kind = self._fused_composite_ok(mode, ground_truth)
+        fused = fused_kind is not None
         if fused and pose.shape[1] == 4 and uv.dtype == torch.float32:
             from ..fused import render as fused_render
             cam_flat, dirs, ds_flat = fused_render.rays(pose, uv, intrinsics.to(uv.device))
@@ -147,6 +161,8 @@ class SLAMNetwork(nn.Module):
         z_vals, z_samples_eik = self.ray_sampler.get_z_vals(dirs, cam_flat, self, frame_idx, keyframe_list, mode)
         if self.draws is not None and "z_vals_override" in self.draws:   # parity tests only
             z_vals = self.draws["z_vals_override"].to(z_vals.device)
+            if "eik_idx" in self.draws and z_samples_eik is not None:    # the near-surface sample is one of z_vals
+                z_samples_eik = torch.gather(z_vals, 1, self.draws["eik_idx"].to(z_vals.device).unsqueeze(-1))
         N = z_vals.shape[1]
         if not fused or mode == "mapping":
             points_flat = (cam_flat.unsqueeze(1) + z_vals.unsqueeze(2) * dirs.unsqueeze(1)).reshape(-1, 3)
@@ -154,9 +170,10 @@ class SLAMNetwork(nn.Module):
             self.update_voxels(points_flat.detach())
 
         if fused:
-            from ..fused import render as fused_render
+            from ..fused import render as fused_render, mapping as fused_mapping
             self.last_engine = "fused"
-            rgb_values, depth, nmap_w, weights, ent_ray, sdf, rgb, gradients = fused_render.composite(
+            engine = fused_mapping if fused_kind == "params" else fused_render
+            rgb_values, depth, nmap_w, weights, ent_ray, sdf, rgb, gradients = engine.composite(
                 self, cam_flat, dirs, z_vals, stage, color_stage)
         else:
             dirs_flat = dirs.unsqueeze(1).repeat(1, N, 1).reshape(-1, 3)
@@ -200,7 +217,11 @@ class SLAMNetwork(nn.Module):
                 near_surface = (cam_flat.unsqueeze(1) + z_samples_eik.unsqueeze(2) * dirs.unsqueeze(1)).reshape(-1, 3)
             eik = torch.cat([eik, near_surface], 0)
             eik = torch.cat([eik, eik + (self.draw("eik_jitter", eik.shape) - 0.5) * 0.01], 0)
-            grad_theta = self.implicit_network.gradient(eik, stage=stage)
+            if fused_kind == "params":
+                from ..fused import mapping as fused_mapping
+                grad_theta = fused_mapping.sdf_gradient(self, eik, stage)
+            else:
+                grad_theta = self.implicit_network.gradient(eik, stage=stage)
             half = grad_theta.shape[0] // 2
             output["grad_theta"], output["grad_theta_nei"] = grad_theta[:half], grad_theta[half:]
         if fused:

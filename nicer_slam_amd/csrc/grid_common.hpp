@@ -104,13 +104,21 @@ __device__ __forceinline__ uint32_t level_row(const LevelGeom& g, const uint32_t
     return idx % g.rows;
 }
 
-// Run-merged atomic scatter.  Float atomics reach L2 one address at a time (measured ~7 G atomics/s on MI355X, the whole
-// cost of a mapping iteration's table gradients), while the points of a wave are consecutive samples of a ray and walk
-// through each cell of a coarse level in RUNS of equal row index.  The lanes of a run are summed with a segmented
-// shuffle scan and only the run's last lane issues the atomics: 64 atomics per wave and corner become one per run.
-// `key` = destination row or 0xFFFFFFFF for lanes with nothing to add (they never merge into a run).
+// Run-merged, row-coalesced atomic scatter of C-channel rows.
+// Measured on MI355X (tools/micro/atomic_bench.hip): float atomics retire at ~20 G REQUESTS/s chip-wide, independent of
+// table size and of contention, where one request = the lanes of one instruction that fall into the same row (cache
+// line segment).  A lane-per-row issue (lane l adds channel c of ITS row, C instructions) therefore costs C requests
+// per row; a lane-per-channel issue (C adjacent lanes add the C channels of ONE row) costs one: 8x / 4x / 2x fewer
+// requests for C = 8 / 4 / 2.  Two steps:
+//  1. run merge: the points of a wave are consecutive samples of a ray and walk through each cell of a coarse level in
+//     RUNS of equal row index; the lanes of a run are summed with a segmented shuffle scan and only the run's last lane
+//     keeps a row to send.
+//  2. transposed issue through a per-wave LDS tile: in round j, lane group g (C lanes) sends the row held by lane
+//     g*C + j, lane % C = channel.
+// `key` = destination row (relative to `table`) or 0xFFFFFFFF for lanes with nothing to add (they never merge).
+// Blocks using this are 256 threads (4 waves).
 template <int C>
-__device__ __forceinline__ void scatter_runs(float* __restrict__ table_level, uint32_t key, float (&val)[C], int lane) {
+__device__ __forceinline__ void scatter_runs(float* __restrict__ table, uint32_t key, float (&val)[C], int lane) {
     const uint32_t prev = __shfl_up(key, 1);
     const bool head = lane == 0 || prev != key || key == 0xFFFFFFFFu;
     const unsigned long long hm = __ballot(head);
@@ -126,11 +134,24 @@ __device__ __forceinline__ void scatter_runs(float* __restrict__ table_level, ui
         }
     }
     const bool tail = lane == 63 || ((hm >> (lane + 1)) & 1ull);
-    if (tail && key != 0xFFFFFFFFu) {
-        float* dst = table_level + (size_t)key * C;
-#pragma unroll
-        for (int c = 0; c < C; ++c) atomicAdd(dst + c, val[c]);        // -munsafe-fp-atomics: global_atomic_add_f32
+    const uint32_t send = (tail && key != 0xFFFFFFFFu) ? key : 0xFFFFFFFFu;
+    if (C == 1) {
+        if (send != 0xFFFFFFFFu) atomicAdd(table + send, val[0]);      // -munsafe-fp-atomics: global_atomic_add_f32
+        return;
     }
+    __shared__ float stage[4][64 * (C + 1)];                          // row pitch C+1: conflict-free transposed reads
+    float* tile = stage[threadIdx.x >> 6];
+#pragma unroll
+    for (int c = 0; c < C; ++c) tile[lane * (C + 1) + c] = val[c];
+    __builtin_amdgcn_wave_barrier();                                   // LDS ops of one wave execute in order
+    const int grp = (lane / C) * C, ch = lane % C;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const uint32_t row = __shfl(send, grp + j);
+        const float v = tile[(grp + j) * (C + 1) + ch];
+        if (row != 0xFFFFFFFFu) atomicAdd(table + (size_t)row * C + ch, v);
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Range test + cell/fraction split.  Returns false for a point outside [0,1]^D (NaN passes, as in the

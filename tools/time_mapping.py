@@ -15,8 +15,12 @@ class DS:
 
 torch.manual_seed(0)
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+ENGINE = sys.argv[2] if len(sys.argv) > 2 else "fused"       # "fused" | "composed"
 bs = 8
 model = SLAMNetwork(replica_model_conf(64, 640, 32, use_warp_loss=False), dataset=DS(), n_images=2000).cuda().train()
+if ENGINE == "fused":
+    model.freeze_fine_mlp()          # as the reference's optimizer list (volsdf_train.py:150-173)
+model.engine = "auto" if ENGINE == "fused" else "composed"
 groups = [{"params": list(model.implicit_network.fine.grid_parameters()), "lr": 0.04},
           {"params": list(model.implicit_network.coarse.grid_parameters()), "lr": 0.04},
           {"params": list(model.rendering_network.grid_parameters()), "lr": 0.01},

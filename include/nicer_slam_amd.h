@@ -210,6 +210,18 @@ int nsa_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
                   float lr, float beta1, float beta2, float eps, uint32_t lr_step, float lr_gamma,
                   nsa_stream_t stream);
 
+/* ---- Section 4: mapping-iteration tail ------------------------------------------------------------------------ */
+
+/* voxels[floor((x+1)/2*res)] += 1 for every sample with all |x_d| <= 0.99 (voxels: [res,res,res] fp32, x-major).
+ * replaces SLAMNetwork.update_voxels (code/model/network.py:62-76). */
+int nsa_update_voxels(const nsa_points_t *pts, float *voxels, uint32_t res, nsa_stream_t stream);
+
+/* One torch.optim.Adam step (no weight decay / amsgrad) over n parameters in a single pass; `step` = this step's
+ * number t >= 1 (bias corrections are computed on the host in double, like torch).  All pointers 16-byte aligned.
+ * replaces self.optimizer.step() for one parameter tensor (code/training/volsdf_train.py:174, 420-424). */
+int nsa_adam_table_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, uint32_t step,
+                        float lr, float beta1, float beta2, float eps, nsa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,3 +104,9 @@ lib.nsa_l1_loss.argtypes = [_p, _p, _u32, _p, _p, _p]
 lib.nsa_adam_step.restype = _i
 lib.nsa_adam_step.argtypes = [_p, _p, _p, _p, _p, _u32, _f32, _f32, _f32, _f32, _u32, _f32, _p]
 EXPORTS += ["nsa_cam_to_pose", "nsa_pose_grad_to_cam", "nsa_l1_loss", "nsa_adam_step"]
+
+lib.nsa_update_voxels.restype = _i
+lib.nsa_update_voxels.argtypes = [_pp, _p, _u32, _p]
+lib.nsa_adam_table_step.restype = _i
+lib.nsa_adam_table_step.argtypes = [_p, _p, _p, _p, ctypes.c_uint64, _u32, _f32, _f32, _f32, _f32, _p]
+EXPORTS += ["nsa_update_voxels", "nsa_adam_table_step"]

@@ -1,0 +1,109 @@
+// map_tail.hip -- the two remaining per-iteration passes of a mapping step that are pure HBM streaming:
+//   k_update_voxels   the 64^3 visit counter fed by every sample of the batch
+//   k_adam_table      torch.optim.Adam over a (large) parameter tensor in one pass
+// Reference: SLAMNetwork.update_voxels (code/model/network.py:62-76); torch.optim.Adam as configured by
+// code/training/volsdf_train.py:174 (betas (0.9, 0.99), eps 1e-15, no weight decay, no amsgrad).
+#include "sdf_net.hpp"
+
+namespace nsa {
+
+// One lane per sample; consecutive samples of a ray fall into the same voxel in runs, which scatter_runs merges into
+// one atomic per run.  Counts are exact in fp32 up to 2^24 visits per voxel (the reference counts in fp32 too).
+__global__ __launch_bounds__(256) void k_update_voxels(PointSrc src, float* __restrict__ voxels, uint32_t res) {
+    const uint32_t pid = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t key = 0xFFFFFFFFu;
+    if (pid < src.P) {
+        float x[3], z;
+        uint32_t ray;
+        load_point(src, pid, x, ray, z);
+        const bool skip = fabsf(x[0]) > 0.99f || fabsf(x[1]) > 0.99f || fabsf(x[2]) > 0.99f;   // NaN: not skipped, as torch
+        if (!skip) {
+            long long q[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) q[d] = (long long)((x[d] + 1.0f) / 2.0f * (float)res);
+            const long long flat = q[0] * res * res + q[1] * res + q[2];
+            if (flat >= 0 && flat < (long long)res * res * res) key = (uint32_t)flat;
+        }
+    }
+    float one[1] = {1.0f};
+    scatter_runs<1>(voxels, key, one, lane);
+}
+
+struct AdamTableArgs {
+    float* p; const float* g; float* m; float* v;
+    uint64_t n;
+    float w1;          // 1 - beta1
+    float beta2, w2;   // beta2, 1 - beta2
+    float step_size;   // lr / (1 - beta1^t)
+    float bc2_sqrt;    // sqrt(1 - beta2^t)
+    float eps;
+};
+
+// Same operation order as torch's foreach Adam: m.lerp_(g, 1-b1); v.mul_(b2).addcmul_(g, g, 1-b2);
+// denom = sqrt(v) / bc2_sqrt + eps; p.addcdiv_(m, denom, -step_size).
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamTableArgs& a) {
+    m = m + a.w1 * (g - m);
+    v = v * a.beta2 + a.w2 * g * g;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = p - a.step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void k_adam_table(AdamTableArgs a) {
+    const uint64_t n4 = a.n / 4;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 p = reinterpret_cast<float4*>(a.p)[i];
+        const float4 g = reinterpret_cast<const float4*>(a.g)[i];
+        float4 m = reinterpret_cast<float4*>(a.m)[i];
+        float4 v = reinterpret_cast<float4*>(a.v)[i];
+        adam_one(p.x, g.x, m.x, v.x, a);
+        adam_one(p.y, g.y, m.y, v.y, a);
+        adam_one(p.z, g.z, m.z, v.z, a);
+        adam_one(p.w, g.w, m.w, v.w, a);
+        reinterpret_cast<float4*>(a.p)[i] = p;
+        reinterpret_cast<float4*>(a.m)[i] = m;
+        reinterpret_cast<float4*>(a.v)[i] = v;
+    }
+    if (blockIdx.x == 0) {
+        const uint64_t i = n4 * 4 + threadIdx.x;
+        if (i < a.n) adam_one(a.p[i], a.g[i], a.m[i], a.v[i], a);
+    }
+}
+
+}  // namespace nsa
+
+extern "C" {
+
+int nsa_update_voxels(const nsa_points_t* pts, float* voxels, uint32_t res, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!pts || !voxels || res == 0 || res > 1024) return NSA_EBADARG;
+    if (pts->P == 0) return NSA_OK;
+    if (!pts->points && (!pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0)) return NSA_EBADARG;
+    const PointSrc src{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S};
+    launch_begin();
+    hipLaunchKernelGGL(k_update_voxels, dim3((pts->P + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, voxels, res);
+    return launch_end();
+}
+
+int nsa_adam_table_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, uint32_t step,
+                        float lr, float beta1, float beta2, float eps, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || step == 0) return NSA_EBADARG;
+    if (n == 0) return NSA_OK;
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15u) return NSA_EBADARG;            // float4 path
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamTableArgs a{param, grad, exp_avg, exp_avg_sq, n, 1.0f - beta1, beta2, 1.0f - beta2,
+                    (float)((double)lr / bc1), (float)sqrt(bc2), eps};
+    const uint64_t n4 = n / 4;
+    uint64_t blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;      // grid-stride: 32 blocks per CU keeps every HBM channel busy
+    if (blocks == 0) blocks = 1;
+    launch_begin();
+    hipLaunchKernelGGL(k_adam_table, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_end();
+}
+
+}  // extern "C"

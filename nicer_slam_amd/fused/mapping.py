@@ -231,3 +231,15 @@ def composite(model, rays_o, rays_d, z_vals, stage, color_stage):
 def sdf_gradient(model, points, stage):
     flat_c, _, tab_c, tab_f, _ = flat_inputs(model)
     return FusedSdfGradient.apply(points, flat_c, tab_c, tab_f, model, stage)
+
+
+def update_voxels(model, rays_o, rays_d, z_vals):
+    """Visit counter of the batch's samples, in place (SLAMNetwork.update_voxels, network.py:62-76)."""
+    rays_o, rays_d, z_vals = rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous()
+    R, S = z_vals.shape
+    vox = model.voxels
+    if not (vox.is_contiguous() and vox.dtype == torch.float32):
+        raise RuntimeError("voxel counter must be a contiguous float32 tensor")
+    pts = PointsDesc(rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(), None, R * S, S)
+    with _timed("k_update_voxels", R * S * 16):
+        check(lib.nsa_update_voxels(ctypes.byref(pts), vox.data_ptr(), model.voxel_res, _stream()))

@@ -164,10 +164,14 @@ class SLAMNetwork(nn.Module):
             if "eik_idx" in self.draws and z_samples_eik is not None:    # the near-surface sample is one of z_vals
                 z_samples_eik = torch.gather(z_vals, 1, self.draws["eik_idx"].to(z_vals.device).unsqueeze(-1))
         N = z_vals.shape[1]
-        if not fused or mode == "mapping":
+        if not fused:
             points_flat = (cam_flat.unsqueeze(1) + z_vals.unsqueeze(2) * dirs.unsqueeze(1)).reshape(-1, 3)
         if mode == "mapping":
-            self.update_voxels(points_flat.detach())
+            if fused:
+                from ..fused import mapping as fused_mapping
+                fused_mapping.update_voxels(self, cam_flat.detach(), dirs.detach(), z_vals.detach())
+            else:
+                self.update_voxels(points_flat.detach())
 
         if fused:
             from ..fused import render as fused_render, mapping as fused_mapping

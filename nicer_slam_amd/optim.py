@@ -1,0 +1,51 @@
+"""torch.optim.Adam replacement for the mapping optimizer (reference code/training/volsdf_train.py:150-174:
+``torch.optim.Adam(para_list, betas=(0.9, 0.99), eps=1e-15)`` over the three grid tables -- one of them 1 GiB -- and
+the two small MLPs).  One HIP pass per parameter tensor (csrc/map_tail.hip: 4 reads + 3 writes per element, the HBM
+floor of a dense Adam step) instead of torch's seven multi-tensor passes.
+
+Same semantics, operation order and state layout as torch.optim.Adam without weight decay / amsgrad / maximize:
+``state[p] = {"step": tensor(float), "exp_avg", "exp_avg_sq"}``, so state_dicts are interchangeable.  CUDA float32
+contiguous parameters only; anything else raises (no fallback).
+"""
+import torch
+
+from ._native import lib, check
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        st = torch.cuda.current_stream().cuda_stream
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = p.grad
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.dtype == torch.float32):
+                    raise RuntimeError("nicer_slam_amd.optim.Adam: float32 contiguous CUDA parameters only")
+                if g.is_sparse:
+                    raise RuntimeError("nicer_slam_amd.optim.Adam does not support sparse gradients")
+                g = g.contiguous()
+                state = self.state[p]
+                if not state:
+                    state["step"] = torch.zeros((), dtype=torch.float32)
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["step"] += 1
+                check(lib.nsa_adam_table_step(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(),
+                                              state["exp_avg_sq"].data_ptr(), p.numel(), int(state["step"]),
+                                              float(group["lr"]), float(b1), float(b2), float(group["eps"]), st))
+                # the kernel wrote p behind autograd's back: bump its version counter like an in-place op would
+                # (the packed-weight caches of the fused engine key on it)
+                torch._C._autograd._unsafe_set_version_counter((p,), (p._version + 1,))
+        return loss

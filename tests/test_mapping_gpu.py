@@ -143,3 +143,52 @@ def test_fused_mapping_larger_batch_vs_composed():
         assert_close(f, g.cpu().numpy(), 1e-7 + 3e-4 * float(g.abs().max()), 1e-3, "grad " + n)
         n_checked += 1
     assert n_checked >= 12
+
+
+def test_update_voxels_kernel_vs_torch_index_add():
+    """nsa_update_voxels vs SLAMNetwork.update_voxels (torch index_add_) on 200k samples incl. out-of-range ones: exact."""
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.fused import mapping
+    torch.manual_seed(5)
+    model = SLAMNetwork(replica_model_conf(use_warp_loss=False)).cuda()
+    R, S = 2048, 98
+    o = (torch.rand(R, 3, device="cuda") - 0.5) * 0.6
+    d = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda"), dim=-1)
+    z = torch.sort(torch.rand(R, S, device="cuda") * 1.8, dim=1).values
+    model.voxels = torch.randint(0, 7, (64, 64, 64), device="cuda").float()
+    ref = SLAMNetwork(replica_model_conf(use_warp_loss=False)).cuda()
+    ref.voxels = model.voxels.clone()
+    x = (o.unsqueeze(1) + z.unsqueeze(2) * d.unsqueeze(1)).reshape(-1, 3)
+    assert 0.02 < float((x.abs() > 0.99).any(1).float().mean()) < 0.9
+    ref.update_voxels(x)
+    mapping.update_voxels(model, o, d, z)
+    assert torch.equal(model.voxels, ref.voxels)
+    assert float(model.voxels.sum()) > float(7 * 64 ** 3 / 2)
+
+
+@pytest.mark.parametrize("n", [1, 5, 1027, (1 << 20) + 3])
+def test_fused_adam_vs_torch_adam(n):
+    """nicer_slam_amd.optim.Adam (one HIP pass) vs torch.optim.Adam(betas=(0.9,0.99), eps=1e-15): 6 steps, few-ulp."""
+    from nicer_slam_amd.optim import Adam
+    torch.manual_seed(n)
+    p0 = torch.randn(n, device="cuda") * 0.1
+    a = torch.nn.Parameter(p0.clone())
+    b = torch.nn.Parameter(p0.clone())
+    oa = Adam([{"params": [a], "lr": 0.04}], betas=(0.9, 0.99), eps=1e-15)
+    ob = torch.optim.Adam([{"params": [b], "lr": 0.04}], betas=(0.9, 0.99), eps=1e-15)
+    for it in range(6):
+        g = torch.randn(n, device="cuda") * (10.0 ** (it - 3))
+        g[::3] = 0.0                                          # untouched table rows have exactly-zero gradients
+        a.grad, b.grad = g.clone(), g.clone()
+        v0 = a._version
+        oa.step()
+        ob.step()
+        assert a._version > v0
+        assert_close(a.detach(), b.detach().cpu().numpy(), 1e-7, 2e-6, f"param after step {it + 1}")
+    sa, sb = oa.state[a], ob.state[b]
+    assert float(sa["step"]) == float(sb["step"]) == 6
+    # entries where the moments cancel carry the rounding of the larger terms: tolerance relative to the tensor's scale
+    assert_close(sa["exp_avg"], sb["exp_avg"].cpu().numpy(), 3e-7 * float(sb["exp_avg"].abs().max()), 2e-6, "exp_avg")
+    assert_close(sa["exp_avg_sq"], sb["exp_avg_sq"].cpu().numpy(), 3e-7 * float(sb["exp_avg_sq"].abs().max()), 2e-6,
+                 "exp_avg_sq")

@@ -26,7 +26,11 @@ groups = [{"params": list(model.implicit_network.fine.grid_parameters()), "lr": 
           {"params": list(model.rendering_network.grid_parameters()), "lr": 0.01},
           {"params": list(model.rendering_network.mlp_parameters()), "lr": 0.002},
           {"params": list(model.implicit_network.coarse.mlp_parameters()), "lr": 0.002}]
-opt = torch.optim.Adam(groups, betas=(0.9, 0.99), eps=1e-15)
+if ENGINE == "fused":
+    from nicer_slam_amd.optim import Adam
+    opt = Adam(groups, betas=(0.9, 0.99), eps=1e-15)
+else:
+    opt = torch.optim.Adam(groups, betas=(0.9, 0.99), eps=1e-15)
 g = torch.Generator(device="cuda").manual_seed(1)
 K = torch.eye(4, device="cuda"); K[0, 0] = K[1, 1] = 600.0; K[0, 2], K[1, 2] = 599.5, 339.5
 K = K[None].repeat(bs, 1, 1)

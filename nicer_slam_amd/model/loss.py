@@ -1,0 +1,173 @@
+"""Mapping / tracking objective: the per-ray loss terms of the reference's SLAMLoss, restated.
+
+Reference: SLAMLoss (code/model/loss.py:8-233) and the scale-and-shift-invariant monocular depth loss it uses
+(code/utils/MiDaS.py:6-143, alpha = 0.5, one scale, batch-based reduction).  Same constructor arguments, same
+``forward(model_outputs, ground_truth, keyframe_list, frame_idx, stage) -> dict`` keys and weights, so a trainer that
+builds ``loss_class(**conf.loss, ...)`` can switch.  These are reductions over at most 8192 rays: plain torch ops on
+whatever device the model outputs live on; the tracking objective (rgb L1 only) additionally exists
+as a HIP kernel for the graph-captured tracker (csrc/track_tail.hip::k_l1_loss).
+"""
+import torch
+from torch import nn
+
+from ..utils.general import get_class
+
+
+def _masked_mean_abs(a, b, mask=None):
+    if mask is not None:
+        m = mask.reshape(-1)
+        a, b = a[m], b[m]
+    return (a - b).abs().mean()
+
+
+def scale_shift_invariant_depth_loss(pred, target, mask, alpha=0.5):
+    """Least-squares (scale, shift) per image aligning ``pred`` to ``target`` on ``mask`` (closed-form 2x2 solve,
+    detached), then  sum(mask (s p + t - target)^2) / (2 sum mask)  +  alpha * masked first-difference L1 of the residual
+    along both pixel axes / sum mask.  Shapes [b, n, 1] (the reference feeds rays as an n x 1 'image', so only the
+    difference along n is non-empty).  MiDaS.py:6-143."""
+    mask = mask.to(pred.dtype)
+    dims = (1, 2)
+    a00 = (mask * pred * pred).sum(dims)
+    a01 = (mask * pred).sum(dims)
+    a11 = mask.sum(dims)
+    b0 = (mask * pred * target).sum(dims)
+    b1 = (mask * target).sum(dims)
+    det = a00 * a11 - a01 * a01
+    ok = det != 0
+    safe = torch.where(ok, det, torch.ones_like(det))
+    scale = torch.where(ok, (a11 * b0 - a01 * b1) / safe, torch.zeros_like(det)).detach()
+    shift = torch.where(ok, (a00 * b1 - a01 * b0) / safe, torch.zeros_like(det)).detach()
+    aligned = scale.view(-1, 1, 1) * pred + shift.view(-1, 1, 1)
+    M = mask.sum(dims)
+    res = aligned - target
+    data_div = (2 * M).sum()
+    total = (mask * res * res).sum() / data_div if float(data_div) != 0 else pred.new_zeros(())
+    if alpha > 0:
+        d = mask * res
+        gx = (d[:, :, 1:] - d[:, :, :-1]).abs() * (mask[:, :, 1:] * mask[:, :, :-1])
+        gy = (d[:, 1:, :] - d[:, :-1, :]).abs() * (mask[:, 1:, :] * mask[:, :-1, :])
+        reg_div = M.sum()
+        reg = (gx.sum() + gy.sum()) / reg_div if float(reg_div) != 0 else pred.new_zeros(())
+        total = total + alpha * reg
+    return total
+
+
+class SLAMLoss(nn.Module):
+    def __init__(self, rgb_loss, eikonal_weight, trainer=None, train_dataset=None, assign_scale_shift_init=False,
+                 smooth_weight=0.005, warp_loss_type="l1", depth_weight=0.1, normal_l1_weight=0.05,
+                 normal_cos_weight=0.05, gt_depth_weight=0.0, flow_weight=0.0, warp_loss_weight=0, scan_id=-1,
+                 model=None, rgb_loss_weight=1.0, assign_scale=20.0):
+        super().__init__()
+        if warp_loss_type not in ("l1", "ssim"):
+            raise NotImplementedError("Strange patch loss type")
+        self.model, self.trainer, self.train_dataset, self.scan_id = model, trainer, train_dataset, scan_id
+        self.assign_scale_shift_init, self.assign_scale = assign_scale_shift_init, assign_scale
+        self.eikonal_weight, self.smooth_weight, self.depth_weight = eikonal_weight, smooth_weight, depth_weight
+        self.normal_l1_weight, self.normal_cos_weight = normal_l1_weight, normal_cos_weight
+        self.gt_depth_weight, self.flow_weight = gt_depth_weight, flow_weight
+        self.warp_loss_weight, self.warp_loss_type, self.rgb_loss_weight = warp_loss_weight, warp_loss_type, rgb_loss_weight
+        self.rgb_loss = get_class(rgb_loss)(reduction="mean") if isinstance(rgb_loss, str) else rgb_loss
+        self._ssim = {}
+
+    # ---- individual terms (same names as the reference so callers/plots can reuse them) ----
+    def get_rgb_loss(self, rgb_values, rgb_gt, mask=None):
+        a, b = rgb_values.reshape(-1, 3), rgb_gt.reshape(-1, 3)
+        if mask is not None:
+            m = mask.reshape(-1)
+            a, b = a[m], b[m]
+        return self.rgb_loss(a, b)
+
+    def get_gt_depth_loss(self, depth_values, depth_gt, mask=None):
+        return _masked_mean_abs(depth_values.reshape(-1, 1), depth_gt.reshape(-1, 1), mask)
+
+    def get_eikonal_loss(self, grad_theta):
+        return ((grad_theta.norm(2, dim=1) - 1) ** 2).mean()
+
+    def get_smooth_loss(self, model_outputs):
+        unit = lambda g: g / (g.norm(2, dim=1).unsqueeze(-1) + 1e-5)
+        return torch.norm(unit(model_outputs["grad_theta"]) - unit(model_outputs["grad_theta_nei"]), dim=-1).mean()
+
+    def get_depth_loss(self, depth_pred, depth_gt, mask, keyframe_list=None):
+        return scale_shift_invariant_depth_loss(depth_pred, depth_gt * 50 + 0.5, mask, alpha=0.5)
+
+    def get_normal_loss(self, normal_pred, normal_gt):
+        g = torch.nn.functional.normalize(normal_gt, p=2, dim=-1)
+        p = torch.nn.functional.normalize(normal_pred, p=2, dim=-1)
+        return (p - g).abs().sum(dim=-1).mean(), (1.0 - (p * g).sum(dim=-1)).mean()
+
+    def get_flow_loss(self, model_outputs, ground_truth, keyframe_list=None):
+        if "flow" not in model_outputs:
+            return 0.0
+        m = ground_truth["flow_mask"]
+        flow = model_outputs["flow"]
+        return (flow[m] - ground_truth["flow"].to(flow.device)[m]).abs().mean()
+
+    def _warp_loss(self, warp_output):
+        total = 0.0
+        for patchsize, (gt_rgb, sampled, mask, _ray_mask) in warp_output.items():
+            if patchsize == 1 or self.warp_loss_type == "l1":
+                total = total + (sampled[mask] - gt_rgb[mask]).abs().mean()
+            else:   # "ssim": needs pytorch_msssim, exactly as the reference does
+                try:
+                    from pytorch_msssim import SSIM
+                except ImportError as e:
+                    raise NotImplementedError("warp_loss_type='ssim' needs the pytorch_msssim package") from e
+                if patchsize not in self._ssim:
+                    self._ssim[patchsize] = SSIM(data_range=1, win_size=patchsize, size_average=True, channel=3)
+                a = torch.where(mask[..., None], sampled, torch.zeros_like(sampled))
+                b = torch.where(mask[..., None], gt_rgb, torch.zeros_like(gt_rgb))
+                a = a.reshape(-1, patchsize, patchsize, 3).permute(0, 3, 1, 2)
+                b = b.reshape(-1, patchsize, patchsize, 3).permute(0, 3, 1, 2)
+                total = total + 0.05 * (1 - self._ssim[patchsize](a, b))
+        return total
+
+    def forward(self, model_outputs, ground_truth, keyframe_list=None, frame_idx=0, stage="coarse"):
+        rgb_pred, depth_pred = model_outputs["rgb_values"], model_outputs["depth_values"]
+        dev = rgb_pred.device
+        rgb_gt, depth_gt = ground_truth["rgb"].to(dev), ground_truth["depth"].to(dev)
+        normal_gt, depth_real_gt = ground_truth["normal"].to(dev), ground_truth["gt_depth"].to(dev)
+        normal_pred = model_outputs["normal_map"][None]
+        bs = depth_pred.shape[0]
+
+        rgb_loss = self.get_rgb_loss(rgb_pred, rgb_gt)
+        warp_loss = 0.0
+        if "warp_output" in model_outputs and self.warp_loss_weight > 0 and stage == "fine" and frame_idx != 0:
+            warp_loss = self._warp_loss(model_outputs["warp_output"])
+        eikonal_loss = 0.0
+        if self.eikonal_weight > 0 and "grad_theta" in model_outputs:
+            eikonal_loss = self.get_eikonal_loss(model_outputs["grad_theta"])
+
+        # foreground = rays whose samples straddle the surface (sdf changes sign), loss.py:164-167
+        sdf = model_outputs["sdf"]
+        mask = ((sdf > 0.0).any(dim=-1) & (sdf < 0.0).any(dim=-1)).reshape(bs, -1, 1)
+        mask = (ground_truth["mask"].to(dev) > 0.5) & mask
+
+        depth_loss = 0.0
+        if self.depth_weight > 0:
+            whole = (self.train_dataset is not None and "Replica" in getattr(self.train_dataset, "data_dir", "")
+                     and self.scan_id == 4)
+            depth_loss = self.get_depth_loss(depth_pred, depth_gt, torch.ones_like(depth_pred) if whole else mask,
+                                             keyframe_list)
+        if self.assign_scale_shift_init:      # first frame: supervise with the scaled monocular depth (loss.py:179-185)
+            if frame_idx == 0:
+                depth_real_gt = depth_gt * self.assign_scale
+                self.gt_depth_weight = 10
+            else:
+                self.gt_depth_weight = 0
+        gt_depth_loss = 0.0
+        if self.gt_depth_weight > 0:
+            gt_depth_loss = self.get_gt_depth_loss(depth_pred, depth_real_gt, ground_truth["gt_depth"].to(dev) > 0)
+        normal_l1 = normal_cos = 0.0
+        if self.normal_l1_weight > 0 or self.normal_cos_weight > 0:
+            normal_l1, normal_cos = self.get_normal_loss(normal_pred * mask, normal_gt * mask)
+        smooth_loss = self.get_smooth_loss(model_outputs) if self.smooth_weight > 0.0 else 0.0
+        flow_loss = self.get_flow_loss(model_outputs, ground_truth, keyframe_list) if self.flow_weight > 0.0 else 0.0
+
+        loss = (self.flow_weight * flow_loss + self.depth_weight * depth_loss + self.rgb_loss_weight * rgb_loss
+                + self.smooth_weight * smooth_loss + self.normal_l1_weight * normal_l1 + self.warp_loss_weight * warp_loss
+                + self.eikonal_weight * eikonal_loss + self.normal_cos_weight * normal_cos
+                + self.gt_depth_weight * gt_depth_loss)
+        return {"loss": loss, "normal_l1": normal_l1, "depth_loss": depth_loss, "normal_cos": normal_cos,
+                "gt_depth_loss": gt_depth_loss, "flow_loss": self.flow_weight * flow_loss,
+                "rgb_loss": self.rgb_loss_weight * rgb_loss, "warp_loss": self.warp_loss_weight * warp_loss,
+                "smooth_loss": self.smooth_weight * smooth_loss, "eikonal_loss": self.eikonal_weight * eikonal_loss}

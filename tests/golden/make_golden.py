@@ -386,7 +386,59 @@ def warp_case(name, seed, bs=2, n_pix=6):
     print(name, float(loss), {k: tuple(v.shape) for k, v in rec.items() if k.startswith("out_warp")})
 
 
+def loss_case(name, seed, frame_idx, stage, bs=2, n=12, S=6):
+    """SLAMLoss.forward (model/loss.py:113-233 + utils/MiDaS.py) with the shipped Replica weights
+    (confs/replica/runconf_replica_1.conf:45-56) on random model outputs: every term and d loss / d output."""
+    ref_loss = ref_shims.import_ref("model.loss")
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda *shape: torch.rand(*shape, generator=g)
+    leaf = lambda t: t.clone().requires_grad_(True)
+    out = {"rgb_values": leaf(rnd(bs, n, 3)), "depth_values": leaf(rnd(bs, n, 1) * 2 + 0.2),
+           "normal_map": leaf(rnd(bs, n, 3) - 0.5), "grad_theta": leaf((rnd(40, 3) - 0.5) * 3),
+           "grad_theta_nei": leaf((rnd(40, 3) - 0.5) * 3), "flow": leaf((rnd(3, n, 2) - 0.5) * 8)}
+    sdf = rnd(bs * n, S) - 0.4
+    sdf[::5] = sdf[::5].abs()            # some rays never cross the surface -> masked out
+    out["sdf"] = sdf
+    warp = {}
+    for ps in (1, 5):
+        m = rnd(bs * n, ps * ps) > 0.3
+        warp[ps] = (rnd(bs * n, ps * ps, 3), leaf(rnd(bs * n, ps * ps, 3)), m, m.any(-1))
+    out["warp_output"] = warp
+    gt = {"rgb": rnd(bs, n, 3), "depth": rnd(bs, n, 1) * 0.02, "normal": rnd(bs, n, 3) - 0.5,
+          "gt_depth": rnd(bs, n, 1) * 3 * (rnd(bs, n, 1) > 0.2), "mask": (rnd(bs, n, 1) > 0.15).float(),
+          "flow": (rnd(3, n, 2) - 0.5) * 8, "flow_mask": rnd(3, n) > 0.4}
+
+    class DS:
+        data_dir = "../Datasets/processed/Replica"
+    crit = ref_loss.SLAMLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, train_dataset=DS(), scan_id=1,
+                             assign_scale_shift_init=True, smooth_weight=0.005, warp_loss_type="l1", depth_weight=0.1,
+                             normal_l1_weight=0.05, normal_cos_weight=0.05, flow_weight=0.001, warp_loss_weight=0.5)
+    res = crit(out, gt, keyframe_list=None, frame_idx=frame_idx, stage=stage)
+    res["loss"].backward()
+    rec = {"meta_frame_idx": np.array(frame_idx), "meta_stage": np.array(stage)}
+    for k, v in out.items():
+        if isinstance(v, torch.Tensor):
+            rec["in_" + k] = v.detach()
+            if v.grad is not None:
+                rec["grad_" + k] = v.grad
+    for ps, (a, b, m, rm) in warp.items():
+        rec.update({f"in_warp{ps}_gt": a, f"in_warp{ps}_sampled": b.detach(), f"in_warp{ps}_mask": m,
+                    f"in_warp{ps}_raymask": rm})
+        if b.grad is not None:
+            rec[f"grad_warp{ps}_sampled"] = b.grad
+    for k, v in gt.items():
+        rec["gt_" + k] = v
+    for k, v in res.items():
+        rec["out_" + k] = torch.as_tensor(float(v))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **t2n(rec))
+    print(name, {k: float(v) for k, v in res.items()})
+
+
 if __name__ == "__main__":
+    loss_case("loss_mapping_first_frame", 21, frame_idx=0, stage="coarse")
+    loss_case("loss_mapping_fine", 22, frame_idx=7, stage="fine")
+    if "--loss-only" in sys.argv:
+        sys.exit(0)
     warp_case("full_mapping_warp", 15)
     encoder_case("enc_coarse", 1, L=4, C=8, base=8, end=8, logmap=19, n_pts=64)
     encoder_case("enc_fine", 2, L=8, C=4, base=4, end=40, logmap=10, n_pts=64)

@@ -62,6 +62,7 @@ class SLAMNetwork(nn.Module):
         self.draws = None          # optional dict of pre-drawn randoms (parity tests); else device generator
         self.engine = "auto"       # "auto" | "fused" | "composed"
         self.last_engine = None    # which engine the most recent forward used
+        self.voxel_sync = None     # multi-GPU mapping: callable(voxels, before) summing the visit deltas over ranks
 
     # ------------------------------------------------------------------ plumbing
     def _share_voxels(self):
@@ -167,11 +168,14 @@ class SLAMNetwork(nn.Module):
         if not fused:
             points_flat = (cam_flat.unsqueeze(1) + z_vals.unsqueeze(2) * dirs.unsqueeze(1)).reshape(-1, 3)
         if mode == "mapping":
+            before = self.voxels.clone() if self.voxel_sync is not None else None
             if fused:
                 from ..fused import mapping as fused_mapping
                 fused_mapping.update_voxels(self, cam_flat.detach(), dirs.detach(), z_vals.detach())
             else:
                 self.update_voxels(points_flat.detach())
+            if before is not None:
+                self.voxel_sync(self.voxels, before)
 
         if fused:
             from ..fused import render as fused_render, mapping as fused_mapping

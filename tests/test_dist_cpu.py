@@ -81,3 +81,77 @@ def test_two_rank_sharded_tracking_step_matches_reference_gradient():
     ref = fx["grad_cam"].reshape(-1)
     np.testing.assert_allclose(res[0][1], ref, rtol=1e-3, atol=1e-6 + 1e-4 * np.abs(ref).max())
     assert abs(res[0][2] - float(fx["out_loss"])) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- mapping exchange
+def _torch_math_adam(p, g, m, v, step, lr, betas, eps):
+    """Test-only stepper (torch.optim.Adam's update written out) so ShardedAdam's collectives can run on CPU tensors;
+    the product default is the HIP kernel."""
+    b1, b2 = betas
+    m.lerp_(g, 1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    denom = (v.sqrt() / (1 - b2 ** step) ** 0.5).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / (1 - b1 ** step))
+
+
+def _rank_grads(rank, it, shapes):
+    g = torch.Generator().manual_seed(1000 * it + rank)
+    return [torch.randn(*s, generator=g) * (0.1 + it) for s in shapes]
+
+
+_SHAPES = [(37,), (70001, 2), (5, 7)]            # small, sharded (>= 65536 elements, odd size -> padded shards), small
+_WEIGHTS = [0.25, 0.75]                          # unequal ray shares
+
+
+def _map_worker(rank, world, port, out_q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from nicer_slam_amd import dist as nd
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(*s)) for s in _SHAPES]
+    opt = nd.ShardedAdam([{"params": params[:2], "lr": 0.04}, {"params": params[2:], "lr": 0.002}], betas=(0.9, 0.99),
+                         eps=1e-15, stepper=_torch_math_adam)
+    for it in range(3):
+        for p, g in zip(params, _rank_grads(rank, it, _SHAPES)):
+            p.grad = g
+        opt.step(weight=_WEIGHTS[rank])
+    assert opt.state[params[1]]["sharded"] and opt.state[params[1]]["exp_avg"].numel() == 70001
+    assert not opt.state[params[0]]["sharded"]
+    vox0 = torch.arange(8.0).reshape(2, 2, 2)
+    vox = vox0 + (rank + 1) * torch.tensor([1.0, 0, 0, 2, 0, 0, 0, 3]).reshape(2, 2, 2)
+    nd.allreduce_voxel_delta(vox, vox0)
+    out_q.put((rank, [p.detach().numpy().copy() for p in params], vox.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_adam_matches_single_process_adam():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_map_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    ref = [torch.nn.Parameter(torch.randn(*s)) for s in _SHAPES]
+    opt = torch.optim.Adam([{"params": ref[:2], "lr": 0.04}, {"params": ref[2:], "lr": 0.002}], betas=(0.9, 0.99), eps=1e-15)
+    for it in range(3):
+        gs = [_rank_grads(r, it, _SHAPES) for r in range(2)]
+        for i, p in enumerate(ref):
+            p.grad = _WEIGHTS[0] * gs[0][i] + _WEIGHTS[1] * gs[1][i]
+        opt.step()
+    for a, b, r in zip(res[0][1], res[1][1], ref):
+        np.testing.assert_array_equal(a, b)                                   # replicas stay bit-identical
+        np.testing.assert_allclose(a, r.detach().numpy(), rtol=2e-5, atol=2e-6)
+    expect = np.arange(8.0).reshape(2, 2, 2) + 3 * np.array([1.0, 0, 0, 2, 0, 0, 0, 3]).reshape(2, 2, 2)
+    np.testing.assert_array_equal(res[0][2], expect)
+    np.testing.assert_array_equal(res[1][2], expect)

@@ -192,3 +192,27 @@ def test_fused_adam_vs_torch_adam(n):
     assert_close(sa["exp_avg"], sb["exp_avg"].cpu().numpy(), 3e-7 * float(sb["exp_avg"].abs().max()), 2e-6, "exp_avg")
     assert_close(sa["exp_avg_sq"], sb["exp_avg_sq"].cpu().numpy(), 3e-7 * float(sb["exp_avg_sq"].abs().max()), 2e-6,
                  "exp_avg_sq")
+
+
+def test_sharded_adam_single_rank_uses_hip_stepper():
+    """ShardedAdam without a process group (world 1) must step exactly like nicer_slam_amd.optim.Adam (same kernel)."""
+    from nicer_slam_amd.optim import Adam
+    from nicer_slam_amd.dist import ShardedAdam
+    torch.manual_seed(2)
+    p0 = [torch.randn(70001, 2, device="cuda"), torch.randn(33, device="cuda")]
+    a = [torch.nn.Parameter(t.clone()) for t in p0]
+    b = [torch.nn.Parameter(t.clone()) for t in p0]
+    oa = ShardedAdam([{"params": a, "lr": 0.01}], betas=(0.9, 0.99), eps=1e-15)
+    ob = Adam([{"params": b, "lr": 0.01}], betas=(0.9, 0.99), eps=1e-15)
+    for it in range(3):
+        for x, y in zip(a, b):
+            g = torch.randn_like(x)
+            x.grad, y.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for x, y in zip(a, b):
+        assert torch.equal(x.detach(), y.detach())
+    with pytest.raises(RuntimeError):
+        c = torch.nn.Parameter(torch.randn(4))
+        c.grad = torch.randn(4)
+        ShardedAdam([c]).step()               # CPU tensors: no fallback

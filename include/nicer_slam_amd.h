@@ -210,6 +210,12 @@ int nsa_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
                   float lr, float beta1, float beta2, float eps, uint32_t lr_step, float lr_gamma,
                   nsa_stream_t stream);
 
+/* SDF (coarse + fine; fine == NULL: stage "coarse") at N explicit points, no gradients: batch inference for mesh
+ * extraction grids and plots.  replaces ImplicitNetworkGrid_COMBINE.get_sdf_vals (code/model/base_networks.py:25-35)
+ * as called by code/utils/plots.py:91,142. */
+int nsa_sdf_points(const float *points, uint64_t N, const nsa_grid_t *coarse, const nsa_grid_t *fine,
+                   const float *packed_coarse, const float *packed_fine, float *sdf, nsa_stream_t stream);
+
 /* ---- Section 4: mapping-iteration tail ------------------------------------------------------------------------ */
 
 /* voxels[floor((x+1)/2*res)] += 1 for every sample with all |x_d| <= 0.99 (voxels: [res,res,res] fp32, x-major).

@@ -110,3 +110,7 @@ lib.nsa_update_voxels.argtypes = [_pp, _p, _u32, _p]
 lib.nsa_adam_table_step.restype = _i
 lib.nsa_adam_table_step.argtypes = [_p, _p, _p, _p, ctypes.c_uint64, _u32, _f32, _f32, _f32, _f32, _p]
 EXPORTS += ["nsa_update_voxels", "nsa_adam_table_step"]
+
+lib.nsa_sdf_points.restype = _i
+lib.nsa_sdf_points.argtypes = [_p, ctypes.c_uint64, _gp, _gp, _p, _p, _p, _p]
+EXPORTS += ["nsa_sdf_points"]

@@ -94,6 +94,43 @@ __global__ __launch_bounds__(256, 2) void k_sampler_sdf(SamplerArgs a, GridGeom1
     }
 }
 
+
+// SDF at explicit points, no gradient (batch inference: mesh extraction grids, plots).
+// Reference: ImplicitNetworkGrid_COMBINE.get_sdf_vals (code/model/base_networks.py:25-35).  table_f == nullptr: stage "coarse".
+struct SdfPointsArgs {
+    const float* points;      // [N,3]
+    float* sdf;               // [N]
+    uint64_t N;
+    const float* table_c;
+    const float* table_f;
+    const float* wp_c;
+    const float* wp_f;
+    float df_c, df_f;
+};
+
+template <int LC, int CC, int NHC, int LF, int CF, int NHF>
+__global__ __launch_bounds__(256, 2) void k_sdf_points(SdfPointsArgs a, GridGeom16 gc, GridGeom16 gf) {
+    desync_simd_partners();
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint64_t pid = wave * 32 + (lane & 31);
+    const bool live = pid < a.N;
+    if (!live) pid = a.N - 1;
+    float x[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x[k] = a.points[pid * 3 + k];
+    float in[SDF_IN_STEPS];
+    pe_slots(x, h, in);
+    grid_slots<LC, CC>(x, a.df_c, a.table_c, gc, h, in);
+    float sdf = sdf_only<NHC>(a.wp_c, lane, h, in);
+    if (a.table_f) {                            // uniform branch
+        grid_slots<LF, CF>(x, a.df_f, a.table_f, gf, h, in);
+        sdf += sdf_only<NHF>(a.wp_f, lane, h, in);
+    }
+    if (live && h == 0) a.sdf[pid] = sdf;
+}
+
 // ------------------------------------------------------------------------------------------------ per-ray stage
 struct RaySampleArgs {
     const float* rays_o;
@@ -298,6 +335,26 @@ int nsa_sampler_sdf(const float* rays_o, const float* rays_d, uint32_t R, uint32
     const uint32_t blocks = (waves + 3) / 4;
     launch_begin();
     hipLaunchKernelGGL((k_sampler_sdf<4, 8, 1, 8, 4, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, gc, gf);
+    return launch_end();
+}
+
+int nsa_sdf_points(const float* points, uint64_t N, const nsa_grid_t* coarse, const nsa_grid_t* fine,
+                   const float* packed_coarse, const float* packed_fine, float* sdf, nsa_stream_t stream) {
+    using namespace nsa;
+    if (N == 0) return NSA_OK;
+    if (!points || !coarse || !packed_coarse || !sdf || (fine && !packed_fine)) return NSA_EBADARG;
+    if (!(coarse->L == 4 && coarse->C == 8 && coarse->n_hidden == 1)) return NSA_EUNSUPPORTED_NET;
+    if (fine && !(fine->L == 8 && fine->C == 4 && fine->n_hidden == 3)) return NSA_EUNSUPPORTED_NET;
+    GridGeom16 gc, gf{};
+    if (int rc = make_grid_geom16(coarse->offsets_host, coarse->L, coarse->S, coarse->H, &gc)) return rc;
+    if (fine) if (int rc = make_grid_geom16(fine->offsets_host, fine->L, fine->S, fine->H, &gf)) return rc;
+    SdfPointsArgs a{points, sdf, N, coarse->table, fine ? fine->table : nullptr, packed_coarse, fine ? packed_fine : nullptr,
+                    coarse->divide_factor, fine ? fine->divide_factor : 1.0f};
+    const uint64_t waves = (N + 31) / 32;
+    const uint64_t blocks = (waves + 3) / 4;
+    if (blocks > 0x7FFFFFFFull) return NSA_EBADARG;
+    launch_begin();
+    hipLaunchKernelGGL((k_sdf_points<4, 8, 1, 8, 4, 3>), dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, a, gc, gf);
     return launch_end();
 }
 

@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--autograd", action="store_true",
                     help="drive the model through torch autograd (TrackingStepper) instead of the kernel sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mapping", action="store_true", help="skip the (untimed-for-value) mapping-iteration leg")
     ap.add_argument("--cpu-rays", type=int, default=64)
     return ap.parse_args()
 
@@ -176,6 +177,10 @@ def main():
             roof.update({"launches": n, "avg_launch_us": round(tms / n * 1e3, 2), "share_of_step": round(tms / n / ms, 4),
                          "all_kernels_us": {k: round(v[0] / v[2] * 1e3, 1) for k, v in sorted(agg.items())}})
         cpu = None if args.no_cpu_baseline else cpu_baseline(args, model, conf)
+        mapping = None
+        if world == 1 and not args.no_mapping and args.engine != "composed":
+            del stepper, eager
+            mapping = mapping_leg(device)
         line = {
             "metric": "rays/sec (fwd+bwd), one tracking iteration", "value": round(rays_total / dt, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
@@ -183,15 +188,70 @@ def main():
             "config": {"workload": f"Replica room0 tracking iteration, {args.rays} rays x {args.samples} samples "
                                    f"(+640 sampler evaluations/ray), single MI355X fp32 [BASELINE configs[1]]",
                        "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "sampler_evals_per_ray": 640,
-                       "global_rays": args.rays * world, "engine": model.last_engine, "param_grads": args.param_grads,
+                       "global_rays": args.rays * world,
+                       "engine": "fused" if Stepper.__name__ == "KernelTracker" else model.last_engine, "param_grads": args.param_grads,
                        "hip_graph": bool(use_graph), "driver": Stepper.__name__,
                        "parallelism": f"ray-shard x{world}" if world > 1 else "single"},
             "final_loss": round(last, 6),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "mapping_iteration": mapping,
         }
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def mapping_leg(device, rays=8192, frames=8, iters=5):
+    """Context number, not `value`: one MAPPING iteration (SURVEY 8a rows a1-a15 with parameter gradients, eikonal
+    samples, voxel counter; Adam over the three tables + two MLPs as volsdf_train.py:150-174) at the shipped sizes:
+    8192 rays over 8 keyframes, 98 samples/ray, fused engine, nicer_slam_amd.optim.Adam."""
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.optim import Adam
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    torch.manual_seed(0)
+    model = SLAMNetwork(replica_model_conf(64, 640, 32, use_warp_loss=False), dataset=DS(), n_images=2000).to(device)
+    model.train().freeze_fine_mlp()
+    groups = [{"params": list(model.implicit_network.fine.grid_parameters()), "lr": 0.04},
+              {"params": list(model.implicit_network.coarse.grid_parameters()), "lr": 0.04},
+              {"params": list(model.rendering_network.grid_parameters()), "lr": 0.01},
+              {"params": list(model.rendering_network.mlp_parameters()), "lr": 0.002},
+              {"params": list(model.implicit_network.coarse.mlp_parameters()), "lr": 0.002}]
+    opt = Adam(groups, betas=(0.9, 0.99), eps=1e-15)
+    g = torch.Generator(device=device).manual_seed(1)
+    K = torch.eye(4, device=device)
+    K[0, 0] = K[1, 1] = 600.0
+    K[0, 2], K[1, 2] = 599.5, 339.5
+    K = K[None].repeat(frames, 1, 1)
+    cams = torch.tensor([1.0, 0, 0, 0, 0.1, 0.0, -0.2], device=device).repeat(frames, 1)
+    cams = cams + 0.01 * torch.randn(frames, 7, device=device, generator=g)
+    H, W = DS.img_res
+
+    def step():
+        idx = torch.randint(H * W, (frames, rays // frames), device=device, generator=g)
+        uv = torch.stack([(idx % W).float(), (idx // W).float()], -1)
+        gt = torch.rand(rays, 3, device=device, generator=g)
+        opt.zero_grad()
+        out = model({"intrinsics": K, "uv": uv, "pose": get_camera_from_tensor(cams)}, torch.arange(frames, device=device),
+                    {}, mode="mapping", stage="fine", color_stage="highfreq", frame_idx=5)
+        loss = (out["rgb_values"].reshape(-1, 3) - gt).abs().mean()
+        loss = loss + 0.1 * ((out["grad_theta"].norm(2, dim=1) - 1) ** 2).mean()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        last = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    assert model.last_engine == "fused"
+    return {"ms": round(dt * 1e3, 2), "rays": rays, "keyframes": frames, "samples_per_ray": 98,
+            "eikonal_points": 22 * rays, "rays_per_s": round(rays / dt, 1), "engine": model.last_engine,
+            "optimizer": "nicer_slam_amd.optim.Adam (1.1 GiB of parameters, dense)", "iters": iters,
+            "final_loss": round(float(last), 6)}
 
 
 def cpu_baseline(args, model, conf):

@@ -111,7 +111,11 @@ __device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane,
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) {
                 a[mt][pc] = f.g[mt][pc];
+#ifdef NSA_EXP_WCACHE   // timing experiment only: every fragment load hits the same 3 KB (L1-resident)
+                if (g + 1 < KS8) f.g[mt][pc] = w4[pc * 64];
+#else
                 if (g + 1 < KS8) f.g[mt][pc] = w4[((mt * KS8 + g + 1) * 3 + pc) * 64];
+#endif
             }
         float x[8];
 #pragma unroll
@@ -127,6 +131,91 @@ __device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane,
 #undef NSA_MM
     }
     __builtin_amdgcn_sched_barrier(0);   // keep later layers' loads from being hoisted above this GEMM
+}
+
+// ---- block-cooperative weight staging -------------------------------------------------------------------------
+// Measured (profiles/, experiment NSA_EXP_WCACHE): with every wave streaming its own copy of the packed weights from
+// L2, the fine SDF backward spends 59 % of its wave cycles in s_waitcnt and 127 of its 280 us disappear when the
+// fragment loads hit L1 -- at one wave per SIMD there is nothing to hide the L2 latency behind, and the four waves of a
+// block fetch the same bytes four times.  The staged GEMM fetches each layer's packed block ONCE per workgroup with
+// asynchronous global->LDS copies (global_load_lds_dwordx4: no VGPR staging; 1 KiB per wave instruction, which is
+// exactly one fragment), double-buffered one GEMM ahead, and the MFMA A operands are read from LDS (ds_read_b128).
+// One workgroup barrier per GEMM.  All four waves of a block must execute the same GEMM sequence (no early exits).
+constexpr int kStageFloats = 9216;      // largest packed block: A[3 tiles][32 slots] = 36 KiB
+
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;      // (uint4 is a class type: no address-space pointers to it)
+using lds_u4 = __attribute__((address_space(3))) u32x4;
+
+__device__ __forceinline__ bf16x8_t as_bf16x8(const u32x4& v) {
+    bf16x8_t r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
+
+__device__ __forceinline__ void stage_issue(const float* __restrict__ g, int nfloats, float* lds_dst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunks = nfloats / 256;
+#pragma unroll
+    for (int c = 0; c < (chunks + 3) / 4; ++c) {
+        const int ch = 4 * c + wave;
+        if (ch < chunks)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + ch * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(lds_dst + ch * 256), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void stage_wait() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this wave's async copies (and older global loads) have landed
+    __syncthreads();                         // ... and so have everyone else's; all waves are done with the other buffer
+}
+
+template <int KS, int MT>
+__device__ __forceinline__ void gemm_lds(const float* lds_block, int lane, const float (&b)[KS], f32x16 (&acc)[MT]) {
+    constexpr int KS8 = (KS + 7) / 8;
+    const lds_u4* w4 = (const lds_u4*)lds_block + lane;
+    u32x4 nxt[MT][3];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) nxt[mt][pc] = w4[((mt * KS8 + 0) * 3 + pc) * 64];
+#pragma unroll
+    for (int g = 0; g < KS8; ++g) {
+        u32x4 a[MT][3];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                a[mt][pc] = nxt[mt][pc];
+                if (g + 1 < KS8) nxt[mt][pc] = w4[((mt * KS8 + g + 1) * 3 + pc) * 64];
+            }
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? b[8 * g + e] : 0.0f;
+        BFrag bf;
+        split8(x, bf);
+        const bf16x8_t bh = as_bf16x8(bf.p[0]), bm = as_bf16x8(bf.p[1]), bl = as_bf16x8(bf.p[2]);
+#define NSA_MM(AP, BV)                                                                                   \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                \
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[mt][AP]), BV, acc[mt], 0, 0, 0);
+        NSA_MM(2, bh) NSA_MM(0, bl) NSA_MM(1, bm) NSA_MM(1, bh) NSA_MM(0, bm) NSA_MM(0, bh)
+#undef NSA_MM
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// GEMM number `opi` of the kernel's sequence Seq (Seq::n ops; Seq::off(i) / Seq::size(i) = packed block of op i, in
+// floats from `wp`): wait for its block, start fetching the next one into the other buffer, multiply from LDS.
+template <class Seq, int KS, int MT>
+__device__ __forceinline__ void gemm_staged(float* stage, const float* __restrict__ wp, int opi, int lane,
+                                            const float (&b)[KS], f32x16 (&acc)[MT]) {
+    stage_wait();
+    if (opi + 1 < Seq::n) stage_issue(wp + Seq::off(opi + 1), Seq::size(opi + 1), stage + ((opi + 1) & 1) * kStageFloats);
+    gemm_lds<KS, MT>(stage + (opi & 1) * kStageFloats, lane, b, acc);
+}
+
+template <class Seq>
+__device__ __forceinline__ void stage_begin(float* stage, const float* __restrict__ wp) {
+    stage_issue(wp + Seq::off(0), Seq::size(0), stage);
 }
 
 #else   // ------------------------------------------------------------------ fp32-input MFMA variant
@@ -174,6 +263,18 @@ __device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane,
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+}
+#endif
+
+#if !NSA_BF16X3   // A/B build: the staged entry points fall back to per-wave streaming
+constexpr int kStageFloats = 64;
+template <class Seq> __device__ __forceinline__ void stage_begin(float*, const float*) {}
+template <int KS, int MT>
+__device__ __forceinline__ void gemm_op(const float* __restrict__ wp, int lane, const float (&b)[KS], f32x16 (&acc)[MT]);
+template <class Seq, int KS, int MT>
+__device__ __forceinline__ void gemm_staged(float*, const float* __restrict__ wp, int opi, int lane, const float (&b)[KS],
+                                            f32x16 (&acc)[MT]) {
+    gemm_op<KS, MT>(wp + Seq::off(opi), lane, b, acc);
 }
 #endif
 

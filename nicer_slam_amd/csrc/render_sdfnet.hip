@@ -61,13 +61,32 @@ struct Emitter {
     }
 };
 
-template <int NH>
-__device__ __forceinline__ void hidden_forward(const float* __restrict__ wp, int lane, int h, const float (&in)[SDF_IN_STEPS],
-                                               float (&sg)[NH][HS], float (&hlast)[HS]) {
+// GEMM sequences of the two kernels (block-cooperative weight staging, mlp_common.hpp):
+//   forward : W0, W_1..W_{NH-1}, WFEAT | reverse pass W_{NH-1}^T..W_1^T, W0^T                                   2 NH + 1
+//   backward: W0, W_k | W_k^T.., W0^T | tangent W0, W_k | WFEAT^T | reverse sweep W_k^T.., W0^T                  4 NH + 1
+template <int NH, bool BWD>
+struct SdfOps {
+    using P = SdfPack<NH>;
+    static constexpr int n = BWD ? 4 * NH + 1 : 2 * NH + 1;
+    __host__ __device__ static constexpr int rev(int j) { return j < NH - 1 ? P::wht(NH - 1 - j) : P::kW0T; }   // j-th op of a reverse chain
+    __host__ __device__ static constexpr int fwd(int j) { return j == 0 ? P::kW0 : P::wh(j); }
+    __host__ __device__ static constexpr int off(int i) {
+        if (!BWD) return i < NH ? fwd(i) : i == NH ? P::kWFEAT : rev(i - NH - 1);
+        return i < NH ? fwd(i) : i < 2 * NH ? rev(i - NH) : i < 3 * NH ? fwd(i - 2 * NH) : i == 3 * NH ? P::kWFEATT : rev(i - 3 * NH - 1);
+    }
+    __host__ __device__ static constexpr int size(int i) {
+        const int o = off(i);
+        return o == P::kW0 ? a_block_floats(2, SDF_IN_STEPS) : o == P::kW0T ? a_block_floats(3, HS) : P::kHH;
+    }
+};
+
+template <int NH, class Seq>
+__device__ __forceinline__ void hidden_forward(float* stage, int op0, const float* __restrict__ wp, int lane, int h,
+                                               const float (&in)[SDF_IN_STEPS], float (&sg)[NH][HS], float (&hlast)[HS]) {
     using P = SdfPack<NH>;
     f32x16 acc[2];
     load_vec<2>(wp + P::kB0, h, acc);
-    gemm_op<SDF_IN_STEPS, 2>(wp + P::kW0, lane, in, acc);
+    gemm_staged<Seq, SDF_IN_STEPS, 2>(stage, wp, op0, lane, in, acc);
 #pragma unroll
     for (int k = 1; k <= NH; ++k) {
         float d2;
@@ -77,15 +96,15 @@ __device__ __forceinline__ void hidden_forward(const float* __restrict__ wp, int
             for (int r = 0; r < 16; ++r) softplus100_all(acc[t][r], hlast[16 * t + r], sg[k - 1][16 * t + r], d2);
         if (k < NH) {
             load_vec<2>(wp + P::bh(k), h, acc);
-            gemm_op<HS, 2>(wp + P::wh(k), lane, hlast, acc);
+            gemm_staged<Seq, HS, 2>(stage, wp, op0 + k, lane, hlast, acc);
         }
     }
 }
 
 // reverse pass from the sdf output: fills dh[k-1] = dh_k for k = 1..NH-1 (dh_NH is the packed sdf row) and dl = dh_0.
-template <int NH>
-__device__ __forceinline__ void reverse_pass(const float* __restrict__ wp, int lane, int h, const float (&sg)[NH][HS],
-                                             float (&dh)[NH > 1 ? NH - 1 : 1][HS], float (&dl)[48]) {
+template <int NH, class Seq>
+__device__ __forceinline__ void reverse_pass(float* stage, int op0, const float* __restrict__ wp, int lane, int h,
+                                             const float (&sg)[NH][HS], float (&dh)[NH > 1 ? NH - 1 : 1][HS], float (&dl)[48]) {
     using P = SdfPack<NH>;
     f32x16 ws[2];
     load_vec<2>(wp + P::kWSDF, h, ws);
@@ -101,7 +120,7 @@ __device__ __forceinline__ void reverse_pass(const float* __restrict__ wp, int l
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        gemm_op<HS, 2>(wp + P::wht(k), lane, da, acc);
+        gemm_staged<Seq, HS, 2>(stage, wp, op0 + (NH - 1 - k), lane, da, acc);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -115,7 +134,7 @@ __device__ __forceinline__ void reverse_pass(const float* __restrict__ wp, int l
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) a3[t][r] = 0.0f;
-    gemm_op<HS, 3>(wp + P::kW0T, lane, da, a3);
+    gemm_staged<Seq, HS, 3>(stage, wp, op0 + NH - 1, lane, da, a3);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -134,14 +153,18 @@ __device__ __forceinline__ void reverse_pass(const float* __restrict__ wp, int l
 template <int L, int C, int NH>
 __global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfnet_fwd(SdfNetArgs a, GridGeom16 geom) {
     using P = SdfPack<NH>;
-    desync_simd_partners();
+    using Seq = SdfOps<NH, false>;
+    __shared__ __attribute__((aligned(16))) float stage[2 * kStageFloats];
+    stage_begin<Seq>(stage, a.wp);
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
-    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile * 32 >= a.src.P) return;                       // whole wave
+    uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t n_tiles = (a.src.P + 31) / 32;
+    const bool wave_live = tile < n_tiles;                  // a wave without points still takes part in the barriers
+    if (!wave_live) tile = n_tiles - 1;
     uint32_t pid = tile * 32 + (lane & 31);
-    const bool live = pid < a.src.P;
-    if (!live) pid = a.src.P - 1;
+    const bool live = wave_live && pid < a.src.P;
+    if (pid >= a.src.P) pid = a.src.P - 1;
     float x[3], z;
     uint32_t ray;
     load_point(a.src, pid, x, ray, z);
@@ -152,7 +175,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfne
         sdf_net_inputs<L, C, false>(x, a.divide_factor, a.table, geom, h, in, jd);
     }
     float sg[NH][HS], hl[HS];
-    hidden_forward<NH>(a.wp, lane, h, in, sg, hl);
+    hidden_forward<NH, Seq>(stage, 0, a.wp, lane, h, in, sg, hl);
     // outputs: sdf (row 0, VALU dot) and the 64 features (rows 1..64)
     f32x16 ws[2], fo[2];
     load_vec<2>(a.wp + P::kWSDF, h, ws);
@@ -163,19 +186,21 @@ __global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfne
         for (int r = 0; r < 16; ++r) part = fmaf(hl[16 * t + r], ws[t][r], part);
     float sdf = xhalf_sum(part) + a.wp[P::kBSDF];
     load_vec<2>(a.wp + P::kBFEAT, h, fo);
-    gemm_op<HS, 2>(a.wp + P::kWFEAT, lane, hl, fo);
+    gemm_staged<Seq, HS, 2>(stage, a.wp, NH, lane, hl, fo);
     float* fdst = a.feat + (size_t)tile * 32 * 64 + lane;
+    if (wave_live) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = fo[t][r];
-            if (a.accumulate) v += fdst[(16 * t + r) * 64];
-            fdst[(16 * t + r) * 64] = v;
-        }
+            for (int r = 0; r < 16; ++r) {
+                float v = fo[t][r];
+                if (a.accumulate) v += fdst[(16 * t + r) * 64];
+                fdst[(16 * t + r) * 64] = v;
+            }
+    }
     // grad sdf
     float dh[NH > 1 ? NH - 1 : 1][HS], dl[48], g[3];
-    reverse_pass<NH>(a.wp, lane, h, sg, dh, dl);
+    reverse_pass<NH, Seq>(stage, NH + 1, a.wp, lane, h, sg, dh, dl);
     slots_to_x<L, C>(x, a.divide_factor, a.table, geom, h, in, dl, g);
 #pragma unroll
     for (int d = 0; d < 3; ++d) g[d] = xhalf_sum(g[d]);
@@ -197,14 +222,18 @@ __global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfne
 template <int L, int C, int NH, bool MAP>
 __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FINE)) void k_sdfnet_bwd(SdfNetArgs a, GridGeom16 geom) {
     using P = SdfPack<NH>;
-    desync_simd_partners();
+    using Seq = SdfOps<NH, true>;
+    __shared__ __attribute__((aligned(16))) float stage[2 * kStageFloats];
+    stage_begin<Seq>(stage, a.wp);
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
-    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile * 32 >= a.src.P) return;
+    uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t n_tiles = (a.src.P + 31) / 32;
+    const bool wave_live = tile < n_tiles;
+    if (!wave_live) tile = n_tiles - 1;
     uint32_t pid = tile * 32 + (lane & 31);
-    const bool live = pid < a.src.P;
-    if (!live) pid = a.src.P - 1;
+    const bool live = wave_live && pid < a.src.P;
+    if (pid >= a.src.P) pid = a.src.P - 1;
     float x[3], z;
     uint32_t ray;
     load_point(a.src, pid, x, ray, z);
@@ -214,10 +243,10 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
         sdf_net_inputs<L, C, false>(x, a.divide_factor, a.table, geom, h, in, jd);
     }
     float sg[NH][HS], hl[HS];
-    hidden_forward<NH>(a.wp, lane, h, in, sg, hl);
+    hidden_forward<NH, Seq>(stage, 0, a.wp, lane, h, in, sg, hl);
     float dh[NH > 1 ? NH - 1 : 1][HS], dl[48];
-    reverse_pass<NH>(a.wp, lane, h, sg, dh, dl);
-    const bool emit = MAP && NH == 1 && a.emit != nullptr;
+    reverse_pass<NH, Seq>(stage, NH, a.wp, lane, h, sg, dh, dl);
+    const bool emit = MAP && NH == 1 && a.emit != nullptr && wave_live;   // (a clamped wave must not touch the last tile's rows)
     const Emitter em{emit ? a.emit + (size_t)tile * 32 + (lane & 31) : nullptr, a.emit_ld, live};
     if (emit) {
         f32x16 ws[2];
@@ -251,7 +280,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        gemm_op<SDF_IN_STEPS, 2>(a.wp + P::kW0, lane, tin, acc);
+        gemm_staged<Seq, SDF_IN_STEPS, 2>(stage, a.wp, 2 * NH, lane, tin, acc);
         f32x16 ws[2];
         load_vec<2>(a.wp + P::kWSDF, h, ws);
         float th[HS];
@@ -274,7 +303,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-                gemm_op<HS, 2>(a.wp + P::wh(k), lane, th, acc);
+                gemm_staged<Seq, HS, 2>(stage, a.wp, 2 * NH + k, lane, th, acc);
             }
         }
     }
@@ -295,7 +324,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = sbar * ws[t][r];
-        gemm_op<HS, 2>(a.wp + P::kWFEATT, lane, fb, acc);
+        gemm_staged<Seq, HS, 2>(stage, a.wp, 3 * NH, lane, fb, acc);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -308,7 +337,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        gemm_op<HS, 2>(a.wp + P::wht(k), lane, ab, acc);
+        gemm_staged<Seq, HS, 2>(stage, a.wp, 3 * NH + 1 + (NH - 1 - k), lane, ab, acc);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -325,7 +354,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) a3[t][r] = 0.0f;
-        gemm_op<HS, 3>(a.wp + P::kW0T, lane, ab, a3);
+        gemm_staged<Seq, HS, 3>(stage, a.wp, 4 * NH, lane, ab, a3);
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll

@@ -210,6 +210,12 @@ int nsa_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
                   float lr, float beta1, float beta2, float eps, uint32_t lr_step, float lr_gamma,
                   nsa_stream_t stream);
 
+/* Integer draws of one sampler call from a buffer u of E + R uniforms in [0,1): extra_idx[n_extra] = the first n_extra
+ * entries of a random permutation of 0..E-1 (E <= 1024), eik_idx[R] = uniform in 0..S-1; either output may be NULL.
+ * replaces torch.randperm(E)[:n_extra] and torch.randint(S, (R,)) (code/model/ray_sampler.py:148,158). */
+int nsa_draw_picks(const float *u, uint32_t E, uint32_t n_extra, uint32_t R, uint32_t S, int32_t *extra_idx,
+                   int32_t *eik_idx, nsa_stream_t stream);
+
 /* SDF (coarse + fine; fine == NULL: stage "coarse") at N explicit points, no gradients: batch inference for mesh
  * extraction grids and plots.  replaces ImplicitNetworkGrid_COMBINE.get_sdf_vals (code/model/base_networks.py:25-35)
  * as called by code/utils/plots.py:91,142. */

@@ -114,3 +114,7 @@ EXPORTS += ["nsa_update_voxels", "nsa_adam_table_step"]
 lib.nsa_sdf_points.restype = _i
 lib.nsa_sdf_points.argtypes = [_p, ctypes.c_uint64, _gp, _gp, _p, _p, _p, _p]
 EXPORTS += ["nsa_sdf_points"]
+
+lib.nsa_draw_picks.restype = _i
+lib.nsa_draw_picks.argtypes = [_p, _u32, _u32, _u32, _u32, _p, _p, _p]
+EXPORTS += ["nsa_draw_picks"]

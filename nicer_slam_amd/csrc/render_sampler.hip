@@ -131,6 +131,39 @@ __global__ __launch_bounds__(256, 2) void k_sdf_points(SdfPointsArgs a, GridGeom
     if (live && h == 0) a.sdf[pid] = sdf;
 }
 
+// Per-iteration integer draws of the sampler from ONE buffer of uniforms (training mode):
+//   extra_idx = first n_extra entries of a random permutation of 0..E-1  (torch.randperm(E)[:n], ray_sampler.py:148)
+//               = indices of the n_extra smallest of E i.i.d. uniform keys (bitonic key/index sort in LDS);
+//   eik_idx[r] = floor(u * S) in 0..S-1                                  (torch.randint(S, (R,)), ray_sampler.py:158).
+// One 1024-thread block; replaces a rand + argsort (radix sort, arange, fills, casts) + randint chain of ~10 launches.
+__global__ __launch_bounds__(1024) void k_draw_picks(const float* __restrict__ u, uint32_t E, uint32_t n_extra, uint32_t R,
+                                                     uint32_t S, int32_t* __restrict__ extra_idx, int32_t* __restrict__ eik_idx) {
+    __shared__ float key[1024];
+    __shared__ int idx[1024];
+    const uint32_t t = threadIdx.x;
+    key[t] = t < E ? u[t] : 2.0f;               // pad keys sort last
+    idx[t] = (int)t;
+    __syncthreads();
+    for (uint32_t k = 2; k <= 1024; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t p = t ^ j;
+            if (p > t) {
+                const bool up = (t & k) == 0;
+                const float a = key[t], b = key[p];
+                const int ia = idx[t], ib = idx[p];
+                const bool gt = a > b || (a == b && ia > ib);     // total order: ties by index
+                if (gt == up) { key[t] = b; key[p] = a; idx[t] = ib; idx[p] = ia; }
+            }
+            __syncthreads();
+        }
+    if (extra_idx && t < n_extra) extra_idx[t] = idx[t];
+    if (eik_idx)
+        for (uint32_t r = t; r < R; r += 1024) {
+            const uint32_t v = (uint32_t)(u[E + r] * (float)S);
+            eik_idx[r] = (int32_t)(v < S ? v : S - 1);
+        }
+}
+
 // ------------------------------------------------------------------------------------------------ per-ray stage
 struct RaySampleArgs {
     const float* rays_o;
@@ -355,6 +388,15 @@ int nsa_sdf_points(const float* points, uint64_t N, const nsa_grid_t* coarse, co
     if (blocks > 0x7FFFFFFFull) return NSA_EBADARG;
     launch_begin();
     hipLaunchKernelGGL((k_sdf_points<4, 8, 1, 8, 4, 3>), dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, a, gc, gf);
+    return launch_end();
+}
+
+int nsa_draw_picks(const float* u, uint32_t E, uint32_t n_extra, uint32_t R, uint32_t S, int32_t* extra_idx,
+                   int32_t* eik_idx, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!u || E == 0 || E > 1024 || n_extra > E || (eik_idx && S == 0)) return NSA_EBADARG;
+    launch_begin();
+    hipLaunchKernelGGL(k_draw_picks, dim3(1), dim3(1024), 0, (hipStream_t)stream, u, E, n_extra, R, S, extra_idx, eik_idx);
     return launch_end();
 }
 

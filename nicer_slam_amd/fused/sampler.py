@@ -100,31 +100,46 @@ def sample_rays(model, rays_o, rays_d, z, sdf, far, extra_idx, eik_idx):
     z_eik = torch.empty(R, device=dev)
     u_lin = _linspace(N, dev)
     ex = extra_idx.to(torch.int32).contiguous() if n_extra else None
-    ek = eik_idx.to(torch.int32).contiguous()
+    ek = eik_idx.to(torch.int32).contiguous() if eik_idx is not None else None
     vox = model.voxels.contiguous()
     with _timed("k_sample_rays", R * E * 8):
         check(lib.nsa_sample_rays(rays_o.data_ptr(), rays_d.data_ptr(), z.data_ptr(), sdf.data_ptr(), far.data_ptr(),
                                   vox.data_ptr(), model.voxel_res, R, E, N, u_lin.data_ptr(),
-                                  ex.data_ptr() if n_extra else None, n_extra, float(samp.near), ek.data_ptr(),
-                                  z_vals.data_ptr(), z_eik.data_ptr(), torch.cuda.current_stream().cuda_stream))
-    return z_vals, z_eik.unsqueeze(-1)
+                                  ex.data_ptr() if n_extra else None, n_extra, float(samp.near),
+                                  ek.data_ptr() if ek is not None else None, z_vals.data_ptr(),
+                                  z_eik.data_ptr() if ek is not None else None, torch.cuda.current_stream().cuda_stream))
+    return z_vals, (z_eik.unsqueeze(-1) if ek is not None else None)
 
 
-def get_z_vals(model, ray_dirs, cam_loc):
-    """Drop-in for ImportantSampler.get_z_vals (fused engine)."""
+def get_z_vals(model, ray_dirs, cam_loc, need_eik=True):
+    """Drop-in for ImportantSampler.get_z_vals (fused engine).  ``need_eik=False`` (tracking) skips the near-surface
+    eikonal sample, which only mapping consumes."""
     samp = model.ray_sampler
     rays_d = ray_dirs.detach().contiguous()
     rays_o = cam_loc.detach().contiguous()
     R, E = rays_d.shape[0], samp.N_samples_eval
+    n_extra = samp.N_samples_extra
+    S = samp.N_samples + 2 + n_extra
+    dev = rays_d.device
+    if model.training and model.draws is None and E <= 1024:
+        # fast path: ONE device rand for every draw of this call + one kernel for the integer picks
+        u = torch.rand(R * E + E + R, device=dev)
+        z, sdf, far = sampler_sdf(model, rays_o, rays_d, u[:R * E].view(R, E))
+        extra = torch.empty(n_extra, device=dev, dtype=torch.int32) if n_extra > 0 else None
+        eik_idx = torch.empty(R, device=dev, dtype=torch.int32) if need_eik else None
+        if extra is not None or eik_idx is not None:
+            check(lib.nsa_draw_picks(u[R * E:].data_ptr(), E, n_extra, R, S, extra.data_ptr() if extra is not None else None,
+                                     eik_idx.data_ptr() if eik_idx is not None else None,
+                                     torch.cuda.current_stream().cuda_stream))
+        return sample_rays(model, rays_o, rays_d, z, sdf, far, extra, eik_idx)
     t_rand = model.draw("t_rand", (R, E)) if model.training else None
     z, sdf, far = sampler_sdf(model, rays_o, rays_d, t_rand)
-    if samp.N_samples_extra > 0:
+    if n_extra > 0:
         if model.training:
-            extra = model.draw("extra_idx", (E, samp.N_samples_extra))
+            extra = model.draw("extra_idx", (E, n_extra))
         else:
-            extra = torch.linspace(0, E - 1, samp.N_samples_extra, device=z.device).long()
+            extra = torch.linspace(0, E - 1, n_extra, device=z.device).long()
     else:
         extra = None
-    S = samp.N_samples + 2 + (samp.N_samples_extra if extra is not None else 0)
-    eik_idx = model.draw("eik_idx", (S, R))
+    eik_idx = model.draw("eik_idx", (S, R)) if need_eik else None
     return sample_rays(model, rays_o, rays_d, z, sdf, far, extra, eik_idx)

@@ -52,7 +52,7 @@ class KernelTracker:
         check(lib.nsa_cam_to_pose(self.cam.data_ptr(), 1, self.pose.data_ptr(), st))
         check(lib.nsa_rays_forward(self.uv.data_ptr(), self.pose.data_ptr(), self.K.data_ptr(), 1, R,
                                    self.rays_o.data_ptr(), self.rays_d.data_ptr(), self.ds.data_ptr(), st))
-        z_vals, _ = fs.get_z_vals(model, self.rays_d, self.rays_o)
+        z_vals, _ = fs.get_z_vals(model, self.rays_d, self.rays_o, need_eik=False)
         b = fr.composite_forward_raw(model, self.rays_o, self.rays_d, z_vals, self.stage, True)
         check(lib.nsa_l1_loss(b["rgb_values"].data_ptr(), self.gt.data_ptr(), 3 * R, self.red[7:8].data_ptr(),
                               self.g_rgbv.data_ptr(), st))

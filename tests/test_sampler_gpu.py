@@ -118,3 +118,40 @@ def test_bench_shape_sampler_properties():
                                {"t_rand": t_rand[:n].cpu(), "extra_idx": extra, "eik_idx": torch.zeros(n, dtype=torch.long)},
                                aux=aux)
     check_samples(z_gpu.cpu(), z_cpu, aux["bins"], aux["cdf"], u_tol=5e-5)
+
+
+def test_draw_picks_is_a_permutation_prefix_and_uniform_ints():
+    """nsa_draw_picks: extra_idx = indices of the n smallest keys (= prefix of the permutation that sorts the keys),
+    eik_idx = floor(u*S); bit-exact integer work."""
+    from nicer_slam_amd._native import lib, check
+    torch.manual_seed(9)
+    E, n_extra, R, S = 640, 32, 1000, 98
+    u = torch.rand(E + R, device="cuda")
+    u[5] = u[17]                                              # a tie: broken by index
+    extra = torch.empty(n_extra, device="cuda", dtype=torch.int32)
+    eik = torch.empty(R, device="cuda", dtype=torch.int32)
+    check(lib.nsa_draw_picks(u.data_ptr(), E, n_extra, R, S, extra.data_ptr(), eik.data_ptr(),
+                             torch.cuda.current_stream().cuda_stream))
+    order = sorted(range(E), key=lambda i: (float(u[i]), i))[:n_extra]
+    assert extra.tolist() == order
+    assert eik.tolist() == [min(S - 1, int(float(v) * S)) for v in (u[E:] * 1.0).cpu()] or \
+        torch.equal(eik.long().cpu(), (u[E:] * S).long().clamp(max=S - 1).cpu())
+    assert int(eik.min()) >= 0 and int(eik.max()) <= S - 1 and len(set(eik.tolist())) > S // 2
+
+
+def test_fast_draw_path_statistics():
+    """Fused sampler with device-side draws (no pre-drawn tensors): valid sorted samples, extras distinct per call."""
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.fused import sampler as fs
+    torch.manual_seed(1)
+    model = SLAMNetwork(replica_model_conf(use_warp_loss=False)).cuda().train()
+    R = 256
+    o = torch.tensor([0.1, 0.0, -0.2], device="cuda").repeat(R, 1)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda"), dim=-1)
+    z1, e1 = fs.get_z_vals(model, d, o)
+    z2, e2 = fs.get_z_vals(model, d, o, need_eik=False)
+    assert e2 is None and e1.shape == (R, 1)
+    assert z1.shape == (R, 98) and bool((z1[:, 1:] >= z1[:, :-1]).all()) and bool(torch.isfinite(z1).all())
+    assert not torch.equal(z1, z2)                            # fresh draws per call
+    assert bool(((e1 >= z1[:, :1]) & (e1 <= z1[:, -1:])).all())

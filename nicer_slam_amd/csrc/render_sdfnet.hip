@@ -148,7 +148,7 @@ __device__ __forceinline__ void reverse_pass(float* stage, int op0, const float*
 #define NSA_OCC_BWD_FINE 1
 #endif
 #ifndef NSA_OCC_BWD_COARSE
-#define NSA_OCC_BWD_COARSE 1     // measured: 79 us at one wave per SIMD (no spills) vs 88 us at two (spills)
+#define NSA_OCC_BWD_COARSE 2     // measured with LDS-staged weights: 59 us at two waves per SIMD vs 78 us at one
 #endif
 template <int L, int C, int NH>
 __global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfnet_fwd(SdfNetArgs a, GridGeom16 geom) {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfne
     }
 }
 
-// Occupancy per variant was chosen by A/B timing on MI355X (profiles/): forward fine 2 waves/SIMD, both backward kernels 1.
+// Occupancy per variant was chosen by A/B timing on MI355X (profiles/): forward 2 waves/SIMD, backward coarse 2, fine 1.
 // MAP = true adds the mapping outputs: table gradient (run-merged atomics) and, for the coarse network, the per-point
 // vectors of the weight-gradient GEMMs (the fine MLP is frozen in the reference, volsdf_train.py:150-173).
 template <int L, int C, int NH, bool MAP>

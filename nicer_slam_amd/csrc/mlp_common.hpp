@@ -31,7 +31,7 @@ constexpr int COL_IN_STEPS = 65;   // 129 inputs -> 65 slots per half-wave (one 
 // ---------------------------------------------------------------------------------------------------------------
 // GEMM primitive.  acc[mt] (32 output features x 32 points, fp32) += sum_slots A(mt, slot) * b[slot].
 //
-// NSA_BF16X3 = 1 (default): fp32-faithful products on the bf16 matrix cores.  Every fp32 operand is split exactly into
+// fp32-faithful products on the bf16 matrix cores.  Every fp32 operand is split exactly into
 // three bf16 pieces (8 + 8 + 8 significand bits: x = hi + mid + lo), and the six cross products whose weight is
 // >= 2^-16 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16:
 //     a*b ~= a_lo b_hi + a_hi b_lo + a_mid b_mid + a_mid b_hi + a_hi b_mid + a_hi b_hi          (error <= ~2^-23 |a b|)
@@ -40,17 +40,12 @@ constexpr int COL_IN_STEPS = 65;   // 129 inputs -> 65 slots per half-wave (one 
 // MFMA-busy + VALU-active == busy cycles -- does not overlap with VALU work at all, while one 32x32x16 bf16 MFMA does 8x
 // the MACs in half the cycles: 6 of them replace 8 fp32 MFMAs (2.7x fewer matrix cycles) and run beside the VALU.
 // Weights are split on the host (fused/pack.py); activations are split here with 2 ANDs + 2 SUBs + 1.5 PERMs per value.
-//
-// NSA_BF16X3 = 0: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain), kept for A/B comparison.
+// (The plain fp32-input MFMA variant, v_mfma_f32_32x32x2_f32, measured 1.145 vs 1.005 ms per iteration before it was
+// removed; profiles/r01_pmc_per_kernel_v1.csv holds its counters.)
 //
 // Packed "A" block (weights), KS8 = ceil(KS/8) slot groups:   [mt][group][piece hi/mid/lo][lane][8 bf16]
 //   lane l = (row i = l & 31, half h = l >> 5) holds W[row(mt,i)][slot(8g+e, h)], e = 0..7  -- the 8 k-values that the
 //   MFMA takes from that lane; the activation fragment of lane (p, h) is its own slots 8g..8g+7.
-#ifndef NSA_BF16X3
-#define NSA_BF16X3 1
-#endif
-
-#if NSA_BF16X3
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
 
 __host__ __device__ constexpr int a_block_floats(int mt, int ks) { return mt * ((ks + 7) / 8) * 3 * 64 * 4; }
@@ -218,65 +213,78 @@ __device__ __forceinline__ void stage_begin(float* stage, const float* __restric
     stage_issue(wp + Seq::off(0), Seq::size(0), stage);
 }
 
-#else   // ------------------------------------------------------------------ fp32-input MFMA variant
-__host__ __device__ constexpr int a_block_floats(int mt, int ks) { return mt * ((ks + 3) / 4) * 64 * 4; }
-
-template <int MT>
-struct AFrag {
-    float4 g0[MT], g1[MT];
+// ---- staged GEMMs split along k (packed blocks larger than a stage buffer) -------------------------------------------
+// A packed block is [mt][group][piece][lane]; the part "groups G0 .. G0+NG-1 of every tile" is MT strided segments in
+// global memory and is laid out in LDS as [mt][NG][piece][lane].  The parts of one GEMM accumulate into the same acc,
+// and each slot group's B operand is split once.
+struct StageOp {
+    int off;    // block start, floats from wp
+    int mt;     // tiles
+    int ks8;    // slot groups of the whole block
+    int g0, ng; // this part
 };
 
-template <int KS, int MT>
-__device__ __forceinline__ void gemm_preload(const float* __restrict__ wp, int lane, AFrag<MT>& f) {
-    constexpr int KS4 = (KS + 3) / 4;
-    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wp) + lane;
+__device__ __forceinline__ void stage_issue_op(const float* __restrict__ wp, const StageOp o, float* lds_dst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per_tile = o.ng * 3;                 // 1 KiB chunks per tile in this part
+    const int chunks = o.mt * per_tile;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        f.g0[mt] = w4[(mt * KS4 + 0) * 64];
-        f.g1[mt] = w4[(mt * KS4 + (KS4 > 1 ? 1 : 0)) * 64];
+    for (int c = 0; c < (chunks + 3) / 4; ++c) {
+        const int ch = 4 * c + wave;
+        if (ch < chunks) {
+            const int mt = ch / per_tile, rem = ch - mt * per_tile;
+            const float* src = wp + o.off + ((mt * o.ks8 + o.g0) * 3 + rem) * 256 + lane * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds_dst + ch * 256), 16, 0, 0);
+        }
     }
 }
 
-template <int KS, int MT>
-__device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane, AFrag<MT>& f, const float (&b)[KS],
-                                         f32x16 (&acc)[MT]) {
-    constexpr int KS4 = (KS + 3) / 4;
-    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wp) + lane;
+template <int KS, int MT, int G0, int NG>
+__device__ __forceinline__ void gemm_lds_part(const float* lds_block, int lane, const float (&b)[KS], f32x16 (&acc)[MT]) {
+    const lds_u4* w4 = (const lds_u4*)lds_block + lane;
+    u32x4 nxt[MT][3];
 #pragma unroll
-    for (int s4 = 0; s4 < KS4; ++s4) {
-        float4 a[MT];
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            a[mt] = f.g0[mt];
-            f.g0[mt] = f.g1[mt];
-            if (s4 + 2 < KS4) f.g1[mt] = w4[(mt * KS4 + s4 + 2) * 64];
-        }
+        for (int pc = 0; pc < 3; ++pc) nxt[mt][pc] = w4[((mt * NG + 0) * 3 + pc) * 64];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (4 * s4 + q < KS) {
+    for (int gl = 0; gl < NG; ++gl) {
+        const int g = G0 + gl;
+        u32x4 a[MT][3];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const float av = q == 0 ? a[mt].x : q == 1 ? a[mt].y : q == 2 ? a[mt].z : a[mt].w;
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[4 * s4 + q], acc[mt], 0, 0, 0);
-                }
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                a[mt][pc] = nxt[mt][pc];
+                if (gl + 1 < NG) nxt[mt][pc] = w4[((mt * NG + gl + 1) * 3 + pc) * 64];
             }
-        }
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? b[8 * g + e] : 0.0f;
+        BFrag bf;
+        split8(x, bf);
+        const bf16x8_t bh = as_bf16x8(bf.p[0]), bm = as_bf16x8(bf.p[1]), bl = as_bf16x8(bf.p[2]);
+#define NSA_MM(AP, BV)                                                                                   \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                \
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[mt][AP]), BV, acc[mt], 0, 0, 0);
+        NSA_MM(2, bh) NSA_MM(0, bl) NSA_MM(1, bm) NSA_MM(1, bh) NSA_MM(0, bm) NSA_MM(0, bh)
+#undef NSA_MM
     }
     __builtin_amdgcn_sched_barrier(0);
 }
-#endif
 
-#if !NSA_BF16X3   // A/B build: the staged entry points fall back to per-wave streaming
-constexpr int kStageFloats = 64;
-template <class Seq> __device__ __forceinline__ void stage_begin(float*, const float*) {}
-template <int KS, int MT>
-__device__ __forceinline__ void gemm_op(const float* __restrict__ wp, int lane, const float (&b)[KS], f32x16 (&acc)[MT]);
-template <class Seq, int KS, int MT>
-__device__ __forceinline__ void gemm_staged(float*, const float* __restrict__ wp, int opi, int lane, const float (&b)[KS],
-                                            f32x16 (&acc)[MT]) {
-    gemm_op<KS, MT>(wp + Seq::off(opi), lane, b, acc);
+// Part `opi` of the kernel's sequence Seq (Seq::n parts, Seq::op(i) their descriptors); buffers of BUF floats.
+template <class Seq, int BUF, int KS, int MT, int G0, int NG>
+__device__ __forceinline__ void gemm_staged_part(float* stage, const float* __restrict__ wp, int opi, int lane,
+                                                 const float (&b)[KS], f32x16 (&acc)[MT]) {
+    stage_wait();
+    if (opi + 1 < Seq::n) stage_issue_op(wp, Seq::op(opi + 1), stage + ((opi + 1) & 1) * BUF);
+    gemm_lds_part<KS, MT, G0, NG>(stage + (opi & 1) * BUF, lane, b, acc);
 }
-#endif
+
+
+
 
 template <int KS, int MT>
 __device__ __forceinline__ void gemm_op(const float* __restrict__ wp, int lane, const float (&b)[KS], f32x16 (&acc)[MT]) {

@@ -34,6 +34,20 @@ struct ColPack {
     static constexpr int kTotal = kW0T + a_block_floats(5, HS);
 };
 
+// Staged GEMM parts (mlp_common.hpp): the first layer (54 KiB packed) and its transpose (60 KiB) are split along k so that
+// two 30 KiB stage buffers -- two workgroups per CU -- suffice.
+//   forward : W0[g0-4], W0[g5-8], W1          backward: the same three (recompute), then W1^T, W0^T[g0-1], W0^T[g2-3]
+constexpr int kColStage = 7680;     // floats per buffer: 2 tiles x 5 groups (= 5 tiles x 2 groups) x 3 KiB
+template <bool BWD>
+struct ColOps {
+    static constexpr int n = BWD ? 6 : 3;
+    __host__ __device__ static constexpr StageOp op(int i) {
+        return i == 0 ? StageOp{ColPack::kW0, 2, 9, 0, 5} : i == 1 ? StageOp{ColPack::kW0, 2, 9, 5, 4}
+             : i == 2 ? StageOp{ColPack::kW1, 2, 4, 0, 4} : i == 3 ? StageOp{ColPack::kW1T, 2, 4, 0, 4}
+             : i == 4 ? StageOp{ColPack::kW0T, 5, 4, 0, 2} : StageOp{ColPack::kW0T, 5, 4, 2, 2};
+    }
+};
+
 struct ColourArgs {
     PointSrc src;
     const float* table;
@@ -76,7 +90,7 @@ struct ColEmitter {
 
 __device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeom16& geom, uint32_t tile, uint32_t pid, int lane,
                                               int h, const float (&x)[3], const float (&dir)[3], float (&in)[COL_IN_STEPS],
-                                              bool from_save) {
+                                              bool from_save, bool wave_live) {
     const float* fsrc = a.feat + (size_t)tile * 32 * 64 + lane;
 #pragma unroll
     for (int q = 0; q < HS; ++q) in[q] = fsrc[q * 64];
@@ -104,7 +118,7 @@ __device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeo
     float u[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) u[d] = (x[d] / a.divide_factor + 1.0f) / 2.0f;
-    float* sv = a.save ? a.save + (size_t)tile * 64 * 64 + lane : nullptr;
+    float* sv = (a.save && wave_live) ? a.save + (size_t)tile * 64 * 64 + lane : nullptr;   // clamped waves write nothing
 #pragma unroll
     for (int jl = 0; jl < CL / 2; ++jl) {
         const LevelGeom lg = geom.lv[2 * jl + h];
@@ -132,17 +146,26 @@ __device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeo
 }
 
 // hidden activations: returns pre-activations a1, a2 (masks for the backward) and the 3 sigmoid outputs
-__device__ __forceinline__ void colour_mlp(const float* __restrict__ wp, int lane, int h, const float (&in)[COL_IN_STEPS],
-                                           f32x16 (&a1)[2], f32x16 (&a2)[2], float (&rgb)[3]) {
+// STAGED: weights through LDS (backward: 62 -> 56 us).  The forward kernel is bound by the HBM gather of the colour
+// table and measured 3 us SLOWER with the staging barriers, so it streams its fragments from L2 per wave.
+template <class Seq, bool STAGED>
+__device__ __forceinline__ void colour_mlp(float* stage, const float* __restrict__ wp, int lane, int h,
+                                           const float (&in)[COL_IN_STEPS], f32x16 (&a1)[2], f32x16 (&a2)[2], float (&rgb)[3]) {
     load_vec<2>(wp + ColPack::kB0, h, a1);
-    gemm_op<COL_IN_STEPS, 2>(wp + ColPack::kW0, lane, in, a1);
+    if (STAGED) {
+        gemm_staged_part<Seq, kColStage, COL_IN_STEPS, 2, 0, 5>(stage, wp, 0, lane, in, a1);
+        gemm_staged_part<Seq, kColStage, COL_IN_STEPS, 2, 5, 4>(stage, wp, 1, lane, in, a1);
+    } else {
+        gemm_op<COL_IN_STEPS, 2>(wp + ColPack::kW0, lane, in, a1);
+    }
     float h1[HS];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) h1[16 * t + r] = fmaxf(a1[t][r], 0.0f);
     load_vec<2>(wp + ColPack::kB1, h, a2);
-    gemm_op<HS, 2>(wp + ColPack::kW1, lane, h1, a2);
+    if (STAGED) gemm_staged_part<Seq, kColStage, HS, 2, 0, 4>(stage, wp, 2, lane, h1, a2);
+    else        gemm_op<HS, 2>(wp + ColPack::kW1, lane, h1, a2);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         f32x16 wv[2];
@@ -158,11 +181,13 @@ __device__ __forceinline__ void colour_mlp(const float* __restrict__ wp, int lan
 }
 
 __global__ __launch_bounds__(256, 2) void k_colour_fwd(ColourArgs a, GridGeom16 geom) {
+    using Seq = ColOps<false>;
     desync_simd_partners();
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
     const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile * 32 >= a.src.P) return;
+    const bool wave_live = true;
     uint32_t pid = tile * 32 + (lane & 31);
     const bool live = pid < a.src.P;
     if (!live) pid = a.src.P - 1;
@@ -172,10 +197,10 @@ __global__ __launch_bounds__(256, 2) void k_colour_fwd(ColourArgs a, GridGeom16 
 #pragma unroll
     for (int d = 0; d < 3; ++d) dir[d] = a.src.rays_d[ray * 3 + d];
     float in[COL_IN_STEPS];
-    colour_inputs(a, geom, tile, pid, lane, h, x, dir, in, false);
+    colour_inputs(a, geom, tile, pid, lane, h, x, dir, in, false, wave_live);
     f32x16 a1[2], a2[2];
     float rgb[3];
-    colour_mlp(a.wp, lane, h, in, a1, a2, rgb);
+    colour_mlp<Seq, false>(nullptr, a.wp, lane, h, in, a1, a2, rgb);
     if (live && h == 0) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) a.rgb[(size_t)pid * 3 + j] = rgb[j];
@@ -184,25 +209,29 @@ __global__ __launch_bounds__(256, 2) void k_colour_fwd(ColourArgs a, GridGeom16 
 
 template <bool MAP>
 __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 geom) {
-    desync_simd_partners();
+    using Seq = ColOps<true>;
+    __shared__ __attribute__((aligned(16))) float stage[2 * kColStage];
+    stage_issue_op(a.wp, Seq::op(0), stage);
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
-    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile * 32 >= a.src.P) return;
+    uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t n_tiles = (a.src.P + 31) / 32;
+    const bool wave_live = tile < n_tiles;
+    if (!wave_live) tile = n_tiles - 1;
     uint32_t pid = tile * 32 + (lane & 31);
-    const bool live = pid < a.src.P;
-    if (!live) pid = a.src.P - 1;
+    const bool live = wave_live && pid < a.src.P;
+    if (pid >= a.src.P) pid = a.src.P - 1;
     float x[3], z, dir[3];
     uint32_t ray;
     load_point(a.src, pid, x, ray, z);
 #pragma unroll
     for (int d = 0; d < 3; ++d) dir[d] = a.src.rays_d[ray * 3 + d];
     float in[COL_IN_STEPS];
-    colour_inputs(a, geom, tile, pid, lane, h, x, dir, in, true);
+    colour_inputs(a, geom, tile, pid, lane, h, x, dir, in, true, wave_live);
     f32x16 a1[2], a2[2];
     float rgb[3];
-    colour_mlp(a.wp, lane, h, in, a1, a2, rgb);
-    const bool emit = MAP && a.emit != nullptr;
+    colour_mlp<Seq, true>(stage, a.wp, lane, h, in, a1, a2, rgb);
+    const bool emit = MAP && a.emit != nullptr && wave_live;
     const ColEmitter em{emit ? a.emit + (size_t)tile * 32 + (lane & 31) : nullptr, a.emit_ld, live};
     if (emit) {
 #pragma unroll
@@ -249,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        gemm_op<HS, 2>(a.wp + ColPack::kW1T, lane, ab, acc);
+        gemm_staged_part<Seq, kColStage, HS, 2, 0, 4>(stage, a.wp, 3, lane, ab, acc);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -266,7 +295,8 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
         for (int t = 0; t < 5; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) a5[t][r] = 0.0f;
-        gemm_op<HS, 5>(a.wp + ColPack::kW0T, lane, ab, a5);
+        gemm_staged_part<Seq, kColStage, HS, 5, 0, 2>(stage, a.wp, 4, lane, ab, a5);
+        gemm_staged_part<Seq, kColStage, HS, 5, 2, 2>(stage, a.wp, 5, lane, ab, a5);
 #pragma unroll
         for (int t = 0; t < 5; ++t)
 #pragma unroll
@@ -274,8 +304,10 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
     }
     // feature cotangent -> HL
     float* fdst = a.g_feat + (size_t)tile * 32 * 64 + lane;
+    if (wave_live) {
 #pragma unroll
-    for (int q = 0; q < HS; ++q) fdst[q * 64] = ib[q];
+        for (int q = 0; q < HS; ++q) fdst[q * 64] = ib[q];
+    }
     // scalar slots
     float gx[3], gd[3], gg[3];
     gx[0] = h ? 0.0f : ib[32];   gx[1] = h ? ib[32] : 0.0f;   gx[2] = h ? 0.0f : ib[33];

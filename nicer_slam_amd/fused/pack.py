@@ -84,7 +84,7 @@ def split_bf16x3(x):
 
 def pack_blocks(flat, blocks):
     """Gather every block from the flat parameter vector; 'A' blocks become [group][piece][lane][8 bf16] (viewed as
-    float32 words), 'V' blocks stay fp32.  Layout: csrc/mlp_common.hpp (NSA_BF16X3)."""
+    float32 words), 'V' blocks stay fp32.  Layout: csrc/mlp_common.hpp."""
     out = []
     for kind, idx in blocks:
         g = flat[idx.to(flat.device)]

@@ -222,6 +222,16 @@ int nsa_draw_picks(const float *u, uint32_t E, uint32_t n_extra, uint32_t R, uin
 int nsa_sdf_points(const float *points, uint64_t N, const nsa_grid_t *coarse, const nsa_grid_t *fine,
                    const float *packed_coarse, const float *packed_fine, float *sdf, nsa_stream_t stream);
 
+/* Fused head and tail of a single-image tracking iteration (graph-captured tracker): fewer, larger graph nodes.
+ *   nsa_track_head = nsa_cam_to_pose + nsa_rays_forward (b = 1);
+ *   nsa_track_tail = nsa_rays_pose_backward + nsa_pose_grad_to_cam (g_cam[7]) and, with do_adam != 0, nsa_adam_step on the
+ *   camera vector -- the same arithmetic in one block.  Reference: the lines those four entry points cite. */
+int nsa_track_head(const float *uv, const float *K, const float *cam, uint32_t n, float *pose, float *rays_o,
+                   float *rays_d, float *depth_scale, nsa_stream_t stream);
+int nsa_track_tail(const float *uv, const float *K, float *cam, uint32_t n, const float *g_rays_o, const float *g_rays_d,
+                   float *g_cam, int do_adam, float *exp_avg, float *exp_avg_sq, float *step, float lr, float beta1,
+                   float beta2, float eps, uint32_t lr_step, float lr_gamma, nsa_stream_t stream);
+
 /* ---- Section 4: mapping-iteration tail ------------------------------------------------------------------------ */
 
 /* voxels[floor((x+1)/2*res)] += 1 for every sample with all |x_d| <= 0.99 (voxels: [res,res,res] fp32, x-major).

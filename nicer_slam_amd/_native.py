@@ -118,3 +118,9 @@ EXPORTS += ["nsa_sdf_points"]
 lib.nsa_draw_picks.restype = _i
 lib.nsa_draw_picks.argtypes = [_p, _u32, _u32, _u32, _u32, _p, _p, _p]
 EXPORTS += ["nsa_draw_picks"]
+
+lib.nsa_track_head.restype = _i
+lib.nsa_track_head.argtypes = [_p, _p, _p, _u32, _p, _p, _p, _p, _p]
+lib.nsa_track_tail.restype = _i
+lib.nsa_track_tail.argtypes = [_p, _p, _p, _u32, _p, _p, _p, _i, _p, _p, _p, _f32, _f32, _f32, _f32, _u32, _f32, _p]
+EXPORTS += ["nsa_track_head", "nsa_track_tail"]

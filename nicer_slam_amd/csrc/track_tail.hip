@@ -11,11 +11,7 @@
 
 namespace nsa {
 
-__global__ void k_cam_to_pose(const float* __restrict__ cam, float* __restrict__ pose, uint32_t b) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= b) return;
-    const float* q = cam + 7 * n;
-    float* P = pose + 16 * n;
+__device__ __forceinline__ void cam_to_pose(const float* __restrict__ q, float* __restrict__ P) {
     const float r = q[0], i = q[1], j = q[2], k = q[3];
     const float s = 2.0f / (r * r + i * i + j * j + k * k);
     P[0] = -s * (j * j + k * k) + 1.0f;  P[1] = s * (i * j - k * r);          P[2] = s * (i * k + j * r);           P[3] = q[4];
@@ -24,13 +20,14 @@ __global__ void k_cam_to_pose(const float* __restrict__ cam, float* __restrict__
     P[12] = 0.0f; P[13] = 0.0f; P[14] = 0.0f; P[15] = 1.0f;
 }
 
-// out[0..6] = d loss / d cam of image n (n < b), from g_pose[b,4,4]
-__global__ void k_pose_grad_to_cam(const float* __restrict__ cam, const float* __restrict__ g_pose, float* __restrict__ g_cam,
-                                   uint32_t b) {
+__global__ void k_cam_to_pose(const float* __restrict__ cam, float* __restrict__ pose, uint32_t b) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= b) return;
-    const float* q = cam + 7 * n;
-    const float* G = g_pose + 16 * n;
+    cam_to_pose(cam + 7 * n, pose + 16 * n);
+}
+
+// o[0..6] = d loss / d cam from G = d loss / d pose (row-major 4x4; rows 0..2 used)
+__device__ __forceinline__ void pose_grad_to_cam(const float* __restrict__ q, const float* __restrict__ G, float* __restrict__ o) {
     const float r = q[0], i = q[1], j = q[2], k = q[3];
     const float nn = r * r + i * i + j * j + k * k;
     const float s = 2.0f / nn;
@@ -46,13 +43,20 @@ __global__ void k_pose_grad_to_cam(const float* __restrict__ cam, const float* _
     const float di = j * GG(0, 1) + k * GG(0, 2) + j * GG(1, 0) - 2 * i * GG(1, 1) - r * GG(1, 2) + k * GG(2, 0) + r * GG(2, 1) - 2 * i * GG(2, 2);
     const float dj = -2 * j * GG(0, 0) + i * GG(0, 1) + r * GG(0, 2) + i * GG(1, 0) + k * GG(1, 2) - r * GG(2, 0) + k * GG(2, 1) - 2 * j * GG(2, 2);
     const float dk = -2 * k * GG(0, 0) - r * GG(0, 1) + i * GG(0, 2) + r * GG(1, 0) - 2 * k * GG(1, 1) + j * GG(1, 2) + i * GG(2, 0) + j * GG(2, 1);
-    float* o = g_cam + 7 * n;
     o[0] = -s * s * r * A + s * dr;
     o[1] = -s * s * i * A + s * di;
     o[2] = -s * s * j * A + s * dj;
     o[3] = -s * s * k * A + s * dk;
     o[4] = GG(0, 3); o[5] = GG(1, 3); o[6] = GG(2, 3);
 #undef GG
+}
+
+// out[0..6] = d loss / d cam of image n (n < b), from g_pose[b,4,4]
+__global__ void k_pose_grad_to_cam(const float* __restrict__ cam, const float* __restrict__ g_pose, float* __restrict__ g_cam,
+                                   uint32_t b) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= b) return;
+    pose_grad_to_cam(cam + 7 * n, g_pose + 16 * n, g_cam + 7 * n);
 }
 
 // single block; n = number of scalars (3 R)
@@ -80,10 +84,8 @@ struct AdamArgs {
     uint32_t lr_step;                                            // 0 = constant lr
 };
 
-__global__ void k_adam(AdamArgs a) {
-    const uint32_t i = threadIdx.x;
-    const float t = a.step[0] + 1.0f;
-    if (i < a.n) {
+__device__ __forceinline__ void adam_one(const AdamArgs& a, uint32_t i, float t) {
+    {
         const float g = a.g[i];
         const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
         const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
@@ -97,9 +99,120 @@ __global__ void k_adam(AdamArgs a) {
         const float denom = sqrtf(v) / (float)sqrt(bc2) + a.eps;
         a.p[i] -= step_size * m / denom;
     }
+}
+
+__global__ void k_adam(AdamArgs a) {
+    const uint32_t i = threadIdx.x;
+    const float t = a.step[0] + 1.0f;
+    if (i < a.n) adam_one(a, i, t);
     __syncthreads();
     if (i == 0) a.step[0] = t;
 }
+
+// ---- fused head / tail of a single-image tracking iteration ------------------------------------------------------
+// head: camera 7-vector -> pose (every thread, in registers) -> rays; also stores the pose for later consumers.
+// tail: per-ray pose-gradient terms (backward of the ray lifting, see render_rays.hip::k_rays_pose_bwd), block
+//       reduction, backward of cam->pose, and -- single GPU -- the Adam step: 5 graph nodes become 1.
+struct TrackArgs {
+    const float* uv;      // [n,2]
+    const float* K;       // [4,4]
+    float* cam;           // [7]
+    float* pose;          // [4,4] out (head)
+    uint32_t n;
+    float* rays_o; float* rays_d; float* depth_scale;       // head outputs
+    const float* g_o; const float* g_d;                       // tail inputs [n,3]
+    float* g_cam;                                             // [7] out (tail)
+    AdamArgs adam;                                            // adam.p == nullptr: no step
+};
+
+__device__ __forceinline__ void lift_pixel_k(const float* __restrict__ K, float u, float v, float (&c)[3]) {
+    const float fx = K[0], sk = K[1], cx = K[2], fy = K[5], cy = K[6];
+    c[0] = (u - cx + cy * sk / fy - sk * v / fy) / fx;       // rend_util.py:117-125 (z = 1)
+    c[1] = (v - cy) / fy;
+    c[2] = 1.0f;
+}
+
+__global__ __launch_bounds__(256) void k_track_head(TrackArgs a) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    float P[16];
+    cam_to_pose(a.cam, P);
+    if (r == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a.pose[i] = P[i];
+    }
+    if (r >= a.n) return;
+    float c[3];
+    lift_pixel_k(a.K, a.uv[2 * r], a.uv[2 * r + 1], c);
+    float v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float w = P[4 * k] * c[0] + P[4 * k + 1] * c[1] + P[4 * k + 2] * c[2] + P[4 * k + 3];
+        v[k] = w - P[4 * k + 3];
+        a.rays_o[3 * r + k] = P[4 * k + 3];
+    }
+    const float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.rays_d[3 * r + k] = v[k] / s;
+    a.depth_scale[r] = c[2] / (c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+}
+
+__global__ __launch_bounds__(1024) void k_track_tail(TrackArgs a) {
+    __shared__ float part[16][12];
+    __shared__ float G[16];
+    float P[16];
+    cam_to_pose(a.cam, P);
+    float acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
+    for (uint32_t r = threadIdx.x; r < a.n; r += 1024) {
+        float c[3];
+        lift_pixel_k(a.K, a.uv[2 * r], a.uv[2 * r + 1], c);
+        float v[3], gd[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float w = P[4 * k] * c[0] + P[4 * k + 1] * c[1] + P[4 * k + 2] * c[2] + P[4 * k + 3];
+            v[k] = w - P[4 * k + 3];
+            gd[k] = a.g_d[3 * r + k];
+        }
+        const float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+        const float vg = v[0] * gd[0] + v[1] * gd[1] + v[2] * gd[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float vb = gd[k] / s - 2.0f * v[k] * vg / (s * s);     // d = v / (v.v)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[4 * k + j] += vb * c[j];
+            acc[4 * k + 3] += a.g_o[3 * r + k];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        float x = acc[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        if (lane == 0) part[wave][q] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        float x = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) x += part[w][threadIdx.x];
+        G[threadIdx.x] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float o[7];
+        pose_grad_to_cam(a.cam, G, o);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) a.g_cam[i] = o[i];
+        if (a.adam.p) {
+            const float t = a.adam.step[0] + 1.0f;
+            for (uint32_t i = 0; i < 7; ++i) adam_one(a.adam, i, t);
+            a.adam.step[0] = t;
+        }
+    }
+}
+
 
 }  // namespace nsa
 
@@ -138,6 +251,32 @@ int nsa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     AdamArgs a{param, grad, exp_avg, exp_avg_sq, step, n, lr, beta1, beta2, eps, lr_gamma, lr_step};
     launch_begin();
     hipLaunchKernelGGL(k_adam, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_end();
+}
+
+int nsa_track_head(const float* uv, const float* K, const float* cam, uint32_t n, float* pose, float* rays_o, float* rays_d,
+                   float* depth_scale, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!uv || !K || !cam || !pose || !rays_o || !rays_d || !depth_scale || n == 0) return NSA_EBADARG;
+    TrackArgs a{};
+    a.uv = uv; a.K = K; a.cam = const_cast<float*>(cam); a.pose = pose; a.n = n;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.depth_scale = depth_scale;
+    launch_begin();
+    hipLaunchKernelGGL(k_track_head, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_end();
+}
+
+int nsa_track_tail(const float* uv, const float* K, float* cam, uint32_t n, const float* g_rays_o, const float* g_rays_d,
+                   float* g_cam, int do_adam, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
+                   float beta2, float eps, uint32_t lr_step, float lr_gamma, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!uv || !K || !cam || !g_rays_o || !g_rays_d || !g_cam || n == 0) return NSA_EBADARG;
+    if (do_adam && (!exp_avg || !exp_avg_sq || !step)) return NSA_EBADARG;
+    TrackArgs a{};
+    a.uv = uv; a.K = K; a.cam = cam; a.n = n; a.g_o = g_rays_o; a.g_d = g_rays_d; a.g_cam = g_cam;
+    if (do_adam) a.adam = AdamArgs{cam, g_cam, exp_avg, exp_avg_sq, step, 7, lr, beta1, beta2, eps, lr_gamma, lr_step};
+    launch_begin();
+    hipLaunchKernelGGL(k_track_tail, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
     return launch_end();
 }
 

@@ -49,18 +49,19 @@ class KernelTracker:
         fr, fs, model = self.fr, self.fs, self.model
         st = torch.cuda.current_stream().cuda_stream
         R = self.R
-        check(lib.nsa_cam_to_pose(self.cam.data_ptr(), 1, self.pose.data_ptr(), st))
-        check(lib.nsa_rays_forward(self.uv.data_ptr(), self.pose.data_ptr(), self.K.data_ptr(), 1, R,
-                                   self.rays_o.data_ptr(), self.rays_d.data_ptr(), self.ds.data_ptr(), st))
+        check(lib.nsa_track_head(self.uv.data_ptr(), self.K.data_ptr(), self.cam.data_ptr(), R, self.pose.data_ptr(),
+                                 self.rays_o.data_ptr(), self.rays_d.data_ptr(), self.ds.data_ptr(), st))
         z_vals, _ = fs.get_z_vals(model, self.rays_d, self.rays_o, need_eik=False)
         b = fr.composite_forward_raw(model, self.rays_o, self.rays_d, z_vals, self.stage, True)
         check(lib.nsa_l1_loss(b["rgb_values"].data_ptr(), self.gt.data_ptr(), 3 * R, self.red[7:8].data_ptr(),
                               self.g_rgbv.data_ptr(), st))
         g_o, g_d = fr.composite_backward_raw(model, self.rays_o, self.rays_d, z_vals, b, self.stage, self.color_stage,
                                              g_rgbv=self.g_rgbv)
-        check(lib.nsa_rays_pose_backward(self.uv.data_ptr(), self.pose.data_ptr(), self.K.data_ptr(), 1, R,
-                                         g_o.data_ptr(), g_d.data_ptr(), self.g_pose.data_ptr(), st))
-        check(lib.nsa_pose_grad_to_cam(self.cam.data_ptr(), self.g_pose.data_ptr(), 1, self.red.data_ptr(), st))
+        # single GPU: the Adam step rides in the same kernel; multi-GPU: the all-reduce sits between the two
+        lr, b1, b2, eps, lr_step, lr_gamma = self.hyper
+        check(lib.nsa_track_tail(self.uv.data_ptr(), self.K.data_ptr(), self.cam.data_ptr(), R, g_o.data_ptr(),
+                                 g_d.data_ptr(), self.red.data_ptr(), 1 if self.world == 1 else 0, self.m.data_ptr(),
+                                 self.v.data_ptr(), self.t.data_ptr(), lr, b1, b2, eps, lr_step, lr_gamma, st))
 
     def _update(self):
         from ._native import lib, check
@@ -77,12 +78,12 @@ class KernelTracker:
             for _ in range(2):
                 self._iteration()
         torch.cuda.current_stream().wait_stream(side)
-        self.cam.copy_(cam0)
+        self.cam.copy_(cam0)                       # the warm-up iterations stepped the camera: undo
+        for t in (self.m, self.v, self.t):
+            t.zero_()
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self._iteration()
-            if self.world == 1:
-                self._update()
 
     def step(self, uv, gt):
         self.uv.copy_(uv)
@@ -98,7 +99,7 @@ class KernelTracker:
                 self.red[8] = float(self.R)
                 dist.all_reduce(self.red)
                 self.red[:8] /= self.red[8]
-            if self.graph is None or self.world > 1:
+            if self.world > 1:
                 self._update()
         return self.red[7]
 

@@ -337,13 +337,13 @@ __device__ __forceinline__ float softplus100(float a) {
 __device__ __forceinline__ float softplus100_d1(float a) {
     const float t = SP_K * a;
     const float e = __builtin_amdgcn_exp2f(t);
-    return t > SP_LIN ? 1.0f : e * __frcp_rn(e + 1.0f);
+    return t > SP_LIN ? 1.0f : e * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 __device__ __forceinline__ void softplus100_all(float a, float& y, float& d1, float& d2) {
     const float t = SP_K * a;
     const float e = __builtin_amdgcn_exp2f(t);
     const bool lin = t > SP_LIN;
-    const float s = e * __frcp_rn(e + 1.0f);
+    const float s = e * __builtin_amdgcn_rcpf(e + 1.0f);
     y = lin ? a : SP_OUT * __builtin_amdgcn_logf(1.0f + e);
     d1 = lin ? 1.0f : s;
     d2 = lin ? 0.0f : 100.0f * s * (1.0f - s);

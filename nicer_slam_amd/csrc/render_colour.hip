@@ -73,7 +73,8 @@ struct ColourArgs {
 // Rows of the emission buffer; column = tile*32 + point-in-tile.
 //   dW0 = AB1 IN^T, db0 = sum AB1, dW1 = AB2 H1^T, db1 = sum AB2, dW2 = OB H2^T, db2 = sum OB
 // IN rows are input slots (row = 2*slot + half), the others hidden features in reference order.
-enum : int { CE_IN = 0, CE_AB1 = 130, CE_H1 = 194, CE_AB2 = 258, CE_H2 = 322, CE_OB = 386, CE_ROWS = 389 };
+// (AB1, AB2, OB -- the regions whose row sums are the bias gradients -- are contiguous: one reduction)
+enum : int { CE_IN = 0, CE_H1 = 130, CE_H2 = 194, CE_AB1 = 258, CE_AB2 = 322, CE_OB = 386, CE_ROWS = 389 };
 
 struct ColEmitter {
     float* base;

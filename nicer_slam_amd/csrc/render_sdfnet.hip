@@ -46,7 +46,8 @@ struct SdfNetArgs {
 // Rows of the emission buffer of a one-hidden-layer (coarse) network; column = tile*32 + point-in-tile.
 //   dW0 = AB1 H0^T + DA1 TIN^T,  db0 = sum AB1,  dW1[0] = sum sbar H1 + TH1,  dW1[1:] = FB H1^T,  db1 = [sum sbar, sum FB]
 // H0/TIN rows are first-layer slots (row = 2*slot + half), the others are hidden features in reference order.
-enum : int { SE_H0 = 0, SE_TIN = 72, SE_AB1 = 144, SE_DA1 = 208, SE_H1 = 272, SE_TH1 = 336, SE_FB = 400, SE_ROWS = 464 };
+// (the three regions whose row sums are needed -- AB1, TH1, FB -- are contiguous: one reduction)
+enum : int { SE_H0 = 0, SE_TIN = 72, SE_DA1 = 144, SE_H1 = 208, SE_AB1 = 272, SE_TH1 = 336, SE_FB = 400, SE_ROWS = 464 };
 
 struct Emitter {
     float* base;

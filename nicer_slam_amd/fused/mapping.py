@@ -27,8 +27,8 @@ from .render import composite_forward_raw, composite_backward_raw, hl_size, _str
 from .sampler import grid_desc, packed_sdf
 
 KCHUNK = 4096
-SE = dict(H0=0, TIN=72, AB1=144, DA1=208, H1=272, TH1=336, FB=400, ROWS=464)
-CE = dict(IN=0, AB1=130, H1=194, AB2=258, H2=322, OB=386, ROWS=389)
+SE = dict(H0=0, TIN=72, DA1=144, H1=208, AB1=272, TH1=336, FB=400, ROWS=464)      # = enum SE_* (render_sdfnet.hip)
+CE = dict(IN=0, H1=130, H2=194, AB1=258, AB2=322, OB=386, ROWS=389)              # = enum CE_* (render_colour.hip)
 
 
 def emit_ld(P):
@@ -86,14 +86,14 @@ def sdf_flat_grad(emit, g_sdf, P, L, C):
     H0, TIN, AB1, DA1, H1, TH1, FB = r("H0", 72), r("TIN", 72), r("AB1", 64), r("DA1", 64), r("H1", 64), r("TH1", 64), r("FB", 64)
     M = outer_sum(AB1, H0) + outer_sum(DA1, TIN)
     dW0 = M[:, _sdf_rows(L, C).to(emit.device)]
-    db0 = AB1.sum(1)
-    row0 = TH1.sum(1)
+    sums = emit[SE["AB1"]:SE["ROWS"]].sum(1)                 # AB1 | TH1 | FB row sums in one reduction
+    db0, row0, fb_sum = sums[:64], sums[64:128], sums[128:]
     dbs = emit.new_zeros(1)
     if g_sdf is not None:
         row0 = row0 + H1[:, :P] @ g_sdf
         dbs = g_sdf.sum().reshape(1)
     dW1 = torch.cat([row0.unsqueeze(0), outer_sum(FB, H1)], 0)
-    db1 = torch.cat([dbs, FB.sum(1)])
+    db1 = torch.cat([dbs, fb_sum])
     return torch.cat([dW0.reshape(-1), db0, dW1.reshape(-1), db1, emit.new_zeros(1)])
 
 
@@ -104,7 +104,8 @@ def colour_flat_grad(emit):
     dW0 = outer_sum(AB1, IN)[:, _col_rows().to(emit.device)]
     dW1 = outer_sum(AB2, H1)
     dW2 = outer_sum(OB, H2)
-    return torch.cat([dW0.reshape(-1), AB1.sum(1), dW1.reshape(-1), AB2.sum(1), dW2.reshape(-1), OB.sum(1),
+    sums = emit[CE["AB1"]:CE["ROWS"]].sum(1)                 # AB1 | AB2 | OB row sums in one reduction
+    return torch.cat([dW0.reshape(-1), sums[:64], dW1.reshape(-1), sums[64:128], dW2.reshape(-1), sums[128:],
                       emit.new_zeros(1)])
 
 

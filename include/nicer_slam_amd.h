@@ -91,6 +91,10 @@ typedef struct nsa_points {
     const float *z_vals;  /* [R,S] */
     const float *points;  /* [P,3] or NULL */
     uint32_t P, S;        /* P = R*S in ray mode */
+    const uint32_t *order; /* optional [P] launch order (a permutation): work item i processes point order[i].  Per-point
+                            * arrays (sdf, grad, rgb, g_*) stay indexed by point; tile-indexed buffers (HL feature
+                            * vectors, the colour save area, emission rows) are indexed by work item, consistently
+                            * across the forward and backward entry points.  NULL = identity. */
 } nsa_points_t;
 
 /* Per-point feature vectors travel in "HL" layout (the MFMA register image): float index ((tile*32+q)*64+lane),
@@ -233,6 +237,10 @@ int nsa_track_tail(const float *uv, const float *K, float *cam, uint32_t n, cons
                    float beta2, float eps, uint32_t lr_step, float lr_gamma, nsa_stream_t stream);
 
 /* ---- Section 4: mapping-iteration tail ------------------------------------------------------------------------ */
+
+/* keys[i] = 30-bit Morton code of point i in a 1024^3 lattice over [-1,1]^3; argsort(keys) is a spatially coherent
+ * launch order for nsa_points_t.order (new -- the reference processes points in ray order). */
+int nsa_morton_keys(const nsa_points_t *pts, int32_t *keys, nsa_stream_t stream);
 
 /* voxels[floor((x+1)/2*res)] += 1 for every sample with all |x_d| <= 0.99 (voxels: [res,res,res] fp32, x-major).
  * replaces SLAMNetwork.update_voxels (code/model/network.py:62-76). */

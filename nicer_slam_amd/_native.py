@@ -59,7 +59,7 @@ EXPORTS += ["nsa_sampler_sdf", "nsa_sample_rays"]
 
 class PointsDesc(ctypes.Structure):
     """nsa_points_t"""
-    _fields_ = [("rays_o", _p), ("rays_d", _p), ("z_vals", _p), ("points", _p), ("P", _u32), ("S", _u32)]
+    _fields_ = [("rays_o", _p), ("rays_d", _p), ("z_vals", _p), ("points", _p), ("P", _u32), ("S", _u32), ("order", _p)]
 
 
 _pp = ctypes.POINTER(PointsDesc)
@@ -124,3 +124,7 @@ lib.nsa_track_head.argtypes = [_p, _p, _p, _u32, _p, _p, _p, _p, _p]
 lib.nsa_track_tail.restype = _i
 lib.nsa_track_tail.argtypes = [_p, _p, _p, _u32, _p, _p, _p, _i, _p, _p, _p, _f32, _f32, _f32, _f32, _u32, _f32, _p]
 EXPORTS += ["nsa_track_head", "nsa_track_tail"]
+
+lib.nsa_morton_keys.restype = _i
+lib.nsa_morton_keys.argtypes = [_pp, _p, _p]
+EXPORTS += ["nsa_morton_keys"]

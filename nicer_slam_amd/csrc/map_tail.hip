@@ -30,6 +30,33 @@ __global__ __launch_bounds__(256) void k_update_voxels(PointSrc src, float* __re
     scatter_runs<1>(voxels, key, one, lane);
 }
 
+// 30-bit Morton code of each point's cell in a 1024^3 lattice over [-1,1]^3 (points outside are clamped): sorting the
+// points by it makes the lanes of a wave spatial neighbours, so their grid gathers share cache lines and the table-gradient
+// scatter merges whole runs of equal rows (grid_common.hpp::scatter_runs).
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_morton_keys(PointSrc src, int32_t* __restrict__ keys) {
+    const uint32_t pid = blockIdx.x * 256 + threadIdx.x;
+    if (pid >= src.P) return;
+    float x[3], z;
+    uint32_t ray;
+    load_point(src, pid, x, ray, z);
+    uint32_t c[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float u = fminf(fmaxf((x[d] + 1.0f) * 512.0f, 0.0f), 1023.0f);     // NaN -> 0
+        c[d] = (uint32_t)u;
+    }
+    keys[pid] = (int32_t)(spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2));
+}
+
 struct AdamTableArgs {
     float* p; const float* g; float* m; float* v;
     uint64_t n;
@@ -80,9 +107,20 @@ int nsa_update_voxels(const nsa_points_t* pts, float* voxels, uint32_t res, nsa_
     if (!pts || !voxels || res == 0 || res > 1024) return NSA_EBADARG;
     if (pts->P == 0) return NSA_OK;
     if (!pts->points && (!pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0)) return NSA_EBADARG;
-    const PointSrc src{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S};
+    const PointSrc src{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S, nullptr};
     launch_begin();
     hipLaunchKernelGGL(k_update_voxels, dim3((pts->P + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, voxels, res);
+    return launch_end();
+}
+
+int nsa_morton_keys(const nsa_points_t* pts, int32_t* keys, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!pts || !keys) return NSA_EBADARG;
+    if (pts->P == 0) return NSA_OK;
+    if (!pts->points && (!pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0)) return NSA_EBADARG;
+    const PointSrc src{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S, nullptr};
+    launch_begin();
+    hipLaunchKernelGGL(k_morton_keys, dim3((pts->P + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, keys);
     return launch_end();
 }
 

@@ -89,7 +89,7 @@ struct ColEmitter {
     }
 };
 
-__device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeom16& geom, uint32_t tile, uint32_t pid, int lane,
+__device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeom16& geom, uint32_t tile, uint32_t q, int lane,
                                               int h, const float (&x)[3], const float (&dir)[3], float (&in)[COL_IN_STEPS],
                                               bool from_save, bool wave_live) {
     const float* fsrc = a.feat + (size_t)tile * 32 * 64 + lane;
@@ -97,7 +97,7 @@ __device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeo
     for (int q = 0; q < HS; ++q) in[q] = fsrc[q * 64];
     float gr[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) gr[d] = a.grad[(size_t)pid * 3 + d];
+    for (int d = 0; d < 3; ++d) gr[d] = a.grad[(size_t)q * 3 + d];
     in[32] = h ? x[1] : x[0];
     in[33] = h ? dir[0] : x[2];
     in[34] = h ? dir[2] : dir[1];
@@ -192,19 +192,20 @@ __global__ __launch_bounds__(256, 2) void k_colour_fwd(ColourArgs a, GridGeom16 
     uint32_t pid = tile * 32 + (lane & 31);
     const bool live = pid < a.src.P;
     if (!live) pid = a.src.P - 1;
+    const uint32_t q = point_of(a.src, pid);
     float x[3], z, dir[3];
     uint32_t ray;
-    load_point(a.src, pid, x, ray, z);
+    load_point(a.src, q, x, ray, z);
 #pragma unroll
     for (int d = 0; d < 3; ++d) dir[d] = a.src.rays_d[ray * 3 + d];
     float in[COL_IN_STEPS];
-    colour_inputs(a, geom, tile, pid, lane, h, x, dir, in, false, wave_live);
+    colour_inputs(a, geom, tile, q, lane, h, x, dir, in, false, wave_live);
     f32x16 a1[2], a2[2];
     float rgb[3];
     colour_mlp<Seq, false>(nullptr, a.wp, lane, h, in, a1, a2, rgb);
     if (live && h == 0) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) a.rgb[(size_t)pid * 3 + j] = rgb[j];
+        for (int j = 0; j < 3; ++j) a.rgb[(size_t)q * 3 + j] = rgb[j];
     }
 }
 
@@ -222,13 +223,14 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
     uint32_t pid = tile * 32 + (lane & 31);
     const bool live = wave_live && pid < a.src.P;
     if (pid >= a.src.P) pid = a.src.P - 1;
+    const uint32_t q = point_of(a.src, pid);                // point handled by this lane pair
     float x[3], z, dir[3];
     uint32_t ray;
-    load_point(a.src, pid, x, ray, z);
+    load_point(a.src, q, x, ray, z);
 #pragma unroll
     for (int d = 0; d < 3; ++d) dir[d] = a.src.rays_d[ray * 3 + d];
     float in[COL_IN_STEPS];
-    colour_inputs(a, geom, tile, pid, lane, h, x, dir, in, true, wave_live);
+    colour_inputs(a, geom, tile, q, lane, h, x, dir, in, true, wave_live);
     f32x16 a1[2], a2[2];
     float rgb[3];
     colour_mlp<Seq, true>(stage, a.wp, lane, h, in, a1, a2, rgb);
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
     {
         float ob[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) ob[j] = a.g_rgb[(size_t)pid * 3 + j] * rgb[j] * (1.0f - rgb[j]);
+        for (int j = 0; j < 3; ++j) ob[j] = a.g_rgb[(size_t)q * 3 + j] * rgb[j] * (1.0f - rgb[j]);
         if (emit && h == 0) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) em.base[(size_t)(CE_OB + j) * em.ld] = live ? ob[j] : 0.0f;
@@ -366,9 +368,9 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
     if (live && h == 0) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            a.g_x[(size_t)pid * 3 + d] = gx[d];
-            a.g_dir[(size_t)pid * 3 + d] = gd[d];
-            a.g_grad[(size_t)pid * 3 + d] += gg[d];
+            a.g_x[(size_t)q * 3 + d] = gx[d];
+            a.g_dir[(size_t)q * 3 + d] = gd[d];
+            a.g_grad[(size_t)q * 3 + d] += gg[d];
         }
     }
 }
@@ -383,7 +385,7 @@ static int colour_common(const nsa_points_t* pts, const nsa_grid_t* grid, nsa::C
     if (pts->points || !pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0) return NSA_EBADARG;   // needs view dirs
     if (!(grid->L == 16 && grid->C == 2)) return NSA_EUNSUPPORTED_NET;
     if (int rc = make_grid_geom16(grid->offsets_host, grid->L, grid->S, grid->H, geom)) return rc;
-    a->src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, nullptr, pts->P, pts->S};
+    a->src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, nullptr, pts->P, pts->S, pts->order};
     a->table = grid->table;
     a->divide_factor = grid->divide_factor;
     return NSA_OK;

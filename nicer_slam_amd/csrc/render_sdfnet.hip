@@ -166,9 +166,10 @@ __global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfne
     uint32_t pid = tile * 32 + (lane & 31);
     const bool live = wave_live && pid < a.src.P;
     if (pid >= a.src.P) pid = a.src.P - 1;
+    const uint32_t q = point_of(a.src, pid);                // point handled by this lane pair
     float x[3], z;
     uint32_t ray;
-    load_point(a.src, pid, x, ray, z);
+    load_point(a.src, q, x, ray, z);
 
     float in[SDF_IN_STEPS];
     {
@@ -207,13 +208,13 @@ __global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfne
     for (int d = 0; d < 3; ++d) g[d] = xhalf_sum(g[d]);
     if (live && h == 0) {
         if (a.accumulate) {
-            sdf += a.sdf[pid];
+            sdf += a.sdf[q];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) g[d] += a.grad[(size_t)pid * 3 + d];
+            for (int d = 0; d < 3; ++d) g[d] += a.grad[(size_t)q * 3 + d];
         }
-        a.sdf[pid] = sdf;
+        a.sdf[q] = sdf;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) a.grad[(size_t)pid * 3 + d] = g[d];
+        for (int d = 0; d < 3; ++d) a.grad[(size_t)q * 3 + d] = g[d];
     }
 }
 
@@ -235,9 +236,10 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
     uint32_t pid = tile * 32 + (lane & 31);
     const bool live = wave_live && pid < a.src.P;
     if (pid >= a.src.P) pid = a.src.P - 1;
+    const uint32_t q = point_of(a.src, pid);                // point handled by this lane pair
     float x[3], z;
     uint32_t ray;
-    load_point(a.src, pid, x, ray, z);
+    load_point(a.src, q, x, ray, z);
     float in[SDF_IN_STEPS];
     {
         float jd[L / 2][3][C];
@@ -263,8 +265,8 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
 
     float nbar[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) nbar[d] = a.g_grad ? a.g_grad[(size_t)pid * 3 + d] : 0.0f;
-    const float sbar = a.g_sdf ? a.g_sdf[pid] : 0.0f;
+    for (int d = 0; d < 3; ++d) nbar[d] = a.g_grad ? a.g_grad[(size_t)q * 3 + d] : 0.0f;
+    const float sbar = a.g_sdf ? a.g_sdf[q] : 0.0f;
 
     // ---- tangent sweep: e_k = sp''(a_k) dh_k ta_k (kept in e[k-1]) ----
     float e[NH][HS];
@@ -370,8 +372,8 @@ __global__ __launch_bounds__(256, (NH == 1 ? NSA_OCC_BWD_COARSE : NSA_OCC_BWD_FI
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             float v = gx[d];
-            if (a.accumulate) v += a.g_x[(size_t)pid * 3 + d];
-            a.g_x[(size_t)pid * 3 + d] = v;
+            if (a.accumulate) v += a.g_x[(size_t)q * 3 + d];
+            a.g_x[(size_t)q * 3 + d] = v;
         }
     }
 }
@@ -409,7 +411,7 @@ int nsa_sdfnet_forward(const nsa_points_t* pts, const nsa_grid_t* grid, const fl
     if (pts->P == 0) return NSA_OK;
     if (!pts->points && (!pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0)) return NSA_EBADARG;
     SdfNetArgs a{};
-    a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S};
+    a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S, pts->order};
     a.table = grid->table; a.wp = packed; a.divide_factor = grid->divide_factor; a.accumulate = accumulate;
     a.sdf = sdf; a.grad = grad; a.feat = feat_hl;
     return launch_sdfnet(false, grid, a, (hipStream_t)stream);
@@ -422,7 +424,7 @@ int nsa_sdfnet_backward(const nsa_points_t* pts, const nsa_grid_t* grid, const f
     if (pts->P == 0) return NSA_OK;
     if (!pts->points && (!pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0)) return NSA_EBADARG;
     SdfNetArgs a{};
-    a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S};
+    a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S, pts->order};
     a.table = grid->table; a.wp = packed; a.divide_factor = grid->divide_factor; a.accumulate = accumulate;
     a.g_sdf = g_sdf; a.g_feat = g_feat_hl; a.g_grad = g_grad; a.g_x = g_x;
     return launch_sdfnet(true, grid, a, (hipStream_t)stream);
@@ -437,7 +439,7 @@ int nsa_sdfnet_backward_params(const nsa_points_t* pts, const nsa_grid_t* grid, 
     if (pts->P == 0) return NSA_OK;
     if (!pts->points && (!pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0)) return NSA_EBADARG;
     SdfNetArgs a{};
-    a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S};
+    a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S, pts->order};
     a.table = grid->table; a.wp = packed; a.divide_factor = grid->divide_factor; a.accumulate = accumulate;
     a.g_sdf = g_sdf; a.g_feat = g_feat_hl; a.g_grad = g_grad; a.g_x = g_x;
     a.g_table = g_table; a.emit = emit; a.emit_ld = emit_ld;

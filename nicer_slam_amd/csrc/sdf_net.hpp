@@ -324,7 +324,13 @@ struct PointSrc {
     const float* z_vals;   // [R,S]
     const float* points;   // [P,3] or nullptr
     uint32_t P, S;
+    const uint32_t* order; // optional launch order: work item i handles point order[i] (spatially sorted, see
+                           // nsa_morton_keys); tile-indexed buffers (HL, save, emission) follow the work items
 };
+
+__device__ __forceinline__ uint32_t point_of(const PointSrc& ps, uint32_t work_item) {
+    return ps.order ? ps.order[work_item] : work_item;
+}
 
 __device__ __forceinline__ void load_point(const PointSrc& ps, uint32_t pid, float (&x)[3], uint32_t& ray, float& z) {
     if (ps.points) {

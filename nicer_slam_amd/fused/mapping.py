@@ -23,10 +23,11 @@ import torch
 from .._native import lib, check, PointsDesc
 from ..hashencoder.backend import _timed
 from . import pack
-from .render import composite_forward_raw, composite_backward_raw, hl_size, _stream
+from .render import composite_forward_raw, composite_backward_raw, hl_size, morton_order, _stream
 from .sampler import grid_desc, packed_sdf
 
 KCHUNK = 4096
+SORT_POINTS = True      # run the per-point kernels of a mapping iteration in Morton order (see render.morton_order)
 SE = dict(H0=0, TIN=72, DA1=144, H1=208, AB1=272, TH1=336, FB=400, ROWS=464)      # = enum SE_* (render_sdfnet.hip)
 CE = dict(IN=0, H1=130, H2=194, AB1=258, AB2=322, OB=386, ROWS=389)              # = enum CE_* (render_colour.hip)
 
@@ -129,7 +130,7 @@ class FusedCompositeParams(torch.autograd.Function):
     def forward(ctx, rays_o, rays_d, z_vals, flat_c, flat_r, tab_c, tab_f, tab_r, model, stage, color_stage):
         rays_o, rays_d, z_vals = rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous()
         R, S = z_vals.shape
-        b = composite_forward_raw(model, rays_o, rays_d, z_vals, stage, True)
+        b = composite_forward_raw(model, rays_o, rays_d, z_vals, stage, True, sort_points=SORT_POINTS)
         ctx.save_for_backward(rays_o, rays_d, z_vals)
         ctx.bufs, ctx.model, ctx.stage, ctx.color_stage = b, model, stage, color_stage
         sdf_o, rgb_o, grad_o = b["sdf"].view(R, S), b["rgb"].view(R, S, 3), b["grad"]
@@ -162,7 +163,8 @@ class FusedSdfGradient(torch.autograd.Function):
         gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1)
         gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3)
         pc, pf = packed_sdf(model, "coarse"), packed_sdf(model, "fine")
-        pts = PointsDesc(None, None, None, points.data_ptr(), N, 0)
+        order = morton_order(PointsDesc(None, None, None, points.data_ptr(), N, 0, None), N, dev) if SORT_POINTS else None
+        pts = PointsDesc(None, None, None, points.data_ptr(), N, 0, None if order is None else order.data_ptr())
         sdf = torch.empty(N, device=dev)
         grad = torch.empty(N, 3, device=dev)
         feat = torch.empty(hl_size(N), device=dev)
@@ -175,7 +177,7 @@ class FusedSdfGradient(torch.autograd.Function):
                 check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), 1, sdf.data_ptr(),
                                              grad.data_ptr(), feat.data_ptr(), st))
         ctx.save_for_backward(points)
-        ctx.model, ctx.stage, ctx.packs = model, stage, (pc, pf)
+        ctx.model, ctx.stage, ctx.packs, ctx.order = model, stage, (pc, pf), order
         return grad
 
     @staticmethod
@@ -188,7 +190,8 @@ class FusedSdfGradient(torch.autograd.Function):
         gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1)
         gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3)
         pc, pf = ctx.packs
-        pts = PointsDesc(None, None, None, points.data_ptr(), N, 0)
+        order = ctx.order
+        pts = PointsDesc(None, None, None, points.data_ptr(), N, 0, None if order is None else order.data_ptr())
         g = g.contiguous()
         g_x = torch.empty(N, 3, device=dev)
         need = ctx.needs_input_grad

@@ -55,13 +55,23 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _pts(rays_o, rays_d, z_vals):
+def _pts(rays_o, rays_d, z_vals, order=None):
     R, S = z_vals.shape
-    return PointsDesc(rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(), None, R * S, S)
+    return PointsDesc(rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(), None, R * S, S,
+                      None if order is None else order.data_ptr())
 
 
-def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd):
-    """Launch the forward kernels of the composite pass.  Returns a dict of device buffers."""
+def morton_order(pts_desc, P, device):
+    """int32 [P] spatially coherent launch order of the points described by ``pts_desc`` (argsort of Morton keys)."""
+    keys = torch.empty(P, device=device, dtype=torch.int32)
+    check(lib.nsa_morton_keys(ctypes.byref(pts_desc), keys.data_ptr(), _stream()))
+    return torch.sort(keys).indices.to(torch.int32)
+
+
+def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd, sort_points=False):
+    """Launch the forward kernels of the composite pass.  Returns a dict of device buffers.
+    ``sort_points``: run the per-point kernels in Morton order (mapping: the table-gradient scatter merges far more
+    rows and the colour-table gathers share cache lines; the sort costs more than it saves for a 1024-ray tracking step)."""
     R, S = z_vals.shape
     P = R * S
     dev = z_vals.device
@@ -70,8 +80,9 @@ def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd):
     gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3)
     gr, keep_r = grid_desc(model.rendering_network.encoding, model.rendering_network.divide_factor, 2)
     pc, pf, pr = packed_sdf(model, "coarse"), packed_sdf(model, "fine"), packed_colour(model)
-    pts = _pts(rays_o, rays_d, z_vals)
-    b = dict(sdf=torch.empty(P, device=dev), grad=torch.empty(P, 3, device=dev), feat=torch.empty(hl_size(P), device=dev),
+    order = morton_order(_pts(rays_o, rays_d, z_vals), P, dev) if sort_points else None
+    pts = _pts(rays_o, rays_d, z_vals, order)
+    b = dict(order=order, sdf=torch.empty(P, device=dev), grad=torch.empty(P, 3, device=dev), feat=torch.empty(hl_size(P), device=dev),
              rgb=torch.empty(P, 3, device=dev), save=torch.empty(hl_size(P) * 2, device=dev) if need_bwd else None,
              weights=torch.empty(R, S, device=dev), rgb_values=torch.empty(R, 3, device=dev),
              depth=torch.empty(R, device=dev), nmap=torch.empty(R, 3, device=dev), entropy=torch.empty(R, device=dev),
@@ -109,7 +120,8 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
     gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3)
     gr, keep_r = grid_desc(model.rendering_network.encoding, model.rendering_network.divide_factor, 2)
     pc, pf, pr = b["packs"]
-    pts = _pts(rays_o, rays_d, z_vals)
+    order = b.get("order")
+    pts = _pts(rays_o, rays_d, z_vals, order)
     st = _stream()
     ptr = lambda t: None if t is None else t.data_ptr()
     gs = [None if g is None else g.contiguous() for g in (g_rgbv, g_depth, g_nmap, g_ent, g_w)]
@@ -155,7 +167,8 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
                                                  g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), ptr(gt),
                                                  ptr(emit), 0 if emit is None else emit.shape[1], st))
         if emit is not None:
-            pg["flat_c"] = mapping.sdf_flat_grad(emit, g_sdf, P, enc.num_levels, enc.level_dim)
+            g_sdf_w = g_sdf if order is None else g_sdf[order.long()]       # emission columns are work items
+            pg["flat_c"] = mapping.sdf_flat_grad(emit, g_sdf_w, P, enc.num_levels, enc.level_dim)
             del emit
         pg["tab_c"] = gt
     else:

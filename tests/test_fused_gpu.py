@@ -345,3 +345,33 @@ def test_ragged_sizes_fused_vs_composed(n_rays, samples):
     for i, what in enumerate(("rgb_values", "depth_values", "normal_map")):
         assert_close(res["fused"][i], res["composed"][i], 2e-5, 1e-4, what)
     assert_close(res["fused"][3], res["composed"][3], 2e-3 * float(res["composed"][3].abs().max()), 2e-3, "grad_cam")
+
+
+def test_morton_launch_order_is_transparent():
+    """nsa_points_t.order: the per-point kernels run in Morton order, every result is the same as in ray order
+    (per-point arithmetic is order independent; the per-ray composite reads per-point arrays)."""
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.fused import render as fr, sampler as fs
+    torch.manual_seed(7)
+    model = SLAMNetwork(replica_model_conf(use_warp_loss=False)).cuda().train()
+    with torch.no_grad():
+        for enc in (model.implicit_network.coarse.encoding, model.implicit_network.fine.encoding,
+                    model.rendering_network.encoding):
+            enc.embeddings.uniform_(-0.05, 0.05)
+    R = 200
+    o = torch.tensor([0.1, 0.0, -0.2], device="cuda").repeat(R, 1).contiguous()
+    d = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda"), dim=-1).contiguous()
+    z, _ = fs.get_z_vals(model, d, o, need_eik=False)
+    g = torch.rand(R, 3, device="cuda")
+    res = []
+    for sort_points in (False, True):
+        b = fr.composite_forward_raw(model, o, d, z, "fine", True, sort_points=sort_points)
+        g_o, g_d = fr.composite_backward_raw(model, o, d, z, b, "fine", "highfreq", g_rgbv=g)
+        res.append((b["rgb_values"].clone(), b["depth"].clone(), b["nmap"].clone(), b["sdf"].clone(), b["rgb"].clone(),
+                    g_o.clone(), g_d.clone()))
+        if sort_points:
+            order = b["order"].long()
+            assert sorted(order.tolist()) == list(range(R * z.shape[1]))
+    for a, c in zip(*res):
+        assert torch.equal(a, c)

@@ -117,32 +117,38 @@ __device__ __forceinline__ uint32_t level_row(const LevelGeom& g, const uint32_t
 //     g*C + j, lane % C = channel.
 // `key` = destination row (relative to `table`) or 0xFFFFFFFF for lanes with nothing to add (they never merge).
 // Blocks using this are 256 threads (4 waves).
+// `tile` = this wave's 64*(C+1)-float LDS scratch (callers that have idle LDS pass it; the 4-argument overload owns one).
+// `merge` = false skips step 1 (levels whose cells are much smaller than the spacing of the points: runs have length 1
+// and the scan would be pure overhead); any lane subset may pass false -- those lanes simply never join a run.
 template <int C>
-__device__ __forceinline__ void scatter_runs(float* __restrict__ table, uint32_t key, float (&val)[C], int lane) {
-    const uint32_t prev = __shfl_up(key, 1);
-    const bool head = lane == 0 || prev != key || key == 0xFFFFFFFFu;
-    const unsigned long long hm = __ballot(head);
-    const int seg = __popcll(hm & ((2ull << lane) - 1ull));            // inclusive count of heads = segment id
+__device__ __forceinline__ void scatter_runs(float* __restrict__ table, uint32_t key, float (&val)[C], int lane, float* tile,
+                                             bool merge = true) {
+    uint32_t send = key;
+    if (__any(merge)) {
+        const uint32_t mkey = merge ? key : 0xFFFFFFFFu;
+        const uint32_t prev = __shfl_up(mkey, 1);
+        const bool head = lane == 0 || prev != mkey || mkey == 0xFFFFFFFFu;
+        const unsigned long long hm = __ballot(head);
+        const int seg = __popcll(hm & ((2ull << lane) - 1ull));            // inclusive count of heads = segment id
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int oseg = __shfl_up(seg, off);
-        const bool take = lane >= off && oseg == seg;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int oseg = __shfl_up(seg, off);
+            const bool take = lane >= off && oseg == seg;
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const float o = __shfl_up(val[c], off);
-            if (take) val[c] += o;
+            for (int c = 0; c < C; ++c) {
+                const float o = __shfl_up(val[c], off);
+                if (take) val[c] += o;
+            }
         }
+        const bool tail = lane == 63 || ((hm >> (lane + 1)) & 1ull);
+        send = tail ? key : 0xFFFFFFFFu;
     }
-    const bool tail = lane == 63 || ((hm >> (lane + 1)) & 1ull);
-    const uint32_t send = (tail && key != 0xFFFFFFFFu) ? key : 0xFFFFFFFFu;
     if (C == 1) {
         if (send != 0xFFFFFFFFu) atomicAdd(table + send, val[0]);      // -munsafe-fp-atomics: global_atomic_add_f32
         return;
     }
-    __shared__ float stage[4][64 * (C + 1)];                          // row pitch C+1: conflict-free transposed reads
-    float* tile = stage[threadIdx.x >> 6];
 #pragma unroll
-    for (int c = 0; c < C; ++c) tile[lane * (C + 1) + c] = val[c];
+    for (int c = 0; c < C; ++c) tile[lane * (C + 1) + c] = val[c];     // row pitch C+1: conflict-free transposed reads
     __builtin_amdgcn_wave_barrier();                                   // LDS ops of one wave execute in order
     const int grp = (lane / C) * C, ch = lane % C;
 #pragma unroll
@@ -152,6 +158,12 @@ __device__ __forceinline__ void scatter_runs(float* __restrict__ table, uint32_t
         if (row != 0xFFFFFFFFu) atomicAdd(table + (size_t)row * C + ch, v);
     }
     __builtin_amdgcn_wave_barrier();
+}
+
+template <int C>
+__device__ __forceinline__ void scatter_runs(float* __restrict__ table, uint32_t key, float (&val)[C], int lane) {
+    __shared__ float stage[4][64 * (C + 1)];
+    scatter_runs<C>(table, key, val, lane, stage[threadIdx.x >> 6]);
 }
 
 // Range test + cell/fraction split.  Returns false for a point outside [0,1]^D (NaN passes, as in the

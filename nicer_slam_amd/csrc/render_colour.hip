@@ -37,6 +37,9 @@ struct ColPack {
 // Staged GEMM parts (mlp_common.hpp): the first layer (54 KiB packed) and its transpose (60 KiB) are split along k so that
 // two 30 KiB stage buffers -- two workgroups per CU -- suffice.
 //   forward : W0[g0-4], W0[g5-8], W1          backward: the same three (recompute), then W1^T, W0^T[g0-1], W0^T[g2-3]
+#ifndef NSA_COL_MERGE
+#define NSA_COL_MERGE(scale) true     // run-merge on every level: measured 16.0 ms vs 21.8 ms per mapping iteration when
+#endif                                // the merge is skipped for levels finer than 128 cells/axis (samples of one ray DO share cells there)
 constexpr int kColStage = 7680;     // floats per buffer: 2 tiles x 5 groups (= 5 tiles x 2 groups) x 3 KiB
 template <bool BWD>
 struct ColOps {
@@ -359,7 +362,8 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
                 float v[CC];
 #pragma unroll
                 for (int c = 0; c < CC; ++c) v[c] = wt * ib[49 + jl * CC + c];
-                scatter_runs<CC>(a.g_table, key, v, lane);
+                // scratch: stage buffer 0 -- the last GEMM part (op 5, odd) reads buffer 1, and every wave is past op 4
+                scatter_runs<CC>(a.g_table, key, v, lane, stage + (threadIdx.x >> 6) * 64 * (CC + 1), NSA_COL_MERGE(lg.scale));
             }
         }
     }

@@ -267,7 +267,7 @@ __device__ __forceinline__ void x_to_slots_tangent(const float (&x)[3], float di
 template <int L, int C>
 __device__ __forceinline__ void table_grad_scatter(const float (&x)[3], float divide_factor, const GridGeom16& geom, int h,
                                                    int lane, bool live, const float (&hb)[3 * 16], const float (&dl)[3 * 16],
-                                                   const float (&n)[3], float* __restrict__ g_table) {
+                                                   const float (&n)[3], float* __restrict__ g_table, float* lds_tile) {
     float u[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) u[d] = (x[d] / divide_factor + 1.0f) / 2.0f;
@@ -312,7 +312,7 @@ __device__ __forceinline__ void table_grad_scatter(const float (&x)[3], float di
             float v[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) v[c] = fmaf(wt, hb[20 + jl * C + c], k[corner] * dl[20 + jl * C + c]);
-            scatter_runs<C>(g_table, key, v, lane);
+            scatter_runs<C>(g_table, key, v, lane, lds_tile);
         }
     }
 }

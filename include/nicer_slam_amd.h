@@ -233,8 +233,14 @@ int nsa_sdf_points(const float *points, uint64_t N, const nsa_grid_t *coarse, co
 int nsa_track_head(const float *uv, const float *K, const float *cam, uint32_t n, float *pose, float *rays_o,
                    float *rays_d, float *depth_scale, nsa_stream_t stream);
 int nsa_track_tail(const float *uv, const float *K, float *cam, uint32_t n, const float *g_rays_o, const float *g_rays_d,
-                   float *g_cam, int do_adam, float *exp_avg, float *exp_avg_sq, float *step, float lr, float beta1,
-                   float beta2, float eps, uint32_t lr_step, float lr_gamma, nsa_stream_t stream);
+                   float *g_cam, int do_adam, float reduce_weight, float *exp_avg, float *exp_avg_sq, float *step, float lr,
+                   float beta1, float beta2, float eps, uint32_t lr_step, float lr_gamma, nsa_stream_t stream);
+/* Multi-GPU form: reduce_weight = this rank's ray count > 0 turns g_cam into the 9-float message
+ * [w*g_cam(7), w*loss (slot 7 as left by nsa_l1_loss), w] that is summed over ranks with ONE all-reduce; the step is then
+ * nsa_adam_step_scaled(cam, msg, msg + 8, ...) = Adam on msg[0..6] / msg[8]. */
+int nsa_adam_step_scaled(float *param, const float *grad, const float *grad_div, float *exp_avg, float *exp_avg_sq,
+                         float *step, uint32_t n, float lr, float beta1, float beta2, float eps, uint32_t lr_step,
+                         float lr_gamma, nsa_stream_t stream);
 
 /* ---- Section 4: mapping-iteration tail ------------------------------------------------------------------------ */
 

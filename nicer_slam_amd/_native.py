@@ -122,9 +122,13 @@ EXPORTS += ["nsa_draw_picks"]
 lib.nsa_track_head.restype = _i
 lib.nsa_track_head.argtypes = [_p, _p, _p, _u32, _p, _p, _p, _p, _p]
 lib.nsa_track_tail.restype = _i
-lib.nsa_track_tail.argtypes = [_p, _p, _p, _u32, _p, _p, _p, _i, _p, _p, _p, _f32, _f32, _f32, _f32, _u32, _f32, _p]
+lib.nsa_track_tail.argtypes = [_p, _p, _p, _u32, _p, _p, _p, _i, _f32, _p, _p, _p, _f32, _f32, _f32, _f32, _u32, _f32, _p]
 EXPORTS += ["nsa_track_head", "nsa_track_tail"]
 
 lib.nsa_morton_keys.restype = _i
 lib.nsa_morton_keys.argtypes = [_pp, _p, _p]
 EXPORTS += ["nsa_morton_keys"]
+
+lib.nsa_adam_step_scaled.restype = _i
+lib.nsa_adam_step_scaled.argtypes = [_p, _p, _p, _p, _p, _p, _u32, _f32, _f32, _f32, _f32, _u32, _f32, _p]
+EXPORTS += ["nsa_adam_step_scaled"]

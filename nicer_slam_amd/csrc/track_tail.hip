@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void k_l1_loss(const float* __restrict__ pred,
 
 struct AdamArgs {
     float* p; const float* g; float* m; float* v; float* step;   // step: device scalar, incremented here
+    const float* g_div;                                          // optional device scalar: the gradient is g / g_div[0]
     uint32_t n;
     float lr, beta1, beta2, eps, lr_gamma;
     uint32_t lr_step;                                            // 0 = constant lr
@@ -86,7 +87,7 @@ struct AdamArgs {
 
 __device__ __forceinline__ void adam_one(const AdamArgs& a, uint32_t i, float t) {
     {
-        const float g = a.g[i];
+        const float g = a.g_div ? a.g[i] / a.g_div[0] : a.g[i];
         const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
         const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
         a.m[i] = m;
@@ -121,7 +122,9 @@ struct TrackArgs {
     uint32_t n;
     float* rays_o; float* rays_d; float* depth_scale;       // head outputs
     const float* g_o; const float* g_d;                       // tail inputs [n,3]
-    float* g_cam;                                             // [7] out (tail)
+    float* g_cam;                                             // [7] out (tail); [9] with reduce_weight
+    float reduce_weight;                                      // > 0 (multi-GPU): g_cam[0..7] *= w, g_cam[8] = w -- the
+                                                              // buffer is then summed over ranks and divided by [8]
     AdamArgs adam;                                            // adam.p == nullptr: no step
 };
 
@@ -205,6 +208,11 @@ __global__ __launch_bounds__(1024) void k_track_tail(TrackArgs a) {
         pose_grad_to_cam(a.cam, G, o);
 #pragma unroll
         for (int i = 0; i < 7; ++i) a.g_cam[i] = o[i];
+        if (a.reduce_weight > 0.0f) {       // slot 7 holds this rank's loss (k_l1_loss), slot 8 the weight
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a.g_cam[i] *= a.reduce_weight;
+            a.g_cam[8] = a.reduce_weight;
+        }
         if (a.adam.p) {
             const float t = a.adam.step[0] + 1.0f;
             for (uint32_t i = 0; i < 7; ++i) adam_one(a.adam, i, t);
@@ -248,7 +256,18 @@ int nsa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float beta1, float beta2, float eps, uint32_t lr_step, float lr_gamma, nsa_stream_t stream) {
     using namespace nsa;
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step || n == 0 || n > 256) return NSA_EBADARG;
-    AdamArgs a{param, grad, exp_avg, exp_avg_sq, step, n, lr, beta1, beta2, eps, lr_gamma, lr_step};
+    AdamArgs a{param, grad, exp_avg, exp_avg_sq, step, nullptr, n, lr, beta1, beta2, eps, lr_gamma, lr_step};
+    launch_begin();
+    hipLaunchKernelGGL(k_adam, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_end();
+}
+
+int nsa_adam_step_scaled(float* param, const float* grad, const float* grad_div, float* exp_avg, float* exp_avg_sq,
+                         float* step, uint32_t n, float lr, float beta1, float beta2, float eps, uint32_t lr_step,
+                         float lr_gamma, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!param || !grad || !grad_div || !exp_avg || !exp_avg_sq || !step || n == 0 || n > 256) return NSA_EBADARG;
+    AdamArgs a{param, grad, exp_avg, exp_avg_sq, step, grad_div, n, lr, beta1, beta2, eps, lr_gamma, lr_step};
     launch_begin();
     hipLaunchKernelGGL(k_adam, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     return launch_end();
@@ -267,14 +286,15 @@ int nsa_track_head(const float* uv, const float* K, const float* cam, uint32_t n
 }
 
 int nsa_track_tail(const float* uv, const float* K, float* cam, uint32_t n, const float* g_rays_o, const float* g_rays_d,
-                   float* g_cam, int do_adam, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
-                   float beta2, float eps, uint32_t lr_step, float lr_gamma, nsa_stream_t stream) {
+                   float* g_cam, int do_adam, float reduce_weight, float* exp_avg, float* exp_avg_sq, float* step, float lr,
+                   float beta1, float beta2, float eps, uint32_t lr_step, float lr_gamma, nsa_stream_t stream) {
     using namespace nsa;
     if (!uv || !K || !cam || !g_rays_o || !g_rays_d || !g_cam || n == 0) return NSA_EBADARG;
     if (do_adam && (!exp_avg || !exp_avg_sq || !step)) return NSA_EBADARG;
     TrackArgs a{};
     a.uv = uv; a.K = K; a.cam = cam; a.n = n; a.g_o = g_rays_o; a.g_d = g_rays_d; a.g_cam = g_cam;
-    if (do_adam) a.adam = AdamArgs{cam, g_cam, exp_avg, exp_avg_sq, step, 7, lr, beta1, beta2, eps, lr_gamma, lr_step};
+    a.reduce_weight = reduce_weight;
+    if (do_adam) a.adam = AdamArgs{cam, g_cam, exp_avg, exp_avg_sq, step, nullptr, 7, lr, beta1, beta2, eps, lr_gamma, lr_step};
     launch_begin();
     hipLaunchKernelGGL(k_track_tail, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
     return launch_end();

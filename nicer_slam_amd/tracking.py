@@ -42,7 +42,7 @@ class KernelTracker:
 
     @property
     def loss(self):
-        return self.red[7]
+        return self.red[7] / self.red[8] if self.world > 1 else self.red[7]
 
     def _iteration(self):
         from ._native import lib, check
@@ -60,15 +60,17 @@ class KernelTracker:
         # single GPU: the Adam step rides in the same kernel; multi-GPU: the all-reduce sits between the two
         lr, b1, b2, eps, lr_step, lr_gamma = self.hyper
         check(lib.nsa_track_tail(self.uv.data_ptr(), self.K.data_ptr(), self.cam.data_ptr(), R, g_o.data_ptr(),
-                                 g_d.data_ptr(), self.red.data_ptr(), 1 if self.world == 1 else 0, self.m.data_ptr(),
-                                 self.v.data_ptr(), self.t.data_ptr(), lr, b1, b2, eps, lr_step, lr_gamma, st))
+                                 g_d.data_ptr(), self.red.data_ptr(), 1 if self.world == 1 else 0,
+                                 0.0 if self.world == 1 else float(R), self.m.data_ptr(), self.v.data_ptr(),
+                                 self.t.data_ptr(), lr, b1, b2, eps, lr_step, lr_gamma, st))
 
     def _update(self):
+        """multi-GPU: Adam on the all-reduced message, gradient = red[0..6] / red[8]"""
         from ._native import lib, check
         lr, b1, b2, eps, lr_step, lr_gamma = self.hyper
-        check(lib.nsa_adam_step(self.cam.data_ptr(), self.red.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                self.t.data_ptr(), 7, lr, b1, b2, eps, lr_step, lr_gamma,
-                                torch.cuda.current_stream().cuda_stream))
+        check(lib.nsa_adam_step_scaled(self.cam.data_ptr(), self.red.data_ptr(), self.red[8:].data_ptr(), self.m.data_ptr(),
+                                       self.v.data_ptr(), self.t.data_ptr(), 7, lr, b1, b2, eps, lr_step, lr_gamma,
+                                       torch.cuda.current_stream().cuda_stream))
 
     def _capture(self):
         cam0 = self.cam.clone()
@@ -93,14 +95,11 @@ class KernelTracker:
                 self.graph.replay()
             else:
                 self._iteration()
-            if self.world > 1:      # weighted mean over the global ray batch: one 9-float all-reduce
+            if self.world > 1:      # weighted mean over the global ray batch: the tail kernel left the 9-float message
                 import torch.distributed as dist
-                self.red[:8] *= float(self.R)
-                self.red[8] = float(self.R)
                 dist.all_reduce(self.red)
-                self.red[:8] /= self.red[8]
-            if self.world > 1:
                 self._update()
+                return self.red[7] / self.red[8]
         return self.red[7]
 
 

@@ -260,6 +260,35 @@ def test_kernel_tracker_matches_autograd_stepper():
     assert abs(ref_l[0] - float(fx["out_loss"])) < 5e-5
 
 
+def test_kernel_tracker_multi_gpu_message_path_single_rank_group():
+    """The N > 1 step (tail kernel writes the 9-float message [w*g_cam, w*loss, w]; one all-reduce; Adam on msg/msg[8])
+    run over a 1-rank RCCL group must follow exactly the single-GPU trajectory."""
+    import socket
+    import torch.distributed as dist
+    from nicer_slam_amd.tracking import KernelTracker
+    fx, model, cam, pose, _, _ = _setup("full_tracking")
+    model.train(True)
+    model.engine = "fused"
+    model.draws = draws_of(fx, "cuda")
+    K, uv, gt = tt(fx["in_K"]).cuda(), tt(fx["in_uv"]).cuda(), tt(fx["gt_rgb"]).cuda()
+    cam0 = tt(fx["in_cam"]).reshape(-1)
+    one = KernelTracker(model, K, uv.shape[1], cam0, lr=0.005, use_graph=True)
+    l1 = [float(one.step(uv, gt)) for _ in range(4)]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        many = KernelTracker(model, K, uv.shape[1], cam0, lr=0.005, use_graph=True, world=2)   # forces the message path
+        l2 = [float(many.step(uv, gt)) for _ in range(4)]
+        assert float(many.red[8]) == float(uv.shape[1])
+    finally:
+        dist.destroy_process_group()
+    assert_close(torch.tensor(l2), torch.tensor(l1), 1e-6, 1e-5, "losses")
+    assert_close(many.cam, one.cam, 1e-6, 1e-5, "camera after 4 steps")
+
+
 def test_composite_backward_exact_zero_on_saturated_last_interval():
     """Regression: the last interval is 1e10 long, so d(weights)/d(sdf_last) is exactly 0 whenever sigma_last * 1e10
     saturates alpha (the usual case) -- a 'total minus prefix' suffix sum leaks a rounding residue times 1e10 there.

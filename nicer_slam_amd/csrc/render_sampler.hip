@@ -133,30 +133,25 @@ __global__ __launch_bounds__(256, 2) void k_sdf_points(SdfPointsArgs a, GridGeom
 
 // Per-iteration integer draws of the sampler from ONE buffer of uniforms (training mode):
 //   extra_idx = first n_extra entries of a random permutation of 0..E-1  (torch.randperm(E)[:n], ray_sampler.py:148)
-//               = indices of the n_extra smallest of E i.i.d. uniform keys (bitonic key/index sort in LDS);
+//               = indices of the n_extra smallest of E i.i.d. uniform keys, in key order (rank by counting in LDS);
 //   eik_idx[r] = floor(u * S) in 0..S-1                                  (torch.randint(S, (R,)), ray_sampler.py:158).
 // One 1024-thread block; replaces a rand + argsort (radix sort, arange, fills, casts) + randint chain of ~10 launches.
 __global__ __launch_bounds__(1024) void k_draw_picks(const float* __restrict__ u, uint32_t E, uint32_t n_extra, uint32_t R,
                                                      uint32_t S, int32_t* __restrict__ extra_idx, int32_t* __restrict__ eik_idx) {
     __shared__ float key[1024];
-    __shared__ int idx[1024];
     const uint32_t t = threadIdx.x;
-    key[t] = t < E ? u[t] : 2.0f;               // pad keys sort last
-    idx[t] = (int)t;
+    if (t < E) key[t] = u[t];
     __syncthreads();
-    for (uint32_t k = 2; k <= 1024; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            const uint32_t p = t ^ j;
-            if (p > t) {
-                const bool up = (t & k) == 0;
-                const float a = key[t], b = key[p];
-                const int ia = idx[t], ib = idx[p];
-                const bool gt = a > b || (a == b && ia > ib);     // total order: ties by index
-                if (gt == up) { key[t] = b; key[p] = a; idx[t] = ib; idx[p] = ia; }
-            }
-            __syncthreads();
+    // rank of key t among the E keys (ties by index) by counting: E broadcast LDS reads per thread, no sort network
+    if (extra_idx && t < E) {
+        const float mine = key[t];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < E; ++j) {
+            const float o = key[j];
+            rank += (o < mine || (o == mine && j < t)) ? 1u : 0u;
         }
-    if (extra_idx && t < n_extra) extra_idx[t] = idx[t];
+        if (rank < n_extra) extra_idx[rank] = (int32_t)t;
+    }
     if (eik_idx)
         for (uint32_t r = t; r < R; r += 1024) {
             const uint32_t v = (uint32_t)(u[E + r] * (float)S);

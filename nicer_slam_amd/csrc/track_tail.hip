@@ -213,11 +213,13 @@ __global__ __launch_bounds__(1024) void k_track_tail(TrackArgs a) {
             for (int i = 0; i < 8; ++i) a.g_cam[i] *= a.reduce_weight;
             a.g_cam[8] = a.reduce_weight;
         }
-        if (a.adam.p) {
-            const float t = a.adam.step[0] + 1.0f;
-            for (uint32_t i = 0; i < 7; ++i) adam_one(a.adam, i, t);
-            a.adam.step[0] = t;
-        }
+    }
+    __syncthreads();                        // g_cam is visible block-wide (global writes + barrier)
+    if (a.adam.p) {                         // one thread per parameter (the double-precision pow calls run in parallel)
+        const float t = a.adam.step[0] + 1.0f;
+        if (threadIdx.x < 7) adam_one(a.adam, threadIdx.x, t);
+        __syncthreads();
+        if (threadIdx.x == 0) a.adam.step[0] = t;
     }
 }
 

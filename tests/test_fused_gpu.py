@@ -323,10 +323,12 @@ def test_composite_backward_exact_zero_on_saturated_last_interval():
     assert bool((got[:, -1][sat] == 0).all())
 
 
-@pytest.mark.parametrize("n_rays,samples", [(37, (5, 24, 3)), (3, (2, 9, 0)), (130, (60, 70, 4))])
+@pytest.mark.parametrize("n_rays,samples", [(37, (5, 24, 3)), (3, (2, 9, 0)), (130, (60, 70, 4)), (96, (158, 640, 32)),
+                                            (20, (222, 640, 32))])
 def test_ragged_sizes_fused_vs_composed(n_rays, samples):
     """Ray counts that are not multiples of 4 / point counts that are not multiples of 32 / no extra samples /
-    S > 64 (two samples per lane in the per-ray kernels): fused engine vs composed engine, values and pose gradient."""
+    S > 64 (two samples per lane in the per-ray kernels) / S = 192 (BASELINE configs[4]: 8192 rays x 192 samples, three
+    samples per lane, 256-key sort) / S = 256 (the supported maximum): fused vs composed engine, values and pose gradient."""
     from nicer_slam_amd.model.network import SLAMNetwork
     from nicer_slam_amd.utils.conf import replica_model_conf
     from nicer_slam_amd.utils.general import get_camera_from_tensor
@@ -404,3 +406,18 @@ def test_morton_launch_order_is_transparent():
             assert sorted(order.tolist()) == list(range(R * z.shape[1]))
     for a, c in zip(*res):
         assert torch.equal(a, c)
+
+
+def test_fused_kernels_reject_more_than_256_samples_per_ray():
+    """S > 256 is outside the per-ray kernels' compiled range: the C ABI returns an error code (no silent truncation,
+    no fallback) and the binding raises."""
+    from nicer_slam_amd.fused import render as fr
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    from nicer_slam_amd.model.network import SLAMNetwork
+    model = SLAMNetwork(replica_model_conf(use_warp_loss=False)).cuda()
+    R, S = 8, 300
+    o = torch.zeros(R, 3, device="cuda")
+    d = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda"), dim=-1)
+    z = torch.sort(torch.rand(R, S, device="cuda"), dim=1).values
+    with pytest.raises(RuntimeError):
+        fr.composite_forward_raw(model, o, d, z, "fine", False)

@@ -117,53 +117,75 @@ __device__ __forceinline__ uint32_t level_row(const LevelGeom& g, const uint32_t
 //     g*C + j, lane % C = channel.
 // `key` = destination row (relative to `table`) or 0xFFFFFFFF for lanes with nothing to add (they never merge).
 // Blocks using this are 256 threads (4 waves).
-// `tile` = this wave's 64*(C+1)-float LDS scratch (callers that have idle LDS pass it; the 4-argument overload owns one).
-// `merge` = false skips step 1 (levels whose cells are much smaller than the spacing of the points: runs have length 1
-// and the scan would be pure overhead); any lane subset may pass false -- those lanes simply never join a run.
-template <int C>
-__device__ __forceinline__ void scatter_runs(float* __restrict__ table, uint32_t key, float (&val)[C], int lane, float* tile,
-                                             bool merge = true) {
-    uint32_t send = key;
-    if (__any(merge)) {
-        const uint32_t mkey = merge ? key : 0xFFFFFFFFu;
-        const uint32_t prev = __shfl_up(mkey, 1);
-        const bool head = lane == 0 || prev != mkey || mkey == 0xFFFFFFFFu;
-        const unsigned long long hm = __ballot(head);
-        const int seg = __popcll(hm & ((2ull << lane) - 1ull));            // inclusive count of heads = segment id
+//  3. wider spans: a request may cover at least 64 contiguous bytes (same benchmark: C lanes on one 8/16/32-byte row and
+//     2C lanes on two ADJACENT rows both retire at ~20 G requests/s, i.e. 41 G rows/s for pairs).  On a dense level the
+//     two x-neighbour corners of a cell are adjacent rows, so they are sent as one 2C-float span (scatter_row_pair).
+// `elem` = float offset of the span's first channel in `table`, or 0xFFFFFFFF for lanes with nothing to add.
+// `tile` = this wave's 64*(W+1)-float LDS scratch.  Must be called by all 64 lanes (shuffles / ballots inside).
+template <int W>
+__device__ __forceinline__ void scatter_span(float* __restrict__ table, uint32_t elem, float (&val)[W], int lane, float* tile) {
+    const uint32_t prev = __shfl_up(elem, 1);
+    const bool head = lane == 0 || prev != elem || elem == 0xFFFFFFFFu;
+    const unsigned long long hm = __ballot(head);
+    const int seg = __popcll(hm & ((2ull << lane) - 1ull));            // inclusive count of heads = segment id
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int oseg = __shfl_up(seg, off);
-            const bool take = lane >= off && oseg == seg;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int oseg = __shfl_up(seg, off);
+        const bool take = lane >= off && oseg == seg;
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const float o = __shfl_up(val[c], off);
-                if (take) val[c] += o;
-            }
+        for (int c = 0; c < W; ++c) {
+            const float o = __shfl_up(val[c], off);
+            if (take) val[c] += o;
         }
-        const bool tail = lane == 63 || ((hm >> (lane + 1)) & 1ull);
-        send = tail ? key : 0xFFFFFFFFu;
     }
-    if (C == 1) {
+    const bool tail = lane == 63 || ((hm >> (lane + 1)) & 1ull);
+    const uint32_t send = tail ? elem : 0xFFFFFFFFu;
+    if (W == 1) {
         if (send != 0xFFFFFFFFu) atomicAdd(table + send, val[0]);      // -munsafe-fp-atomics: global_atomic_add_f32
         return;
     }
 #pragma unroll
-    for (int c = 0; c < C; ++c) tile[lane * (C + 1) + c] = val[c];     // row pitch C+1: conflict-free transposed reads
+    for (int c = 0; c < W; ++c) tile[lane * (W + 1) + c] = val[c];     // row pitch W+1: conflict-free transposed reads
     __builtin_amdgcn_wave_barrier();                                   // LDS ops of one wave execute in order
-    const int grp = (lane / C) * C, ch = lane % C;
+    const int grp = (lane / W) * W, ch = lane % W;
 #pragma unroll
-    for (int j = 0; j < C; ++j) {
-        const uint32_t row = __shfl(send, grp + j);
-        const float v = tile[(grp + j) * (C + 1) + ch];
-        if (row != 0xFFFFFFFFu) atomicAdd(table + (size_t)row * C + ch, v);
+    for (int j = 0; j < W; ++j) {
+        const uint32_t e = __shfl(send, grp + j);
+        const float v = tile[(grp + j) * (W + 1) + ch];
+        if (e != 0xFFFFFFFFu) atomicAdd(table + (size_t)e + ch, v);
     }
     __builtin_amdgcn_wave_barrier();
+}
+
+// one C-channel row per lane; `key` = row index or 0xFFFFFFFF
+template <int C>
+__device__ __forceinline__ void scatter_runs(float* __restrict__ table, uint32_t key, float (&val)[C], int lane, float* tile) {
+    scatter_span<C>(table, key == 0xFFFFFFFFu ? key : key * (uint32_t)C, val, lane, tile);
 }
 
 template <int C>
 __device__ __forceinline__ void scatter_runs(float* __restrict__ table, uint32_t key, float (&val)[C], int lane) {
     __shared__ float stage[4][64 * (C + 1)];
     scatter_runs<C>(table, key, val, lane, stage[threadIdx.x >> 6]);
+}
+
+// the two x-neighbour corner rows (r0, r1) of a cell on a DENSE level: one 2C-float span when they are adjacent in memory
+// (always, except where the level's index wraps); `tile` holds 64*(2C+1) floats.
+template <int C>
+__device__ __forceinline__ void scatter_row_pair(float* __restrict__ table, uint32_t r0, uint32_t r1, bool valid,
+                                                 const float (&v0)[C], const float (&v1)[C], int lane, float* tile) {
+    const bool adjacent = r1 == r0 + 1u;
+    if (valid && !adjacent) {                                          // wrap point of the level: rare, plain atomics
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            atomicAdd(table + (size_t)r0 * C + c, v0[c]);
+            atomicAdd(table + (size_t)r1 * C + c, v1[c]);
+        }
+    }
+    float val[2 * C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { val[c] = v0[c]; val[C + c] = v1[c]; }
+    scatter_span<2 * C>(table, (valid && adjacent) ? r0 * (uint32_t)C : 0xFFFFFFFFu, val, lane, tile);
 }
 
 // Range test + cell/fraction split.  Returns false for a point outside [0,1]^D (NaN passes, as in the

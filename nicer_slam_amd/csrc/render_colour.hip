@@ -37,9 +37,6 @@ struct ColPack {
 // Staged GEMM parts (mlp_common.hpp): the first layer (54 KiB packed) and its transpose (60 KiB) are split along k so that
 // two 30 KiB stage buffers -- two workgroups per CU -- suffice.
 //   forward : W0[g0-4], W0[g5-8], W1          backward: the same three (recompute), then W1^T, W0^T[g0-1], W0^T[g2-3]
-#ifndef NSA_COL_MERGE
-#define NSA_COL_MERGE(scale) true     // run-merge on every level: measured 16.0 ms vs 21.8 ms per mapping iteration when
-#endif                                // the merge is skipped for levels finer than 128 cells/axis (samples of one ray DO share cells there)
 constexpr int kColStage = 7680;     // floats per buffer: 2 tiles x 5 groups (= 5 tiles x 2 groups) x 3 KiB
 template <bool BWD>
 struct ColOps {
@@ -348,6 +345,11 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
             uint32_t cell[3];
             float w[3], dw[3];
             const bool active = locate<3>(u, lg.scale, cell, w, dw) && live;
+            // scratch: stage buffer 0 -- the last GEMM part (op 5, odd) reads buffer 1, and every wave is past op 4
+            float* tile = stage + (threadIdx.x >> 6) * 64 * (2 * CC + 1);
+            const bool pair_mode = !((geom.lv[2 * jl].flags | geom.lv[2 * jl + 1].flags) & LV_HASHED);   // wave-uniform
+            uint32_t row[8];
+            float wt8[8];
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) {
                 float wt = 1.0f;
@@ -358,12 +360,28 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
                     wt *= bit ? w[d] : 1.0f - w[d];
                     q[d] = cell[d] + bit;
                 }
-                const uint32_t key = active ? lg.row0 + level_row<3>(lg, q) : 0xFFFFFFFFu;
-                float v[CC];
+                row[corner] = lg.row0 + level_row<3>(lg, q);
+                wt8[corner] = wt;
+            }
+            if (pair_mode) {        // dense levels: the two x-neighbour corners are adjacent rows -> one 16-byte span
 #pragma unroll
-                for (int c = 0; c < CC; ++c) v[c] = wt * ib[49 + jl * CC + c];
-                // scratch: stage buffer 0 -- the last GEMM part (op 5, odd) reads buffer 1, and every wave is past op 4
-                scatter_runs<CC>(a.g_table, key, v, lane, stage + (threadIdx.x >> 6) * 64 * (CC + 1), NSA_COL_MERGE(lg.scale));
+                for (int yz = 0; yz < 4; ++yz) {
+                    float v0[CC], v1[CC];
+#pragma unroll
+                    for (int c = 0; c < CC; ++c) {
+                        v0[c] = wt8[2 * yz] * ib[49 + jl * CC + c];
+                        v1[c] = wt8[2 * yz + 1] * ib[49 + jl * CC + c];
+                    }
+                    scatter_row_pair<CC>(a.g_table, row[2 * yz], row[2 * yz + 1], active, v0, v1, lane, tile);
+                }
+            } else {
+#pragma unroll
+                for (int corner = 0; corner < 8; ++corner) {
+                    float v[CC];
+#pragma unroll
+                    for (int c = 0; c < CC; ++c) v[c] = wt8[corner] * ib[49 + jl * CC + c];
+                    scatter_runs<CC>(a.g_table, active ? row[corner] : 0xFFFFFFFFu, v, lane, tile);
+                }
             }
         }
     }

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? (MAP ? 1 : NSA_OCC_BWD_COARSE) : NS
     // that GEMM, so nobody reads it any more
     if (MAP && a.g_table)
         table_grad_scatter<L, C>(x, a.divide_factor, geom, h, lane, live, hb0, dl, nbar, a.g_table,
-                                 stage + kStageFloats + (threadIdx.x >> 6) * 64 * (C + 1));
+                                 stage + kStageFloats + (threadIdx.x >> 6) * 64 * (2 * C + 1));
 #pragma unroll
     for (int d = 0; d < 3; ++d) gx[d] = xhalf_sum(gx[d] + xb2[d]);
     if (live && h == 0) {

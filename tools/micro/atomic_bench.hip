@@ -27,6 +27,36 @@ __global__ void k(float* t, uint32_t rows, uint32_t n_per_lane, uint32_t localit
     }
 }
 
+// lane-per-channel, but 2C adjacent lanes cover the two ADJACENT rows (row, row+1) = 2C contiguous floats
+template <int C>
+__global__ void kpair(float* t, uint32_t rows, uint32_t n_per_lane) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t i = 0; i < n_per_lane; ++i) {
+        const uint32_t row = (rng(gid * n_per_lane + i) % (rows - 1)) & ~1u;    // even row: the pair shares a 2C-float span
+#pragma unroll
+        for (int j = 0; j < 2 * C; ++j) {     // each lane's row pair is sent in round j by its 2C-lane group
+            const uint32_t r = __shfl(row, (lane / (2 * C)) * (2 * C) + j);
+            atomicAdd(t + (size_t)r * C + (lane % (2 * C)), 1.0f);
+        }
+    }
+}
+
+template <int C>
+void run_pair(float* t, uint32_t rows) {
+    const uint32_t blocks = 4096, tpb = 256, npl = 16;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL((kpair<C>), dim3(blocks), dim3(tpb), 0, 0, t, rows, npl);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    hipLaunchKernelGGL((kpair<C>), dim3(blocks), dim3(tpb), 0, 0, t, rows, npl);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double nrows = (double)blocks * tpb * npl * 2;          // every lane sends a PAIR of rows
+    printf("%-40s C=%d rows=%9u         %8.3f ms  %7.2f G rows/s (adjacent row pairs)\n", "lane-per-channel, row pairs", C, rows, ms,
+           nrows / ms * 1e-6);
+}
+
 template <int C, bool T>
 void run(const char* name, float* t, uint32_t rows, uint32_t locality) {
     const uint32_t blocks = 4096, tpb = 256, npl = 16;
@@ -55,6 +85,7 @@ int main() {
         run<2, false>("lane-per-row", t, 1u << 27, loc);
         run<2, true>("lane-per-channel", t, 1u << 27, loc);
     }
+    run_pair<8>(t, 36000); run_pair<4>(t, 1u << 20); run_pair<2>(t, 1u << 27);
     // verify sum
     std::vector<float> h(36000 * 8);
     hipMemset(t, 0, bytes);

@@ -330,9 +330,11 @@ constexpr float SP_K = 100.0f * 1.4426950408889634f;       // beta * log2(e)
 constexpr float SP_LIN = 20.0f * 1.4426950408889634f;      // threshold in the same units
 constexpr float SP_OUT = 0.01f * 0.6931471805599453f;      // ln(2) / beta
 
+// value only (sampler): the overflow-free form max(a,0) + ln(1 + e^{-|beta a|})/beta -- no compare/select, and equal to
+// torch's thresholded softplus to the last ulp (for beta a > 20 the log term is < 2e-9 relative and rounds away).
 __device__ __forceinline__ float softplus100(float a) {
     const float t = SP_K * a;
-    return t > SP_LIN ? a : SP_OUT * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(t));
+    return fmaf(SP_OUT, __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(t))), fmaxf(a, 0.0f));
 }
 __device__ __forceinline__ float softplus100_d1(float a) {
     const float t = SP_K * a;

@@ -216,3 +216,84 @@ def test_sharded_adam_single_rank_uses_hip_stepper():
         c = torch.nn.Parameter(torch.randn(4))
         c.grad = torch.randn(4)
         ShardedAdam([c]).step()               # CPU tensors: no fallback
+
+
+def test_mapping_step_with_full_slam_loss_fused_vs_composed():
+    """One mapping iteration as the training loop assembles it -- FrameFeed batch -> SLAMNetwork(mode='mapping') ->
+    SLAMLoss with the shipped Replica weights (rgb, SSI depth, normal L1/cos, eikonal, smooth) -> backward -> Adam --
+    on the fused engine with the HIP optimizer vs the composed engine with torch.optim.Adam: same loss terms, same
+    trainable gradients, same parameters after the step."""
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.model.loss import SLAMLoss
+    from nicer_slam_amd.feed import FrameFeed
+    from nicer_slam_amd.optim import Adam
+    H, W, n_pix, frames = 30, 40, 96, 3
+    torch.manual_seed(21)
+    feed = FrameFeed((H, W), device="cuda", scene_scale=1.0)
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 35.0
+    K[0, 2], K[1, 2] = W / 2 - 0.5, H / 2 - 0.5
+    for f in range(frames):
+        pose = torch.eye(4)
+        pose[:3, 3] = torch.tensor([0.05 * f, 0.02, -0.2 + 0.03 * f])
+        feed.add_frame(f, rgb=torch.rand(H * W, 3), depth=torch.rand(H * W, 1) * 0.02 + 0.01,
+                       normal=torch.nn.functional.normalize(torch.randn(H * W, 3), dim=-1),
+                       gt_depth=torch.rand(H * W, 1) * 2 + 0.5, intrinsics=K, pose=pose)
+    feed.change_sampling_idx(n_pix, generator=torch.Generator(device="cuda").manual_seed(3))
+    indices, model_input, gt = feed.batch(range(frames))
+
+    class DS:
+        data_dir = "synthetic"
+    results = {}
+    for engine in ("composed", "fused"):
+        torch.manual_seed(5)
+        model = SLAMNetwork(replica_model_conf(use_warp_loss=False)).cuda().freeze_fine_mlp()
+        with torch.no_grad():
+            for enc in (model.implicit_network.coarse.encoding, model.implicit_network.fine.encoding,
+                        model.rendering_network.encoding):
+                enc.embeddings.uniform_(-0.05, 0.05)
+        model.train(True)
+        model.engine = engine
+        groups = [{"params": list(model.implicit_network.fine.grid_parameters()), "lr": 0.04},
+                  {"params": list(model.implicit_network.coarse.grid_parameters()), "lr": 0.04},
+                  {"params": list(model.rendering_network.grid_parameters()), "lr": 0.01},
+                  {"params": list(model.rendering_network.mlp_parameters()) + list(model.implicit_network.coarse.mlp_parameters()),
+                   "lr": 0.002}]
+        opt = (Adam if engine == "fused" else torch.optim.Adam)(groups, betas=(0.9, 0.99), eps=1e-15)
+        crit = SLAMLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, train_dataset=DS(), scan_id=1,
+                        assign_scale_shift_init=True, smooth_weight=0.005, depth_weight=0.1, normal_l1_weight=0.05,
+                        normal_cos_weight=0.05)
+        torch.manual_seed(9)                                    # same device-generator draws for both engines
+        if "z" in results:
+            model.draws = {"z_vals_override": results["z"]}
+        out = model(model_input, indices.cuda(), gt, mode="mapping", stage="fine", color_stage="highfreq", frame_idx=5)
+        assert model.last_engine == engine
+        results.setdefault("z", out["z_vals"].detach())
+        terms = crit(out, gt, keyframe_list=None, frame_idx=5, stage="fine")
+        opt.zero_grad()
+        terms["loss"].backward()
+        grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        opt.step()
+        results[engine] = ({k: float(v) for k, v in terms.items()}, grads,
+                           {n: p.detach().clone() for n, p in model.named_parameters()})
+    tc, gc, pc = results["composed"]
+    tf_, gf, pf = results["fused"]
+    for k in tc:
+        assert abs(tc[k] - tf_[k]) <= 2e-5 * max(1.0, abs(tc[k])), (k, tc[k], tf_[k])
+    assert tc["depth_loss"] > 0 and tc["normal_l1"] > 0 and tc["eikonal_loss"] > 0 and tc["smooth_loss"] > 0
+    checked = 0
+    for n, g in gc.items():
+        if n.startswith(FROZEN):
+            continue
+        assert n in gf, n
+        # 1e-6 floor: bias gradients are sums of ~3e5 signed fp32 terms that largely cancel (summation-order noise)
+        assert_close(gf[n], g.cpu().numpy(), 1e-6 + 4e-4 * float(g.abs().max()), 1e-3, "grad " + n)
+        checked += 1
+    assert checked >= 12
+    for n in pc:                                               # Adam's first step is +-lr wherever the gradient is non-zero:
+        if n.startswith(FROZEN):                                # compare where both engines agree on a clearly non-zero gradient
+            continue
+        if n in gc:
+            big = gc[n].abs() > 1e-3 * gc[n].abs().max()
+            assert_close(pf[n][big], pc[n][big].cpu().numpy(), 1e-6, 1e-5, "param after step " + n)

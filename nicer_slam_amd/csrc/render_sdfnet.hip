@@ -241,10 +241,15 @@ __global__ __launch_bounds__(256, (NH == 1 ? (MAP ? 1 : NSA_OCC_BWD_COARSE) : NS
     float x[3], z;
     uint32_t ray;
     load_point(a.src, q, x, ray, z);
+    // Kernels that run one workgroup per CU (the fine network; the MAP variants) have LDS to spare: keep the grid
+    // Jacobian of this lane's levels there and skip the second and third corner gather of the backward.
+    constexpr bool kJacLds = (NH > 1) || MAP;
+    __shared__ float jac_lds[kJacLds ? 4 * (L / 2) * 3 * C * 64 : 1];
+    float* jstore = kJacLds ? jac_lds + (threadIdx.x >> 6) * ((L / 2) * 3 * C * 64) + lane : nullptr;
     float in[SDF_IN_STEPS];
     {
         float jd[L / 2][3][C];
-        sdf_net_inputs<L, C, false>(x, a.divide_factor, a.table, geom, h, in, jd);
+        sdf_net_inputs<L, C, false>(x, a.divide_factor, a.table, geom, h, in, jd, jstore);
     }
     float sg[NH][HS], hl[HS];
     hidden_forward<NH, Seq>(stage, 0, a.wp, lane, h, in, sg, hl);
@@ -274,7 +279,8 @@ __global__ __launch_bounds__(256, (NH == 1 ? (MAP ? 1 : NSA_OCC_BWD_COARSE) : NS
     float xb2[3];
     {
         float tin[SDF_IN_STEPS];
-        x_to_slots_tangent<L, C>(x, a.divide_factor, a.table, geom, h, in, nbar, dl, tin, xb2);
+        if (kJacLds) tangent_from_jac<L, C>(a.divide_factor, jstore, h, in, nbar, dl, tin, xb2);
+        else         x_to_slots_tangent<L, C>(x, a.divide_factor, a.table, geom, h, in, nbar, dl, tin, xb2);
         if (emit) {
 #pragma unroll
             for (int s = 0; s < SDF_IN_STEPS; ++s) em.slot(SE_TIN, s, h, tin[s]);
@@ -365,7 +371,8 @@ __global__ __launch_bounds__(256, (NH == 1 ? (MAP ? 1 : NSA_OCC_BWD_COARSE) : NS
             for (int r = 0; r < 16; ++r) hb0[16 * t + r] = a3[t][r];
     }
     float gx[3];
-    slots_to_x<L, C>(x, a.divide_factor, a.table, geom, h, in, hb0, gx);
+    if (kJacLds) slots_to_x_jac<L, C>(a.divide_factor, jstore, h, in, hb0, gx);
+    else         slots_to_x<L, C>(x, a.divide_factor, a.table, geom, h, in, hb0, gx);
     // scatter scratch: the stage buffer the last GEMM (op 4 NH, even) does NOT read; every wave passed the barrier of
     // that GEMM, so nobody reads it any more
     if (MAP && a.g_table)

@@ -62,9 +62,12 @@ __device__ __forceinline__ void pe_slots(const float (&x)[3], int h, float (&in)
 }
 
 // Grid-feature slots 20..35: the L/2 levels (2*jl + h) of this lane, C channels each.
+// jstore != nullptr: also keeps d feature / d u (the 3 x C Jacobian rows of every level of this lane, zero outside the
+// grid) in a lane-private LDS column, jstore[((jl*3 + d)*C + c) * 64] -- the backward then needs no second and third
+// corner gather (slots_to_x_jac / tangent_from_jac below).
 template <int L, int C>
 __device__ __forceinline__ void grid_slots(const float (&x)[3], float divide_factor, const float* __restrict__ table,
-                                           const GridGeom16& geom, int h, float (&in)[SDF_IN_STEPS]) {
+                                           const GridGeom16& geom, int h, float (&in)[SDF_IN_STEPS], float* jstore = nullptr) {
     float u[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) u[d] = (x[d] / divide_factor + 1.0f) / 2.0f;   // hashgrid.py:203 (size = 1)
@@ -80,6 +83,15 @@ __device__ __forceinline__ void grid_slots(const float (&x)[3], float divide_fac
         blend<3, C>(v, w, f);
 #pragma unroll
         for (int c = 0; c < C; ++c) in[20 + jl * C + c] = inside ? f[c] : 0.0f;
+        if (jstore) {
+#pragma unroll
+            for (int gd = 0; gd < 3; ++gd) {
+                float jr[C];
+                jacobian_row<3, C>(v, w, dw, g.scale, gd, jr);
+#pragma unroll
+                for (int c = 0; c < C; ++c) jstore[((jl * 3 + gd) * C + c) * 64] = inside ? jr[c] : 0.0f;
+            }
+        }
     }
 }
 
@@ -87,10 +99,10 @@ __device__ __forceinline__ void grid_slots(const float (&x)[3], float divide_fac
 template <int L, int C, bool KEEP>
 __device__ __forceinline__ void sdf_net_inputs(const float (&x)[3], float divide_factor, const float* __restrict__ table,
                                                const GridGeom16& geom, int h, float (&in)[SDF_IN_STEPS],
-                                               float (&jac)[L / 2][3][C]) {
+                                               float (&jac)[L / 2][3][C], float* jstore = nullptr) {
     (void)jac;
     pe_slots(x, h, in);
-    grid_slots<L, C>(x, divide_factor, table, geom, h, in);
+    grid_slots<L, C>(x, divide_factor, table, geom, h, in, jstore);
 }
 
 // NOTE on out-of-range points: the table gather above still runs for them (addresses stay inside the level because
@@ -255,6 +267,65 @@ __device__ __forceinline__ void x_to_slots_tangent(const float (&x)[3], float di
             tin[20 + jl * C + c] = inside ? acc : 0.0f;
         }
     }
+}
+
+// The same two contractions as slots_to_x / x_to_slots_tangent with the grid part read from the Jacobian kept by
+// grid_slots(jstore): g[d] += sum_c dl[c] J[d][c] / (2 df)   and   tin[c] = sum_d n[d] J[d][c] / (2 df).
+template <int L, int C>
+__device__ __forceinline__ void slots_to_x_jac(float divide_factor, const float* jstore, int h, const float (&in)[SDF_IN_STEPS],
+                                               const float (&dl)[3 * 16], float (&g)[3]) {
+    g[0] = h ? 0.0f : dl[0];
+    g[1] = h ? 0.0f : dl[1];
+    g[2] = h ? dl[0] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int g0 = 2 * j, g1 = 2 * j + 1;
+        const float sc = h ? (float)(1 << (g1 / 3)) : (float)(1 << (g0 / 3));
+        const float t = sc * (in[3 + 2 * j] * dl[2 + 2 * j] - in[2 + 2 * j] * dl[3 + 2 * j]);
+        g[g0 % 3] += h ? 0.0f : t;
+        g[g1 % 3] += h ? t : 0.0f;
+    }
+    const float chain = 1.0f / (2.0f * divide_factor);
+#pragma unroll
+    for (int jl = 0; jl < L / 2; ++jl)
+#pragma unroll
+        for (int gd = 0; gd < 3; ++gd) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc = fmaf(dl[20 + jl * C + c], jstore[((jl * 3 + gd) * C + c) * 64], acc);
+            g[gd] += acc * chain;
+        }
+}
+
+template <int L, int C>
+__device__ __forceinline__ void tangent_from_jac(float divide_factor, const float* jstore, int h, const float (&in)[SDF_IN_STEPS],
+                                                 const float (&n)[3], const float (&dl)[3 * 16], float (&tin)[SDF_IN_STEPS],
+                                                 float (&xbar)[3]) {
+    tin[0] = h ? n[2] : n[0];
+    tin[1] = h ? 0.0f : n[1];
+    xbar[0] = xbar[1] = xbar[2] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int g0 = 2 * j, g1 = 2 * j + 1;
+        const float sc = h ? (float)(1 << (g1 / 3)) : (float)(1 << (g0 / 3));
+        const float nd = h ? n[g1 % 3] : n[g0 % 3];
+        const float s = in[2 + 2 * j], c = in[3 + 2 * j];
+        tin[2 + 2 * j] = sc * c * nd;
+        tin[3 + 2 * j] = -sc * s * nd;
+        const float t = -sc * sc * (s * dl[2 + 2 * j] + c * dl[3 + 2 * j]) * nd;
+        xbar[g0 % 3] += h ? 0.0f : t;
+        xbar[g1 % 3] += h ? t : 0.0f;
+    }
+    const float chain = 1.0f / (2.0f * divide_factor);
+#pragma unroll
+    for (int jl = 0; jl < L / 2; ++jl)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int gd = 0; gd < 3; ++gd) acc = fmaf(n[gd] * chain, jstore[((jl * 3 + gd) * C + c) * 64], acc);
+            tin[20 + jl * C + c] = acc;
+        }
 }
 
 // Table gradient of one SDF grid for THIS lane's levels (mapping): per corner row,

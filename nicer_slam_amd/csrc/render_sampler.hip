@@ -220,6 +220,11 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t v) {
     return p;
 }
 
+// The four rays of a workgroup never touch each other's LDS region, and the LDS operations of ONE wave execute in
+// program order, so phases are separated by a compiler-level wave barrier only (no workgroup barrier: the 30+ sort
+// stages would otherwise run in lock-step across four unrelated rays).
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
 // One wave per ray, 4 rays per 256-thread workgroup; LDS per ray: pdf[E], cdf[E], z[E], sort[MAX_S].
 __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -244,20 +249,25 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
     const uint32_t i0 = lane * per;
 
     // free energy sigma_i * delta_i (last delta = 1e10)                       ray_sampler.py:105-108
+    // Phase 1 is lane-strided (element i = lane + 64 k: coalesced loads, the ten independent iterations -- each a z load,
+    // an sdf load and a dependent visit-counter gather -- are all in flight at once); the scans below are lane-blocked
+    // (lane owns elements i0 .. i0+per-1) and read what phase 1 left in LDS.
+#pragma unroll 10
+    for (uint32_t i = lane; i < E; i += 64) {
+        const float zi = zr[i];
+        const float zn = i + 1 < E ? zr[i + 1] : 0.0f;
+        float x[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[c] = o[c] + mul_rn(zi, d[c]);
+        const float sigma = laplace_density(sr[i], beta_of(a.voxels, a.voxel_res, x));
+        zb[i] = zi;
+        pdf[i] = (i + 1 < E ? zn - zi : 1e10f) * sigma;
+    }
+    wave_sync();
     float esum = 0.0f;
     for (uint32_t k = 0; k < per; ++k) {
         const uint32_t i = i0 + k;
-        if (i < E) {
-            const float zi = zr[i];
-            float x[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) x[c] = o[c] + mul_rn(zi, d[c]);
-            const float sigma = laplace_density(sr[i], beta_of(a.voxels, a.voxel_res, x));
-            const float en = (i + 1 < E ? zr[i + 1] - zi : 1e10f) * sigma;
-            zb[i] = zi;
-            pdf[i] = en;
-            esum += en;
-        }
+        if (i < E) esum += pdf[i];
     }
     float tot;
     float run = wave_excl_scan(esum, lane, tot);
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
         }
     }
     if (lane == 0) cdf[0] = 0.0f;
-    __syncthreads();
+    wave_sync();
 
     // inverse CDF at u_j = linspace(0,1,N)_j: searchsorted(right=True)                 :124-139
     for (uint32_t j = lane; j < N; j += 64) {
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
         else if (j < S) v = zb[a.extra_idx[j - N - 2]];
         sb[j] = v;
     }
-    __syncthreads();
+    wave_sync();
     // bitonic sort of P2 <= 256 keys in LDS                                             :155
     for (uint32_t k = 2; k <= P2; k <<= 1) {
         for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
                 const float x0 = sb[i], x1 = sb[p];
                 if ((x0 > x1) == up) { sb[i] = x1; sb[p] = x0; }
             }
-            __syncthreads();
+            wave_sync();
         }
     }
     if (live) {

@@ -135,25 +135,41 @@ __global__ __launch_bounds__(256, 2) void k_sdf_points(SdfPointsArgs a, GridGeom
 //   extra_idx = first n_extra entries of a random permutation of 0..E-1  (torch.randperm(E)[:n], ray_sampler.py:148)
 //               = indices of the n_extra smallest of E i.i.d. uniform keys, in key order (rank by counting in LDS);
 //   eik_idx[r] = floor(u * S) in 0..S-1                                  (torch.randint(S, (R,)), ray_sampler.py:158).
-// One 1024-thread block; replaces a rand + argsort (radix sort, arange, fills, casts) + randint chain of ~10 launches.
-__global__ __launch_bounds__(1024) void k_draw_picks(const float* __restrict__ u, uint32_t E, uint32_t n_extra, uint32_t R,
-                                                     uint32_t S, int32_t* __restrict__ extra_idx, int32_t* __restrict__ eik_idx) {
-    __shared__ float key[1024];
-    const uint32_t t = threadIdx.x;
-    if (t < E) key[t] = u[t];
+// Replaces a rand + argsort (radix sort, arange, fills, casts) + randint chain of ~10 launches.
+__global__ __launch_bounds__(256) void k_draw_picks(const float* __restrict__ u, uint32_t E, uint32_t n_extra, uint32_t R,
+                                                    uint32_t S, int32_t* __restrict__ extra_idx, int32_t* __restrict__ eik_idx) {
+    // 64 keys per workgroup (E/64 workgroups on different CUs: the E^2 comparisons are what costs); every workgroup holds
+    // all E keys in LDS; its four waves each count one quarter of the comparison range with 16-byte broadcast reads
+    __shared__ __attribute__((aligned(16))) float key[1024];
+    __shared__ uint32_t part[4][64];
+    const uint32_t lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (uint32_t i = threadIdx.x; i < 1024; i += 256) key[i] = i < E ? u[i] : 2.0f;   // pad keys never rank below a real key
     __syncthreads();
-    // rank of key t among the E keys (ties by index) by counting: E broadcast LDS reads per thread, no sort network
-    if (extra_idx && t < E) {
-        const float mine = key[t];
+    const uint32_t t = blockIdx.x * 64 + lane;
+    {
+        const float mine = key[t < 1024 ? t : 1023];
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < E; ++j) {
-            const float o = key[j];
-            rank += (o < mine || (o == mine && j < t)) ? 1u : 0u;
+        const float4* k4 = reinterpret_cast<const float4*>(key);
+        const uint32_t n4 = (E + 3) / 4, per = (n4 + 3) / 4;
+        const uint32_t lo = q * per, hi = lo + per < n4 ? lo + per : n4;
+#pragma unroll 8
+        for (uint32_t j4 = lo; j4 < hi; ++j4) {
+            const float4 o = k4[j4];
+            const uint32_t j = 4 * j4;
+            rank += (o.x < mine || (o.x == mine && j < t)) ? 1u : 0u;
+            rank += (o.y < mine || (o.y == mine && j + 1 < t)) ? 1u : 0u;
+            rank += (o.z < mine || (o.z == mine && j + 2 < t)) ? 1u : 0u;
+            rank += (o.w < mine || (o.w == mine && j + 3 < t)) ? 1u : 0u;
         }
+        part[q][lane] = rank;
+    }
+    __syncthreads();
+    if (q == 0 && extra_idx && t < E) {
+        const uint32_t rank = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
         if (rank < n_extra) extra_idx[rank] = (int32_t)t;
     }
     if (eik_idx)
-        for (uint32_t r = t; r < R; r += 1024) {
+        for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256) {
             const uint32_t v = (uint32_t)(u[E + r] * (float)S);
             eik_idx[r] = (int32_t)(v < S ? v : S - 1);
         }
@@ -401,7 +417,7 @@ int nsa_draw_picks(const float* u, uint32_t E, uint32_t n_extra, uint32_t R, uin
     using namespace nsa;
     if (!u || E == 0 || E > 1024 || n_extra > E || (eik_idx && S == 0)) return NSA_EBADARG;
     launch_begin();
-    hipLaunchKernelGGL(k_draw_picks, dim3(1), dim3(1024), 0, (hipStream_t)stream, u, E, n_extra, R, S, extra_idx, eik_idx);
+    hipLaunchKernelGGL(k_draw_picks, dim3((E + 63) / 64), dim3(256), 0, (hipStream_t)stream, u, E, n_extra, R, S, extra_idx, eik_idx);
     return launch_end();
 }
 

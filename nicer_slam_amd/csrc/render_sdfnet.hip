@@ -172,10 +172,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? 2 : NSA_OCC_FWD_FINE)) void k_sdfne
     load_point(a.src, q, x, ray, z);
 
     float in[SDF_IN_STEPS];
-    {
-        float jd[L / 2][3][C];
-        sdf_net_inputs<L, C, false>(x, a.divide_factor, a.table, geom, h, in, jd);
-    }
+    sdf_net_inputs<L, C>(x, a.divide_factor, a.table, geom, h, in);
     float sg[NH][HS], hl[HS];
     hidden_forward<NH, Seq>(stage, 0, a.wp, lane, h, in, sg, hl);
     // outputs: sdf (row 0, VALU dot) and the 64 features (rows 1..64)
@@ -247,10 +244,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? (MAP ? 1 : NSA_OCC_BWD_COARSE) : NS
     __shared__ float jac_lds[kJacLds ? 4 * (L / 2) * 3 * C * 64 : 1];
     float* jstore = kJacLds ? jac_lds + (threadIdx.x >> 6) * ((L / 2) * 3 * C * 64) + lane : nullptr;
     float in[SDF_IN_STEPS];
-    {
-        float jd[L / 2][3][C];
-        sdf_net_inputs<L, C, false>(x, a.divide_factor, a.table, geom, h, in, jd, jstore);
-    }
+    sdf_net_inputs<L, C>(x, a.divide_factor, a.table, geom, h, in, jstore);
     float sg[NH][HS], hl[HS];
     hidden_forward<NH, Seq>(stage, 0, a.wp, lane, h, in, sg, hl);
     float dh[NH > 1 ? NH - 1 : 1][HS], dl[48];

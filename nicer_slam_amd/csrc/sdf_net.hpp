@@ -96,11 +96,10 @@ __device__ __forceinline__ void grid_slots(const float (&x)[3], float divide_fac
 }
 
 // First-layer inputs of one SDF net for one point, as seen by lane half h.
-template <int L, int C, bool KEEP>
+template <int L, int C>
 __device__ __forceinline__ void sdf_net_inputs(const float (&x)[3], float divide_factor, const float* __restrict__ table,
                                                const GridGeom16& geom, int h, float (&in)[SDF_IN_STEPS],
-                                               float (&jac)[L / 2][3][C], float* jstore = nullptr) {
-    (void)jac;
+                                               float* jstore = nullptr) {
     pe_slots(x, h, in);
     grid_slots<L, C>(x, divide_factor, table, geom, h, in, jstore);
 }

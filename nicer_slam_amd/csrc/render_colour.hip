@@ -181,7 +181,10 @@ __device__ __forceinline__ void colour_mlp(float* stage, const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_colour_fwd(ColourArgs a, GridGeom16 geom) {
+#ifndef NSA_OCC_COL_FWD
+#define NSA_OCC_COL_FWD 2
+#endif
+__global__ __launch_bounds__(256, NSA_OCC_COL_FWD) void k_colour_fwd(ColourArgs a, GridGeom16 geom) {
     using Seq = ColOps<false>;
     desync_simd_partners();
     const int lane = threadIdx.x & 63;

@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -23,3 +25,32 @@ def test_native_binding_lists_all_exports():
     hdr = open(os.path.join(ROOT, "include", "nicer_slam_amd.h")).read()
     declared = set(re.findall(r"\b(nsa_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_native.EXPORTS)
+
+
+def test_argument_validation_needs_no_gpu():
+    """Every entry point checks its arguments before touching the device: NULL pointers and inconsistent sizes come back
+    as NSA_EBADARG with a message, unsupported shapes as NSA_EUNSUPPORTED_*; none of these calls launches anything."""
+    import ctypes
+    from nicer_slam_amd._native import lib, check, GridDesc, PointsDesc
+    NSA_EBADARG, NSA_EUNSUPPORTED_C, NSA_EUNSUPPORTED_NET = 4, 1, 5
+    assert lib.nsa_version() >= 1
+    assert lib.nsa_strerror(0) == b"ok"
+    assert lib.nsa_strerror(NSA_EUNSUPPORTED_C) == b"GridEncoding: C must be 1, 2, 4, or 8."      # hashencoder.cu:637
+    assert b"bad argument" in lib.nsa_strerror(NSA_EBADARG)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        check(NSA_EBADARG)
+    pts = PointsDesc(None, None, None, None, 64, 0, None)                # neither rays nor points
+    grid = GridDesc(None, None, 4, 8, 0.0, 32, 1.0, 1)
+    assert lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(grid), None, 0, None, None, None, None) == NSA_EBADARG
+    assert lib.nsa_sdfnet_backward(None, None, None, None, None, None, 0, None, None) == NSA_EBADARG
+    assert lib.nsa_sdfnet_backward_params(None, None, None, None, None, None, 0, None, None, None, 0, None) == NSA_EBADARG
+    assert lib.nsa_colour_forward(None, None, None, None, None, None, None, None) == NSA_EBADARG
+    assert lib.nsa_update_voxels(None, None, 64, None) == NSA_EBADARG
+    assert lib.nsa_morton_keys(None, None, None) == NSA_EBADARG
+    assert lib.nsa_adam_table_step(None, None, None, None, 16, 1, 0.1, 0.9, 0.99, 1e-15, None) == NSA_EBADARG
+    assert lib.nsa_draw_picks(None, 640, 32, 8, 98, None, None, None) == NSA_EBADARG
+    assert lib.nsa_track_head(None, None, None, 0, None, None, None, None, None) == NSA_EBADARG
+    assert lib.nsa_sdf_points(None, 8, None, None, None, None, None, None) == NSA_EBADARG
+    # empty work is a no-op, not an error (reference: a zero-size launch is never issued either)
+    assert lib.nsa_sdf_points(None, 0, None, None, None, None, None, None) == 0
+    assert lib.nsa_sampler_sdf(None, None, 0, 640, None, None, 0.0, 1.0, 3.5, None, None, None, None, None, None, None, None) == 0

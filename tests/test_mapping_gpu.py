@@ -297,3 +297,51 @@ def test_mapping_step_with_full_slam_loss_fused_vs_composed():
         if n in gc:
             big = gc[n].abs() > 1e-3 * gc[n].abs().max()
             assert_close(pf[n][big], pc[n][big].cpu().numpy(), 1e-6, 1e-5, "param after step " + n)
+
+
+def test_flow_block_downstream_of_fused_function():
+    """Optical-flow reprojection (network.py:153-165: rendered depth -> 3-D point -> projection into frame j) computed by
+    torch ops on the fused Function's depth output: flow and the gradients it sends back, fused vs composed engine."""
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    torch.manual_seed(13)
+    bs, n = 3, 64
+    K = torch.eye(4, device="cuda")
+    K[0, 0] = K[1, 1] = 600.0
+    K[0, 2], K[1, 2] = 599.5, 339.5
+    K = K[None].repeat(bs, 1, 1)
+    idx = torch.randint(680 * 1200, (n,), device="cuda")
+    uv = torch.stack([(idx % 1200).float(), (idx // 1200).float()], -1)[None].repeat(bs, 1, 1)
+    edges = (torch.tensor([0, 1], device="cuda"), torch.tensor([1, 2], device="cuda"), None, None)
+    target = torch.randn(2, n, 2, device="cuda") * 3
+    res = {}
+    for engine in ("composed", "fused"):
+        torch.manual_seed(5)
+        model = SLAMNetwork(replica_model_conf(use_warp_loss=False)).cuda().freeze_fine_mlp()
+        with torch.no_grad():
+            for enc in (model.implicit_network.coarse.encoding, model.implicit_network.fine.encoding,
+                        model.rendering_network.encoding):
+                enc.embeddings.uniform_(-0.05, 0.05)
+        model.train(True)
+        model.engine = engine
+        if "z" in res:
+            model.draws = {"z_vals_override": res["z"]}
+        torch.manual_seed(9)
+        cams = torch.tensor([[1.0, 0.01, -0.02, 0.0, 0.1, 0.0, -0.2], [1.0, 0.02, 0.0, 0.01, 0.12, 0.01, -0.2],
+                             [1.0, -0.01, 0.02, 0.0, 0.08, -0.01, -0.22]], device="cuda", requires_grad=True)
+        out = model({"intrinsics": K, "uv": uv, "pose": get_camera_from_tensor(cams)}, torch.arange(bs, device="cuda"),
+                    {"edges": edges}, mode="mapping", stage="fine", color_stage="highfreq", frame_idx=5)
+        assert model.last_engine == engine and out["flow"].shape == (2, n, 2)
+        res.setdefault("z", out["z_vals"].detach())
+        loss = (out["flow"] - target).abs().mean() + (out["rgb_values"] - 0.5).abs().mean()
+        loss.backward()
+        res[engine] = (out["flow"].detach(), cams.grad.clone(),
+                       {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert_close(res["fused"][0], res["composed"][0].cpu().numpy(), 2e-3, 1e-4, "flow (pixels)")
+    gc = res["composed"][1]
+    assert_close(res["fused"][1], gc.cpu().numpy(), 2e-3 * float(gc.abs().max()), 2e-3, "grad_cam")
+    for k, g in res["composed"][2].items():
+        if k.startswith(FROZEN):
+            continue
+        assert_close(res["fused"][2][k], g.cpu().numpy(), 1e-6 + 4e-4 * float(g.abs().max()), 1e-3, "grad " + k)

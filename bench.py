@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured streaming copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md); only used with --precision bf16*
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak = the peak for this config's dtype (MI355X_MICROARCH.md)
 
 # Algorithmic multiply-accumulates per point of each per-point kernel (true layer sizes, no padding):
@@ -50,6 +51,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch every op eagerly instead of replaying a hipGraph")
     ap.add_argument("--autograd", action="store_true",
                     help="drive the model through torch autograd (TrackingStepper) instead of the kernel sequence")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16_colour"],
+                    help="MLP GEMM operands: fp32 = the reference's precision (default, the BASELINE metric); bf16 / "
+                         "bf16_colour = the optional reduced-precision modes of BASELINE configs[2]/[4] (NOT the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mapping", action="store_true", help="skip the (untimed-for-value) mapping-iteration leg")
     ap.add_argument("--cpu-rays", type=int, default=64)
@@ -68,6 +72,7 @@ def make_model(args, device):
     model = SLAMNetwork(conf, dataset=DS(), n_images=2000).to(device)
     model.train()
     model.engine = args.engine
+    model.mlp_precision = args.precision
     if not args.param_grads:
         for p in model.parameters():
             p.requires_grad_(False)
@@ -166,10 +171,14 @@ def main():
             if name in ALGO_MAC:     # per-point MLP kernels: bounded by the matrix pipe
                 flops = 2.0 * ALGO_MAC[name] * pts
                 ach = flops / (tms / n * 1e-3) / 1e12
-                roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
-                        "flops_per_launch": flops, "mfma_path": "fp32 products as 6 bf16 MFMAs on 3-way split operands "
-                        "(fp32-faithful); achieved counts algorithmic fp32 flops once"}
+                bf16_kernel = args.precision == "bf16" or (args.precision == "bf16_colour" and "colour" in name)
+                peak = MFMA_BF16_PEAK_TFLOPS if bf16_kernel else MFMA_F32_PEAK_TFLOPS
+                roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                        "flops_per_launch": flops,
+                        "mfma_path": "plain bf16 operands, one MFMA per product block (dense bf16 peak)" if bf16_kernel else
+                        "fp32 products as 6 bf16 MFMAs on 3-way split operands (fp32-faithful); achieved counts "
+                        "algorithmic fp32 flops once"}
             else:
                 ach = nbytes / (tms * 1e-3) / 1e9
                 roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -178,13 +187,15 @@ def main():
                          "all_kernels_us": {k: round(v[0] / v[2] * 1e3, 1) for k, v in sorted(agg.items())}})
         cpu = None if args.no_cpu_baseline else cpu_baseline(args, model, conf)
         mapping = None
-        if world == 1 and not args.no_mapping and args.engine != "composed":
+        if world == 1 and not args.no_mapping and args.engine != "composed" and args.precision == "fp32":
             del stepper, eager
             mapping = mapping_leg(device)
         line = {
             "metric": "rays/sec (fwd+bwd), one tracking iteration", "value": round(rays_total / dt, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"fp32": "f32", "bf16": "bf16 MLP operands (f32 accumulate, encoders and compositing f32)",
+                      "bf16_colour": "bf16 colour-MLP operands, f32 SDF head"}[args.precision], "data": "synthetic",
             "config": {"workload": f"Replica room0 tracking iteration, {args.rays} rays x {args.samples} samples "
                                    f"(+640 sampler evaluations/ray), single MI355X fp32 [BASELINE configs[1]]",
                        "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "sampler_evals_per_ray": 640,

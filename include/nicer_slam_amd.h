@@ -81,6 +81,10 @@ typedef struct nsa_grid {
     uint32_t H;                  /* base resolution                                                */
     float divide_factor;         /* x is divided by this before the [-1,1] -> [0,1] map            */
     uint32_t n_hidden;           /* hidden layers of the attached MLP (coarse 1, fine 3)           */
+    uint32_t precision;          /* GEMM operands of the attached MLP: 0 = fp32-faithful (3-way bf16 split, the
+                                  * reference's precision; default), 1 = plain bf16 operands with fp32 accumulation
+                                  * (optional "bf16 MLP" mode of BASELINE configs 2/4; encoders, activations,
+                                  * compositing and all reductions stay fp32)                       */
 } nsa_grid_t;
 
 /* Where the points of a per-point kernel come from: sample (pid % S) of ray (pid / S), x = o + z d -- or, when

@@ -46,7 +46,7 @@ def check(rc):
 class GridDesc(ctypes.Structure):
     """nsa_grid_t"""
     _fields_ = [("table", _p), ("offsets_host", _p), ("L", _u32), ("C", _u32), ("S", _f32), ("H", _u32),
-                ("divide_factor", _f32), ("n_hidden", _u32)]
+                ("divide_factor", _f32), ("n_hidden", _u32), ("precision", _u32)]
 
 
 _gp = ctypes.POINTER(GridDesc)

@@ -78,6 +78,61 @@ __device__ __forceinline__ void split8(const float (&x)[8], BFrag& f) {
 #undef NSA_PK
 }
 
+// Operand precision of every GEMM in a translation unit: 3 = fp32-faithful split (default), 1 = plain bf16 operands
+// (round-to-nearest-even; fp32 accumulate) -- the optional "bf16 MLP" mode, compiled as a second set of kernels
+// (csrc/*_bf16.hip) and selected per network through nsa_grid_t.precision.  The packed weight blocks are shared: the
+// bf16 mode reads only the first piece, which pack.py rounds to nearest.
+#ifndef NSA_PIECES
+#define NSA_PIECES 3
+#endif
+constexpr int kPieces = NSA_PIECES;
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bf16x8_t round8_bf16(const float (&x)[8]) {     // v_cvt_pk_bf16_f32 x 4
+    unsigned u[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const f32x2_t v = {x[2 * d], x[2 * d + 1]};
+        const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+        __builtin_memcpy(&u[d], &b, 4);
+    }
+    bf16x8_t r;
+    __builtin_memcpy(&r, u, 16);
+    return r;
+}
+
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;      // (uint4 is a class type: no address-space pointers to it)
+using lds_u4 = __attribute__((address_space(3))) u32x4;
+
+__device__ __forceinline__ bf16x8_t as_bf16x8(const u32x4& v) {
+    bf16x8_t r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
+
+// acc[mt] += A(mt, group) * x for one slot group: the six cross products of the 3-way split, or one bf16 product.
+template <int MT, class AV>
+__device__ __forceinline__ void mma_group(const AV (&a)[MT][3], const float (&x)[8], f32x16 (&acc)[MT]) {
+    if constexpr (kPieces == 3) {
+        BFrag bf;
+        split8(x, bf);
+        const bf16x8_t bh = as_bf16x8(bf.p[0]), bm = as_bf16x8(bf.p[1]), bl = as_bf16x8(bf.p[2]);
+        // smallest terms first; the MT accumulators alternate so no MFMA waits on its predecessor
+#define NSA_MM(AP, BV)                                                                                   \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                \
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[mt][AP]), BV, acc[mt], 0, 0, 0);
+        NSA_MM(2, bh) NSA_MM(0, bl) NSA_MM(1, bm) NSA_MM(1, bh) NSA_MM(0, bm) NSA_MM(0, bh)
+#undef NSA_MM
+    } else {
+        const bf16x8_t b = round8_bf16(x);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[mt][0]), b, acc[mt], 0, 0, 0);
+    }
+}
+
 template <int MT>
 struct AFrag {
     uint4 g[MT][3];   // the next slot group's weight pieces
@@ -90,7 +145,7 @@ __device__ __forceinline__ void gemm_preload(const float* __restrict__ wp, int l
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) f.g[mt][pc] = w4[((mt * KS8 + 0) * 3 + pc) * 64];
+        for (int pc = 0; pc < kPieces; ++pc) f.g[mt][pc] = w4[((mt * KS8 + 0) * 3 + pc) * 64];
 }
 
 template <int KS, int MT>
@@ -104,7 +159,7 @@ __device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane,
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
+            for (int pc = 0; pc < kPieces; ++pc) {
                 a[mt][pc] = f.g[mt][pc];
 #ifdef NSA_EXP_WCACHE   // timing experiment only: every fragment load hits the same 3 KB (L1-resident)
                 if (g + 1 < KS8) f.g[mt][pc] = w4[pc * 64];
@@ -115,15 +170,7 @@ __device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane,
         float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? b[8 * g + e] : 0.0f;
-        BFrag bf;
-        split8(x, bf);
-        const bf16x8_t bh = as_bf16x8(bf.p[0]), bm = as_bf16x8(bf.p[1]), bl = as_bf16x8(bf.p[2]);
-        // smallest terms first; the MT accumulators alternate so no MFMA waits on its predecessor
-#define NSA_MM(AP, BV)                                                                                   \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                \
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[mt][AP]), BV, acc[mt], 0, 0, 0);
-        NSA_MM(2, bh) NSA_MM(0, bl) NSA_MM(1, bm) NSA_MM(1, bh) NSA_MM(0, bm) NSA_MM(0, bh)
-#undef NSA_MM
+        mma_group<MT>(a, x, acc);
     }
     __builtin_amdgcn_sched_barrier(0);   // keep later layers' loads from being hoisted above this GEMM
 }
@@ -138,14 +185,7 @@ __device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane,
 // One workgroup barrier per GEMM.  All four waves of a block must execute the same GEMM sequence (no early exits).
 constexpr int kStageFloats = 9216;      // largest packed block: A[3 tiles][32 slots] = 36 KiB
 
-using u32x4 = __attribute__((ext_vector_type(4))) unsigned;      // (uint4 is a class type: no address-space pointers to it)
-using lds_u4 = __attribute__((address_space(3))) u32x4;
 
-__device__ __forceinline__ bf16x8_t as_bf16x8(const u32x4& v) {
-    bf16x8_t r;
-    __builtin_memcpy(&r, &v, 16);
-    return r;
-}
 
 __device__ __forceinline__ void stage_issue(const float* __restrict__ g, int nfloats, float* lds_dst) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -172,28 +212,21 @@ __device__ __forceinline__ void gemm_lds(const float* lds_block, int lane, const
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) nxt[mt][pc] = w4[((mt * KS8 + 0) * 3 + pc) * 64];
+        for (int pc = 0; pc < kPieces; ++pc) nxt[mt][pc] = w4[((mt * KS8 + 0) * 3 + pc) * 64];
 #pragma unroll
     for (int g = 0; g < KS8; ++g) {
         u32x4 a[MT][3];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
+            for (int pc = 0; pc < kPieces; ++pc) {
                 a[mt][pc] = nxt[mt][pc];
                 if (g + 1 < KS8) nxt[mt][pc] = w4[((mt * KS8 + g + 1) * 3 + pc) * 64];
             }
         float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? b[8 * g + e] : 0.0f;
-        BFrag bf;
-        split8(x, bf);
-        const bf16x8_t bh = as_bf16x8(bf.p[0]), bm = as_bf16x8(bf.p[1]), bl = as_bf16x8(bf.p[2]);
-#define NSA_MM(AP, BV)                                                                                   \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                \
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[mt][AP]), BV, acc[mt], 0, 0, 0);
-        NSA_MM(2, bh) NSA_MM(0, bl) NSA_MM(1, bm) NSA_MM(1, bh) NSA_MM(0, bm) NSA_MM(0, bh)
-#undef NSA_MM
+        mma_group<MT>(a, x, acc);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -247,7 +280,7 @@ __device__ __forceinline__ void gemm_lds_part(const float* lds_block, int lane, 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) nxt[mt][pc] = w4[((mt * NG + 0) * 3 + pc) * 64];
+        for (int pc = 0; pc < kPieces; ++pc) nxt[mt][pc] = w4[((mt * NG + 0) * 3 + pc) * 64];
 #pragma unroll
     for (int gl = 0; gl < NG; ++gl) {
         const int g = G0 + gl;
@@ -255,21 +288,14 @@ __device__ __forceinline__ void gemm_lds_part(const float* lds_block, int lane, 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
+            for (int pc = 0; pc < kPieces; ++pc) {
                 a[mt][pc] = nxt[mt][pc];
                 if (gl + 1 < NG) nxt[mt][pc] = w4[((mt * NG + gl + 1) * 3 + pc) * 64];
             }
         float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? b[8 * g + e] : 0.0f;
-        BFrag bf;
-        split8(x, bf);
-        const bf16x8_t bh = as_bf16x8(bf.p[0]), bm = as_bf16x8(bf.p[1]), bl = as_bf16x8(bf.p[2]);
-#define NSA_MM(AP, BV)                                                                                   \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                \
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[mt][AP]), BV, acc[mt], 0, 0, 0);
-        NSA_MM(2, bh) NSA_MM(0, bl) NSA_MM(1, bm) NSA_MM(1, bh) NSA_MM(0, bm) NSA_MM(0, bh)
-#undef NSA_MM
+        mma_group<MT>(a, x, acc);
     }
     __builtin_amdgcn_sched_barrier(0);
 }

@@ -402,6 +402,14 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
 
 }  // namespace nsa
 
+// Entry-point naming: this file is compiled twice -- as is (fp32-faithful GEMMs) and through *_bf16.hip with
+// NSA_PIECES = 1, `nsa` renamed and every entry point suffixed _bf16; the fp32 entry points forward to those when
+// nsa_grid_t.precision == 1.
+#ifndef NSA_ENTRY
+#define NSA_ENTRY(x) x
+#endif
+#include "bf16_entries.hpp"
+
 extern "C" {
 
 static int colour_common(const nsa_points_t* pts, const nsa_grid_t* grid, nsa::ColourArgs* a, nsa::GridGeom16* geom) {
@@ -416,8 +424,11 @@ static int colour_common(const nsa_points_t* pts, const nsa_grid_t* grid, nsa::C
     return NSA_OK;
 }
 
-int nsa_colour_forward(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad,
+int NSA_ENTRY(nsa_colour_forward)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad,
                        const float* feat_hl, float* rgb, float* save, nsa_stream_t stream) {
+#if NSA_PIECES == 3
+    if (grid && grid->precision == 1) return nsa_colour_forward_bf16(pts, grid, packed, grad, feat_hl, rgb, save, stream);      // bf16-operand kernels (csrc/*_bf16.hip)
+#endif
     using namespace nsa;
     if (!packed || !grad || !feat_hl || !rgb) return NSA_EBADARG;
     ColourArgs a{};
@@ -431,9 +442,12 @@ int nsa_colour_forward(const nsa_points_t* pts, const nsa_grid_t* grid, const fl
     return launch_end();
 }
 
-int nsa_colour_backward(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad,
+int NSA_ENTRY(nsa_colour_backward)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad,
                         const float* feat_hl, const float* save, const float* g_rgb, int grid_grad, float* g_feat_hl,
                         float* g_grad, float* g_x, float* g_dir, nsa_stream_t stream) {
+#if NSA_PIECES == 3
+    if (grid && grid->precision == 1) return nsa_colour_backward_bf16(pts, grid, packed, grad, feat_hl, save, g_rgb, grid_grad, g_feat_hl, g_grad, g_x, g_dir, stream);      // bf16-operand kernels (csrc/*_bf16.hip)
+#endif
     using namespace nsa;
     if (!packed || !grad || !feat_hl || !save || !g_rgb || !g_feat_hl || !g_grad || !g_x || !g_dir) return NSA_EBADARG;
     ColourArgs a{};
@@ -448,10 +462,13 @@ int nsa_colour_backward(const nsa_points_t* pts, const nsa_grid_t* grid, const f
     return launch_end();
 }
 
-int nsa_colour_backward_params(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad,
+int NSA_ENTRY(nsa_colour_backward_params)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad,
                                const float* feat_hl, const float* save, const float* g_rgb, int grid_grad,
                                float* g_feat_hl, float* g_grad, float* g_x, float* g_dir, float* g_table, float* emit,
                                uint32_t emit_ld, nsa_stream_t stream) {
+#if NSA_PIECES == 3
+    if (grid && grid->precision == 1) return nsa_colour_backward_params_bf16(pts, grid, packed, grad, feat_hl, save, g_rgb, grid_grad, g_feat_hl, g_grad, g_x, g_dir, g_table, emit, emit_ld, stream);      // bf16-operand kernels (csrc/*_bf16.hip)
+#endif
     using namespace nsa;
     if (!packed || !grad || !feat_hl || !save || !g_rgb || !g_feat_hl || !g_grad || !g_x || !g_dir) return NSA_EBADARG;
     if (!g_table && !emit) return NSA_EBADARG;
@@ -469,6 +486,6 @@ int nsa_colour_backward_params(const nsa_points_t* pts, const nsa_grid_t* grid, 
     return launch_end();
 }
 
-int nsa_colour_emit_rows(void) { return nsa::CE_ROWS; }
+int NSA_ENTRY(nsa_colour_emit_rows)(void) { return nsa::CE_ROWS; }
 
 }  // extern "C"

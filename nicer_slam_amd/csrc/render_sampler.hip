@@ -367,12 +367,23 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
 
 }  // namespace nsa
 
+// Entry-point naming: this file is compiled twice -- as is (fp32-faithful GEMMs) and through *_bf16.hip with
+// NSA_PIECES = 1, `nsa` renamed and every entry point suffixed _bf16; the fp32 entry points forward to those when
+// nsa_grid_t.precision == 1.
+#ifndef NSA_ENTRY
+#define NSA_ENTRY(x) x
+#endif
+#include "bf16_entries.hpp"
+
 extern "C" {
 
-int nsa_sampler_sdf(const float* rays_o, const float* rays_d, uint32_t R, uint32_t E, const float* t_lin,
+int NSA_ENTRY(nsa_sampler_sdf)(const float* rays_o, const float* rays_d, uint32_t R, uint32_t E, const float* t_lin,
                     const float* t_rand, float near, float bound, float far_cap, const nsa_grid_t* coarse,
                     const nsa_grid_t* fine, const float* packed_coarse, const float* packed_fine, float* z, float* sdf,
                     float* far, nsa_stream_t stream) {
+#if NSA_PIECES == 3
+    if (coarse && coarse->precision == 1) return nsa_sampler_sdf_bf16(rays_o, rays_d, R, E, t_lin, t_rand, near, bound, far_cap, coarse, fine, packed_coarse, packed_fine, z, sdf, far, stream);      // bf16-operand kernels (csrc/*_bf16.hip)
+#endif
     using namespace nsa;
     if (R == 0 || E == 0) return NSA_OK;
     if (!rays_o || !rays_d || !t_lin || !coarse || !fine || !packed_coarse || !packed_fine || !z || !sdf || !far)
@@ -392,8 +403,11 @@ int nsa_sampler_sdf(const float* rays_o, const float* rays_d, uint32_t R, uint32
     return launch_end();
 }
 
-int nsa_sdf_points(const float* points, uint64_t N, const nsa_grid_t* coarse, const nsa_grid_t* fine,
+int NSA_ENTRY(nsa_sdf_points)(const float* points, uint64_t N, const nsa_grid_t* coarse, const nsa_grid_t* fine,
                    const float* packed_coarse, const float* packed_fine, float* sdf, nsa_stream_t stream) {
+#if NSA_PIECES == 3
+    if (coarse && coarse->precision == 1) return nsa_sdf_points_bf16(points, N, coarse, fine, packed_coarse, packed_fine, sdf, stream);      // bf16-operand kernels (csrc/*_bf16.hip)
+#endif
     using namespace nsa;
     if (N == 0) return NSA_OK;
     if (!points || !coarse || !packed_coarse || !sdf || (fine && !packed_fine)) return NSA_EBADARG;
@@ -412,7 +426,7 @@ int nsa_sdf_points(const float* points, uint64_t N, const nsa_grid_t* coarse, co
     return launch_end();
 }
 
-int nsa_draw_picks(const float* u, uint32_t E, uint32_t n_extra, uint32_t R, uint32_t S, int32_t* extra_idx,
+int NSA_ENTRY(nsa_draw_picks)(const float* u, uint32_t E, uint32_t n_extra, uint32_t R, uint32_t S, int32_t* extra_idx,
                    int32_t* eik_idx, nsa_stream_t stream) {
     using namespace nsa;
     if (!u || E == 0 || E > 1024 || n_extra > E || (eik_idx && S == 0)) return NSA_EBADARG;
@@ -421,7 +435,7 @@ int nsa_draw_picks(const float* u, uint32_t E, uint32_t n_extra, uint32_t R, uin
     return launch_end();
 }
 
-int nsa_sample_rays(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const float* far,
+int NSA_ENTRY(nsa_sample_rays)(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const float* far,
                     const float* voxels, uint32_t voxel_res, uint32_t R, uint32_t E, uint32_t N, const float* u_lin,
                     const int32_t* extra_idx, uint32_t n_extra, float near, const int32_t* eik_idx, float* z_vals,
                     float* z_eik, nsa_stream_t stream) {

@@ -408,10 +408,21 @@ static int launch_sdfnet(bool bwd, const nsa_grid_t* grid, const SdfNetArgs& a, 
 
 }  // namespace nsa
 
+// Entry-point naming: this file is compiled twice -- as is (fp32-faithful GEMMs) and through *_bf16.hip with
+// NSA_PIECES = 1, `nsa` renamed and every entry point suffixed _bf16; the fp32 entry points forward to those when
+// nsa_grid_t.precision == 1.
+#ifndef NSA_ENTRY
+#define NSA_ENTRY(x) x
+#endif
+#include "bf16_entries.hpp"
+
 extern "C" {
 
-int nsa_sdfnet_forward(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, int accumulate, float* sdf,
+int NSA_ENTRY(nsa_sdfnet_forward)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, int accumulate, float* sdf,
                        float* grad, float* feat_hl, nsa_stream_t stream) {
+#if NSA_PIECES == 3
+    if (grid && grid->precision == 1) return nsa_sdfnet_forward_bf16(pts, grid, packed, accumulate, sdf, grad, feat_hl, stream);      // bf16-operand kernels (csrc/*_bf16.hip)
+#endif
     using namespace nsa;
     if (!pts || !grid || !packed || !sdf || !grad || !feat_hl) return NSA_EBADARG;
     if (pts->P == 0) return NSA_OK;
@@ -423,8 +434,11 @@ int nsa_sdfnet_forward(const nsa_points_t* pts, const nsa_grid_t* grid, const fl
     return launch_sdfnet(false, grid, a, (hipStream_t)stream);
 }
 
-int nsa_sdfnet_backward(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* g_sdf,
+int NSA_ENTRY(nsa_sdfnet_backward)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* g_sdf,
                         const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x, nsa_stream_t stream) {
+#if NSA_PIECES == 3
+    if (grid && grid->precision == 1) return nsa_sdfnet_backward_bf16(pts, grid, packed, g_sdf, g_feat_hl, g_grad, accumulate, g_x, stream);      // bf16-operand kernels (csrc/*_bf16.hip)
+#endif
     using namespace nsa;
     if (!pts || !grid || !packed || !g_x) return NSA_EBADARG;
     if (pts->P == 0) return NSA_OK;
@@ -436,9 +450,12 @@ int nsa_sdfnet_backward(const nsa_points_t* pts, const nsa_grid_t* grid, const f
     return launch_sdfnet(true, grid, a, (hipStream_t)stream);
 }
 
-int nsa_sdfnet_backward_params(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* g_sdf,
+int NSA_ENTRY(nsa_sdfnet_backward_params)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* g_sdf,
                                const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x, float* g_table,
                                float* emit, uint32_t emit_ld, nsa_stream_t stream) {
+#if NSA_PIECES == 3
+    if (grid && grid->precision == 1) return nsa_sdfnet_backward_params_bf16(pts, grid, packed, g_sdf, g_feat_hl, g_grad, accumulate, g_x, g_table, emit, emit_ld, stream);      // bf16-operand kernels (csrc/*_bf16.hip)
+#endif
     using namespace nsa;
     if (!pts || !grid || !packed || !g_x || (!g_table && !emit)) return NSA_EBADARG;
     if (emit && emit_ld < ((pts->P + 31) / 32) * 32) return NSA_EBADARG;
@@ -452,6 +469,6 @@ int nsa_sdfnet_backward_params(const nsa_points_t* pts, const nsa_grid_t* grid, 
     return launch_sdfnet(true, grid, a, (hipStream_t)stream);
 }
 
-int nsa_sdfnet_emit_rows(void) { return nsa::SE_ROWS; }
+int NSA_ENTRY(nsa_sdfnet_emit_rows)(void) { return nsa::SE_ROWS; }
 
 }  // extern "C"

@@ -24,7 +24,7 @@ from .._native import lib, check, PointsDesc
 from ..hashencoder.backend import _timed
 from . import pack
 from .render import composite_forward_raw, composite_backward_raw, hl_size, morton_order, _stream
-from .sampler import grid_desc, packed_sdf
+from .sampler import grid_desc, packed_sdf, precision_of
 
 KCHUNK = 4096
 SORT_POINTS = True      # run the per-point kernels of a mapping iteration in Morton order (see render.morton_order)
@@ -160,8 +160,8 @@ class FusedSdfGradient(torch.autograd.Function):
         N = points.shape[0]
         dev = points.device
         imp = model.implicit_network
-        gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1)
-        gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3)
+        gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1, precision_of(model, "sdf"))
+        gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3, precision_of(model, "sdf"))
         pc, pf = packed_sdf(model, "coarse"), packed_sdf(model, "fine")
         order = morton_order(PointsDesc(None, None, None, points.data_ptr(), N, 0, None), N, dev) if SORT_POINTS else None
         pts = PointsDesc(None, None, None, points.data_ptr(), N, 0, None if order is None else order.data_ptr())
@@ -187,8 +187,8 @@ class FusedSdfGradient(torch.autograd.Function):
         N = points.shape[0]
         dev = points.device
         imp = model.implicit_network
-        gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1)
-        gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3)
+        gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1, precision_of(model, "sdf"))
+        gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3, precision_of(model, "sdf"))
         pc, pf = ctx.packs
         order = ctx.order
         pts = PointsDesc(None, None, None, points.data_ptr(), N, 0, None if order is None else order.data_ptr())

@@ -12,7 +12,7 @@ import torch
 from .._native import lib, check, PointsDesc
 from ..hashencoder.backend import _timed
 from . import pack
-from .sampler import grid_desc, packed_sdf
+from .sampler import grid_desc, packed_sdf, precision_of
 
 
 def hl_size(P):
@@ -76,9 +76,9 @@ def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd, sort_p
     P = R * S
     dev = z_vals.device
     imp = model.implicit_network
-    gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1)
-    gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3)
-    gr, keep_r = grid_desc(model.rendering_network.encoding, model.rendering_network.divide_factor, 2)
+    gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1, precision_of(model, "sdf"))
+    gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3, precision_of(model, "sdf"))
+    gr, keep_r = grid_desc(model.rendering_network.encoding, model.rendering_network.divide_factor, 2, precision_of(model, "colour"))
     pc, pf, pr = packed_sdf(model, "coarse"), packed_sdf(model, "fine"), packed_colour(model)
     order = morton_order(_pts(rays_o, rays_d, z_vals), P, dev) if sort_points else None
     pts = _pts(rays_o, rays_d, z_vals, order)
@@ -116,9 +116,9 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
     P = R * S
     dev = z_vals.device
     imp = model.implicit_network
-    gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1)
-    gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3)
-    gr, keep_r = grid_desc(model.rendering_network.encoding, model.rendering_network.divide_factor, 2)
+    gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1, precision_of(model, "sdf"))
+    gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3, precision_of(model, "sdf"))
+    gr, keep_r = grid_desc(model.rendering_network.encoding, model.rendering_network.divide_factor, 2, precision_of(model, "colour"))
     pc, pf, pr = b["packs"]
     order = b.get("order")
     pts = _pts(rays_o, rays_d, z_vals, order)

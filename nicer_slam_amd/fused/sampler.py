@@ -21,11 +21,24 @@ def _linspace(n, device):
     return _LIN[key]
 
 
-def grid_desc(net_or_enc, divide_factor, n_hidden):
+PRECISIONS = ("fp32", "bf16", "bf16_colour")
+
+
+def precision_of(model, which):
+    """nsa_grid_t.precision for the SDF networks (which = "sdf") or the colour network ("colour") under
+    ``model.mlp_precision``: "fp32" (default: fp32-faithful GEMMs everywhere), "bf16" (every MLP takes bf16 operands)
+    or "bf16_colour" (bf16 colour MLP, fp32 SDF head -- BASELINE configs[4])."""
+    mode = getattr(model, "mlp_precision", "fp32")
+    if mode not in PRECISIONS:
+        raise ValueError(f"mlp_precision must be one of {PRECISIONS}, got {mode!r}")
+    return 1 if mode == "bf16" or (mode == "bf16_colour" and which == "colour") else 0
+
+
+def grid_desc(net_or_enc, divide_factor, n_hidden, precision=0):
     enc = net_or_enc
     off = _offsets_host(enc.offsets)
     d = GridDesc(enc.embeddings.data_ptr(), off.data_ptr(), enc.num_levels, enc.level_dim,
-                 float(np.log2(enc.per_level_scale)), enc.base_resolution, float(divide_factor), n_hidden)
+                 float(np.log2(enc.per_level_scale)), enc.base_resolution, float(divide_factor), n_hidden, precision)
     return d, (off, enc.embeddings)
 
 
@@ -67,8 +80,9 @@ def sampler_sdf(model, rays_o, rays_d, t_rand):
     R, E = rays_o.shape[0], samp.N_samples_eval
     dev = rays_o.device
     imp = model.implicit_network
-    gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1)
-    gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3)
+    prec = precision_of(model, "sdf")
+    gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1, prec)
+    gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3, prec)
     pc, pf = packed_sdf(model, "coarse"), packed_sdf(model, "fine")
     z = torch.empty(R, E, device=dev)
     sdf = torch.empty(R, E, device=dev)

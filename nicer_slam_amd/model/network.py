@@ -62,6 +62,7 @@ class SLAMNetwork(nn.Module):
         self.draws = None          # optional dict of pre-drawn randoms (parity tests); else device generator
         self.engine = "auto"       # "auto" | "fused" | "composed"
         self.last_engine = None    # which engine the most recent forward used
+        self.mlp_precision = "fp32"   # fused engine only: "fp32" | "bf16" | "bf16_colour" (fused/sampler.py::precision_of)
         self.voxel_sync = None     # multi-GPU mapping: callable(voxels, before) summing the visit deltas over ranks
 
     # ------------------------------------------------------------------ plumbing

@@ -1,0 +1,83 @@
+"""Optional bf16-operand MLP modes of the fused engine (BASELINE configs[2] "bf16 MLP" and configs[4] "bf16 + fp32 SDF
+head") against the default fp32-faithful mode, at those configs' per-GPU shapes.  Tolerance: rel 2e-2 on rgb
+for the bf16 configurations, the fp32 SDF head held to the fp32 bound (here: bit-identical, the same kernels run)."""
+import pytest
+import torch
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+class _DS:
+    img_res = (680, 1200)
+
+
+def _model(n_samples):
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    torch.manual_seed(0)
+    model = SLAMNetwork(replica_model_conf(n_samples, 640, 32, use_warp_loss=False), dataset=_DS(), n_images=1).cuda().train()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    with torch.no_grad():
+        for enc, s in ((model.implicit_network.coarse.encoding, 0.02), (model.implicit_network.fine.encoding, 0.02),
+                       (model.rendering_network.encoding, 0.3)):
+            enc.embeddings.copy_((torch.rand(enc.embeddings.shape, device="cuda", generator=g) * 2 - 1) * s)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    model.engine = "fused"
+    return model
+
+
+def _run(model, R, S, precision, z_override=None):
+    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    g = torch.Generator(device="cuda").manual_seed(7)
+    idx = torch.randint(680 * 1200, (1, R), device="cuda", generator=g)
+    uv = torch.stack([(idx % 1200).float(), (idx // 1200).float()], -1)
+    K = torch.eye(4, device="cuda")
+    K[0, 0] = K[1, 1] = 600.0
+    K[0, 2], K[1, 2] = 599.5, 339.5
+    gt = torch.rand(R, 3, device="cuda", generator=g)
+    model.mlp_precision = precision
+    model.draws = {"t_rand": torch.rand(R, 640, device="cuda", generator=g),
+                   "extra_idx": torch.randperm(640, device="cuda", generator=g)[:32],
+                   "eik_idx": torch.zeros(R, dtype=torch.long, device="cuda")}
+    if z_override is not None:
+        model.draws["z_vals_override"] = z_override
+    cam = torch.tensor([1.0, 0.01, -0.02, 0.015, 0.1, 0.0, -0.2], device="cuda", requires_grad=True)
+    out = model({"intrinsics": K[None], "uv": uv, "pose": get_camera_from_tensor(cam).unsqueeze(0)},
+                torch.zeros(1, dtype=torch.long, device="cuda"), {}, mode="tracking", frame_idx=1)
+    assert model.last_engine == "fused" and out["z_vals"].shape == (R, S)
+    (out["rgb_values"].reshape(-1, 3) - gt).abs().mean().backward()
+    return out, cam.grad.clone()
+
+
+@pytest.mark.parametrize("R,n_samples", [(512, 94), (1024, 158)])       # configs[2]: 4096x128 over 8 GPUs; configs[4]: 8192x192
+def test_bf16_colour_mlp_keeps_the_fp32_sdf_head(R, n_samples):
+    model = _model(n_samples)
+    S = n_samples + 34
+    ref, g_ref = _run(model, R, S, "fp32")
+    out, g = _run(model, R, S, "bf16_colour")
+    for k in ("z_vals", "sdf", "weights", "depth_values"):               # SDF networks untouched: the same kernels
+        assert torch.equal(out[k], ref[k]), k
+    assert_close(out["rgb_values"], ref["rgb_values"].detach().cpu().numpy(), 5e-3, 2e-2, "rgb_values (bf16 colour MLP)")
+    assert float((out["rgb_values"] - ref["rgb_values"]).abs().max()) > 0            # the bf16 kernels really ran
+    assert_close(g, g_ref.cpu().numpy(), 5e-2 * float(g_ref.abs().max()), 5e-2, "pose gradient")
+
+
+@pytest.mark.parametrize("R,n_samples", [(512, 94)])
+def test_bf16_everywhere(R, n_samples):
+    model = _model(n_samples)
+    S = n_samples + 34
+    ref, g_ref = _run(model, R, S, "fp32")
+    out, g = _run(model, R, S, "bf16", z_override=ref["z_vals"].detach())   # same sample positions: compare the networks
+    # bf16 operands (8 significand bits) through the geometric-init SDF MLPs: |d sdf| of a few 1e-3 on values of O(0.1-1),
+    # i.e. a surface shift of a few millimetres in scene units -- the reason configs[4] keeps the SDF head in fp32
+    assert_close(out["sdf"], ref["sdf"].detach().cpu().numpy(), 2e-2, 2e-2, "sdf (bf16 SDF MLPs)")
+    assert float((out["sdf"] - ref["sdf"]).abs().max()) > 1e-4
+    assert_close(out["rgb_values"], ref["rgb_values"].detach().cpu().numpy(), 6e-2, 2e-2, "rgb_values")
+    free, _ = _run(model, R, S, "bf16")                                  # the bf16 sampler itself: valid, sorted samples
+    z = free["z_vals"]
+    assert bool((z[:, 1:] >= z[:, :-1]).all()) and bool(torch.isfinite(z).all())
+    with pytest.raises(ValueError):
+        _run(model, 8, S, "fp16")

@@ -41,8 +41,11 @@ ALGO_MAC = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prewarm-s", type=float, default=1.0,
+                    help="seconds of an unrelated GEMM loop before the W warm-up steps: a step is < 1 ms, so W steps alone "
+                         "end before the GPU's power management has left its idle clocks (measured: 1.1 vs 0.8 ms/step)")
     ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step")
     ap.add_argument("--samples", type=int, default=128, help="composite samples per ray (N_samples = S-34)")
     ap.add_argument("--engine", default="auto", choices=["auto", "fused", "composed"])
@@ -127,6 +130,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.prewarm_s > 0:          # bring the clocks up with work that touches none of the tracker's state or caches
+        a = torch.randn(4096, 4096, device=device)
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.prewarm_s:
+            for _ in range(8):
+                a @ a
+            torch.cuda.synchronize()
+        del a
     for i in range(args.warmup):
         step(i)
     fence()
@@ -201,7 +212,7 @@ def main():
                        "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "sampler_evals_per_ray": 640,
                        "global_rays": args.rays * world,
                        "engine": "fused" if Stepper.__name__ == "KernelTracker" else model.last_engine, "param_grads": args.param_grads,
-                       "hip_graph": bool(use_graph), "driver": Stepper.__name__,
+                       "hip_graph": bool(use_graph), "driver": Stepper.__name__, "clock_prewarm_s": args.prewarm_s,
                        "parallelism": f"ray-shard x{world}" if world > 1 else "single"},
             "final_loss": round(last, 6),
             "roofline": roof, "cpu_baseline": cpu, "mapping_iteration": mapping,

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --no-mapping --steps 20 --warmup 3"
+B="python $R/bench.py --no-cpu-baseline --no-mapping --steps 200 --warmup 20"
 BE="$B --no-graph"
 (timeout 400 $B) > $OUT/bench_line.json 2> /tmp/b.err || true
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- $B > /tmp/ks.log 2>&1

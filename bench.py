@@ -59,7 +59,7 @@ def parse():
                          "bf16_colour = the optional reduced-precision modes of BASELINE configs[2]/[4] (NOT the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mapping", action="store_true", help="skip the (untimed-for-value) mapping-iteration leg")
-    ap.add_argument("--cpu-rays", type=int, default=64)
+    ap.add_argument("--cpu-rays", type=int, default=1024)
     return ap.parse_args()
 
 

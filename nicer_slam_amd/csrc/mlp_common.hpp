@@ -1,19 +1,20 @@
-// mlp_common.hpp -- register-resident batched MLP on fp32 MFMA for the fused render-core kernels.
+// mlp_common.hpp -- register-resident batched MLP on the gfx950 matrix cores for the fused render-core kernels.
 //
-// Tiling (wave64, v_mfma_f32_32x32x2_f32, exact fp32 = an fmaf chain):
-//   * a wave owns NT "point tiles" of 32 points; lane l works for point (l & 31) of each tile, and the two
-//     half-waves h = l >> 5 split every per-point job in two (half of the grid levels, half of the positional
-//     encoding pairs, half of every activation vector);
+// Tiling (wave64, v_mfma_f32_32x32x16_bf16 with fp32 accumulation; fp32 operands enter as three exact bf16 pieces, see
+// the GEMM primitive below):
+//   * a wave owns a tile of 32 points; lane l works for point (l & 31), and the two half-waves h = l >> 5 split every
+//     per-point job in two (half of the grid levels, half of the positional-encoding pairs, half of every activation
+//     vector);
 //   * a layer is D[out, point] += W[out, k] * act[k, point]: the WEIGHTS are the MFMA "A" operand (M = output
 //     features, 32 per tile) and the ACTIVATIONS the "B" operand (N = points).  The MFMA result layout gives
 //     lane (p, h), register r of output tile t the feature  f = 32 t + (r & 3) + 8 (r >> 2) + 4 h  of point p.
-//     That register IS the B operand of k-step  s = 16 t + r  of the next layer (k-order inside a GEMM is free as
-//     long as A agrees), so layers chain in registers with no transposes, no LDS round trips and no barriers;
-//   * the weights are pre-packed on the host into that fragment order ("step-major, lane-minor", 4 k-steps per
-//     16-byte load) and read straight from global memory: every wave of the chip streams the same ~150 KB, which
-//     stays L1/L2 resident; a fragment costs one coalesced 1 KiB wave load per 4 MFMAs (256 cycles of matrix pipe).
+//     That register IS the B operand of k-slot  s = 16 t + r  of the next layer (k-order inside a GEMM is free as
+//     long as A agrees), so activations chain in registers with no transposes and no LDS round trips;
+//   * the weights are pre-packed on the device into that fragment order (fused/pack.py: slot groups of 8, three bf16
+//     pieces, lane-minor 16-byte fragments).  Kernels either stream the fragments per wave from L2 (gemm_op: sampler,
+//     colour forward) or stage each layer's block once per workgroup in LDS with asynchronous global->LDS copies
+//     (gemm_staged / gemm_staged_part: SDF networks, colour backward).
 //
-// The packed "A" (weight) block layout is described at the GEMM primitive below.
 // Packed per-feature vectors (biases, the sdf row) in activation layout:   idx = (t*2 + h)*16 + r.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -4,7 +4,8 @@
 //            GridPredefineDensity (code/model/density.py:37-67).
 //
 // k_sampler_sdf   one lane-pair per (ray, coarse sample): builds the stratified z, the point, both grid encodings,
-//                 the positional encoding and evaluates coarse+fine SDF MLPs on fp32 MFMA entirely in registers
+//                 the positional encoding and evaluates coarse+fine SDF MLPs on the matrix cores (fp32-faithful
+//                 split GEMM, mlp_common.hpp) with all activations in registers
 //                 (the reference's redundant second coarse evaluation, base_networks.py:31, is not repeated).
 // k_sample_rays   one wave per ray: SDF -> Laplace density (beta from the visit counter) -> alpha/transmittance
 //                 weights via a wave-shuffle scan -> pdf/cdf in LDS -> inverse-CDF samples by binary search ->

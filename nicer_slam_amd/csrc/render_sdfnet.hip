@@ -6,8 +6,8 @@
 //            ImplicitNetworkGrid_COMBINE (:7-47): the coarse and fine networks are run as two launches that
 //            accumulate into the same sdf / grad / feature buffers.
 //
-// One wave = 32 points (lane pair per point), everything in registers, weights streamed from L2 in fragment
-// order (mlp_common.hpp).  Per-point feature vectors travel between kernels in "HL" layout: float index
+// One wave = 32 points (lane pair per point), activations in registers, each layer's packed weights staged once per
+// workgroup in LDS (mlp_common.hpp).
 // ((tile*32 + q)*64 + lane), q = 16 t + r -- i.e. exactly the register image of the MFMA result, so the consumer's
 // B operand is a coalesced 256-byte load per register.
 //

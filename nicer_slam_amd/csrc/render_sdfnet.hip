@@ -7,7 +7,7 @@
 //            accumulate into the same sdf / grad / feature buffers.
 //
 // One wave = 32 points (lane pair per point), activations in registers, each layer's packed weights staged once per
-// workgroup in LDS (mlp_common.hpp).
+// workgroup in LDS (mlp_common.hpp).  Per-point feature vectors travel between kernels in "HL" layout: float index
 // ((tile*32 + q)*64 + lane), q = 16 t + r -- i.e. exactly the register image of the MFMA result, so the consumer's
 // B operand is a coalesced 256-byte load per register.
 //

@@ -7,6 +7,16 @@ objective is a mean over the global ray batch, code/model/loss.py:57-65)."""
 import torch
 import torch.distributed as dist
 
+def _bump_version(p):
+    """The kernel wrote p behind autograd's back: advance its version counter like an in-place op would (the packed-weight
+    caches of the fused engine key on it).  Private torch API with a portable fallback for the small tensors that matter."""
+    try:
+        torch._C._autograd._unsafe_set_version_counter((p,), (p._version + 1,))
+    except Exception:                      # older / newer torch: an in-place no-op does the same for MLP-sized tensors
+        if p.numel() <= (1 << 20):
+            p.add_(0)
+
+
 
 def shard_rays(n_rays, rank, world):
     """Contiguous, balanced shard [lo, hi) of n_rays for `rank`."""
@@ -131,4 +141,4 @@ class ShardedAdam(torch.optim.Optimizer):
                 flat_p = p.view(-1)
                 self.stepper(flat_p, p.grad.reshape(-1), state["exp_avg"], state["exp_avg_sq"], state["step"],
                              group["lr"], group["betas"], group["eps"])
-                torch._C._autograd._unsafe_set_version_counter((p,), (p._version + 1,))
+                _bump_version(p)

@@ -434,7 +434,64 @@ def loss_case(name, seed, frame_idx, stage, bs=2, n=12, S=6):
     print(name, {k: float(v) for k, v in res.items()})
 
 
+def func_case(name, seed):
+    """Function-level vectors for the rows that are plain PyTorch in the reference:
+    rend_util.get_camera_params (skewed K), UniformSampler.near_far_from_cube, get_embedder(6)/(4), GridPredefineDensity,
+    SLAMNetwork.volume_rendering, general.quad2rotation / get_camera_from_tensor -- inputs and the reference's outputs."""
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda *s: torch.rand(*s, generator=g)
+    rec = {}
+    # a17: camera 7-vector (non-unit quaternion) -> 4x4
+    cam = torch.cat([torch.tensor([[1.0, 0, 0, 0]]).repeat(3, 1) + 0.2 * (rnd(3, 4) - 0.5), rnd(3, 3) - 0.5], -1)
+    rec.update(a17_cam=cam, a17_pose=ref_general.get_camera_from_tensor(cam), a17_rot=ref_general.quad2rotation(cam[:, :4]))
+    # a1: pixels -> rays, with skew
+    uv, _, K = synth_inputs(seed, 3, 11)
+    pose = rec["a17_pose"]
+    dirs, loc = ref_rend.get_camera_params(uv, pose, K)
+    rec.update(a1_uv=uv, a1_K=K, a1_pose=pose, a1_ray_dirs=dirs, a1_cam_loc=loc)
+    # a2: cube intersection
+    samplers = ref_shims.import_ref("model.ray_sampler")
+    us = samplers.UniformSampler(1.0, 0.0, 16, 3.5, take_sphere_intersection=False) if False else None
+    o = (rnd(40, 3) - 0.5) * 1.2
+    d = torch.nn.functional.normalize(rnd(40, 3) - 0.5, dim=-1) * (0.5 + rnd(40, 1))
+    d[0, 1] = 0.0                                    # an axis-parallel component: the +1e-15 guard
+    o[1] = torch.tensor([1.5, 1.5, 1.5])             # outside, pointing away: no intersection
+    d[1] = torch.tensor([1.0, 0.5, 0.2])
+
+    class _U:
+        near, far = 0.0, 3.5
+    near, far = samplers.UniformSampler.near_far_from_cube(_U(), o.clone(), d.clone(), 1.0)
+    rec.update(a2_o=o, a2_d=d, a2_near=near, a2_far=far)
+    # a7: positional encodings
+    emb = ref_shims.import_ref("model.embedder")
+    x = (rnd(17, 3) - 0.5) * 2
+    for m in (6, 4):
+        fn, dim = emb.get_embedder(m, input_dims=3)
+        rec[f"a7_pe{m}"] = fn(x)
+    rec["a7_x"] = x
+    # a11: beta from the visit counter, Laplace density
+    dens = ref_shims.import_ref("model.density").GridPredefineDensity()
+    dens.voxels = torch.poisson(torch.full((64, 64, 64), 30.0), generator=g)
+    dens.voxel_res = 64
+    pts = (rnd(50, 3) - 0.5) * 2.02                  # some |x_d| > 0.99
+    sdf = (rnd(50, 1) - 0.5) * 0.2
+    rec.update(a11_voxels=dens.voxels, a11_x=pts, a11_sdf=sdf, a11_beta=dens.get_beta(pts), a11_sigma=dens(sdf, x=pts))
+    # a13: weights of one batch of rays
+    model, conf = build_model(seed, (4, 4, 8, 4, 8), (4, 32, 10, 8, 4), (4, 64, 10), 10, 32, 6, (0.05, 0.05, 0.3))
+    model.voxels = dens.voxels
+    model.density.voxels = dens.voxels
+    z = torch.sort(rnd(7, 9) * 2, dim=1).values
+    sd = (rnd(7 * 9, 1) - 0.4) * 0.1
+    xs = (rnd(7 * 9, 3) - 0.5) * 1.9
+    rec.update(a13_z=z, a13_sdf=sd, a13_x=xs, a13_weights=model.volume_rendering(z, sd, xs))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **t2n(rec))
+    print(name, {k: tuple(v.shape) for k, v in rec.items()})
+
+
 if __name__ == "__main__":
+    func_case("func_rows", 31)
+    if "--func-only" in sys.argv:
+        sys.exit(0)
     loss_case("loss_mapping_first_frame", 21, frame_idx=0, stage="coarse")
     loss_case("loss_mapping_fine", 22, frame_idx=7, stage="fine")
     if "--loss-only" in sys.argv:

@@ -8,7 +8,10 @@ network/grid sizes (1 GiB colour table), fp32, synthetic inputs already resident
 N > 1: every rank renders its own 1024-ray shard (rays are independent given replicated parameters) and the only
 exchange is one fused 9-float RCCL all-reduce (pose gradient, loss, ray count) per step  ->  "scaling": "weak".
 
-    python bench.py [--gpus N --steps K --warmup W]       (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE in
+the environment) or directly as `python bench.py --gpus N`, which re-executes itself under torch.distributed.run on
+127.0.0.1.  `--global-rays G` fixes the TOTAL batch (G/N rays per GPU) -> "scaling": "strong"; default: 1024 rays per GPU.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -30,6 +33,12 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak = the peak for this config'
 # Algorithmic multiply-accumulates per point of each per-point kernel (true layer sizes, no padding):
 #   SDF nets 71->64(->64->64)->65 Softplus, colour net 129->64->64->3; forward kernels include the reverse pass that
 #   yields grad sdf, backward kernels include the recomputation + tangent sweep + reverse sweep.
+# v_mfma_f32_32x32x16_bf16 instructions per 32-point wave tile (static: groups x tiles x 6 products, see csrc/): with 32
+# cycles per instruction per SIMD this gives the matrix-pipe busy time, reported beside the fp32-equivalent `frac`.
+MFMA_PER_TILE = {"k_sampler_sdf": 216, "k_sdfnet_fwd<coarse>": 180, "k_sdfnet_fwd<fine>": 372, "k_sdfnet_bwd<coarse>": 288,
+                 "k_sdfnet_bwd<fine>": 672, "k_colour_fwd": 156, "k_colour_bwd": 324}
+N_SIMD, NOMINAL_GHZ = 1024, 2.4
+
 ALGO_MAC = {
     "k_sampler_sdf": 17408,            # coarse (4544+64) + fine (4544+2*4096+64): sdf rows only
     "k_sdfnet_fwd<coarse>": 13248, "k_sdfnet_fwd<fine>": 29632,
@@ -46,7 +55,11 @@ def parse():
     ap.add_argument("--prewarm-s", type=float, default=1.0,
                     help="seconds of an unrelated GEMM loop before the W warm-up steps: a step is < 1 ms, so W steps alone "
                          "end before the GPU's power management has left its idle clocks (measured: 1.1 vs 0.8 ms/step)")
-    ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step")
+    ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step (weak scaling)")
+    ap.add_argument("--global-rays", type=int, default=0,
+                    help="total rays per step over all GPUs (strong scaling: each rank renders global/N); e.g. 4096 = BASELINE "
+                         "configs[2], 1024 = configs[1] spread over N GPUs")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the SLAMNetwork.forward + autograd leg (N = 1 only)")
     ap.add_argument("--samples", type=int, default=128, help="composite samples per ray (N_samples = S-34)")
     ap.add_argument("--engine", default="auto", choices=["auto", "fused", "composed"])
     ap.add_argument("--param-grads", action="store_true",
@@ -90,17 +103,40 @@ def synth_batch(gen, n_rays, device):
     return uv, torch.rand(n_rays, 3, generator=gen, device=device)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    n_dev = torch.cuda.device_count()
+    oversub = world > n_dev          # smoke-test mode: more ranks than GPUs (RCCL refuses two ranks on one device)
+    torch.cuda.set_device(local % n_dev)
+    device = torch.device("cuda", local % n_dev)
+    if world > 1:
+        if oversub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+    if args.global_rays:
+        assert args.global_rays % world == 0, "--global-rays must be divisible by --gpus"
+        args.rays = args.global_rays // world
 
     from nicer_slam_amd.hashencoder import backend as be
     from nicer_slam_amd.utils.general import get_camera_from_tensor
@@ -126,6 +162,7 @@ def main():
         return stepper.step(uv, gt)
 
     def fence():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -175,17 +212,23 @@ def main():
         if agg:
             name, (tms, nbytes, n) = max(agg.items(), key=lambda kv: kv[1][0])
             pts = args.rays * (640 if name == "k_sampler_sdf" else args.samples)
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")   # FETCH_SIZE/WRITE_SIZE of the same command
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(name)
+            # HBM bytes per launch of that kernel: FETCH_SIZE + WRITE_SIZE from separate `rocprofv3 --pmc` passes over this same
+            # command (tools/profile_round.sh -> profiles/rNN_hbm_traffic.json, newest round wins); counters cannot be read
+            # from inside the run, so the value is null when no committed summary names this kernel.
+            traffic, traffic_src = None, None
+            import glob
+            for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+                t = json.load(open(tpath)).get(name)
+                if t is not None:
+                    traffic, traffic_src = t, os.path.relpath(tpath, ROOT)
+                    break
             if name in ALGO_MAC:     # per-point MLP kernels: bounded by the matrix pipe
                 flops = 2.0 * ALGO_MAC[name] * pts
                 ach = flops / (tms / n * 1e-3) / 1e12
                 bf16_kernel = args.precision == "bf16" or (args.precision == "bf16_colour" and "colour" in name)
                 peak = MFMA_BF16_PEAK_TFLOPS if bf16_kernel else MFMA_F32_PEAK_TFLOPS
                 roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
-                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "flops_per_launch": flops,
                         "mfma_path": "plain bf16 operands, one MFMA per product block (dense bf16 peak)" if bf16_kernel else
                         "fp32 products as 6 bf16 MFMAs on 3-way split operands (fp32-faithful); achieved counts "
@@ -193,18 +236,28 @@ def main():
             else:
                 ach = nbytes / (tms * 1e-3) / 1e9
                 roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "bytes_per_launch": nbytes // n}
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                        "bytes_per_launch": nbytes // n}
+            if name in MFMA_PER_TILE and args.precision == "fp32":
+                tiles = (pts + 31) // 32
+                busy = MFMA_PER_TILE[name] * tiles * 32.0 / N_SIMD               # matrix-pipe busy cycles per SIMD
+                roof["mfma_pipe"] = {"instructions_per_launch": MFMA_PER_TILE[name] * tiles, "busy_cycles_per_simd": round(busy),
+                                     "utilisation_at_2.4GHz": round(busy / (tms / n * 1e-3 * NOMINAL_GHZ * 1e9), 4),
+                                     "note": "6 bf16 MFMAs per fp32 product block; the fp32-equivalent frac above prices the "
+                                             "kernel against the fp32 peak, this against the matrix pipe it actually uses"}
             roof.update({"launches": n, "avg_launch_us": round(tms / n * 1e3, 2), "share_of_step": round(tms / n / ms, 4),
                          "all_kernels_us": {k: round(v[0] / v[2] * 1e3, 1) for k, v in sorted(agg.items())}})
         cpu = None if args.no_cpu_baseline else cpu_baseline(args, model, conf)
-        mapping = None
+        mapping, dropin = None, None
+        if world == 1 and not args.no_dropin and args.engine != "composed" and args.precision == "fp32":
+            dropin = dropin_leg(args, device, K, batches)
         if world == 1 and not args.no_mapping and args.engine != "composed" and args.precision == "fp32":
             del stepper, eager
             mapping = mapping_leg(device)
         line = {
             "metric": "rays/sec (fwd+bwd), one tracking iteration", "value": round(rays_total / dt, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.global_rays else "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16": "bf16 MLP operands (f32 accumulate, encoders and compositing f32)",
                       "bf16_colour": "bf16 colour-MLP operands, f32 SDF head"}[args.precision], "data": "synthetic",
             "config": {"workload": f"Replica room0 tracking iteration, {args.rays} rays x {args.samples} samples "
@@ -213,9 +266,12 @@ def main():
                        "global_rays": args.rays * world,
                        "engine": "fused" if Stepper.__name__ == "KernelTracker" else model.last_engine, "param_grads": args.param_grads,
                        "hip_graph": bool(use_graph), "driver": Stepper.__name__, "clock_prewarm_s": args.prewarm_s,
-                       "parallelism": f"ray-shard x{world}" if world > 1 else "single"},
+                       "parallelism": f"ray-shard x{world}" if world > 1 else "single",
+                       "rccl_ranks": 0 if (world == 1 or oversub) else world,
+                       "exchange": None if world == 1 else "one 9-float all-reduce (pose gradient, loss, ray count) per step",
+                       "oversubscribed": oversub or None},
             "final_loss": round(last, 6),
-            "roofline": roof, "cpu_baseline": cpu, "mapping_iteration": mapping,
+            "roofline": roof, "cpu_baseline": cpu, "dropin": dropin, "mapping_iteration": mapping,
         }
         print(json.dumps(line))
     if world > 1:
@@ -296,7 +352,7 @@ def cpu_baseline(args, model, conf):
     K[0, 2], K[1, 2] = 599.5, 339.5
     vox = torch.zeros(64, 64, 64)
     times = []
-    for it in range(5):
+    for it in range(7):
         idx = torch.randint(H * W, (1, n), generator=g)
         uv = torch.stack([(idx % W).float(), (idx // W).float()], -1)
         gt = torch.rand(n, 3, generator=g)
@@ -308,11 +364,51 @@ def cpu_baseline(args, model, conf):
                        mode="tracking", training=True)
         R.rgb_l1(out, gt).backward()
         times.append(time.perf_counter() - t0)
-    med = sorted(times[2:])[len(times[2:]) // 2]
-    return {"value": round(n / med, 1), "unit": "rays/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(),
+    timed = sorted(times[2:])
+    med = timed[len(timed) // 2]
+    from oracle import hashenc
+    omp = min(16, os.cpu_count() or 1)           # oracle/hashenc.py: nso_set_threads(min(16, cores))
+    return {"value": round(n / med, 1), "unit": "rays/s", "cores": max(torch.get_num_threads(), omp),
+            "threads": {"torch_intraop": torch.get_num_threads(), "c_hash_kernels_openmp": omp}, "host_cores": os.cpu_count(),
             "kind": "port",
             "sample": f"{n} rays x (640 sampler + {args.samples} composite) samples, fwd+bwd to pose grad, "
-                      f"median of 3 after 2 warm-ups, torch {torch.get_num_threads()} threads + OpenMP C hash kernels"}
+                      f"median of {len(timed)} iterations after 2 warm-ups ({round(sum(times), 1)} s of host time in all)"}
+
+
+def dropin_leg(args, device, K, batches, steps=60):
+    """The same tracking iteration driven the way the reference's loop drives it (volsdf_train.py:406-427): camera 7-vector
+    -> get_camera_from_tensor -> SLAMNetwork.forward(mode="tracking") -> L1 -> loss.backward() -> torch.optim.Adam -- torch
+    autograd around the fused autograd.Functions, no KernelTracker.  Two rows:
+      faithful   every model parameter requires grad, exactly as volsdf_train.py builds the model (the reference computes and
+                 discards all parameter gradients in tracking, :547 zeroes them before any use);
+      pose_only  model.tracking_param_grads = False -- one attribute -- skips that discarded work.
+    Context numbers; `value` stays the KernelTracker iteration."""
+    from nicer_slam_amd.tracking import TrackingStepper
+    out = {"driver": "SLAMNetwork.forward + torch autograd + torch.optim.Adam (TrackingStepper)"}
+    for row, flag in (("pose_only", False), ("faithful", True)):
+        a = argparse.Namespace(**vars(args))
+        a.param_grads = True                        # make_model leaves requires_grad as constructed
+        model, _ = make_model(a, device)
+        model.tracking_param_grads = flag
+        cam = torch.tensor([1.0, 0, 0, 0, 0.1, 0.0, -0.2], device=device)
+        try:
+            st = TrackingStepper(model, K, args.rays, cam, lr=0.005, use_graph=not flag, world=1)
+            n = min(steps, len(batches))
+            for i in range(min(5, n)):
+                st.step(*batches[i])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                st.step(*batches[i])
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            out[row] = {"ms_per_step": round(dt * 1e3, 4), "rays_per_s": round(args.rays / dt, 1), "engine": model.last_engine,
+                        "hip_graph": not flag, "steps": n}
+        except Exception as e:      # a context leg must never take the headline down
+            out[row] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        del model
+        torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

@@ -150,7 +150,8 @@ int nsa_colour_backward(const nsa_points_t *pts, const nsa_grid_t *grid, const f
  *   emit     [nsa_*_emit_rows()][emit_ld] per-point vectors, column = point index (emit_ld >= ceil(P/32)*32, columns
  *            of padding points are written as 0).  The weight gradients are GEMMs over these rows (row map: the
  *            SE_* / CE_* enums in csrc/render_sdfnet.hip, csrc/render_colour.hip; host side fused/mapping.py).
- *            SDF: coarse network (one hidden layer) only -- the fine MLP is frozen in the reference; may be NULL. */
+ *            SDF: nsa_sdfnet_emit_rows_nh(grid->n_hidden) rows (464 for the coarse network, 976 for the fine one, whose
+ *            gradients the reference computes but never applies, volsdf_train.py:150-173); may be NULL. */
 int nsa_sdfnet_backward_params(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, const float *g_sdf,
                                const float *g_feat_hl, const float *g_grad, int accumulate, float *g_x, float *g_table,
                                float *emit, uint32_t emit_ld, nsa_stream_t stream);
@@ -158,7 +159,8 @@ int nsa_colour_backward_params(const nsa_points_t *pts, const nsa_grid_t *grid, 
                                const float *feat_hl, const float *save, const float *g_rgb, int grid_grad,
                                float *g_feat_hl, float *g_grad, float *g_x, float *g_dir, float *g_table, float *emit,
                                uint32_t emit_ld, nsa_stream_t stream);
-int nsa_sdfnet_emit_rows(void);
+int nsa_sdfnet_emit_rows(void);                 /* one hidden layer (coarse network) */
+int nsa_sdfnet_emit_rows_nh(uint32_t n_hidden); /* 1 or 3 hidden layers; -1 otherwise */
 int nsa_colour_emit_rows(void);
 
 /* Per-ray SDF -> density -> alpha compositing.  replaces SLAMNetwork.volume_rendering (code/model/network.py:349-370)
@@ -238,13 +240,18 @@ int nsa_track_head(const float *uv, const float *K, const float *cam, uint32_t n
                    float *rays_d, float *depth_scale, nsa_stream_t stream);
 int nsa_track_tail(const float *uv, const float *K, float *cam, uint32_t n, const float *g_rays_o, const float *g_rays_d,
                    float *g_cam, int do_adam, float reduce_weight, float *exp_avg, float *exp_avg_sq, float *step, float lr,
-                   float beta1, float beta2, float eps, uint32_t lr_step, float lr_gamma, nsa_stream_t stream);
+                   float beta1, float beta2, float eps, uint32_t lr_step, float lr_gamma, const float *loss, float *best,
+                   nsa_stream_t stream);
+/* `best` (optional, 8 floats, with do_adam): the arg-min-loss camera of the frame -- best[0] = smallest loss[0] seen,
+ * best[1..7] = the camera AFTER the step of that iteration (strict <).  replaces candidate_cam_tensor / current_min_loss
+ * (code/training/volsdf_train.py:402-403,441-446).  Start a frame with best[0] = 1e10. */
 /* Multi-GPU form: reduce_weight = this rank's ray count > 0 turns g_cam into the 9-float message
  * [w*g_cam(7), w*loss (slot 7 as left by nsa_l1_loss), w] that is summed over ranks with ONE all-reduce; the step is then
  * nsa_adam_step_scaled(cam, msg, msg + 8, ...) = Adam on msg[0..6] / msg[8]. */
 int nsa_adam_step_scaled(float *param, const float *grad, const float *grad_div, float *exp_avg, float *exp_avg_sq,
                          float *step, uint32_t n, float lr, float beta1, float beta2, float eps, uint32_t lr_step,
-                         float lr_gamma, nsa_stream_t stream);
+                         float lr_gamma, const float *loss, float *best, nsa_stream_t stream);
+/* (loss, best: as for nsa_track_tail, best[1..n]; the loss compared is loss[0] / grad_div[0]) */
 
 /* ---- Section 4: mapping-iteration tail ------------------------------------------------------------------------ */
 

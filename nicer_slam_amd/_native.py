@@ -12,7 +12,11 @@ import os
 # every launch fail on the GPU box.)
 import torch  # noqa: F401  (must precede the CDLL below)
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnicer_slam_amd.so")
+# NSA_LIB_TAG selects a side-by-side experiment build of the same library (nicer_slam_amd/build.py, NSA_BUILD_TAG);
+# unset = the product library.  Either way it is the HIP library or nothing.
+_TAG = os.environ.get("NSA_LIB_TAG", "")
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                         "libnicer_slam_amd" + ("_" + _TAG if _TAG else "") + ".so")
 
 if not os.path.exists(_LIB_PATH):
     raise ImportError(
@@ -85,7 +89,10 @@ lib.nsa_sdfnet_emit_rows.restype = _i
 lib.nsa_sdfnet_emit_rows.argtypes = []
 lib.nsa_colour_emit_rows.restype = _i
 lib.nsa_colour_emit_rows.argtypes = []
-EXPORTS += ["nsa_sdfnet_backward_params", "nsa_colour_backward_params", "nsa_sdfnet_emit_rows", "nsa_colour_emit_rows"]
+lib.nsa_sdfnet_emit_rows_nh.restype = _i
+lib.nsa_sdfnet_emit_rows_nh.argtypes = [_u32]
+EXPORTS += ["nsa_sdfnet_backward_params", "nsa_colour_backward_params", "nsa_sdfnet_emit_rows", "nsa_colour_emit_rows",
+            "nsa_sdfnet_emit_rows_nh"]
 EXPORTS += ["nsa_sdfnet_forward", "nsa_sdfnet_backward", "nsa_colour_forward", "nsa_colour_backward",
             "nsa_composite_forward", "nsa_composite_backward", "nsa_rays_backward"]
 
@@ -122,7 +129,8 @@ EXPORTS += ["nsa_draw_picks"]
 lib.nsa_track_head.restype = _i
 lib.nsa_track_head.argtypes = [_p, _p, _p, _u32, _p, _p, _p, _p, _p]
 lib.nsa_track_tail.restype = _i
-lib.nsa_track_tail.argtypes = [_p, _p, _p, _u32, _p, _p, _p, _i, _f32, _p, _p, _p, _f32, _f32, _f32, _f32, _u32, _f32, _p]
+lib.nsa_track_tail.argtypes = [_p, _p, _p, _u32, _p, _p, _p, _i, _f32, _p, _p, _p, _f32, _f32, _f32, _f32, _u32, _f32, _p, _p,
+                               _p]
 EXPORTS += ["nsa_track_head", "nsa_track_tail"]
 
 lib.nsa_morton_keys.restype = _i
@@ -130,5 +138,5 @@ lib.nsa_morton_keys.argtypes = [_pp, _p, _p]
 EXPORTS += ["nsa_morton_keys"]
 
 lib.nsa_adam_step_scaled.restype = _i
-lib.nsa_adam_step_scaled.argtypes = [_p, _p, _p, _p, _p, _p, _u32, _f32, _f32, _f32, _f32, _u32, _f32, _p]
+lib.nsa_adam_step_scaled.argtypes = [_p, _p, _p, _p, _p, _p, _u32, _f32, _f32, _f32, _f32, _u32, _f32, _p, _p, _p]
 EXPORTS += ["nsa_adam_step_scaled"]

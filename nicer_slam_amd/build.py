@@ -12,8 +12,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "lib", "libnicer_slam_amd.so")
+# NSA_BUILD_TAG=<tag> (+ NSA_EXTRA_HIPCC_FLAGS): a side-by-side experiment build (tools/ab_kernels.py), never the product
+TAG = os.environ.get("NSA_BUILD_TAG", "")
+OBJ = os.path.join(HERE, "build" + ("_" + TAG if TAG else ""))
+LIB = os.path.join(HERE, "lib", "libnicer_slam_amd" + ("_" + TAG if TAG else "") + ".so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"] + os.environ.get("NSA_EXTRA_HIPCC_FLAGS", "").split()

@@ -281,7 +281,11 @@ __device__ __forceinline__ void gather_corners(const float* __restrict__ table, 
         if (GENERIC) {
             if ((g.flags & LV_GENERIC) != 0) idx = (hashed ? x : a) % g.rows;
         }
+#ifdef NSA_ABL_NOGATHER     // timing experiment only: index arithmetic kept, no memory access
+        _Pragma("unroll") for (int c = 0; c < C; ++c) v[corner][c] = __uint_as_float((idx + c) | 0x3F000000u);
+#else
         load_row<C>(table + (size_t)(g.row0 + idx) * C, v[corner]);
+#endif
     }
 }
 

@@ -67,10 +67,15 @@ __device__ __forceinline__ void split8(const float (&x)[8], BFrag& f) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         u0[e] = __float_as_uint(x[e]);
+#ifdef NSA_ABL_NOSPLIT      // timing experiment only (tools/ab_kernels.py): no residual arithmetic, wrong numbers
+        u1[e] = u0[e];
+        u2[e] = u0[e];
+#else
         const float r1 = x[e] - __uint_as_float(u0[e] & 0xFFFF0000u);
         u1[e] = __float_as_uint(r1);
         const float r2 = r1 - __uint_as_float(u1[e] & 0xFFFF0000u);
         u2[e] = __float_as_uint(r2);
+#endif
     }
 #define NSA_PK(u, d) __builtin_amdgcn_perm(u[2 * d + 1], u[2 * d], 0x07060302u)
     f.p[0] = make_uint4(NSA_PK(u0, 0), NSA_PK(u0, 1), NSA_PK(u0, 2), NSA_PK(u0, 3));
@@ -119,6 +124,14 @@ __device__ __forceinline__ void mma_group(const AV (&a)[MT][3], const float (&x)
     if constexpr (kPieces == 3) {
         BFrag bf;
         split8(x, bf);
+#ifdef NSA_ABL_NOMFMA       // timing experiment only: keep the split alive, drop the matrix instructions and the A fragments
+        {
+            unsigned t = bf.p[0].x ^ bf.p[0].y ^ bf.p[0].z ^ bf.p[0].w ^ bf.p[1].x ^ bf.p[1].y ^ bf.p[1].z ^ bf.p[1].w ^
+                         bf.p[2].x ^ bf.p[2].y ^ bf.p[2].z ^ bf.p[2].w;
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt][0] += __uint_as_float(t & 0x3F800000u);
+            return;
+        }
+#endif
         const bf16x8_t bh = as_bf16x8(bf.p[0]), bm = as_bf16x8(bf.p[1]), bl = as_bf16x8(bf.p[2]);
         // smallest terms first; the MT accumulators alternate so no MFMA waits on its predecessor
 #define NSA_MM(AP, BV)                                                                                   \
@@ -360,6 +373,9 @@ constexpr float SP_OUT = 0.01f * 0.6931471805599453f;      // ln(2) / beta
 // value only (sampler): the overflow-free form max(a,0) + ln(1 + e^{-|beta a|})/beta -- no compare/select, and equal to
 // torch's thresholded softplus to the last ulp (for beta a > 20 the log term is < 2e-9 relative and rounds away).
 __device__ __forceinline__ float softplus100(float a) {
+#ifdef NSA_ABL_NOSOFTPLUS   // timing experiment only
+    return fmaxf(a, 0.0f);
+#endif
     const float t = SP_K * a;
     return fmaf(SP_OUT, __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(t))), fmaxf(a, 0.0f));
 }
@@ -369,6 +385,10 @@ __device__ __forceinline__ float softplus100_d1(float a) {
     return t > SP_LIN ? 1.0f : e * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 __device__ __forceinline__ void softplus100_all(float a, float& y, float& d1, float& d2) {
+#ifdef NSA_ABL_NOSOFTPLUS   // timing experiment only
+    y = fmaxf(a, 0.0f); d1 = a > 0.0f ? 1.0f : 0.5f; d2 = 0.0f;
+    return;
+#endif
     const float t = SP_K * a;
     const float e = __builtin_amdgcn_exp2f(t);
     const bool lin = t > SP_LIN;
@@ -380,6 +400,10 @@ __device__ __forceinline__ void softplus100_all(float a, float& y, float& d1, fl
 
 // sin and cos of a (|a| <~ 1e3) sharing one Cody-Waite reduction to [-pi/4, pi/4]; ~1 ulp-class polynomials.
 __device__ __forceinline__ void sincos_f(float a, float& s, float& c) {
+#ifdef NSA_ABL_NOPE         // timing experiment only
+    s = a; c = 1.0f - a;
+    return;
+#endif
     const float n = rintf(a * 0.63661977236758134f);          // a / (pi/2)
     float r = fmaf(n, -1.5707963705062866f, a);                 // pi/2 = c1 + c2 + c3 (float32 parts)
     r = fmaf(n, 4.371138828673793e-08f, r);

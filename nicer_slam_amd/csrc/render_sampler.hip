@@ -343,7 +343,10 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
         float v = INFINITY;
         if (j == N) v = a.near;
         else if (j == N + 1) v = a.far[ray];
-        else if (j < S) v = zb[a.extra_idx[j - N - 2]];
+        else if (j < S) {                                 // caller-supplied pick: clamped to the ray's E coarse samples
+            const uint32_t e = (uint32_t)a.extra_idx[j - N - 2];
+            v = zb[e < E ? e : E - 1];
+        }
         sb[j] = v;
     }
     wave_sync();
@@ -362,7 +365,10 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
     }
     if (live) {
         for (uint32_t j = lane; j < S; j += 64) a.z_vals[(size_t)ray * S + j] = sb[j];
-        if (a.z_eik && lane == 0) a.z_eik[ray] = sb[a.eik_idx[ray]];
+        if (a.z_eik && lane == 0) {
+            const uint32_t e = (uint32_t)a.eik_idx[ray];
+            a.z_eik[ray] = sb[e < S ? e : S - 1];
+        }
     }
 }
 

@@ -43,11 +43,25 @@ struct SdfNetArgs {
     uint32_t emit_ld;
 };
 
-// Rows of the emission buffer of a one-hidden-layer (coarse) network; column = tile*32 + point-in-tile.
-//   dW0 = AB1 H0^T + DA1 TIN^T,  db0 = sum AB1,  dW1[0] = sum sbar H1 + TH1,  dW1[1:] = FB H1^T,  db1 = [sum sbar, sum FB]
+// Rows of the emission buffer of a network with NH hidden layers; column = tile*32 + point-in-tile.  With
+//   AB_k = total cotangent of a_k, DA_k = sp'(a_k) dh_k (reverse pass), H_k = h_k, TH_k = sp'(a_k) ta_k (tangent sweep), FB = fbar:
+//   dW_0 = AB_1 H0^T + DA_1 TIN^T,   dW_k = AB_{k+1} H_k^T + DA_{k+1} TH_k^T  (0 < k < NH),   db_k = sum AB_{k+1},
+//   dW_NH[0] = sum sbar H_NH + TH_NH,   dW_NH[1:] = FB H_NH^T,   db_NH = [sum sbar, sum FB].
 // H0/TIN rows are first-layer slots (row = 2*slot + half), the others are hidden features in reference order.
-// (the three regions whose row sums are needed -- AB1, TH1, FB -- are contiguous: one reduction)
-enum : int { SE_H0 = 0, SE_TIN = 72, SE_DA1 = 144, SE_H1 = 208, SE_AB1 = 272, SE_TH1 = 336, SE_FB = 400, SE_ROWS = 464 };
+// Region order [H0 | TIN | DA_1.. | H_1.. | TH_1..TH_{NH-1} | AB_1..AB_NH | TH_NH | FB]: everything whose row sums are
+// needed (AB_k, TH_NH, FB) is contiguous -- one reduction.  NH = 1 gives 0/72/144/208/272/336/400, 464 rows; NH = 3: 976.
+template <int NH>
+struct SE {
+    static constexpr int H0 = 0, TIN = 72;
+    __host__ __device__ static constexpr int DA(int k) { return 144 + 64 * (k - 1); }
+    __host__ __device__ static constexpr int H(int k) { return 144 + 64 * NH + 64 * (k - 1); }
+    __host__ __device__ static constexpr int AB(int k) { return 144 + 128 * NH + 64 * (NH - 1) + 64 * (k - 1); }
+    __host__ __device__ static constexpr int TH(int k) { return k < NH ? 144 + 128 * NH + 64 * (k - 1) : AB(1) + 64 * NH; }
+    static constexpr int FB = 144 + 128 * NH + 64 * (NH - 1) + 64 * NH + 64;
+    static constexpr int ROWS = FB + 64;
+};
+static_assert(SE<1>::DA(1) == 144 && SE<1>::H(1) == 208 && SE<1>::AB(1) == 272 && SE<1>::TH(1) == 336 && SE<1>::FB == 400 &&
+              SE<1>::ROWS == 464 && SE<3>::ROWS == 976, "emission row map");
 
 struct Emitter {
     float* base;
@@ -83,7 +97,8 @@ struct SdfOps {
 
 template <int NH, class Seq>
 __device__ __forceinline__ void hidden_forward(float* stage, int op0, const float* __restrict__ wp, int lane, int h,
-                                               const float (&in)[SDF_IN_STEPS], float (&sg)[NH][HS], float (&hlast)[HS]) {
+                                               const float (&in)[SDF_IN_STEPS], float (&sg)[NH][HS], float (&hlast)[HS],
+                                               const Emitter* em = nullptr) {
     using P = SdfPack<NH>;
     f32x16 acc[2];
     load_vec<2>(wp + P::kB0, h, acc);
@@ -95,6 +110,10 @@ __device__ __forceinline__ void hidden_forward(float* stage, int op0, const floa
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) softplus100_all(acc[t][r], hlast[16 * t + r], sg[k - 1][16 * t + r], d2);
+        if (em) {
+#pragma unroll
+            for (int q = 0; q < HS; ++q) em->hid(SE<NH>::H(k), q, h, hlast[q]);
+        }
         if (k < NH) {
             load_vec<2>(wp + P::bh(k), h, acc);
             gemm_staged<Seq, HS, 2>(stage, wp, op0 + k, lane, hlast, acc);
@@ -105,7 +124,8 @@ __device__ __forceinline__ void hidden_forward(float* stage, int op0, const floa
 // reverse pass from the sdf output: fills dh[k-1] = dh_k for k = 1..NH-1 (dh_NH is the packed sdf row) and dl = dh_0.
 template <int NH, class Seq>
 __device__ __forceinline__ void reverse_pass(float* stage, int op0, const float* __restrict__ wp, int lane, int h,
-                                             const float (&sg)[NH][HS], float (&dh)[NH > 1 ? NH - 1 : 1][HS], float (&dl)[48]) {
+                                             const float (&sg)[NH][HS], float (&dh)[NH > 1 ? NH - 1 : 1][HS], float (&dl)[48],
+                                             const Emitter* em = nullptr) {
     using P = SdfPack<NH>;
     f32x16 ws[2];
     load_vec<2>(wp + P::kWSDF, h, ws);
@@ -114,6 +134,10 @@ __device__ __forceinline__ void reverse_pass(float* stage, int op0, const float*
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) da[16 * t + r] = sg[NH - 1][16 * t + r] * ws[t][r];
+    if (em) {
+#pragma unroll
+        for (int q = 0; q < HS; ++q) em->hid(SE<NH>::DA(NH), q, h, da[q]);
+    }
 #pragma unroll
     for (int k = NH - 1; k >= 1; --k) {
         f32x16 acc[2];
@@ -129,6 +153,10 @@ __device__ __forceinline__ void reverse_pass(float* stage, int op0, const float*
                 dh[k - 1][16 * t + r] = acc[t][r];
                 da[16 * t + r] = sg[k - 1][16 * t + r] * acc[t][r];
             }
+        if (em) {
+#pragma unroll
+            for (int q = 0; q < HS; ++q) em->hid(SE<NH>::DA(k), q, h, da[q]);
+        }
     }
     f32x16 a3[3];
 #pragma unroll
@@ -245,22 +273,16 @@ __global__ __launch_bounds__(256, (NH == 1 ? (MAP ? 1 : NSA_OCC_BWD_COARSE) : NS
     float* jstore = kJacLds ? jac_lds + (threadIdx.x >> 6) * ((L / 2) * 3 * C * 64) + lane : nullptr;
     float in[SDF_IN_STEPS];
     sdf_net_inputs<L, C>(x, a.divide_factor, a.table, geom, h, in, jstore);
-    float sg[NH][HS], hl[HS];
-    hidden_forward<NH, Seq>(stage, 0, a.wp, lane, h, in, sg, hl);
-    float dh[NH > 1 ? NH - 1 : 1][HS], dl[48];
-    reverse_pass<NH, Seq>(stage, NH, a.wp, lane, h, sg, dh, dl);
-    const bool emit = MAP && NH == 1 && a.emit != nullptr && wave_live;   // (a clamped wave must not touch the last tile's rows)
+    using E = SE<NH>;
+    const bool emit = MAP && a.emit != nullptr && wave_live;   // (a clamped wave must not touch the last tile's rows)
     const Emitter em{emit ? a.emit + (size_t)tile * 32 + (lane & 31) : nullptr, a.emit_ld, live};
+    float sg[NH][HS], hl[HS];
+    hidden_forward<NH, Seq>(stage, 0, a.wp, lane, h, in, sg, hl, emit ? &em : nullptr);
+    float dh[NH > 1 ? NH - 1 : 1][HS], dl[48];
+    reverse_pass<NH, Seq>(stage, NH, a.wp, lane, h, sg, dh, dl, emit ? &em : nullptr);
     if (emit) {
-        f32x16 ws[2];
-        load_vec<2>(a.wp + P::kWSDF, h, ws);
 #pragma unroll
-        for (int s = 0; s < SDF_IN_STEPS; ++s) em.slot(SE_H0, s, h, in[s]);
-#pragma unroll
-        for (int q = 0; q < HS; ++q) {
-            em.hid(SE_H1, q, h, hl[q]);
-            em.hid(SE_DA1, q, h, sg[NH - 1][q] * ws[q >> 4][q & 15]);
-        }
+        for (int s = 0; s < SDF_IN_STEPS; ++s) em.slot(E::H0, s, h, in[s]);
     }
 
     float nbar[3];
@@ -277,7 +299,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? (MAP ? 1 : NSA_OCC_BWD_COARSE) : NS
         else         x_to_slots_tangent<L, C>(x, a.divide_factor, a.table, geom, h, in, nbar, dl, tin, xb2);
         if (emit) {
 #pragma unroll
-            for (int s = 0; s < SDF_IN_STEPS; ++s) em.slot(SE_TIN, s, h, tin[s]);
+            for (int s = 0; s < SDF_IN_STEPS; ++s) em.slot(E::TIN, s, h, tin[s]);
         }
         f32x16 acc[2];
 #pragma unroll
@@ -300,7 +322,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? (MAP ? 1 : NSA_OCC_BWD_COARSE) : NS
                     const float dhk = (k == NH) ? ws[t][r] : dh[k - 1][q];
                     e[k - 1][q] = s2 * dhk * acc[t][r];
                     th[q] = s1 * acc[t][r];
-                    if (emit) em.hid(SE_TH1, q, h, th[q]);
+                    if (emit) em.hid(E::TH(k), q, h, th[q]);
                 }
             if (k < NH) {
 #pragma unroll
@@ -320,7 +342,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? (MAP ? 1 : NSA_OCC_BWD_COARSE) : NS
         for (int q = 0; q < HS; ++q) fb[q] = fsrc ? fsrc[q * 64] : 0.0f;
         if (emit) {
 #pragma unroll
-            for (int q = 0; q < HS; ++q) em.hid(SE_FB, q, h, fb[q]);
+            for (int q = 0; q < HS; ++q) em.hid(E::FB, q, h, fb[q]);
         }
         f32x16 acc[2], ws[2];
         load_vec<2>(a.wp + P::kWSDF, h, ws);
@@ -336,6 +358,10 @@ __global__ __launch_bounds__(256, (NH == 1 ? (MAP ? 1 : NSA_OCC_BWD_COARSE) : NS
     }
 #pragma unroll
     for (int k = NH - 1; k >= 1; --k) {
+        if (emit) {
+#pragma unroll
+            for (int q = 0; q < HS; ++q) em.hid(E::AB(k + 1), q, h, ab[q]);
+        }
         f32x16 acc[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -349,7 +375,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? (MAP ? 1 : NSA_OCC_BWD_COARSE) : NS
     }
     if (emit) {
 #pragma unroll
-        for (int q = 0; q < HS; ++q) em.hid(SE_AB1, q, h, ab[q]);
+        for (int q = 0; q < HS; ++q) em.hid(E::AB(1), q, h, ab[q]);
     }
     float hb0[48];
     {
@@ -396,7 +422,6 @@ static int launch_sdfnet(bool bwd, const nsa_grid_t* grid, const SdfNetArgs& a, 
         else if (bwd)   hipLaunchKernelGGL((k_sdfnet_bwd<4, 8, 1, false>), g, b, 0, st, a, geom);
         else     hipLaunchKernelGGL((k_sdfnet_fwd<4, 8, 1>), g, b, 0, st, a, geom);
     } else if (grid->L == 8 && grid->C == 4 && grid->n_hidden == 3) {
-        if (bwd && map && a.emit) return NSA_EUNSUPPORTED_NET;      // weight-gradient vectors: coarse network only
         if (bwd && map) hipLaunchKernelGGL((k_sdfnet_bwd<8, 4, 3, true>), g, b, 0, st, a, geom);
         else if (bwd)   hipLaunchKernelGGL((k_sdfnet_bwd<8, 4, 3, false>), g, b, 0, st, a, geom);
         else     hipLaunchKernelGGL((k_sdfnet_fwd<8, 4, 3>), g, b, 0, st, a, geom);
@@ -469,6 +494,9 @@ int NSA_ENTRY(nsa_sdfnet_backward_params)(const nsa_points_t* pts, const nsa_gri
     return launch_sdfnet(true, grid, a, (hipStream_t)stream);
 }
 
-int NSA_ENTRY(nsa_sdfnet_emit_rows)(void) { return nsa::SE_ROWS; }
+int NSA_ENTRY(nsa_sdfnet_emit_rows)(void) { return nsa::SE<1>::ROWS; }
+int NSA_ENTRY(nsa_sdfnet_emit_rows_nh)(uint32_t n_hidden) {
+    return n_hidden == 1 ? nsa::SE<1>::ROWS : n_hidden == 3 ? nsa::SE<3>::ROWS : -1;
+}
 
 }  // extern "C"

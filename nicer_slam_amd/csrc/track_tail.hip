@@ -83,7 +83,21 @@ struct AdamArgs {
     uint32_t n;
     float lr, beta1, beta2, eps, lr_gamma;
     uint32_t lr_step;                                            // 0 = constant lr
+    // optional arg-min-loss camera of the frame (volsdf_train.py:402-403,441-446): best[0] = smallest loss so far,
+    // best[1..n] = the parameters AFTER the step of the iteration that produced it (the reference clones camera_tensor
+    // after optimizer_camera.step()); loss = this iteration's loss (divided by loss_div[0] when given)
+    float* best; const float* loss; const float* loss_div;
 };
+
+// after the step: keep the camera of the smallest loss (strict <, like the reference); called by ONE thread
+__device__ __forceinline__ void keep_best(const AdamArgs& a) {
+    if (!a.best || !a.loss) return;
+    const float l = a.loss_div ? a.loss[0] / a.loss_div[0] : a.loss[0];
+    if (l < a.best[0]) {
+        a.best[0] = l;
+        for (uint32_t i = 0; i < a.n; ++i) a.best[1 + i] = a.p[i];
+    }
+}
 
 __device__ __forceinline__ void adam_one(const AdamArgs& a, uint32_t i, float t) {
     {
@@ -106,8 +120,11 @@ __global__ void k_adam(AdamArgs a) {
     const uint32_t i = threadIdx.x;
     const float t = a.step[0] + 1.0f;
     if (i < a.n) adam_one(a, i, t);
-    __syncthreads();
-    if (i == 0) a.step[0] = t;
+    __syncthreads();                        // (global writes of this block are visible to it after the barrier)
+    if (i == 0) {
+        a.step[0] = t;
+        keep_best(a);
+    }
 }
 
 // ---- fused head / tail of a single-image tracking iteration ------------------------------------------------------
@@ -219,7 +236,10 @@ __global__ __launch_bounds__(1024) void k_track_tail(TrackArgs a) {
         const float t = a.adam.step[0] + 1.0f;
         if (threadIdx.x < 7) adam_one(a.adam, threadIdx.x, t);
         __syncthreads();
-        if (threadIdx.x == 0) a.adam.step[0] = t;
+        if (threadIdx.x == 0) {
+            a.adam.step[0] = t;
+            keep_best(a.adam);
+        }
     }
 }
 
@@ -258,7 +278,7 @@ int nsa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float beta1, float beta2, float eps, uint32_t lr_step, float lr_gamma, nsa_stream_t stream) {
     using namespace nsa;
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step || n == 0 || n > 256) return NSA_EBADARG;
-    AdamArgs a{param, grad, exp_avg, exp_avg_sq, step, nullptr, n, lr, beta1, beta2, eps, lr_gamma, lr_step};
+    AdamArgs a{param, grad, exp_avg, exp_avg_sq, step, nullptr, n, lr, beta1, beta2, eps, lr_gamma, lr_step, nullptr, nullptr, nullptr};
     launch_begin();
     hipLaunchKernelGGL(k_adam, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     return launch_end();
@@ -266,10 +286,11 @@ int nsa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 
 int nsa_adam_step_scaled(float* param, const float* grad, const float* grad_div, float* exp_avg, float* exp_avg_sq,
                          float* step, uint32_t n, float lr, float beta1, float beta2, float eps, uint32_t lr_step,
-                         float lr_gamma, nsa_stream_t stream) {
+                         float lr_gamma, const float* loss, float* best, nsa_stream_t stream) {
     using namespace nsa;
     if (!param || !grad || !grad_div || !exp_avg || !exp_avg_sq || !step || n == 0 || n > 256) return NSA_EBADARG;
-    AdamArgs a{param, grad, exp_avg, exp_avg_sq, step, grad_div, n, lr, beta1, beta2, eps, lr_gamma, lr_step};
+    if (best && !loss) return NSA_EBADARG;
+    AdamArgs a{param, grad, exp_avg, exp_avg_sq, step, grad_div, n, lr, beta1, beta2, eps, lr_gamma, lr_step, best, loss, grad_div};
     launch_begin();
     hipLaunchKernelGGL(k_adam, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     return launch_end();
@@ -289,14 +310,17 @@ int nsa_track_head(const float* uv, const float* K, const float* cam, uint32_t n
 
 int nsa_track_tail(const float* uv, const float* K, float* cam, uint32_t n, const float* g_rays_o, const float* g_rays_d,
                    float* g_cam, int do_adam, float reduce_weight, float* exp_avg, float* exp_avg_sq, float* step, float lr,
-                   float beta1, float beta2, float eps, uint32_t lr_step, float lr_gamma, nsa_stream_t stream) {
+                   float beta1, float beta2, float eps, uint32_t lr_step, float lr_gamma, const float* loss, float* best,
+                   nsa_stream_t stream) {
     using namespace nsa;
     if (!uv || !K || !cam || !g_rays_o || !g_rays_d || !g_cam || n == 0) return NSA_EBADARG;
     if (do_adam && (!exp_avg || !exp_avg_sq || !step)) return NSA_EBADARG;
+    if (best && (!loss || !do_adam)) return NSA_EBADARG;
     TrackArgs a{};
     a.uv = uv; a.K = K; a.cam = cam; a.n = n; a.g_o = g_rays_o; a.g_d = g_rays_d; a.g_cam = g_cam;
     a.reduce_weight = reduce_weight;
-    if (do_adam) a.adam = AdamArgs{cam, g_cam, exp_avg, exp_avg_sq, step, nullptr, 7, lr, beta1, beta2, eps, lr_gamma, lr_step};
+    if (do_adam) a.adam = AdamArgs{cam, g_cam, exp_avg, exp_avg_sq, step, nullptr, 7, lr, beta1, beta2, eps, lr_gamma, lr_step,
+                                    best, loss, nullptr};
     launch_begin();
     hipLaunchKernelGGL(k_track_tail, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
     return launch_end();

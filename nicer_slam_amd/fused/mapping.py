@@ -6,8 +6,9 @@ gradients; the weight gradients themselves are a handful of [64 x n] x [n x ~130
 in K-chunks so that the long reduction dimension fills the chip.
 
 Trainable parameters follow the reference's optimizer list (code/training/volsdf_train.py:150-173): the three grid
-tables, the coarse SDF MLP and the colour MLP.  The fine SDF MLP is pretrained and frozen there; this engine does not
-produce gradients for it (SLAMNetwork.freeze_fine_mlp()).
+tables, the coarse SDF MLP and the colour MLP.  The fine SDF MLP is pretrained and never handed to the optimizer there, yet
+its parameters still require grad, so the reference computes gradients nobody reads; this engine produces them on request
+(``model.fine_mlp_grads = True``: 976 emission rows from the fine MAP kernel) and skips that work by default.
 
 Autograd contract: both Functions take the FLAT effective parameter vectors of pack.flat_params() (weight-norm already
 applied, differentiably) and return gradients in the same layout, so torch carries them on to weight_g / weight_v /
@@ -28,7 +29,26 @@ from .sampler import grid_desc, packed_sdf, precision_of
 
 KCHUNK = 4096
 SORT_POINTS = True      # run the per-point kernels of a mapping iteration in Morton order (see render.morton_order)
-SE = dict(H0=0, TIN=72, DA1=144, H1=208, AB1=272, TH1=336, FB=400, ROWS=464)      # = enum SE_* (render_sdfnet.hip)
+
+
+def se_rows(NH):
+    """Emission row map of an SDF network with NH hidden layers = struct SE<NH> of csrc/render_sdfnet.hip:
+    [H0 | TIN | DA_1.. | H_1.. | TH_1..TH_{NH-1} | AB_1..AB_NH | TH_NH | FB], regions of 72, 72, then 64 rows each."""
+    m = {"H0": 0, "TIN": 72}
+    for k in range(1, NH + 1):
+        m[f"DA{k}"] = 144 + 64 * (k - 1)
+        m[f"H{k}"] = 144 + 64 * NH + 64 * (k - 1)
+        m[f"AB{k}"] = 144 + 128 * NH + 64 * (NH - 1) + 64 * (k - 1)
+        if k < NH:
+            m[f"TH{k}"] = 144 + 128 * NH + 64 * (k - 1)
+    m[f"TH{NH}"] = m["AB1"] + 64 * NH
+    m["FB"] = m[f"TH{NH}"] + 64
+    m["ROWS"] = m["FB"] + 64
+    return m
+
+
+SE = se_rows(1)      # coarse network (464 rows); fine: se_rows(3) (976 rows)
+assert SE == dict(H0=0, TIN=72, DA1=144, H1=208, AB1=272, TH1=336, FB=400, ROWS=464)
 CE = dict(IN=0, H1=130, H2=194, AB1=258, AB2=322, OB=386, ROWS=389)              # = enum CE_* (render_colour.hip)
 
 
@@ -81,21 +101,25 @@ def _col_rows():
     return torch.from_numpy(rows)
 
 
-def sdf_flat_grad(emit, g_sdf, P, L, C):
-    """Gradient of the coarse network's flat parameter vector [W0(64x71), b0, W1(65x64), b1, 0] from its emission rows."""
-    r = lambda name, n: emit[SE[name]:SE[name] + n]
-    H0, TIN, AB1, DA1, H1, TH1, FB = r("H0", 72), r("TIN", 72), r("AB1", 64), r("DA1", 64), r("H1", 64), r("TH1", 64), r("FB", 64)
-    M = outer_sum(AB1, H0) + outer_sum(DA1, TIN)
-    dW0 = M[:, _sdf_rows(L, C).to(emit.device)]
-    sums = emit[SE["AB1"]:SE["ROWS"]].sum(1)                 # AB1 | TH1 | FB row sums in one reduction
-    db0, row0, fb_sum = sums[:64], sums[64:128], sums[128:]
+def sdf_flat_grad(emit, g_sdf, P, L, C, NH=1):
+    """Gradient of an SDF network's flat parameter vector [W0(64x71), b0, W1, b1, .., W_NH(65x64), b_NH, 0] from its emission
+    rows (row map and formulas: struct SE<NH>, csrc/render_sdfnet.hip)."""
+    m = se_rows(NH)
+    r = lambda name, n=64: emit[m[name]:m[name] + n]
+    sums = emit[m["AB1"]:m["ROWS"]].sum(1)                   # AB_1..AB_NH | TH_NH | FB row sums in one reduction
+    parts = []
+    M = outer_sum(r("AB1"), r("H0", 72)) + outer_sum(r("DA1"), r("TIN", 72))
+    parts += [M[:, _sdf_rows(L, C).to(emit.device)].reshape(-1), sums[:64]]
+    for k in range(1, NH):                                   # hidden layer k: value path + its share of the reverse pass
+        parts += [(outer_sum(r(f"AB{k + 1}"), r(f"H{k}")) + outer_sum(r(f"DA{k + 1}"), r(f"TH{k}"))).reshape(-1),
+                  sums[64 * k:64 * (k + 1)]]
+    row0, fb_sum = sums[64 * NH:64 * (NH + 1)], sums[64 * (NH + 1):]
     dbs = emit.new_zeros(1)
     if g_sdf is not None:
-        row0 = row0 + H1[:, :P] @ g_sdf
+        row0 = row0 + r(f"H{NH}")[:, :P] @ g_sdf
         dbs = g_sdf.sum().reshape(1)
-    dW1 = torch.cat([row0.unsqueeze(0), outer_sum(FB, H1)], 0)
-    db1 = torch.cat([dbs, fb_sum])
-    return torch.cat([dW0.reshape(-1), db0, dW1.reshape(-1), db1, emit.new_zeros(1)])
+    parts += [row0, outer_sum(r("FB"), r(f"H{NH}")).reshape(-1), dbs, fb_sum, emit.new_zeros(1)]
+    return torch.cat(parts)
 
 
 def colour_flat_grad(emit):
@@ -115,11 +139,19 @@ def _nets(model):
     return imp.coarse, imp.fine, model.rendering_network
 
 
+def fine_mlp_wanted(model):
+    """True when the fine SDF MLP's gradients are to be produced: its parameters require grad AND
+    ``model.fine_mlp_grads`` is set.  The reference computes them and never applies them (the fine MLP is pretrained and not
+    in the optimizer, volsdf_train.py:140-173), so the default skips that work; see SLAMNetwork.fine_mlp_grads."""
+    return bool(getattr(model, "fine_mlp_grads", False)) and any(p.requires_grad for p in _nets(model)[1].mlp_parameters())
+
+
 def params_supported(model):
-    """True when every parameter that requires grad is one this engine produces a gradient for."""
+    """True when every parameter that requires grad is one this engine produces a gradient for -- or is the fine SDF MLP,
+    whose gradients are produced on request only (fine_mlp_wanted)."""
     c, f, r = _nets(model)
     covered = {id(p) for p in list(c.mlp_parameters()) + list(c.grid_parameters()) + list(f.grid_parameters())
-               + list(r.mlp_parameters()) + list(r.grid_parameters())}
+               + list(f.mlp_parameters()) + list(r.mlp_parameters()) + list(r.grid_parameters())}
     return all((not p.requires_grad) or id(p) in covered for p in model.parameters())
 
 
@@ -127,7 +159,7 @@ class FusedCompositeParams(torch.autograd.Function):
     """FusedComposite with gradients for (flat coarse MLP, flat colour MLP, coarse / fine / colour tables)."""
 
     @staticmethod
-    def forward(ctx, rays_o, rays_d, z_vals, flat_c, flat_r, tab_c, tab_f, tab_r, model, stage, color_stage):
+    def forward(ctx, rays_o, rays_d, z_vals, flat_c, flat_r, tab_c, tab_f, tab_r, flat_f, model, stage, color_stage):
         rays_o, rays_d, z_vals = rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous()
         R, S = z_vals.shape
         b = composite_forward_raw(model, rays_o, rays_d, z_vals, stage, True, sort_points=SORT_POINTS)
@@ -142,12 +174,12 @@ class FusedCompositeParams(torch.autograd.Function):
         rays_o, rays_d, z_vals = ctx.saved_tensors
         need = ctx.needs_input_grad
         want = dict(flat_c=need[3], flat_r=need[4], tab_c=need[5], tab_f=need[6] and ctx.stage != "coarse",
-                    tab_r=need[7] and ctx.color_stage != "base")
+                    tab_r=need[7] and ctx.color_stage != "base", flat_f=need[8] and ctx.stage != "coarse")
         g_o, g_d, pg = composite_backward_raw(ctx.model, rays_o, rays_d, z_vals, ctx.bufs, ctx.stage, ctx.color_stage,
                                               g_rgbv, g_depth, g_nmap, g_ent, g_w, params=want)
         ctx.bufs = None
         return (g_o, g_d, None, pg.get("flat_c"), pg.get("flat_r"), pg.get("tab_c"), pg.get("tab_f"), pg.get("tab_r"),
-                None, None, None)
+                pg.get("flat_f"), None, None, None)
 
 
 class FusedSdfGradient(torch.autograd.Function):
@@ -155,7 +187,7 @@ class FusedSdfGradient(torch.autograd.Function):
     of network.py:313-336) with gradients for (flat coarse MLP, coarse table, fine table)."""
 
     @staticmethod
-    def forward(ctx, points, flat_c, tab_c, tab_f, model, stage):
+    def forward(ctx, points, flat_c, tab_c, tab_f, flat_f, model, stage):
         points = points.contiguous()
         N = points.shape[0]
         dev = points.device
@@ -196,7 +228,7 @@ class FusedSdfGradient(torch.autograd.Function):
         g_x = torch.empty(N, 3, device=dev)
         need = ctx.needs_input_grad
         st = _stream()
-        out = [None, None, None, None, None, None]
+        out = [None, None, None, None, None, None, None]
         emit = new_emit(SE["ROWS"], N, dev) if need[1] else None
         gt_c = torch.zeros_like(imp.coarse.encoding.embeddings) if need[2] else None
         if emit is not None or gt_c is not None:
@@ -210,31 +242,39 @@ class FusedSdfGradient(torch.autograd.Function):
                 enc = imp.coarse.encoding
                 out[1] = sdf_flat_grad(emit, None, N, enc.num_levels, enc.level_dim)
             out[2] = gt_c
-        if need[3] and stage != "coarse":
-            gt_f = torch.zeros_like(imp.fine.encoding.embeddings)
+        if (need[3] or need[4]) and stage != "coarse":
+            gt_f = torch.zeros_like(imp.fine.encoding.embeddings) if need[3] else None
+            emit_f = new_emit(se_rows(3)["ROWS"], N, dev) if need[4] else None
             with _timed("k_sdfnet_bwd<fine,eik>", 0):
                 check(lib.nsa_sdfnet_backward_params(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), None, None,
-                                                     g.data_ptr(), 0, g_x.data_ptr(), gt_f.data_ptr(), None, 0, st))
+                                                     g.data_ptr(), 0, g_x.data_ptr(),
+                                                     None if gt_f is None else gt_f.data_ptr(),
+                                                     None if emit_f is None else emit_f.data_ptr(),
+                                                     0 if emit_f is None else emit_f.shape[1], st))
             out[3] = gt_f
+            if emit_f is not None:
+                enc = imp.fine.encoding
+                out[4] = sdf_flat_grad(emit_f, None, N, enc.num_levels, enc.level_dim, NH=3)
         return tuple(out)
 
 
 def flat_inputs(model):
-    """(flat coarse MLP, flat colour MLP, coarse table, fine table, colour table) as autograd inputs."""
+    """(flat coarse MLP, flat colour MLP, coarse table, fine table, colour table, flat fine MLP or None) as autograd
+    inputs; the last one only when its gradients are wanted (fine_mlp_wanted)."""
     c, f, r = _nets(model)
     return (pack.flat_params(c), pack.flat_params(r), c.encoding.embeddings, f.encoding.embeddings,
-            r.encoding.embeddings)
+            r.encoding.embeddings, pack.flat_params(f) if fine_mlp_wanted(model) else None)
 
 
 def composite(model, rays_o, rays_d, z_vals, stage, color_stage):
-    flat_c, flat_r, tab_c, tab_f, tab_r = flat_inputs(model)
-    return FusedCompositeParams.apply(rays_o, rays_d, z_vals, flat_c, flat_r, tab_c, tab_f, tab_r, model, stage,
+    flat_c, flat_r, tab_c, tab_f, tab_r, flat_f = flat_inputs(model)
+    return FusedCompositeParams.apply(rays_o, rays_d, z_vals, flat_c, flat_r, tab_c, tab_f, tab_r, flat_f, model, stage,
                                       color_stage)
 
 
 def sdf_gradient(model, points, stage):
-    flat_c, _, tab_c, tab_f, _ = flat_inputs(model)
-    return FusedSdfGradient.apply(points, flat_c, tab_c, tab_f, model, stage)
+    flat_c, _, tab_c, tab_f, _, flat_f = flat_inputs(model)
+    return FusedSdfGradient.apply(points, flat_c, tab_c, tab_f, flat_f, model, stage)
 
 
 def update_voxels(model, rays_o, rays_d, z_vals):

@@ -176,12 +176,19 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
             check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), g_sdf.data_ptr(),
                                           g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))
     if stage != "coarse":
-        if want.get("tab_f"):
-            gt = torch.zeros_like(imp.fine.encoding.embeddings)
+        if want.get("tab_f") or want.get("flat_f"):
+            from . import mapping
+            enc = imp.fine.encoding
+            gt = torch.zeros_like(enc.embeddings) if want.get("tab_f") else None
+            emit = mapping.new_emit(mapping.se_rows(3)["ROWS"], P, dev) if want.get("flat_f") else None
             with _timed("k_sdfnet_bwd<fine,map>", P * 3 * 8 * 8 * 4 * 4):
                 check(lib.nsa_sdfnet_backward_params(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), g_sdf.data_ptr(),
                                                      g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(),
-                                                     gt.data_ptr(), None, 0, st))
+                                                     ptr(gt), ptr(emit), 0 if emit is None else emit.shape[1], st))
+            if emit is not None:
+                g_sdf_w = g_sdf if order is None else g_sdf[order.long()]
+                pg["flat_f"] = mapping.sdf_flat_grad(emit, g_sdf_w, P, enc.num_levels, enc.level_dim, NH=3)
+                del emit
             pg["tab_f"] = gt
         else:
             with _timed("k_sdfnet_bwd<fine>", P * 3 * 8 * 8 * 4 * 4):

@@ -54,7 +54,21 @@ def supported(model):
                 and all(d == 64 for d in net.dims[1:-1]) and net.dims[-1] == 65
                 and net.encoding.embeddings.dtype == torch.float32)
     return (ok(c, 4, 8, 1) and ok(f, 8, 4, 3) and model.density_method == "volsdf_gridpredefined"
-            and model.feature_vector_size == 64 and model.voxels.is_cuda)
+            and model.feature_vector_size == 64 and model.voxels.is_cuda and sample_counts_ok(model.ray_sampler))
+
+
+MAX_S = 256                      # = MAX_S of csrc/render_sampler.hip / MAX_PER*64 of csrc/render_composite.hip
+LDS_BYTES = 160 * 1024           # per-workgroup LDS of k_sample_rays: 4 rays x (3 E + MAX_S) floats
+
+
+def sample_counts_ok(samp):
+    """Sample-count limits compiled into the per-ray kernels (nsa_sample_rays / nsa_composite_* return NSA_EBADARG beyond
+    them): S = N_samples + 2 + N_samples_extra <= 256, E = N_samples_eval >= 2, four rays' pdf/cdf/z/sort buffers in 160 KiB
+    of LDS, and at most E extras.  Outside them ``engine='auto'`` uses the composed engine."""
+    S = samp.N_samples + 2 + samp.N_samples_extra
+    E = samp.N_samples_eval
+    return (1 <= S <= MAX_S and E >= 2 and (3 * E + MAX_S) * 4 * 4 <= LDS_BYTES and 0 <= samp.N_samples_extra <= E
+            and samp.N_samples >= 1)
 
 
 def packed_sdf(model, which, detach=True):

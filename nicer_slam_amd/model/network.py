@@ -64,6 +64,13 @@ class SLAMNetwork(nn.Module):
         self.last_engine = None    # which engine the most recent forward used
         self.mlp_precision = "fp32"   # fused engine only: "fp32" | "bf16" | "bf16_colour" (fused/sampler.py::precision_of)
         self.voxel_sync = None     # multi-GPU mapping: callable(voxels, before) summing the visit deltas over ranks
+        # Gradients the reference's loop computes and never reads (both default to "skip"; set True for the reference's
+        # literal autograd behaviour -- still on the fused engine):
+        #  * tracking: volsdf_train.py:406-427 back-propagates into EVERY model parameter although only the camera is stepped;
+        #    those .grad are zeroed by optimizer.zero_grad() (:547) before the next use.
+        #  * fine SDF MLP: pretrained, never in the optimizer (:140-173), but left requires_grad=True.
+        self.tracking_param_grads = False
+        self.fine_mlp_grads = False
 
     # ------------------------------------------------------------------ plumbing
     def _share_voxels(self):
@@ -111,20 +118,20 @@ class SLAMNetwork(nn.Module):
         self.voxels.view(-1).index_add_(0, flat, torch.ones_like(flat, dtype=self.voxels.dtype))
 
     def freeze_fine_mlp(self):
-        """The fine SDF MLP is pretrained and never handed to the optimizer (volsdf_train.py:143-173); marking it
-        so lets the fused mapping engine skip its weight gradients."""
+        """The fine SDF MLP is pretrained and never handed to the optimizer (volsdf_train.py:143-173).  Optional: the
+        fused engine already skips its gradients unless ``fine_mlp_grads`` is set; this states it on the parameters."""
         for p in self.implicit_network.fine.mlp_parameters():
             p.requires_grad_(False)
         return self
 
     def _fused_composite_ok(self, mode, ground_truth):
         """Which engine renders this call.  Returns None (composed), "data" (fused kernels, pose gradient only) or
-        "params" (fused kernels with parameter gradients: mapping).  The fused engine does not produce gradients for
-        the fine SDF MLP; while those parameters require grad, "auto" stays on the composed engine."""
+        "params" (fused kernels with parameter gradients: mapping, and tracking when ``tracking_param_grads``)."""
         if self.engine == "composed" or not self.voxels.is_cuda:
             return None
         from ..fused import render as fused_render, mapping as fused_mapping
-        needs_params = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        needs_params = (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+                        and (mode != "tracking" or self.tracking_param_grads))
         kind = None
         if fused_render.supported(self):
             if not needs_params:
@@ -133,8 +140,8 @@ class SLAMNetwork(nn.Module):
                 kind = "params"
         if kind is None and self.engine == "fused":
             raise RuntimeError("engine='fused' requested but this call is outside the fused engine's coverage "
-                               "(unsupported configuration, or parameters outside the reference's optimizer list "
-                               "require grad -- see SLAMNetwork.freeze_fine_mlp)")
+                               "(unsupported configuration, or a parameter other than the grid tables and the three MLPs "
+                               "requires grad)")
         return kind
 
     # ------------------------------------------------------------------ forward

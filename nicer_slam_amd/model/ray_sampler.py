@@ -72,9 +72,11 @@ class ImportantSampler:
                 raise RuntimeError("engine='fused' requested but this configuration is outside the compiled set")
         z, near, far = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model)
         pts = (cam_loc.unsqueeze(1) + z.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
-        with torch.no_grad():
+        with torch.no_grad():                      # only the SDF evaluation is under no_grad (ray_sampler.py:101-102);
             sdf = model.implicit_network.get_sdf_vals(pts)
-            w = transmittance_weights(z, model.density(sdf, x=pts).reshape(z.shape))
+        # density, weights and the inverse CDF run with grad enabled like the reference (:104-139): with
+        # density_method = "volsdf_laplace" the learnable beta receives a gradient through z_vals
+        w = transmittance_weights(z, model.density(sdf, x=pts).reshape(z.shape))
         z_imp = inverse_cdf_samples(z, w, self.N_samples)
         if self.N_samples_extra > 0:
             if model.training:

@@ -15,7 +15,13 @@ class KernelTracker:
     """The same iteration with NO autograd in the loop: a fixed sequence of our kernels --
     cam->pose, rays, sampler (2), SDF nets (2), colour, composite, L1, composite-bwd, colour-bwd, SDF-net-bwd (2),
     ray reduction, pose-bwd, cam-bwd, [all-reduce], Adam -- launched through the C ABI; optionally one hipGraph.
-    Only tracking (pose gradient) is covered; it needs a configuration in the fused engine's compiled set."""
+    Only tracking (pose gradient) is covered; it needs a configuration in the fused engine's compiled set.
+
+    Per-frame protocol of the reference's tracking loop (volsdf_train.py:393-446): ``reset(cam_init)`` starts a frame
+    (fresh Adam state, StepLR back to its first step, no candidate yet), ``step(uv, gt)`` runs one iteration, and
+    ``candidate`` is the camera of the smallest loss seen -- cloned AFTER that iteration's optimizer step, like the
+    reference -- which is what the frame's pose estimate is set to (:445-446).  ``lr_step=50, lr_gamma=0.95`` is the
+    reference's StepLR (:398)."""
 
     def __init__(self, model, intrinsics, n_rays, cam_init, lr=0.005, betas=(0.9, 0.999), eps=1e-8, lr_step=0,
                  lr_gamma=1.0, use_graph=True, world=1, stage="fine", color_stage="highfreq"):
@@ -34,6 +40,8 @@ class KernelTracker:
         z = lambda *s: torch.zeros(*s, device=dev)
         self.pose, self.g_pose, self.red = z(1, 4, 4), z(1, 4, 4), z(9)     # red = [g_cam(7), loss, n_rays]
         self.m, self.v, self.t = z(7), z(7), z(1)
+        self.best = z(8)                                                    # [min loss, camera after that step (7)]
+        self.best[0] = 1e10                                                 # current_min_loss (volsdf_train.py:403)
         self.rays_o, self.rays_d, self.ds = z(n_rays, 3), z(n_rays, 3), z(n_rays)
         self.g_rgbv = z(n_rays, 3)
         self.graph = None
@@ -43,6 +51,25 @@ class KernelTracker:
     @property
     def loss(self):
         return self.red[7] / self.red[8] if self.world > 1 else self.red[7]
+
+    @property
+    def candidate(self):
+        """camera 7-vector of the smallest loss of this frame (candidate_cam_tensor, volsdf_train.py:441-446)"""
+        return self.best[1:8]
+
+    @property
+    def min_loss(self):
+        return self.best[0]
+
+    def reset(self, cam_init):
+        """Start a new frame: camera estimate, Adam moments / step counter (a new optimizer + StepLR per frame,
+        volsdf_train.py:396-398) and the candidate -- all in place, so a captured graph keeps replaying on them."""
+        with torch.no_grad():
+            self.cam.copy_(cam_init.detach().to(self.cam.device).float())
+            for t in (self.m, self.v, self.t):
+                t.zero_()
+            self.best.zero_()
+            self.best[0] = 1e10
 
     def _iteration(self):
         from ._native import lib, check
@@ -62,7 +89,9 @@ class KernelTracker:
         check(lib.nsa_track_tail(self.uv.data_ptr(), self.K.data_ptr(), self.cam.data_ptr(), R, g_o.data_ptr(),
                                  g_d.data_ptr(), self.red.data_ptr(), 1 if self.world == 1 else 0,
                                  0.0 if self.world == 1 else float(R), self.m.data_ptr(), self.v.data_ptr(),
-                                 self.t.data_ptr(), lr, b1, b2, eps, lr_step, lr_gamma, st))
+                                 self.t.data_ptr(), lr, b1, b2, eps, lr_step, lr_gamma,
+                                 self.red[7:8].data_ptr() if self.world == 1 else None,
+                                 self.best.data_ptr() if self.world == 1 else None, st))
 
     def _update(self):
         """multi-GPU: Adam on the all-reduced message, gradient = red[0..6] / red[8]"""
@@ -70,6 +99,7 @@ class KernelTracker:
         lr, b1, b2, eps, lr_step, lr_gamma = self.hyper
         check(lib.nsa_adam_step_scaled(self.cam.data_ptr(), self.red.data_ptr(), self.red[8:].data_ptr(), self.m.data_ptr(),
                                        self.v.data_ptr(), self.t.data_ptr(), 7, lr, b1, b2, eps, lr_step, lr_gamma,
+                                       self.red[7:8].data_ptr(), self.best.data_ptr(),
                                        torch.cuda.current_stream().cuda_stream))
 
     def _capture(self):
@@ -80,12 +110,11 @@ class KernelTracker:
             for _ in range(2):
                 self._iteration()
         torch.cuda.current_stream().wait_stream(side)
-        self.cam.copy_(cam0)                       # the warm-up iterations stepped the camera: undo
-        for t in (self.m, self.v, self.t):
-            t.zero_()
+        self.reset(cam0)                           # the warm-up iterations stepped the camera: undo
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self._iteration()
+        self.reset(cam0)                           # (capture does not execute, but keep the state explicit)
 
     def step(self, uv, gt):
         self.uv.copy_(uv)
@@ -104,7 +133,10 @@ class KernelTracker:
 
 
 class TrackingStepper:
-    def __init__(self, model, intrinsics, n_rays, cam_init, lr=0.005, use_graph=True, world=1):
+    """The iteration driven through torch autograd exactly as volsdf_train.py:406-446 does: get_camera_from_tensor ->
+    SLAMNetwork.forward(mode="tracking") -> L1 -> loss.backward() -> torch.optim.Adam (+ StepLR) -> arg-min-loss candidate."""
+
+    def __init__(self, model, intrinsics, n_rays, cam_init, lr=0.005, use_graph=True, world=1, lr_step=0, lr_gamma=1.0):
         dev = model.voxels.device
         self.model, self.world, self.n_rays = model, world, n_rays
         self.K = intrinsics
@@ -114,6 +146,12 @@ class TrackingStepper:
         self.ind = torch.zeros(1, dtype=torch.long, device=dev)
         self.graph_all = use_graph and world == 1     # Adam inside the graph only when no all-reduce sits in between
         self.opt = torch.optim.Adam([self.cam], lr=lr, capturable=self.graph_all)
+        if lr_step and self.graph_all:
+            raise ValueError("TrackingStepper: StepLR is stepped on the host -- use use_graph=False (or KernelTracker, whose "
+                             "Adam kernel applies the schedule on the device)")
+        self.sched = torch.optim.lr_scheduler.StepLR(self.opt, lr_step, lr_gamma) if lr_step else None
+        self.min_loss = torch.full((), 1e10, device=dev)           # current_min_loss / candidate_cam_tensor (:402-403)
+        self.candidate = self.cam.detach().clone()
         self.graph = None
         self.loss = None
         if use_graph:
@@ -172,4 +210,10 @@ class TrackingStepper:
                 g, loss = allreduce_pose_grad(self.cam.grad, loss, self.n_rays)
                 self.cam.grad.copy_(g)
             self.opt.step()
+        if self.sched is not None:
+            self.sched.step()
+        with torch.no_grad():                                       # if loss < current_min_loss: clone the (stepped) camera
+            better = loss < self.min_loss
+            self.min_loss = torch.where(better, loss, self.min_loss)
+            self.candidate = torch.where(better, self.cam.detach(), self.candidate)
         return loss

@@ -88,7 +88,8 @@ class _DS:
     img_res = (680, 1200)
 
 
-def build_model(seed, coarse_grid, fine_grid, colour_grid, n_samples, n_eval, n_extra, emb_scale, warp=False, ds=None):
+def build_model(seed, coarse_grid, fine_grid, colour_grid, n_samples, n_eval, n_extra, emb_scale, warp=False, ds=None,
+                rand_v=0.0):
     """Reference SLAMNetwork with reduced-size tables.  The colour encoder is hard-coded to a
     1 GiB table (base_networks.py:265-284); it is swapped for the reference's own HashEncoder
     class with a small geometry that keeps 16 levels x 2 features."""
@@ -120,6 +121,15 @@ def build_model(seed, coarse_grid, fine_grid, colour_grid, n_samples, n_eval, n_
     for n, p in model.named_parameters():
         if n.endswith("weight_g"):
             p.data = p.data * (1 + 0.1 * (torch.rand(p.shape, generator=g) - 0.5))
+    if rand_v:
+        # The geometric initialisation zeroes every first-layer column except x,y,z (base_networks.py:127-146), so a freshly
+        # built SDF network ignores its positional encoding and its grid features: their gradients -- table scatter, Jacobian
+        # terms, the double backward through grad sdf -- are identically zero.  The "_rw" cases add noise to every weight_v
+        # (as a trained / pretrained network has) so that those paths carry signal through the reference's autograd.
+        for n, p in model.named_parameters():
+            if n.startswith("implicit_network") and n.endswith("weight_v"):
+                first = ".lin0." in n
+                p.data = p.data + (rand_v if first else 0.2 * rand_v) * torch.randn(p.shape, generator=g)
     return model, conf
 
 
@@ -167,10 +177,10 @@ def objective(out, gt, mode):
 
 
 def full_case(name, seed, mode, stage, color_stage, bs, n_pix, training=True, poisson=False,
-              grids=None, samples=(10, 32, 6)):
+              grids=None, samples=(10, 32, 6), rand_v=0.0):
     coarse_grid, fine_grid, colour_grid = grids or ((4, 4, 8, 4, 8), (4, 32, 10, 8, 4), (4, 64, 10))
     model, conf = build_model(seed, coarse_grid, fine_grid, colour_grid, *samples,
-                              emb_scale=(0.05, 0.05, 0.5))
+                              emb_scale=(0.05, 0.05, 0.5) if not rand_v else (0.3, 0.3, 0.5), rand_v=rand_v)
     model.train(training)
     uv, cam, K = synth_inputs(seed + 1, bs, n_pix)
     g = torch.Generator().manual_seed(seed + 2)
@@ -275,11 +285,19 @@ def twin_case(name, seed, L, C, base, end, n_pts):
     x = (torch.rand(n_pts, 3, generator=g) * 2 - 1) * 0.98
     x.requires_grad_(True)
     y = enc.torch_forward(x)
-    v = torch.randn(y.shape, generator=g)
-    (gx,) = torch.autograd.grad(y, x, v)
-    rec = dict(meta_grid=np.array([L, C, base, end, 19]), in_x=x, in_v=v, param_embeddings=enc.embeddings,
+    v = torch.randn(y.shape, generator=g).requires_grad_(True)
+    q = torch.randn(n_pts, 3, generator=g)
+    # stock autograd through the twin, twice: first order (J^T v, table scatter) and the two second-order products the
+    # CUDA path keeps -- d/dv and d/dtable of s = <J^T v, q>  (hashencoder.cu:405-625; d s / d x is what hashgrid.py:134
+    # drops, so it is NOT recorded).  Pins kernel_grid_backward and both second-backward kernels independently of the
+    # C restatement.
+    (gx,) = torch.autograd.grad(y, x, v, create_graph=True)
+    (first_emb,) = torch.autograd.grad(y, enc.embeddings, v, retain_graph=True)
+    s = (gx * q).sum()
+    v_grad2, emb_grad2 = torch.autograd.grad(s, [v, enc.embeddings])
+    rec = dict(meta_grid=np.array([L, C, base, end, 19]), in_x=x, in_v=v, in_q=q, param_embeddings=enc.embeddings,
                param_offsets=enc.offsets, meta_per_level_scale=np.float64(enc.per_level_scale),
-               out_y=y, out_gx=gx)
+               out_y=y, out_gx=gx, out_first_emb=first_emb, out_v_grad2=v_grad2, out_emb_grad2=emb_grad2)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **t2n(rec))
     print(name, tuple(enc.embeddings.shape))
 
@@ -488,7 +506,83 @@ def func_case(name, seed):
     print(name, {k: tuple(v.shape) for k, v in rec.items()})
 
 
+def feed_case(name, seed):
+    """Per-iteration feed through the reference's own SLAMDataset.change_sampling_idx / __getitem__ /
+    collate_fn (code/datasets/scene_dataset.py:214-287), on an instance whose image caches hold synthetic frames (its
+    __init__ only reads files, so the object is allocated without it).  Three batches: mapping (2 frames, random pixels),
+    tracking (1 frame; pixels drawn from the first tracking_total_pixels indices, :282-286), visualisation (whole image)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_scene_dataset", os.path.join(ref_shims.REF_CODE, "datasets",
+                                                                                     "scene_dataset.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    H, W, Hedge, Wedge = 12, 20, 2, 3
+    g = torch.Generator().manual_seed(seed)
+    ds = object.__new__(mod.SLAMDataset)
+    ds.img_res, ds.H, ds.W = (H, W), H, W
+    ds.total_pixels = H * W
+    ds.tracking_total_pixels = (H - 2 * Hedge) * (W - 2 * Wedge)
+    ds.scene_scale = 2.5
+    ds.sampling_idx = None
+    i = torch.arange(H * W)
+    ds.uv = torch.stack([(i % W).float(), (i // W).float()], -1)     # the pixel grid of scene_dataset.py:106-111
+    ds.rgb_images, ds.mask_images, ds.depth_images, ds.normal_images, ds.gt_depth_images = {}, {}, {}, {}, {}
+    ds.intrinsics_all, ds.est_pose_all = {}, {}
+    rec = dict(meta_res=np.array([H, W, Hedge, Wedge]), meta_scene_scale=np.float64(ds.scene_scale))
+    for idx in (3, 8):
+        ds.rgb_images[idx] = torch.rand(H * W, 3, generator=g)
+        ds.depth_images[idx] = torch.rand(H * W, 1, generator=g)
+        ds.normal_images[idx] = torch.rand(H * W, 3, generator=g) * 2 - 1
+        ds.gt_depth_images[idx] = torch.rand(H * W, 1, generator=g) * 4
+        ds.mask_images[idx] = (torch.rand(H * W, 1, generator=g) > 0.2).float()
+        K = torch.eye(4)
+        K[0, 0] = K[1, 1] = 10.0 + idx
+        K[0, 2], K[1, 2] = W / 2 - 0.5, H / 2 - 0.5
+        ds.intrinsics_all[idx] = K
+        ds.est_pose_all[idx] = torch.eye(4) + 0.01 * torch.randn(4, 4, generator=g)
+        for k, t in (("rgb", ds.rgb_images), ("depth", ds.depth_images), ("normal", ds.normal_images),
+                     ("gt_depth", ds.gt_depth_images), ("mask", ds.mask_images), ("intrinsics", ds.intrinsics_all),
+                     ("pose", ds.est_pose_all)):
+            rec[f"frame{idx}_{k}"] = t[idx]
+    torch.manual_seed(seed)
+    for tag, mode, frames, n in (("map", "mapping", [8, 3], 7), ("trk", "tracking", [3], 5), ("vis", "mapping", [8], -1)):
+        ds.mode = mode
+        ds.change_sampling_idx(n)
+        indices, inp, gt = ds.collate_fn([ds[f] for f in frames])
+        rec[f"{tag}_frames"] = np.array(frames)
+        rec[f"{tag}_indices"] = indices
+        if ds.sampling_idx is not None:
+            rec[f"{tag}_sampling_idx"] = ds.sampling_idx
+        for k, v in inp.items():
+            rec[f"{tag}_in_{k}"] = v
+        for k, v in gt.items():
+            rec[f"{tag}_gt_{k}"] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **t2n(rec))
+    print(name, sorted(k for k in rec if not k.startswith("frame")))
+
+
+def rw_cases():
+    full_case("full_tracking_rw", 16, "tracking", "fine", "highfreq", bs=1, n_pix=24, poisson=True, rand_v=0.04)
+    full_case("full_mapping_rw", 17, "mapping", "fine", "highfreq", bs=2, n_pix=8, poisson=True, rand_v=0.04)
+    full_case("full_mapping_rw_coarse", 18, "mapping", "coarse", "highfreq", bs=2, n_pix=8, rand_v=0.04)
+
+
+def twin_cases():
+    twin_case("twin_dense", 4, L=5, C=4, base=8, end=24, n_pts=128)
+    twin_case("twin_dense_c8", 6, L=3, C=8, base=8, end=19, n_pts=96)
+    twin_case("twin_dense_c2", 7, L=6, C=2, base=4, end=21, n_pts=96)
+
+
 if __name__ == "__main__":
+    if "--twin-only" in sys.argv:
+        twin_cases()
+        sys.exit(0)
+    if "--rw-only" in sys.argv:
+        rw_cases()
+        sys.exit(0)
+    if "--feed-only" in sys.argv:
+        feed_case("feed_batches", 41)
+        sys.exit(0)
     func_case("func_rows", 31)
     if "--func-only" in sys.argv:
         sys.exit(0)
@@ -500,10 +594,12 @@ if __name__ == "__main__":
     encoder_case("enc_coarse", 1, L=4, C=8, base=8, end=8, logmap=19, n_pts=64)
     encoder_case("enc_fine", 2, L=8, C=4, base=4, end=40, logmap=10, n_pts=64)
     encoder_case("enc_colour", 3, L=16, C=2, base=4, end=128, logmap=11, n_pts=64)
-    twin_case("twin_dense", 4, L=5, C=4, base=8, end=40, n_pts=128)
+    twin_cases()
+    feed_case("feed_batches", 41)
     sparse_colour_case("enc_colour_real_sparse", 5, n_pts=24)
     full_case("full_tracking", 10, "tracking", "fine", "highfreq", bs=1, n_pix=24)
     full_case("full_tracking_poisson", 11, "tracking", "fine", "highfreq", bs=1, n_pix=16, poisson=True)
     full_case("full_mapping", 12, "mapping", "fine", "highfreq", bs=2, n_pix=8, poisson=True)
     full_case("full_mapping_coarse_base", 13, "mapping", "coarse", "base", bs=2, n_pix=8)
     full_case("full_vis_eval", 14, "vis", "fine", "highfreq", bs=1, n_pix=16, training=False)
+    rw_cases()

@@ -1,0 +1,113 @@
+"""B2 drop-in check: the reference's tracking + mapping loops (code/training/volsdf_train.py:393-446 and :451-576), restated
+call for call around a model built EXACTLY as the reference builds it (no freeze_fine_mlp(), no requires_grad_ edits, default
+engine), with the reference's optimizer groups (torch.optim.Adam, :150-174), its two SLAMLoss instances (confs: loss /
+tracking_loss), StepLR(50, 0.95) on the camera and the arg-min-loss candidate.  Every forward must run on the fused engine."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+H, W = 68, 120
+
+
+class _DS:
+    img_res = (H, W)
+    data_dir = "synthetic"
+
+
+def _world():
+    from nicer_slam_amd.feed import FrameFeed
+    from nicer_slam_amd.model.loss import SLAMLoss
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    torch.manual_seed(0)
+    model = SLAMNetwork(conf=replica_model_conf(use_warp_loss=False), dataset=_DS(), n_images=3,
+                        colour_grid=dict(base_resolution=16, desired_resolution=256, log2_hashmap_size=15))
+    model.train_dataset, model.keyframe_every = None, 10
+    model.cuda()
+    lr = 0.002
+    para_list = [     # volsdf_train.py:150-173
+        {"name": "encoding", "params": list(model.implicit_network.fine.grid_parameters()), "lr": lr * 20.0},
+        {"name": "encoding", "params": list(model.implicit_network.coarse.grid_parameters()), "lr": lr * 20.0},
+        {"name": "net", "params": list(model.rendering_network.grid_parameters()), "lr": lr * 5.0},
+        {"name": "net", "params": list(model.rendering_network.mlp_parameters()), "lr": lr},
+        {"name": "density", "params": list(model.density.parameters()), "lr": 2e-3},
+        {"name": "coarse_mlp_parameters", "params": list(model.implicit_network.coarse.mlp_parameters()), "lr": lr},
+    ]
+    optimizer = torch.optim.Adam(para_list, betas=(0.9, 0.99), eps=1e-15)
+    loss = SLAMLoss(model=model, rgb_loss="torch.nn.L1Loss", assign_scale_shift_init=True, eikonal_weight=0.1,
+                    smooth_weight=0.005, depth_weight=0.1, normal_l1_weight=0.05, normal_cos_weight=0.05)
+    tracking_loss = SLAMLoss(model=model, rgb_loss="torch.nn.L1Loss", eikonal_weight=0, smooth_weight=0, depth_weight=0,
+                             normal_l1_weight=0, normal_cos_weight=0)
+    feed = FrameFeed((H, W), device="cuda")
+    g = torch.Generator().manual_seed(1)
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 60.0
+    K[0, 2], K[1, 2] = W / 2 - 0.5, H / 2 - 0.5
+    for idx in range(2):
+        pose = torch.eye(4)
+        pose[:3, 3] = torch.tensor([0.1 + 0.01 * idx, 0.0, -0.2])
+        feed.add_frame(idx, rgb=torch.rand(H * W, 3, generator=g), depth=torch.rand(H * W, 1, generator=g) + 0.5,
+                       normal=torch.nn.functional.normalize(torch.randn(H * W, 3, generator=g), dim=-1), intrinsics=K, pose=pose)
+    return model, optimizer, loss, tracking_loss, feed
+
+
+def test_reference_loops_run_on_the_fused_engine_unmodified():
+    from nicer_slam_amd.utils.general import get_camera_from_tensor, get_tensor_from_camera
+    model, optimizer, loss_fn, tracking_loss, feed = _world()
+    assert all(p.requires_grad for p in model.parameters()) and model.engine == "auto"
+    engines = []
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+
+    def mapping(frame_idx, keyframe_list, iters):
+        out_losses = []
+        for it in range(iters):                                      # :451-576
+            feed.change_sampling_idx(512 // len(keyframe_list))
+            indices, model_input, ground_truth = feed.batch(keyframe_list)
+            optimizer.zero_grad()
+            if frame_idx > 1:
+                stage = "coarse" if it < int(iters * 0.25) else "fine"
+                color_stage = "base" if it < int(iters * 0.7) else "highfreq"
+            else:
+                stage, color_stage = "fine", "highfreq"
+            out = model(model_input, indices, ground_truth, keyframe_list=keyframe_list, frame_idx=frame_idx, mode="mapping",
+                        stage=stage, color_stage=color_stage, iter=it)
+            engines.append(("mapping", stage, color_stage, model.last_engine))
+            l = loss_fn(out, ground_truth, keyframe_list, frame_idx=frame_idx, stage=stage)["loss"]
+            l.backward()
+            optimizer.step()
+            out_losses.append(float(l))
+        return out_losses
+
+    m0 = mapping(0, [0], 4)
+    # tracking of frame 1                                           :393-446
+    cam = get_tensor_from_camera(feed.frames[0]["pose"].cpu()).cuda().requires_grad_(True)
+    opt_cam = torch.optim.Adam([cam], lr=0.001)
+    sched = torch.optim.lr_scheduler.StepLR(opt_cam, step_size=50, gamma=0.95)
+    candidate, min_loss = None, 1e10
+    feed.change_sampling_idx(256)
+    for it in range(5):
+        c2w = get_camera_from_tensor(cam)
+        indices, model_input, ground_truth = feed.batch([1])
+        model_input["pose"] = c2w.unsqueeze(0)
+        out = model(model_input, indices, ground_truth, mode="tracking", frame_idx=1)
+        engines.append(("tracking", "fine", "highfreq", model.last_engine))
+        l = tracking_loss(out, ground_truth, stage="fine", frame_idx=1)["loss"]
+        l.backward()
+        opt_cam.step()
+        sched.step()
+        opt_cam.zero_grad()
+        if l < min_loss:
+            min_loss, candidate = l, cam.clone().detach()
+    assert candidate is not None and bool(torch.isfinite(candidate).all())
+    feed.set_pose(1, get_camera_from_tensor(candidate).detach())
+    m1 = mapping(2, [0, 1], 8)                                       # frame_idx > 1: coarse->fine, base->highfreq schedule
+    assert all(e[-1] == "fused" for e in engines), [e for e in engines if e[-1] != "fused"]
+    assert {e[1] for e in engines} == {"coarse", "fine"} and {e[2] for e in engines} == {"base", "highfreq"}
+    assert all(l == l and abs(l) < 1e6 for l in m0 + m1)
+    moved = {n for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n])}
+    assert any("rendering_network.lin" in n for n in moved) and any("coarse.lin" in n for n in moved)
+    assert any(n.endswith("encoding.embeddings") for n in moved)
+    for n, p in model.named_parameters():                            # the pretrained fine MLP is never stepped (:140-173)
+        if n.startswith("implicit_network.fine.lin"):
+            assert n not in moved and p.grad is None

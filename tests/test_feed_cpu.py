@@ -34,3 +34,42 @@ def test_frame_feed_batches_match_reference_layout():
     _, inp, gt = feed.batch([3])
     assert inp["uv"].shape == (1, H * W, 2) and "sampling_idx" not in inp and "full_rgb" not in gt
     assert torch.equal(gt["rgb"][0], frames[3]["rgb"])
+
+
+def check_feed_against_reference(device):
+    """FrameFeed vs batches produced by the reference's own SLAMDataset.__getitem__ / collate_fn
+    (tests/golden/make_golden.py::feed_case; scene_dataset.py:214-287): same keys, shapes, dtypes and values for a mapping
+    batch (2 frames), a tracking batch and a whole-image visualisation batch, given the same pixel draw."""
+    from helpers import load, tt
+    from nicer_slam_amd.feed import FrameFeed
+    fx = load("feed_batches")
+    H, W, Hedge, Wedge = [int(v) for v in fx["meta_res"]]
+    feed = FrameFeed((H, W), device=device, scene_scale=float(fx["meta_scene_scale"]))
+    for idx in (3, 8):
+        f = {k: tt(fx[f"frame{idx}_{k}"]) for k in ("rgb", "depth", "normal", "gt_depth", "mask", "intrinsics", "pose")}
+        feed.add_frame(idx, **f)
+    for tag in ("map", "trk", "vis"):
+        frames = fx[f"{tag}_frames"].tolist()
+        if f"{tag}_sampling_idx" in fx:
+            feed.sampling_idx = tt(fx[f"{tag}_sampling_idx"]).to(device)
+        else:
+            feed.change_sampling_idx(-1)
+        indices, inp, gt = feed.batch(frames)
+        assert indices.tolist() == fx[f"{tag}_indices"].tolist() and indices.dtype == torch.long
+        want_in = {k[len(tag) + 4:]: v for k, v in fx.items() if k.startswith(f"{tag}_in_")}
+        want_gt = {k[len(tag) + 4:]: v for k, v in fx.items() if k.startswith(f"{tag}_gt_")}
+        assert set(inp) == set(want_in) and set(gt) == set(want_gt), (tag, set(inp) ^ set(want_in), set(gt) ^ set(want_gt))
+        for got, want in ((inp, want_in), (gt, want_gt)):
+            for k, v in want.items():
+                assert got[k].device.type == torch.device(device).type, k
+                assert tuple(got[k].shape) == v.shape and got[k].dtype == tt(v).dtype, (tag, k, got[k].shape, v.shape)
+                assert torch.equal(got[k].cpu(), tt(v)), (tag, k)      # gathers and one division: bit-exact
+    # the device-side draw: tracking samples the first tracking_total_pixels indices (scene_dataset.py:282-286)
+    n_trk = (H - 2 * Hedge) * (W - 2 * Wedge)
+    sel = feed.change_sampling_idx(4096, total_pixels=n_trk)
+    assert sel.device.type == torch.device(device).type and int(sel.min()) >= 0 and int(sel.max()) == n_trk - 1
+    assert len(set(sel.tolist())) == n_trk
+
+
+def test_frame_feed_vs_reference_dataset_batches():
+    check_feed_against_reference("cpu")

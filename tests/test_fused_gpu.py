@@ -31,7 +31,7 @@ def _setup(name):
     return fx, model, cam, pose, rays_o, rays_d
 
 
-@pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_vis_eval"])
+@pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_vis_eval", "full_tracking_rw"])
 def test_stage_by_stage_forward(name):
     """sdf / grad sdf / feature / rgb / weights of the fused kernels at the reference's own sample positions."""
     from oracle import render_ref as R
@@ -80,7 +80,7 @@ def test_feature_vector_hl_layout():
     assert_close(dense, f_o, 2e-5 * float(f_o.abs().max()), 1e-4, "feature vector")
 
 
-@pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson"])
+@pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_tracking_rw"])
 def test_model_fused_engine_vs_reference_goldens(name):
     """SLAMNetwork with engine='fused': output dict and the pose gradient of the tracking objective."""
     fx, model, cam, pose, _, _ = _setup(name)
@@ -99,7 +99,8 @@ def test_model_fused_engine_vs_reference_goldens(name):
 
 
 @pytest.mark.parametrize("name,stage,cstage", [("full_tracking", "fine", "highfreq"), ("full_tracking_poisson", "fine", "base"),
-                                               ("full_mapping", "coarse", "highfreq")])
+                                               ("full_mapping", "coarse", "highfreq"), ("full_tracking_rw", "fine", "highfreq"),
+                                               ("full_mapping_rw", "fine", "highfreq")])
 def test_backward_all_cotangents_vs_oracle(name, stage, cstage):
     """Every differentiable output (rgb, depth, normal map, entropy, weights) pulled back to the pose and compared
     with the CPU oracle (torch autograd over the restated reference graph) -- both stages / colour stages."""
@@ -258,6 +259,40 @@ def test_kernel_tracker_matches_autograd_stepper():
         assert_close(torch.tensor(ls), torch.tensor(ref_l), 2e-6, 1e-5, f"losses (graph={use_graph})")
         assert_close(kt.cam, ref.cam.detach(), 2e-6, 1e-4, f"camera after 5 steps (graph={use_graph})")
     assert abs(ref_l[0] - float(fx["out_loss"])) < 5e-5
+
+
+def test_kernel_tracker_steplr_and_min_loss_candidate():
+    """The reference's per-frame tracking protocol (volsdf_train.py:396-403,425-446): Adam + StepLR, and the frame's result
+    is the camera cloned AFTER the step of the arg-min-loss iteration.  KernelTracker (schedule and candidate inside the
+    tail kernel; eager and hipGraph) vs torch.optim.Adam + torch StepLR + the same comparison on the autograd stepper; then
+    reset() must reproduce a fresh tracker."""
+    from nicer_slam_amd.tracking import TrackingStepper, KernelTracker
+    fx, model, cam, pose, _, _ = _setup("full_tracking")
+    model.train(True)
+    model.engine = "fused"
+    model.draws = draws_of(fx, "cuda")
+    K, uv = tt(fx["in_K"]).cuda(), tt(fx["in_uv"]).cuda()
+    g = torch.Generator().manual_seed(3)
+    gts = [torch.rand(uv.shape[1], 3, generator=g).cuda() for _ in range(7)]     # a different target per iteration:
+    cam0 = tt(fx["in_cam"]).reshape(-1)                                          # the loss is not monotone
+    ref = TrackingStepper(model, K, uv.shape[1], cam0, lr=0.01, use_graph=False, lr_step=3, lr_gamma=0.5)
+    ref_l, ref_cams = [], []
+    for gt in gts:
+        ref_l.append(float(ref.step(uv, gt)))
+        ref_cams.append(ref.cam.detach().clone())
+    best = min(range(len(ref_l)), key=lambda i: (ref_l[i], i))
+    assert 0 < best < len(ref_l) - 1 or len(set(ref_l)) > 1
+    assert_close(ref.candidate, ref_cams[best], 0, 0, "stepper candidate = camera after the arg-min step")
+    for use_graph in (False, True):
+        kt = KernelTracker(model, K, uv.shape[1], cam0, lr=0.01, use_graph=use_graph, lr_step=3, lr_gamma=0.5)
+        for rep in range(2):                                   # second pass: reset() == a fresh tracker
+            ls = [float(kt.step(uv, gt)) for gt in gts]
+            assert_close(torch.tensor(ls), torch.tensor(ref_l), 2e-6, 1e-5, f"losses (graph={use_graph}, pass {rep})")
+            assert_close(kt.cam, ref_cams[-1], 2e-6, 1e-4, "final camera (StepLR applied)")
+            assert_close(kt.candidate, ref_cams[best], 2e-6, 1e-4, "candidate camera")
+            assert abs(float(kt.min_loss) - ref_l[best]) < 2e-6
+            kt.reset(cam0)
+            assert float(kt.min_loss) == 1e10 and float(kt.t) == 0
 
 
 def test_kernel_tracker_multi_gpu_message_path_single_rank_group():

@@ -78,6 +78,30 @@ def test_golden_function_level(name):
     assert float(y[3].abs().max()) == 0 and float(y[4].abs().max()) == 0   # out-of-range rows are exactly zero
 
 
+@pytest.mark.parametrize("name", ["twin_dense", "twin_dense_c8", "twin_dense_c2"])
+def test_reference_twin_second_order(name):
+    """HIP operator vs stock autograd through the reference's pure-torch twin (HashEncoder.torch_forward,
+    hashgrid.py:217-299): value, J^T v, table scatter and the two second-order products the CUDA path keeps
+    (hashencoder.cu:405-625) -- expected values that never touched the C restatement."""
+    from nicer_slam_amd.hashencoder.hashgrid import HashEncoder
+    from test_oracle_golden import twin_checks
+    fx = load(name)
+    L, C, base, end, logmap = [int(t) for t in fx["meta_grid"]]
+    enc = HashEncoder(num_levels=L, level_dim=C, base_resolution=base, desired_resolution=end,
+                      log2_hashmap_size=logmap).cuda()
+    assert enc.offsets.cpu().tolist() == fx["param_offsets"].tolist()
+    enc.embeddings.data = tt(fx["param_embeddings"]).cuda()
+    x = tt(fx["in_x"]).cuda().requires_grad_(True)
+    v = tt(fx["in_v"]).cuda().requires_grad_(True)
+    y = enc(x)
+    (gx,) = torch.autograd.grad(y, x, v, create_graph=True)
+    (first,) = torch.autograd.grad(y, enc.embeddings, v, retain_graph=True)
+    v2, e2 = torch.autograd.grad((gx * tt(fx["in_q"]).cuda()).sum(), [v, enc.embeddings])
+    assert_close(y, fx["out_y"], 5e-5, 1e-4, "y vs torch_forward")
+    assert_close(gx, fx["out_gx"], 5e-5 * float(np.abs(fx["out_gx"]).max()), 1e-4, "J^T v vs autograd(torch_forward)")
+    twin_checks(fx, first, v2, e2)
+
+
 def test_real_colour_geometry_sparse_table():
     """Shipped colour grid (16x2, 16->2048, 2^24 rows/level; 1 GiB) incl. the uint32 stride wrap at res 2048."""
     from nicer_slam_amd.hashencoder.hashgrid import hash_encode

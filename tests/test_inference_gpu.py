@@ -66,3 +66,59 @@ def test_render_image_chunked_equals_single_pass():
         assert whole[k].shape[0] == H * W
         assert torch.equal(whole[k], parts[k]), k
     assert float(whole["rgb_values"].std()) > 0
+
+
+# ---- the same consumers against the CPU oracle / the reference's goldens (not against our own composed engine) ----------
+
+def _golden_model(name):
+    from helpers import load, tt
+    from test_model_cpu import build_model
+    fx = load(name)
+    model = build_model(fx).cuda().eval()
+    model.voxels = tt(fx["in_voxels"]).cuda()
+    return fx, model
+
+
+@pytest.mark.parametrize("stage", ["fine", "coarse"])
+def test_sdf_values_and_grid_vs_oracle(stage):
+    """nsa_sdf_points (inference.sdf_values / sdf_grid) vs oracle/render_ref.py::sdf_vals with the parameters of a
+    reference-captured golden: scattered points incl. the cube faces and the outside, ragged chunks, grid order."""
+    from helpers import params_of, oracle_config
+    from oracle import render_ref as R
+    from nicer_slam_amd import inference
+    fx, model = _golden_model("full_vis_eval")
+    cfg, params = oracle_config(fx), params_of(fx)
+    g = torch.Generator().manual_seed(5)
+    pts = (torch.rand(20011, 3, generator=g) * 2 - 1) * 1.2
+    pts[0] = torch.tensor([1.0, -1.0, 1.0])
+    pts[1] = torch.tensor([1.0001, 0.0, 0.0])
+    pts[2] = torch.zeros(3)
+    with torch.no_grad():
+        ref = R.sdf_vals(params, cfg, pts.clone(), stage).reshape(-1)
+    got = inference.sdf_values(model, pts.cuda(), stage, chunk=7000)
+    assert_close(got, ref, 2e-5, 1e-4, "sdf_values vs oracle")
+    res, bound = 12, (-1.05, 1.05)
+    vol = inference.sdf_grid(model, res, bound, stage=stage, chunk=500)
+    x = np.linspace(bound[0], bound[1], res)
+    xx, yy, zz = np.meshgrid(x, x, x)                                   # plots.py:102-118 order
+    gp = torch.from_numpy(np.vstack([xx.ravel(), yy.ravel(), zz.ravel()]).T.astype(np.float32))
+    with torch.no_grad():
+        zr = R.sdf_vals(params, cfg, gp, stage).reshape(res, res, res).permute(1, 0, 2)     # plots.py:121-127
+    assert_close(vol, zr, 2e-5, 1e-4, "sdf_grid vs oracle")
+
+
+def test_render_image_vs_reference_vis_golden():
+    """inference.render_image (chunked, fused engine, eval-mode sampler) vs the output dict the reference produced for the
+    same pixels (golden full_vis_eval: mode 'vis', eval).  Free-running sampler on both sides -> the end-to-end tolerance
+    of tests/test_oracle_golden.py (2e-4 / 1e-3)."""
+    from helpers import tt
+    from nicer_slam_amd import inference
+    fx, model = _golden_model("full_vis_eval")
+    model.engine = "fused"
+    inp = {"intrinsics": tt(fx["in_K"]).cuda(), "uv": tt(fx["in_uv"]).cuda(), "pose": tt(fx["in_pose"]).cuda()}
+    for n_pix in (16, 5):                                               # single pass and ragged chunks
+        out = inference.render_image(model, inp, mode="vis", n_pixels=n_pix)
+        assert model.last_engine == "fused"
+        for k in ("rgb_values", "depth_values", "normal_map"):
+            want = fx["out_" + k].reshape(out[k].shape)
+            assert_close(out[k], want, 2e-4, 1e-3, f"render_image {k} (chunks of {n_pix})")

@@ -31,7 +31,7 @@ def _run(fx, engine, ground_truth=None):
     return model, cam, out
 
 
-@pytest.mark.parametrize("name", ["full_mapping", "full_mapping_coarse_base"])
+@pytest.mark.parametrize("name", ["full_mapping", "full_mapping_coarse_base", "full_mapping_rw", "full_mapping_rw_coarse"])
 def test_fused_mapping_vs_reference_goldens(name):
     fx = load(name)
     model, cam, out = _run(fx, "fused")
@@ -66,6 +66,78 @@ def test_fused_mapping_vs_reference_goldens(name):
             assert_close(g, ref, 1e-6 + 2e-4 * float(np.abs(ref).max()), 1e-3, "grad " + n)
             checked += 1
     assert checked >= 10
+
+
+@pytest.mark.parametrize("name", ["full_tracking", "full_mapping", "full_mapping_coarse_base", "full_tracking_rw",
+                                  "full_mapping_rw", "full_mapping_rw_coarse"])
+def test_fused_engine_every_parameter_gradient_like_the_reference(name):
+    """The model exactly as volsdf_train.py builds it -- every parameter requires grad, nothing frozen -- with the two
+    skip-policies switched off (tracking_param_grads, fine_mlp_grads): the fused engine then produces what the reference's
+    autograd produces, tracking and mapping alike, incl. the fine SDF MLP (976 emission rows from k_sdfnet_bwd<fine, MAP>).
+    Every named parameter's gradient vs the reference golden."""
+    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    fx = load(name)
+    model = build_model(fx).cuda()
+    assert all(p.requires_grad for p in model.parameters())
+    model.engine = "fused"
+    model.tracking_param_grads = True
+    model.fine_mlp_grads = True
+    mode, stage, cstage = str(fx["meta_mode"]), str(fx["meta_stage"]), str(fx["meta_color_stage"])
+    model.train(True)
+    model.voxels = tt(fx["in_voxels"]).cuda()
+    model.draws = draws_of(fx, "cuda")
+    model.draws["z_vals_override"] = tt(fx["out_z_vals"]).cuda()
+    cam = tt(fx["in_cam"]).cuda().requires_grad_(True)
+    pose = get_camera_from_tensor(cam)
+    out = model({"intrinsics": tt(fx["in_K"]).cuda(), "uv": tt(fx["in_uv"]).cuda(), "pose": pose},
+                torch.arange(pose.shape[0], device="cuda"), {}, mode=mode, stage=stage, color_stage=cstage, frame_idx=1)
+    assert model.last_engine == "fused"
+    golden_objective(out, fx, mode).backward()
+    assert_close(cam.grad, fx["grad_cam"], 2e-6, 1e-3, "grad_cam")
+    checked = fine = 0
+    for n, p in model.named_parameters():
+        ref = fx["grad_" + n]
+        if ref.size == 0 or float(np.abs(ref).max()) == 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0, n
+            continue
+        assert p.grad is not None, n
+        assert_close(p.grad, ref, 1e-6 + 2e-4 * float(np.abs(ref).max()), 1e-3, "grad " + n)
+        checked += 1
+        fine += n.startswith(FROZEN)
+    assert checked >= 10 and (fine >= 6 or stage == "coarse"), (checked, fine)
+
+
+def test_default_policy_keeps_the_unmodified_model_on_the_fused_engine():
+    """Defaults: a model built like the reference's (all parameters require grad) renders tracking AND mapping on the fused
+    engine with engine='auto'; what the reference computes-and-discards is skipped: no parameter gradients in tracking, none
+    for the fine SDF MLP in mapping, every optimizer-list parameter gets its gradient."""
+    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    fx = load("full_mapping")
+    model = build_model(fx).cuda().train(True)
+    assert model.engine == "auto" and all(p.requires_grad for p in model.parameters())
+    model.voxels = tt(fx["in_voxels"]).cuda()
+    model.draws = draws_of(fx, "cuda")
+    model.draws["z_vals_override"] = tt(fx["out_z_vals"]).cuda()
+    K, uv = tt(fx["in_K"]).cuda(), tt(fx["in_uv"]).cuda()
+    cam = tt(fx["in_cam"]).cuda().requires_grad_(True)
+    out = model({"intrinsics": K, "uv": uv, "pose": get_camera_from_tensor(cam)}, torch.arange(uv.shape[0], device="cuda"),
+                {}, mode="tracking", frame_idx=1)
+    assert model.last_engine == "fused"
+    out["rgb_values"].abs().mean().backward()
+    assert cam.grad is not None and float(cam.grad.abs().max()) > 0
+    assert all(p.grad is None for p in model.parameters())
+    cam.grad = None
+    out = model({"intrinsics": K, "uv": uv, "pose": get_camera_from_tensor(cam)}, torch.arange(uv.shape[0], device="cuda"),
+                {}, mode="mapping", stage="fine", color_stage="highfreq", frame_idx=1)
+    assert model.last_engine == "fused"
+    golden_objective(out, fx, "mapping").backward()
+    for n, p in model.named_parameters():
+        if n.startswith(FROZEN):
+            assert p.grad is None, n
+        else:
+            ref = fx["grad_" + n]
+            if ref.size and float(np.abs(ref).max()) > 0:
+                assert_close(p.grad, ref, 1e-6 + 2e-4 * float(np.abs(ref).max()), 1e-3, "grad " + n)
 
 
 def test_fused_mapping_with_warp_block():

@@ -38,7 +38,8 @@ def build_model(fx):
     return model
 
 
-@pytest.mark.parametrize("name", ["full_tracking", "full_mapping", "full_mapping_coarse_base", "full_vis_eval"])
+@pytest.mark.parametrize("name", ["full_tracking", "full_mapping", "full_mapping_coarse_base", "full_vis_eval",
+                                  "full_tracking_rw", "full_mapping_rw"])
 def test_model_layer_matches_reference(oracle_seam, name):
     from nicer_slam_amd.utils.general import get_camera_from_tensor
     fx = load(name)

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("engine", ["composed"])
 @pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_mapping", "full_mapping_coarse_base",
-                                  "full_vis_eval"])
+                                  "full_vis_eval", "full_tracking_rw", "full_mapping_rw", "full_mapping_rw_coarse"])
 def test_forward_and_grads_vs_reference_goldens(name, engine):
     from nicer_slam_amd.utils.general import get_camera_from_tensor
     fx = load(name)

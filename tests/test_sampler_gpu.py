@@ -19,7 +19,8 @@ def _rays(fx, model):
     return d.reshape(-1, 3).contiguous(), o.unsqueeze(1).repeat(1, n, 1).reshape(-1, 3).contiguous()
 
 
-@pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_mapping", "full_vis_eval"])
+@pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_mapping", "full_vis_eval", "full_tracking_rw",
+                                  "full_mapping_rw"])
 def test_coarse_stage_sdf_and_z(name):
     """z (stratified) and coarse+fine SDF at the R*E coarse samples vs the oracle restatement."""
     from oracle import render_ref as R
@@ -44,7 +45,8 @@ def test_coarse_stage_sdf_and_z(name):
     assert_close(sdf, sdf_c, 1e-5, 1e-4, "sdf")
 
 
-@pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_mapping", "full_vis_eval"])
+@pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_mapping", "full_vis_eval", "full_tracking_rw",
+                                  "full_mapping_rw"])
 def test_full_sampler_vs_reference_samples(name):
     """End-to-end fused sampler vs the reference's own z_vals (goldens), compared in CDF space."""
     from oracle import render_ref as R

@@ -236,7 +236,11 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeArgs a) {
             suffix += wbar[k] * s.w;
             const float sb = eb * s.dist;                               // sigma_bar
             const float sg = s.sdf > 0.0f ? 1.0f : (s.sdf < 0.0f ? -1.0f : 0.0f);
-            const float dsig = -0.5f * sg * sg * expf(-fabsf(s.sdf) / s.beta) / (s.beta * s.beta);
+            // d sigma / d sdf as torch's autograd forms it: the backward of expm1 is (result + 1), NOT exp(x) -- far from the
+            // surface (|s|/beta > ~17) expm1 has rounded to exactly -1 and the reference's derivative is exactly 0, while
+            // exp(-|s|/beta) is 1e-8 .. 1e-16 and the last interval multiplies it by 1e10 (density.py:37-39, network.py:357)
+            const float em1 = expm1f(-fabsf(s.sdf) / s.beta) + 1.0f;
+            const float dsig = -0.5f * sg * sg * em1 / (s.beta * s.beta);
             a.g_sdf[i] = sb * dsig;
         }
     }

@@ -67,37 +67,27 @@ def test_config0_256_rays_64_samples_vs_oracle(poisson):
     check_samples(out["z_vals"].cpu(), free["z_vals"], free["sampler_bins"], free["sampler_cdf"], u_tol=5e-5)
     for k in ("rgb_values", "depth_values", "normal_map"):
         assert_close(out[k], free[k], 2e-4, 1e-3, "free-running " + k)
-    # (2) everything downstream of the sampler from the GPU's sample set: tight
-    dc["z_vals_override"] = out["z_vals"].detach().cpu()
+    # (2) everything downstream of the sampler, tight, from a FIXED sample set on both sides: the GPU's samples with the far
+    # sample pulled 2e-4 inside.  As drawn, the far sample sits exactly ON the cube face, where every grid's in-range test
+    # (hashencoder.cu:155-159) hangs on the last ulp of o + z d; the two sides build their rays with differently ordered fp32
+    # sums (as the reference on CUDA vs on CPU would), so that one sample may be inside on one side and outside on the other
+    #  -- with a finest-level Jacobian of ~600/unit that shows in the pose gradient, not in the rendered values.
+    z_fix = out["z_vals"].detach().clone()
+    z_fix[:, -1] = torch.maximum(z_fix[:, -1] * (1 - 2e-4), z_fix[:, -2])
+    model.draws = dict(draws, z_vals_override=z_fix)
+    cam2 = cam.detach().clone().requires_grad_(True)
+    out = model({"intrinsics": K[None], "uv": uv, "pose": get_camera_from_tensor(cam2).unsqueeze(0)},
+                torch.zeros(1, dtype=torch.long, device="cuda"), {}, mode="tracking", frame_idx=1)
+    assert model.last_engine == "fused"
+    loss = (out["rgb_values"].reshape(-1, 3) - gt).abs().mean()
+    loss.backward()
+    dc["z_vals_override"] = z_fix.cpu()
     cam_c = cam.detach().cpu().clone().requires_grad_(True)
     ref = R.render(params, cfg, uv.cpu(), R.camera_from_tensor(cam_c).unsqueeze(0), K[None].cpu(), vox, dc,
                    mode="tracking", training=True)
-    # The far sample sits exactly ON the cube face, where every grid's in-range test (hashencoder.cu:155-159) hangs on the
-    # last ulp of o + z d; the two sides build their rays with differently ordered fp32 sums (as the reference on CUDA vs on
-    # CPU would), so a far sample may land inside on one side and outside on the other.  Per-sample tensors are
-    # compared without that sample; rays whose far sample flipped are counted, bounded, and left out of the per-ray checks.
-    inner = slice(0, S - 1)
-    for k in ("sdf", "depth_vals"):
-        assert_close(out[k][:, inner], ref[k][:, inner], 2e-5, 1e-4, k)
-    assert_close(out["rgb"][:, inner], ref["rgb"][:, inner], 2e-5, 1e-4, "rgb per sample")
-    flipped = ((out["sdf"][:, -1].cpu() - ref["sdf"][:, -1]).abs() > 1e-4)
-    assert int(flipped.sum()) <= Rn // 50, int(flipped.sum())
-    keep = ~flipped
-    assert_close(out["weights"].cpu()[keep], ref["weights"][keep], 2e-5, 1e-4, "weights")
-    for k in ("rgb_values", "depth_values", "normal_map"):
-        assert_close(out[k].cpu()[0][keep], ref[k][0][keep], 2e-5, 1e-4, k)
-    if not bool(flipped.any()):
-        assert_close(out["entropy"], ref["entropy"], 2e-5, 1e-4, "entropy")
-        l_ref = R.rgb_l1(ref, gt.cpu())
-        l_ref.backward()
-        assert_close(loss, l_ref, 1e-6, 1e-5, "loss")
-        assert_close(cam.grad, cam_c.grad, 1e-3 * float(cam_c.grad.abs().max()), 1e-3, "pose gradient")
-    else:       # same objective restricted to the rays both sides agree on
-        l_ref = (ref["rgb_values"].reshape(-1, 3) - gt.cpu())[keep].abs().sum() / (3 * Rn)
-        l_ref.backward()
-        cam2 = cam.detach().clone().requires_grad_(True)
-        model.draws = dict(draws, z_vals_override=out["z_vals"].detach())
-        o2 = model({"intrinsics": K[None], "uv": uv, "pose": get_camera_from_tensor(cam2).unsqueeze(0)},
-                   torch.zeros(1, dtype=torch.long, device="cuda"), {}, mode="tracking", frame_idx=1)
-        ((o2["rgb_values"].reshape(-1, 3) - gt)[keep.cuda()].abs().sum() / (3 * Rn)).backward()
-        assert_close(cam2.grad, cam_c.grad, 1e-3 * float(cam_c.grad.abs().max()), 1e-3, "pose gradient (agreeing rays)")
+    for k in ("sdf", "depth_vals", "rgb", "weights", "rgb_values", "depth_values", "normal_map", "entropy"):
+        assert_close(out[k], ref[k], 2e-5, 1e-4, k)
+    l_ref = R.rgb_l1(ref, gt.cpu())
+    l_ref.backward()
+    assert_close(loss, l_ref, 1e-6, 1e-5, "loss")
+    assert_close(cam2.grad, cam_c.grad, 1e-3 * float(cam_c.grad.abs().max()), 1e-3, "pose gradient")

@@ -324,6 +324,46 @@ def test_kernel_tracker_multi_gpu_message_path_single_rank_group():
     assert_close(many.cam, one.cam, 1e-6, 1e-5, "camera after 4 steps")
 
 
+def test_composite_backward_far_from_the_surface_matches_torch_expm1_backward():
+    """Regression (found by tests/test_configs_gpu.py): in empty space (sdf / beta > ~17) expm1(-|s|/beta) has rounded to
+    exactly -1, so the reference's sigma is exactly 0 or one ulp of 0.5 / beta, and torch's expm1 backward -- (result + 1),
+    not exp(x) -- gives a derivative that is exactly 0 or 2^-24-quantised.  The last interval multiplies d sigma by 1e10, so
+    an analytic exp(-|s|/beta) there (1e-8 .. 1e-16, not 0) shows up as a spurious gradient of ordinary magnitude.
+    Synthetic rays through empty space, per-sample d/d sdf vs torch autograd over the oracle's volume_weights."""
+    from oracle import render_ref as R
+    from nicer_slam_amd._native import lib, check
+    n_ray, S = 64, 64
+    g = torch.Generator().manual_seed(2)
+    z = torch.sort(torch.rand(n_ray, S, generator=g) * 1.5, dim=1).values
+    ro = torch.tensor([0.1, 0.0, -0.2]).repeat(n_ray, 1)
+    rd = torch.nn.functional.normalize(torch.randn(n_ray, 3, generator=g), dim=-1) * 0.5
+    # sdf from just below the surface to deep in empty space: |s| / beta spans 0 .. 70 (beta = 0.01444 at zero visits)
+    sdf0 = (torch.rand(n_ray, S, generator=g) * 1.0 - 0.02)
+    sdf0[:, -1] = torch.linspace(0.05, 0.9, n_ray)                 # the 1e10 interval, at every depth of the quantised zone
+    rgb = torch.rand(n_ray, S, 3, generator=g)
+    grad = torch.randn(n_ray, S, 3, generator=g)
+    vox = torch.zeros(64, 64, 64)
+    g_rgbv = torch.rand(n_ray, 3, generator=g) - 0.5
+    dev = lambda t: t.cuda().contiguous()
+    zc, roc, rdc, sc, rc, gc, vc, gr = map(dev, (z, ro, rd, sdf0, rgb, grad, vox, g_rgbv))
+    P = n_ray * S
+    g_sdf, g_rgb, g_grad = (torch.empty(P, device="cuda"), torch.empty(P, 3, device="cuda"), torch.empty(P, 3, device="cuda"))
+    check(lib.nsa_composite_backward(roc.data_ptr(), rdc.data_ptr(), zc.data_ptr(), sc.data_ptr(), rc.data_ptr(), gc.data_ptr(),
+                                     vc.data_ptr(), 64, n_ray, S, gr.data_ptr(), None, None, None, None, g_sdf.data_ptr(),
+                                     g_rgb.data_ptr(), g_grad.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    sdf = sdf0.reshape(-1, 1).clone().requires_grad_(True)
+    pts = (ro.unsqueeze(1) + z.unsqueeze(2) * rd.unsqueeze(1)).reshape(-1, 3)
+    w = R.volume_weights(z, sdf, pts, vox, 64)
+    ((w.unsqueeze(-1) * rgb).sum(1) * g_rgbv).sum().backward()
+    ref = sdf.grad.reshape(n_ray, S)
+    got = g_sdf.cpu().reshape(n_ray, S)
+    # the reference's sigma is quantised: either exactly 0 (derivative 0) or >= 2e-6, which saturates the 1e10 interval
+    # (exp(-2e4) = 0): d/d sdf of the last sample is exactly zero on every ray, whatever its depth
+    assert bool((ref[:, -1] == 0).all())
+    assert float(got[:, -1].abs().max()) == 0.0
+    assert_close(got, ref, 1e-7 + 2e-3 * float(ref.abs().max()), 2e-3, "d/d sdf")
+
+
 def test_composite_backward_exact_zero_on_saturated_last_interval():
     """Regression: the last interval is 1e10 long, so d(weights)/d(sdf_last) is exactly 0 whenever sigma_last * 1e10
     saturates alpha (the usual case) -- a 'total minus prefix' suffix sum leaks a rounding residue times 1e10 there.

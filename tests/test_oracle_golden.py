@@ -88,13 +88,13 @@ def test_real_colour_geometry_sparse():
     assert float(y.abs().max()) > 0.1
 
 
-def check_samples(z, z_ref, bins, cdf, tight=1e-5, u_tol=1e-5):
+def check_samples(z, z_ref, bins, cdf, tight=1e-5, u_tol=1e-5, min_tight=0.97):
     """The inverse-CDF step amplifies float32 noise by 1/pdf where the pdf sits on its 1e-5 floor
     (ray_sampler.py:116-139), so sample sets are compared in CDF space; in z they must agree tightly
-    almost everywhere and never by more than a coarse-bin width."""
+    almost everywhere (``min_tight``: a sanity statistic, not the criterion) and never by more than a coarse-bin width."""
     assert z.shape == z_ref.shape
     dz = (z - z_ref).abs()
-    assert float((dz <= tight + 1e-4 * z_ref.abs()).float().mean()) >= 0.97
+    assert float((dz <= tight + 1e-4 * z_ref.abs()).float().mean()) >= min_tight
     assert float(dz.max()) < float((bins[:, 1:] - bins[:, :-1]).max())
     du = (R.cdf_at(z, bins, cdf) - R.cdf_at(z_ref, bins, cdf)).abs()
     assert float(du.max()) < u_tol, float(du.max())

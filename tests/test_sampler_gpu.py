@@ -65,8 +65,12 @@ def test_full_sampler_vs_reference_samples(name):
     aux = {}
     zo, zo_eik = R.importance_z(params, cfg, d.cpu(), o.cpu(), tt(fx["in_voxels"]), model.training, draws_of(fx), aux=aux)
     # u-space tolerance 5e-5: a few float32 ulps of a cdf whose 1e-5-floor bins each carry ~1e-5 of mass
-    check_samples(z_vals.cpu(), tt(fx["out_z_vals"]), aux["bins"], aux["cdf"], u_tol=5e-5)
-    check_samples(z_vals.cpu(), zo, aux["bins"], aux["cdf"], u_tol=5e-5)
+    # "_rw" cases: the cdf saturates after two bins, so the u = 1 sample (one of the 18 columns) lands on the last coarse
+    # sample or just below it depending on whether cumsum's final value rounds to 1 or 1 + 2^-23 (searchsorted right=True,
+    # ray_sampler.py:124-139) -- identical in CDF space, 4e-4 apart in z on every ray
+    mt = 0.94 if name.endswith("_rw") else 0.97
+    check_samples(z_vals.cpu(), tt(fx["out_z_vals"]), aux["bins"], aux["cdf"], u_tol=5e-5, min_tight=mt)
+    check_samples(z_vals.cpu(), zo, aux["bins"], aux["cdf"], u_tol=5e-5, min_tight=mt)
     idx = draws_of(fx)["eik_idx"]
     assert_close(z_eik.cpu().reshape(-1), z_vals.cpu()[torch.arange(z_vals.shape[0]), idx], 0, 0, "z_eik")
 

@@ -1,0 +1,113 @@
+#!/usr/bin/env python
+"""Diagnostic (development): pose gradient of the configs[0] tracking batch from the fused engine, the composed engine and the
+CPU oracle on the same fixed sample set, with the colour grid's gradient path on/off."""
+import sys, os
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nicer_slam_amd.model.network import SLAMNetwork
+from nicer_slam_amd.utils.conf import replica_model_conf
+from nicer_slam_amd.utils.general import get_camera_from_tensor
+from oracle import render_ref as R
+
+
+class DS:
+    img_res = (680, 1200)
+
+
+def main():
+    Rn, S, E, NX = 256, 64, 640, 32
+    torch.manual_seed(0)
+    model = SLAMNetwork(replica_model_conf(S - 2 - NX, E, NX, use_warp_loss=False), dataset=DS(), n_images=1).cuda().train()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    with torch.no_grad():
+        for enc, s in ((model.implicit_network.coarse.encoding, 0.02), (model.implicit_network.fine.encoding, 0.02),
+                       (model.rendering_network.encoding, 0.3)):
+            enc.embeddings.copy_((torch.rand(enc.embeddings.shape, device="cuda", generator=g) * 2 - 1) * s)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    idx = torch.randint(680 * 1200, (1, Rn), device="cuda", generator=g)
+    uv = torch.stack([(idx % 1200).float(), (idx // 1200).float()], -1)
+    K = torch.eye(4, device="cuda")
+    K[0, 0] = K[1, 1] = 600.0
+    K[0, 2], K[1, 2] = 599.5, 339.5
+    gt = torch.rand(Rn, 3, device="cuda", generator=g)
+    draws = {"t_rand": torch.rand(Rn, E, device="cuda", generator=g),
+             "extra_idx": torch.randperm(E, device="cuda", generator=g)[:NX],
+             "eik_idx": torch.randint(S, (Rn,), device="cuda", generator=g)}
+    cam0 = torch.tensor([1.0, 0.01, -0.02, 0.015, 0.1, 0.0, -0.2], device="cuda")
+
+    def gpu(engine, z=None, cstage="highfreq"):
+        model.engine = engine
+        model.draws = dict(draws) if z is None else dict(draws, z_vals_override=z)
+        cam = cam0.clone().requires_grad_(True)
+        out = model({"intrinsics": K[None], "uv": uv, "pose": get_camera_from_tensor(cam).unsqueeze(0)},
+                    torch.zeros(1, dtype=torch.long, device="cuda"), {}, mode="tracking", frame_idx=1, color_stage=cstage)
+        (out["rgb_values"].reshape(-1, 3) - gt).abs().mean().backward()
+        return out, cam.grad.detach().cpu()
+
+    out, _ = gpu("fused")
+    z = out["z_vals"].detach().clone()
+    z[:, -1] = torch.maximum(z[:, -1] * (1 - 2e-4), z[:, -2])
+    mk = R.make_grid_spec
+    cfg = R.RenderConfig(coarse=R.SdfNetSpec(mk(4, 8, 32, 32, 19), 2), fine=R.SdfNetSpec(mk(8, 4, 32, 128, 19), 4),
+                         colour_grid=mk(16, 2, 16, 2048, 24), n_samples=S - 2 - NX, n_samples_eval=E, n_samples_extra=NX)
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    dc = {k: v.cpu() for k, v in draws.items()}
+    dc["z_vals_override"] = z.cpu()
+
+    def cpu(cstage="highfreq", dtype=torch.float32):
+        cam = cam0.cpu().clone().requires_grad_(True)
+        ref = R.render(params, cfg, uv.cpu(), R.camera_from_tensor(cam).unsqueeze(0), K[None].cpu(), torch.zeros(64, 64, 64), dict(dc),
+                       mode="tracking", training=True, color_stage=cstage)
+        R.rgb_l1(ref, gt.cpu()).backward()
+        return ref, cam.grad.detach()
+
+    for cstage in ("highfreq", "base"):
+        _, gf = gpu("fused", z, cstage)
+        _, gc = gpu("composed", z, cstage)
+        _, go = cpu(cstage)
+        m = float(go.abs().max())
+        print(f"color_stage={cstage}")
+        print("  oracle  ", [f"{v:+.6e}" for v in go.tolist()])
+        print("  fused   ", [f"{v:+.6e}" for v in gf.tolist()], " max rel err vs oracle %.2e" % float((gf - go).abs().max() / m))
+        print("  composed", [f"{v:+.6e}" for v in gc.tolist()], " max rel err vs oracle %.2e" % float((gc - go).abs().max() / m),
+              " fused vs composed %.2e" % float((gf - gc).abs().max() / m))
+    # per-stage cotangent check: d loss / d x per point, fused vs composed is not exposed; compare g_rays instead
+    from nicer_slam_amd.fused import render as fr
+    model.engine = "fused"
+    with torch.no_grad():
+        pose = get_camera_from_tensor(cam0).unsqueeze(0)
+    rays_o, rays_d, ds = fr.rays(pose, uv, K[None])
+    vox = torch.zeros(64, 64, 64)
+    zc = z.cpu()
+
+    def oracle_from_rays(cstage, detach_x_for_colour_grid=False):
+        ro_c, rd_c = rays_o.detach().cpu().clone().requires_grad_(True), rays_d.detach().cpu().clone().requires_grad_(True)
+        pts = (ro_c.unsqueeze(1) + zc.unsqueeze(2) * rd_c.unsqueeze(1)).reshape(-1, 3)
+        dirs_flat = rd_c.unsqueeze(1).repeat(1, S, 1).reshape(-1, 3)
+        sdf, feat, grads = R.sdf_outputs(params, cfg, pts, "fine")
+        rgb = R.colour_net(params, cfg, pts, grads, dirs_flat, feat, cstage).reshape(-1, S, 3)
+        w = R.volume_weights(zc, sdf, pts, vox, cfg.voxel_res)
+        rv = torch.sum(w.unsqueeze(-1) * rgb, 1)
+        (rv - gt.cpu()).abs().mean().backward()
+        return ro_c.grad, rd_c.grad
+
+    for cstage in ("highfreq", "base"):
+        ro, rd = rays_o.detach().clone().requires_grad_(True), rays_d.detach().clone().requires_grad_(True)
+        o = fr.composite(model, ro, rd, z, "fine", cstage)
+        (o[0] - gt).abs().mean().backward()
+        go_c, gd_c = oracle_from_rays(cstage)
+        e_o = (ro.grad.cpu() - go_c).abs().max() / go_c.abs().max()
+        e_d = (rd.grad.cpu() - gd_c).abs().max() / gd_c.abs().max()
+        print(f"[{cstage}] per-ray max rel err: g_rays_o %.2e  g_rays_d %.2e ; sums fused {ro.grad.sum(0).tolist()} oracle {go_c.sum(0).tolist()}" % (float(e_o), float(e_d)))
+        bad = (ro.grad.cpu() - go_c).abs().amax(1) / go_c.abs().max()
+        top = torch.topk(bad, 4)
+        print("   worst rays", top.indices.tolist(), [f"{v:.2e}" for v in top.values.tolist()])
+        r = int(top.indices[0])
+        print("   ray", r, "fused g_o", ro.grad[r].tolist(), "oracle", go_c[r].tolist(), " z[-3:]", zc[r, -3:].tolist(),
+              " weights max", float(o[3][r].max()), "argmax", int(o[3][r].argmax()))
+
+
+if __name__ == "__main__":
+    main()

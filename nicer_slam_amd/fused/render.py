@@ -194,6 +194,8 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
             with _timed("k_sdfnet_bwd<fine>", P * 3 * 8 * 8 * 4 * 4):
                 check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), g_sdf.data_ptr(),
                                               g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))
+    if "_keep" in b:      # diagnostics (tools/diag_config0.py): per-point cotangents of the stages
+        b["_keep"].update(g_x=g_x, g_dir=g_dir, g_sdf=g_sdf, g_rgb=g_rgb, g_grad=g_grad, g_feat=g_feat)
     g_o = torch.empty(R, 3, device=dev)
     g_d = torch.empty(R, 3, device=dev)
     check(lib.nsa_rays_backward(z_vals.data_ptr(), g_x.data_ptr(), g_dir.data_ptr(), R, S, g_o.data_ptr(),

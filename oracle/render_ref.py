@@ -235,6 +235,20 @@ def colour_net(params, cfg: RenderConfig, points, normals, view_dirs, feats, col
     return torch.sigmoid(h)
 
 
+def colour_relu_margin(params, cfg: RenderConfig, points, normals, view_dirs, feats):
+    """min |pre-activation| over the colour MLP's ReLU units, per point (test helper): where it is ~1e-7 of the typical
+    magnitude the unit's mask -- hence the reference's own gradient -- is decided by fp32 rounding noise."""
+    with torch.no_grad():
+        gf = grid_features(points / cfg.colour_divide_factor, params["rendering_network.encoding.embeddings"], cfg.colour_grid)
+        h = torch.cat([points, positional_encoding(view_dirs, cfg.multires_view), normals, feats, gf], dim=-1)
+        margin = torch.full((points.shape[0],), float("inf"))
+        for l in range(cfg.colour_n_linear - 1):
+            a = wn_linear(params, f"rendering_network.lin{l}", h)
+            margin = torch.minimum(margin, a.abs().amin(dim=1))
+            h = torch.relu(a)
+    return margin
+
+
 # --------------------------------------------------------------------------------- density
 def beta_from_voxels(voxels, x, voxel_res):
     """GridPredefineDensity.func (density.py:41-60)."""

@@ -79,15 +79,34 @@ def test_config0_256_rays_64_samples_vs_oracle(poisson):
     out = model({"intrinsics": K[None], "uv": uv, "pose": get_camera_from_tensor(cam2).unsqueeze(0)},
                 torch.zeros(1, dtype=torch.long, device="cuda"), {}, mode="tracking", frame_idx=1)
     assert model.last_engine == "fused"
-    loss = (out["rgb_values"].reshape(-1, 3) - gt).abs().mean()
-    loss.backward()
     dc["z_vals_override"] = z_fix.cpu()
     cam_c = cam.detach().cpu().clone().requires_grad_(True)
     ref = R.render(params, cfg, uv.cpu(), R.camera_from_tensor(cam_c).unsqueeze(0), K[None].cpu(), vox, dc,
                    mode="tracking", training=True)
     for k in ("sdf", "depth_vals", "rgb", "weights", "rgb_values", "depth_values", "normal_map", "entropy"):
         assert_close(out[k], ref[k], 2e-5, 1e-4, k)
-    l_ref = R.rgb_l1(ref, gt.cpu())
+    # Pose gradient.  The colour MLP's ReLUs make the reference's own gradient discontinuous: a unit whose pre-activation is
+    # ~1e-7 (typical: 0.1) at some point takes a different mask in two fp32 evaluations that agree to the last digits (here:
+    # one point in 16k, unit 44 of layer 0 at 7e-7, found with tools/diag_config0.py -- 18 % of that point's gradient).  Rays
+    # holding a point within 2e-6 of a kink are left out of the objective ON BOTH SIDES; their number is bounded.
+    zc = z_fix.cpu()
+    with torch.no_grad():
+        pose_c = R.camera_from_tensor(cam.detach().cpu()).unsqueeze(0)
+        d_c, o_c = R.camera_rays(uv.cpu(), pose_c, K[None].cpu())
+        pts = (o_c.unsqueeze(1) + zc.unsqueeze(2) * d_c.reshape(-1, 3).unsqueeze(1)).reshape(-1, 3)
+    _, feat_c, _ = R.sdf_outputs(params, cfg, pts.clone(), "fine")
+    margin = R.colour_relu_margin(params, cfg, pts, ref["gradients"].detach(), d_c.reshape(-1, 3).unsqueeze(1).repeat(1, S, 1).reshape(-1, 3),
+                                  feat_c.detach())
+    # ~2.1 M ReLU units per batch with a pre-activation density of ~2 per unit length around 0: ~17 sit within 2e-6 of the kink
+    kink = (margin.reshape(Rn, S) < 2e-6).any(dim=1)
+    assert int(kink.sum()) <= Rn // 6, int(kink.sum())
+    keep = (~kink).float().unsqueeze(-1)
+    l_ref = ((ref["rgb_values"].reshape(-1, 3) - gt.cpu()).abs() * keep).sum() / (3 * Rn)
     l_ref.backward()
+    cam2.grad = None
+    out = model({"intrinsics": K[None], "uv": uv, "pose": get_camera_from_tensor(cam2).unsqueeze(0)},
+                torch.zeros(1, dtype=torch.long, device="cuda"), {}, mode="tracking", frame_idx=1)
+    loss = ((out["rgb_values"].reshape(-1, 3) - gt).abs() * keep.cuda()).sum() / (3 * Rn)
+    loss.backward()
     assert_close(loss, l_ref, 1e-6, 1e-5, "loss")
     assert_close(cam2.grad, cam_c.grad, 1e-3 * float(cam_c.grad.abs().max()), 1e-3, "pose gradient")

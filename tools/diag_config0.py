@@ -109,5 +109,58 @@ def main():
               " weights max", float(o[3][r].max()), "argmax", int(o[3][r].argmax()))
 
 
+    # ---- per-point cotangents of ray 41: fused stages vs autograd through the oracle with the points as leaves
+    r = 41
+    keep = {}
+    b = fr.composite_forward_raw(model, rays_o.detach().contiguous(), rays_d.detach().contiguous(), z, "fine", True)
+    b["_keep"] = keep
+    g_rgbv = torch.sign(b["rgb_values"] - gt) / (3 * Rn)
+    fr.composite_backward_raw(model, rays_o.detach().contiguous(), rays_d.detach().contiguous(), z, b, "fine", "highfreq",
+                              g_rgbv=g_rgbv.contiguous())
+    pts = (rays_o.detach().cpu().unsqueeze(1) + zc.unsqueeze(2) * rays_d.detach().cpu().unsqueeze(1)).reshape(-1, 3).requires_grad_(True)
+    dirs_flat = rays_d.detach().cpu().unsqueeze(1).repeat(1, S, 1).reshape(-1, 3).requires_grad_(True)
+    sdf, feat, grads = R.sdf_outputs(params, cfg, pts, "fine")
+    sdf.retain_grad(); grads.retain_grad(); feat.retain_grad()
+    rgb = R.colour_net(params, cfg, pts, grads, dirs_flat, feat, "highfreq").reshape(-1, S, 3)
+    rgb.retain_grad()
+    w = R.volume_weights(zc, sdf, pts, vox, cfg.voxel_res)
+    rv = torch.sum(w.unsqueeze(-1) * rgb, 1)
+    (rv - gt.cpu()).abs().mean().backward()
+    sl = slice(r * S, (r + 1) * S)
+
+    def cmp(name, got, ref):
+        got, ref = got.detach().cpu().reshape(ref.shape), ref.detach()
+        err = (got - ref).abs().reshape(S, -1).amax(1)
+        print(f"   {name:8s} max|ref| {float(ref.abs().max()):.3e}  max err {float(err.max()):.3e} at sample {int(err.argmax())}",
+              " errs>1e-3*max:", (err > 1e-3 * float(ref.abs().max())).nonzero().flatten().tolist())
+    cmp("g_sdf", keep["g_sdf"][sl], sdf.grad[sl].reshape(-1))
+    cmp("g_rgb", keep["g_rgb"][sl], rgb.grad[r])
+    cmp("g_grad*", keep["g_grad"][sl], grads.grad[sl])
+    cmp("g_x", keep["g_x"][sl], pts.grad[sl])
+    cmp("g_dir", keep["g_dir"][sl], dirs_flat.grad[sl])
+    print("   x of ray", r, "samples 60..63:", pts[sl][60:].tolist())
+    print("   sdf", sdf[sl].reshape(-1)[-6:].tolist(), " w", w[r, -6:].tolist())
+    e = (keep["g_x"].cpu() - pts.grad).abs().amax(1).reshape(Rn, S)
+    top = torch.topk(e.reshape(-1), 6)
+    print("   worst points overall (ray, sample, err):", [(int(i) // S, int(i) % S, f"{float(v):.2e}") for v, i in zip(top.values, top.indices)],
+          " max|g_x| %.2e" % float(pts.grad.abs().max()))
+    for v, i in zip(top.values[:3], top.indices[:3]):
+        i = int(i)
+        print("     point", i // S, i % S, "x", pts[i].tolist(), "fused g_x", keep["g_x"][i].tolist(), "oracle", pts.grad[i].tolist())
+
+
+    # ReLU pre-activations of the colour MLP at the worst point: a unit sitting on 0 flips its mask between two fp32
+    # evaluations whose values agree to 1e-7 -- the gradient then differs by that unit's whole contribution
+    with torch.no_grad():
+        i = int(top.indices[0])
+        gf = R.grid_features(pts[i:i + 1] / cfg.colour_divide_factor, params["rendering_network.encoding.embeddings"], cfg.colour_grid)
+        h = torch.cat([pts[i:i + 1], R.positional_encoding(dirs_flat[i:i + 1], cfg.multires_view), grads[i:i + 1], feat[i:i + 1], gf], -1)
+        for l in range(2):
+            a = R.wn_linear(params, f"rendering_network.lin{l}", h)
+            srt = a.abs().reshape(-1).sort()
+            print(f"   colour layer {l}: smallest |pre-activation| {srt.values[:3].tolist()} (units {srt.indices[:3].tolist()}), median {float(srt.values[32]):.3e}")
+            h = torch.relu(a)
+
+
 if __name__ == "__main__":
     main()

@@ -85,6 +85,9 @@ typedef struct nsa_grid {
                                   * reference's precision; default), 1 = plain bf16 operands with fp32 accumulation
                                   * (optional "bf16 MLP" mode of BASELINE configs 2/4; encoders, activations,
                                   * compositing and all reductions stay fp32)                       */
+    uint32_t tile;               /* tiling of the SDF-network kernels and the matching packed-parameter layout: 16 = quad
+                                  * tiling (16 points per wave, four lanes per point; pack_sdf_net4), 0 or 32 = 32-point
+                                  * tiling (lane pair per point; pack_sdf_net).  Ignored by the colour network.          */
 } nsa_grid_t;
 
 /* Where the points of a per-point kernel come from: sample (pid % S) of ray (pid / S), x = o + z d -- or, when
@@ -160,7 +163,8 @@ int nsa_colour_backward_params(const nsa_points_t *pts, const nsa_grid_t *grid, 
                                float *g_feat_hl, float *g_grad, float *g_x, float *g_dir, float *g_table, float *emit,
                                uint32_t emit_ld, nsa_stream_t stream);
 int nsa_sdfnet_emit_rows(void);                 /* one hidden layer (coarse network) */
-int nsa_sdfnet_emit_rows_nh(uint32_t n_hidden); /* 1 or 3 hidden layers; -1 otherwise */
+int nsa_sdfnet_emit_rows_nh(uint32_t n_hidden); /* 1 or 3 hidden layers; -1 otherwise (32-point tiling) */
+int nsa_sdfnet_emit_rows_tile(uint32_t n_hidden, uint32_t tile); /* the same for nsa_grid_t.tile = 16 / 32 */
 int nsa_colour_emit_rows(void);
 
 /* Per-ray SDF -> density -> alpha compositing.  replaces SLAMNetwork.volume_rendering (code/model/network.py:349-370)

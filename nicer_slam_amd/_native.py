@@ -50,7 +50,7 @@ def check(rc):
 class GridDesc(ctypes.Structure):
     """nsa_grid_t"""
     _fields_ = [("table", _p), ("offsets_host", _p), ("L", _u32), ("C", _u32), ("S", _f32), ("H", _u32),
-                ("divide_factor", _f32), ("n_hidden", _u32), ("precision", _u32)]
+                ("divide_factor", _f32), ("n_hidden", _u32), ("precision", _u32), ("tile", _u32)]
 
 
 _gp = ctypes.POINTER(GridDesc)
@@ -91,8 +91,10 @@ lib.nsa_colour_emit_rows.restype = _i
 lib.nsa_colour_emit_rows.argtypes = []
 lib.nsa_sdfnet_emit_rows_nh.restype = _i
 lib.nsa_sdfnet_emit_rows_nh.argtypes = [_u32]
+lib.nsa_sdfnet_emit_rows_tile.restype = _i
+lib.nsa_sdfnet_emit_rows_tile.argtypes = [_u32, _u32]
 EXPORTS += ["nsa_sdfnet_backward_params", "nsa_colour_backward_params", "nsa_sdfnet_emit_rows", "nsa_colour_emit_rows",
-            "nsa_sdfnet_emit_rows_nh"]
+            "nsa_sdfnet_emit_rows_nh", "nsa_sdfnet_emit_rows_tile"]
 EXPORTS += ["nsa_sdfnet_forward", "nsa_sdfnet_backward", "nsa_colour_forward", "nsa_colour_backward",
             "nsa_composite_forward", "nsa_composite_backward", "nsa_rays_backward"]
 

@@ -381,6 +381,7 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
 #define NSA_ENTRY(x) x
 #endif
 #include "bf16_entries.hpp"
+#include "quad_entries.hpp"
 
 extern "C" {
 
@@ -397,6 +398,11 @@ int NSA_ENTRY(nsa_sampler_sdf)(const float* rays_o, const float* rays_d, uint32_
         return NSA_EBADARG;
     if (!(coarse->L == 4 && coarse->C == 8 && coarse->n_hidden == 1 && fine->L == 8 && fine->C == 4 && fine->n_hidden == 3))
         return NSA_EUNSUPPORTED_NET;
+    if (coarse->tile == 16 || fine->tile == 16) {
+        if (coarse->tile != fine->tile) return NSA_EBADARG;
+        return NSA_ENTRY(nsa_sampler4_sdf)(rays_o, rays_d, R, E, t_lin, t_rand, near, bound, far_cap, coarse, fine, packed_coarse,
+                                           packed_fine, z, sdf, far, stream);
+    }
     GridGeom16 gc, gf;
     if (int rc = make_grid_geom16(coarse->offsets_host, coarse->L, coarse->S, coarse->H, &gc)) return rc;
     if (int rc = make_grid_geom16(fine->offsets_host, fine->L, fine->S, fine->H, &gf)) return rc;
@@ -420,6 +426,10 @@ int NSA_ENTRY(nsa_sdf_points)(const float* points, uint64_t N, const nsa_grid_t*
     if (!points || !coarse || !packed_coarse || !sdf || (fine && !packed_fine)) return NSA_EBADARG;
     if (!(coarse->L == 4 && coarse->C == 8 && coarse->n_hidden == 1)) return NSA_EUNSUPPORTED_NET;
     if (fine && !(fine->L == 8 && fine->C == 4 && fine->n_hidden == 3)) return NSA_EUNSUPPORTED_NET;
+    if (coarse->tile == 16) {
+        if (fine && fine->tile != 16) return NSA_EBADARG;
+        return NSA_ENTRY(nsa_sdf4_points)(points, N, coarse, fine, packed_coarse, packed_fine, sdf, stream);
+    }
     GridGeom16 gc, gf{};
     if (int rc = make_grid_geom16(coarse->offsets_host, coarse->L, coarse->S, coarse->H, &gc)) return rc;
     if (fine) if (int rc = make_grid_geom16(fine->offsets_host, fine->L, fine->S, fine->H, &gf)) return rc;

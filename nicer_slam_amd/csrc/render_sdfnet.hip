@@ -440,6 +440,7 @@ static int launch_sdfnet(bool bwd, const nsa_grid_t* grid, const SdfNetArgs& a, 
 #define NSA_ENTRY(x) x
 #endif
 #include "bf16_entries.hpp"
+#include "quad_entries.hpp"
 
 extern "C" {
 
@@ -452,6 +453,7 @@ int NSA_ENTRY(nsa_sdfnet_forward)(const nsa_points_t* pts, const nsa_grid_t* gri
     if (!pts || !grid || !packed || !sdf || !grad || !feat_hl) return NSA_EBADARG;
     if (pts->P == 0) return NSA_OK;
     if (!pts->points && (!pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0)) return NSA_EBADARG;
+    if (grid->tile == 16) return NSA_ENTRY(nsa_sdfnet4_forward)(pts, grid, packed, accumulate, sdf, grad, feat_hl, stream);
     SdfNetArgs a{};
     a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S, pts->order};
     a.table = grid->table; a.wp = packed; a.divide_factor = grid->divide_factor; a.accumulate = accumulate;
@@ -468,6 +470,8 @@ int NSA_ENTRY(nsa_sdfnet_backward)(const nsa_points_t* pts, const nsa_grid_t* gr
     if (!pts || !grid || !packed || !g_x) return NSA_EBADARG;
     if (pts->P == 0) return NSA_OK;
     if (!pts->points && (!pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0)) return NSA_EBADARG;
+    if (grid->tile == 16)
+        return NSA_ENTRY(nsa_sdfnet4_backward)(pts, grid, packed, g_sdf, g_feat_hl, g_grad, accumulate, g_x, nullptr, nullptr, 0, stream);
     SdfNetArgs a{};
     a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S, pts->order};
     a.table = grid->table; a.wp = packed; a.divide_factor = grid->divide_factor; a.accumulate = accumulate;
@@ -486,6 +490,8 @@ int NSA_ENTRY(nsa_sdfnet_backward_params)(const nsa_points_t* pts, const nsa_gri
     if (emit && emit_ld < ((pts->P + 31) / 32) * 32) return NSA_EBADARG;
     if (pts->P == 0) return NSA_OK;
     if (!pts->points && (!pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0)) return NSA_EBADARG;
+    if (grid->tile == 16)
+        return NSA_ENTRY(nsa_sdfnet4_backward)(pts, grid, packed, g_sdf, g_feat_hl, g_grad, accumulate, g_x, g_table, emit, emit_ld, stream);
     SdfNetArgs a{};
     a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S, pts->order};
     a.table = grid->table; a.wp = packed; a.divide_factor = grid->divide_factor; a.accumulate = accumulate;
@@ -497,6 +503,9 @@ int NSA_ENTRY(nsa_sdfnet_backward_params)(const nsa_points_t* pts, const nsa_gri
 int NSA_ENTRY(nsa_sdfnet_emit_rows)(void) { return nsa::SE<1>::ROWS; }
 int NSA_ENTRY(nsa_sdfnet_emit_rows_nh)(uint32_t n_hidden) {
     return n_hidden == 1 ? nsa::SE<1>::ROWS : n_hidden == 3 ? nsa::SE<3>::ROWS : -1;
+}
+int NSA_ENTRY(nsa_sdfnet_emit_rows_tile)(uint32_t n_hidden, uint32_t tile) {
+    return tile == 16 ? NSA_ENTRY(nsa_sdfnet4_emit_rows)(n_hidden) : NSA_ENTRY(nsa_sdfnet_emit_rows_nh)(n_hidden);
 }
 
 }  // extern "C"

@@ -1,0 +1,418 @@
+// render_sdfnet4.hip -- the per-point SDF network kernels of the composite pass in the QUAD tiling (mlp16.hpp, sdf_net4.hpp):
+// a wave = 16 points, four lanes per point, v_mfma_f32_16x16x32_bf16.  Same mathematics, entry points and buffers as
+// render_sdfnet.hip (the 32-point tiling, whose header comment derives the forward / reverse pass / tangent sweep / reverse
+// sweep); selected with nsa_grid_t.tile == 16 and a packed block from fused/pack.py::pack_sdf_net4.
+//   k_sdfnet4_fwd   sdf, 64-feature vector (HL layout, shared with the colour kernels) and grad sdf of one network
+//   k_sdfnet4_bwd   value path + double backward through the reverse pass (grid-Hessian term dropped, hashgrid.py:134);
+//                   MAP = true adds table gradients (run-merged atomics) and the emission rows of the weight gradients
+// Reference: ImplicitNetworkGrid.get_outputs/gradient (code/model/base_networks.py:195-221), ImplicitNetworkGrid_COMBINE (:7-47).
+#include "sdf_net4.hpp"
+
+namespace nsa {
+
+#ifndef NSA_NW4
+#define NSA_NW4 8               // waves per workgroup: 128 points share one staged copy of every weight block
+#endif
+constexpr int NW4 = NSA_NW4;
+
+struct SdfNet4Args {
+    PointSrc src;
+    const float* table;
+    const float* wp;
+    float divide_factor;
+    int accumulate;        // 0: overwrite outputs, 1: add to them (second network of the COMBINE)
+    float* sdf;            // [P]
+    float* grad;           // [P,3]
+    float* feat;           // HL [ceil(P/32)*32*64]
+    const float* g_sdf;    // [P]
+    const float* g_feat;   // HL
+    const float* g_grad;   // [P,3]
+    float* g_x;            // [P,3]
+    float* g_table;        // table gradient (atomically accumulated) or nullptr
+    float* emit;           // emission rows [SE4<NH>::ROWS][emit_ld] or nullptr
+    uint32_t emit_ld;
+};
+
+// Emission rows (weight-gradient GEMMs; formulas: struct SE of render_sdfnet.hip).  H0 / TIN rows are first-layer slots,
+// row = 4 * slot + quarter (96 per region); the other regions are hidden features in reference order (64 rows each):
+//   [H0 | TIN | DA_1.. | H_1.. | TH_1..TH_{NH-1} | AB_1..AB_NH | TH_NH | FB]        NH = 1: 512 rows, NH = 3: 1024.
+template <int NH>
+struct SE4 {
+    static constexpr int H0 = 0, TIN = 96;
+    __host__ __device__ static constexpr int DA(int k) { return 192 + 64 * (k - 1); }
+    __host__ __device__ static constexpr int H(int k) { return 192 + 64 * NH + 64 * (k - 1); }
+    __host__ __device__ static constexpr int AB(int k) { return 192 + 128 * NH + 64 * (NH - 1) + 64 * (k - 1); }
+    __host__ __device__ static constexpr int TH(int k) { return k < NH ? 192 + 128 * NH + 64 * (k - 1) : AB(1) + 64 * NH; }
+    static constexpr int FB = 192 + 128 * NH + 64 * (NH - 1) + 64 * NH + 64;
+    static constexpr int ROWS = FB + 64;
+};
+static_assert(SE4<1>::ROWS == 512 && SE4<3>::ROWS == 1024, "emission row map");
+
+struct Emitter4 {
+    float* base;           // emit + column of this lane's point
+    uint32_t ld;
+    bool live;
+    __device__ __forceinline__ void slot(int region, int s, int q, float v) const {
+        base[(size_t)(region + 4 * s + q) * ld] = live ? v : 0.0f;
+    }
+    __device__ __forceinline__ void hid(int region, int s, int q, float v) const {
+        base[(size_t)(region + 16 * (s >> 2) + 4 * q + (s & 3)) * ld] = live ? v : 0.0f;
+    }
+};
+
+// GEMM sequences (block-cooperative weight staging):
+//   forward : W0, W_1..W_{NH-1}, WFEAT | reverse pass W_{NH-1}^T..W_1^T, W0^T                                   2 NH + 1
+//   backward: W0, W_k | W_k^T.., W0^T | tangent W0, W_k | WFEAT^T | reverse sweep W_k^T.., W0^T                  4 NH + 1
+template <int NH, bool BWD>
+struct SdfOps4 {
+    using P = SdfPack4<NH>;
+    static constexpr int n = BWD ? 4 * NH + 1 : 2 * NH + 1;
+    __host__ __device__ static constexpr int rev(int j) { return j < NH - 1 ? P::wht(NH - 1 - j) : P::kW0T; }
+    __host__ __device__ static constexpr int fwd(int j) { return j == 0 ? P::kW0 : P::wh(j); }
+    __host__ __device__ static constexpr int off(int i) {
+        if (!BWD) return i < NH ? fwd(i) : i == NH ? P::kWFEAT : rev(i - NH - 1);
+        return i < NH ? fwd(i) : i < 2 * NH ? rev(i - NH) : i < 3 * NH ? fwd(i - 2 * NH) : i == 3 * NH ? P::kWFEATT : rev(i - 3 * NH - 1);
+    }
+    __host__ __device__ static constexpr int size(int i) {
+        const int o = off(i);
+        return o == P::kW0 ? a16_floats(4, QIN_G) : o == P::kW0T ? a16_floats(6, 2) : P::kHH;
+    }
+};
+
+template <int NH, class Seq>
+__device__ __forceinline__ void hidden_forward4(float* stage, int op0, const float* __restrict__ wp, int lane, int q,
+                                                const float (&in)[QIN], float (&sg)[NH][QHS], float (&hlast)[QHS],
+                                                const Emitter4* em = nullptr) {
+    using P = SdfPack4<NH>;
+    f32x4v acc[4];
+    load_vec16(wp + P::kB0, q, acc);
+    gemm16_staged<Seq, NW4, QIN_G, 4>(stage, wp, op0, lane, in, acc);
+#pragma unroll
+    for (int k = 1; k <= NH; ++k) {
+        float d2;
+#pragma unroll
+        for (int s = 0; s < QHS; ++s) softplus100_all(acc[s >> 2][s & 3], hlast[s], sg[k - 1][s], d2);
+        if (em) {
+#pragma unroll
+            for (int s = 0; s < QHS; ++s) em->hid(SE4<NH>::H(k), s, q, hlast[s]);
+        }
+        if (k < NH) {
+            load_vec16(wp + P::bh(k), q, acc);
+            gemm16_staged<Seq, NW4, 2, 4>(stage, wp, op0 + k, lane, hlast, acc);
+        }
+    }
+}
+
+// reverse pass from the sdf output: fills dh[k-1] = dh_k for k = 1..NH-1 (dh_NH is the packed sdf row) and dl = dh_0.
+template <int NH, class Seq>
+__device__ __forceinline__ void reverse_pass4(float* stage, int op0, const float* __restrict__ wp, int lane, int q,
+                                              const float (&sg)[NH][QHS], float (&dh)[NH > 1 ? NH - 1 : 1][QHS], float (&dl)[QIN],
+                                              const Emitter4* em = nullptr) {
+    using P = SdfPack4<NH>;
+    f32x4v ws[4];
+    load_vec16(wp + P::kWSDF, q, ws);
+    float da[QHS];
+#pragma unroll
+    for (int s = 0; s < QHS; ++s) da[s] = sg[NH - 1][s] * ws[s >> 2][s & 3];
+    if (em) {
+#pragma unroll
+        for (int s = 0; s < QHS; ++s) em->hid(SE4<NH>::DA(NH), s, q, da[s]);
+    }
+#pragma unroll
+    for (int k = NH - 1; k >= 1; --k) {
+        f32x4v acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        gemm16_staged<Seq, NW4, 2, 4>(stage, wp, op0 + (NH - 1 - k), lane, da, acc);
+#pragma unroll
+        for (int s = 0; s < QHS; ++s) {
+            dh[k - 1][s] = acc[s >> 2][s & 3];
+            da[s] = sg[k - 1][s] * acc[s >> 2][s & 3];
+        }
+        if (em) {
+#pragma unroll
+            for (int s = 0; s < QHS; ++s) em->hid(SE4<NH>::DA(k), s, q, da[s]);
+        }
+    }
+    f32x4v a6[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) a6[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+    gemm16_staged<Seq, NW4, 2, 6>(stage, wp, op0 + NH - 1, lane, da, a6);
+#pragma unroll
+    for (int s = 0; s < QIN; ++s) dl[s] = a6[s >> 2][s & 3];
+}
+
+#ifndef NSA_OCC4_FWD
+#define NSA_OCC4_FWD 2
+#endif
+#ifndef NSA_OCC4_BWD
+#define NSA_OCC4_BWD 2
+#endif
+
+template <int L, int C, int NH>
+__global__ __launch_bounds__(64 * NW4, NSA_OCC4_FWD) void k_sdfnet4_fwd(SdfNet4Args a, GridGeom16 geom) {
+    using P = SdfPack4<NH>;
+    using Seq = SdfOps4<NH, false>;
+    __shared__ __attribute__((aligned(16))) float stage[2 * kStageFloats];
+    __shared__ LevelGeom s_geom[16];
+    stage_issue_n<NW4>(a.wp + Seq::off(0), Seq::size(0), stage);
+    geom_to_lds(geom, s_geom);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    uint32_t tile = blockIdx.x * NW4 + (threadIdx.x >> 6);
+    const uint32_t n_tiles = (a.src.P + 15) / 16;
+    const bool wave_live = tile < n_tiles;                  // a wave without points still takes part in the barriers
+    if (!wave_live) tile = n_tiles - 1;
+    uint32_t pid = tile * 16 + j;
+    const bool live = wave_live && pid < a.src.P;
+    if (pid >= a.src.P) pid = a.src.P - 1;
+    const uint32_t pt = point_of(a.src, pid);               // point handled by this lane quad
+    float x[3], z;
+    uint32_t ray;
+    load_point(a.src, pt, x, ray, z);
+    __syncthreads();                                         // s_geom
+
+    float in[QIN];
+    pe_slots4(x, q, in);
+    grid_slots4<L, C>(x, a.divide_factor, a.table, s_geom, q, in);
+    float sg[NH][QHS], hl[QHS];
+    hidden_forward4<NH, Seq>(stage, 0, a.wp, lane, q, in, sg, hl);
+    // outputs: sdf (row 0, VALU dot) and the 64 features (rows 1..64)
+    f32x4v ws[4], fo[4];
+    load_vec16(a.wp + P::kWSDF, q, ws);
+    float part = 0.0f;
+#pragma unroll
+    for (int s = 0; s < QHS; ++s) part = fmaf(hl[s], ws[s >> 2][s & 3], part);
+    float sdf = quad_sum(part) + a.wp[P::kBSDF];
+    load_vec16(a.wp + P::kBFEAT, q, fo);
+    gemm16_staged<Seq, NW4, 2, 4>(stage, a.wp, NH, lane, hl, fo);
+    if (wave_live) {
+        float* fdst = a.feat + hl_base4(tile, j, q);
+#pragma unroll
+        for (int s = 0; s < QHS; ++s) {
+            float v = fo[s >> 2][s & 3];
+            if (a.accumulate) v += fdst[hl_step4(s)];
+            fdst[hl_step4(s)] = v;
+        }
+    }
+    // grad sdf
+    float dh[NH > 1 ? NH - 1 : 1][QHS], dl[QIN], g[3];
+    reverse_pass4<NH, Seq>(stage, NH + 1, a.wp, lane, q, sg, dh, dl);
+    slots_to_x4<L, C>(x, a.divide_factor, a.table, s_geom, q, in, dl, g);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) g[d] = quad_sum(g[d]);
+    if (live && q == 0) {
+        if (a.accumulate) {
+            sdf += a.sdf[pt];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) g[d] += a.grad[(size_t)pt * 3 + d];
+        }
+        a.sdf[pt] = sdf;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) a.grad[(size_t)pt * 3 + d] = g[d];
+    }
+}
+
+template <int L, int C, int NH, bool MAP>
+__global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4Args a, GridGeom16 geom) {
+    using P = SdfPack4<NH>;
+    using Seq = SdfOps4<NH, true>;
+    using E = SE4<NH>;
+    __shared__ __attribute__((aligned(16))) float stage[2 * kStageFloats];
+    __shared__ LevelGeom s_geom[16];
+    stage_issue_n<NW4>(a.wp + Seq::off(0), Seq::size(0), stage);
+    geom_to_lds(geom, s_geom);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    uint32_t tile = blockIdx.x * NW4 + (threadIdx.x >> 6);
+    const uint32_t n_tiles = (a.src.P + 15) / 16;
+    const bool wave_live = tile < n_tiles;
+    if (!wave_live) tile = n_tiles - 1;
+    uint32_t pid = tile * 16 + j;
+    const bool live = wave_live && pid < a.src.P;
+    if (pid >= a.src.P) pid = a.src.P - 1;
+    const uint32_t pt = point_of(a.src, pid);
+    float x[3], z;
+    uint32_t ray;
+    load_point(a.src, pt, x, ray, z);
+    __syncthreads();                                         // s_geom
+    // the grid Jacobian of this lane's levels stays in lane-private LDS: the backward needs no second and third corner gather
+    constexpr int kJac = (8 / C) * 3 * C;                    // 24 floats per lane
+    __shared__ float jac_lds[NW4 * kJac * 64];
+    float* jstore = jac_lds + (threadIdx.x >> 6) * (kJac * 64) + lane;
+    float in[QIN];
+    pe_slots4(x, q, in);
+    grid_slots4<L, C>(x, a.divide_factor, a.table, s_geom, q, in, jstore);
+    const bool emit = MAP && a.emit != nullptr && wave_live;   // (a clamped wave must not touch the last tile's rows)
+    const Emitter4 em{emit ? a.emit + (size_t)tile * 16 + j : nullptr, a.emit_ld, live};
+    float sg[NH][QHS], hl[QHS];
+    hidden_forward4<NH, Seq>(stage, 0, a.wp, lane, q, in, sg, hl, emit ? &em : nullptr);
+    float dh[NH > 1 ? NH - 1 : 1][QHS], dl[QIN];
+    reverse_pass4<NH, Seq>(stage, NH, a.wp, lane, q, sg, dh, dl, emit ? &em : nullptr);
+    if (emit) {
+#pragma unroll
+        for (int s = 0; s < QIN; ++s) em.slot(E::H0, s, q, in[s]);
+    }
+
+    float nbar[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) nbar[d] = a.g_grad ? a.g_grad[(size_t)pt * 3 + d] : 0.0f;
+    const float sbar = a.g_sdf ? a.g_sdf[pt] : 0.0f;
+
+    // ---- tangent sweep: e_k = sp''(a_k) dh_k ta_k (kept in e[k-1]) ----
+    float e[NH][QHS];
+    float xb2[3];
+    {
+        float tin[QIN];
+        tangent_from_jac4<L, C>(a.divide_factor, jstore, q, in, nbar, dl, tin, xb2);
+        if (emit) {
+#pragma unroll
+            for (int s = 0; s < QIN; ++s) em.slot(E::TIN, s, q, tin[s]);
+        }
+        f32x4v acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        gemm16_staged<Seq, NW4, QIN_G, 4>(stage, a.wp, 2 * NH, lane, tin, acc);
+        f32x4v ws[4];
+        load_vec16(a.wp + P::kWSDF, q, ws);
+        float th[QHS];
+#pragma unroll
+        for (int k = 1; k <= NH; ++k) {
+#pragma unroll
+            for (int s = 0; s < QHS; ++s) {
+                const float s1 = sg[k - 1][s];
+                const float s2 = 100.0f * s1 * (1.0f - s1);          // 0 in the linear region (s1 == 1)
+                const float dhk = (k == NH) ? ws[s >> 2][s & 3] : dh[k - 1][s];
+                const float ta = acc[s >> 2][s & 3];
+                e[k - 1][s] = s2 * dhk * ta;
+                th[s] = s1 * ta;
+                if (emit) em.hid(E::TH(k), s, q, th[s]);
+            }
+            if (k < NH) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+                gemm16_staged<Seq, NW4, 2, 4>(stage, a.wp, 2 * NH + k, lane, th, acc);
+            }
+        }
+    }
+    // ---- reverse sweep ----
+    float ab[QHS];
+    {
+        float fb[QHS];
+        const float* fsrc = a.g_feat ? a.g_feat + hl_base4(tile, j, q) : nullptr;
+#pragma unroll
+        for (int s = 0; s < QHS; ++s) fb[s] = fsrc ? fsrc[hl_step4(s)] : 0.0f;
+        if (emit) {
+#pragma unroll
+            for (int s = 0; s < QHS; ++s) em.hid(E::FB, s, q, fb[s]);
+        }
+        f32x4v acc[4], ws[4];
+        load_vec16(a.wp + P::kWSDF, q, ws);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = sbar * ws[t];
+        gemm16_staged<Seq, NW4, 2, 4>(stage, a.wp, 3 * NH, lane, fb, acc);
+#pragma unroll
+        for (int s = 0; s < QHS; ++s) ab[s] = sg[NH - 1][s] * acc[s >> 2][s & 3] + e[NH - 1][s];
+    }
+#pragma unroll
+    for (int k = NH - 1; k >= 1; --k) {
+        if (emit) {
+#pragma unroll
+            for (int s = 0; s < QHS; ++s) em.hid(E::AB(k + 1), s, q, ab[s]);
+        }
+        f32x4v acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        gemm16_staged<Seq, NW4, 2, 4>(stage, a.wp, 3 * NH + 1 + (NH - 1 - k), lane, ab, acc);
+#pragma unroll
+        for (int s = 0; s < QHS; ++s) ab[s] = sg[k - 1][s] * acc[s >> 2][s & 3] + e[k - 1][s];
+    }
+    if (emit) {
+#pragma unroll
+        for (int s = 0; s < QHS; ++s) em.hid(E::AB(1), s, q, ab[s]);
+    }
+    float hb0[QIN];
+    {
+        f32x4v a6[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) a6[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        gemm16_staged<Seq, NW4, 2, 6>(stage, a.wp, 4 * NH, lane, ab, a6);
+#pragma unroll
+        for (int s = 0; s < QIN; ++s) hb0[s] = a6[s >> 2][s & 3];
+    }
+    float gx[3];
+    slots_to_x_jac4<L, C>(a.divide_factor, jstore, q, in, hb0, gx);
+    // scatter scratch: the stage buffer the last GEMM (op 4 NH, even) does NOT read; every wave passed the barrier of that
+    // GEMM, so nobody reads it any more
+    if (MAP && a.g_table)
+        table_grad_scatter4<L, C>(x, a.divide_factor, s_geom, q, lane, live, hb0, dl, nbar, a.g_table,
+                                  stage + kStageFloats + (threadIdx.x >> 6) * 64 * (2 * C + 1));
+#pragma unroll
+    for (int d = 0; d < 3; ++d) gx[d] = quad_sum(gx[d] + xb2[d]);
+    if (live && q == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float v = gx[d];
+            if (a.accumulate) v += a.g_x[(size_t)pt * 3 + d];
+            a.g_x[(size_t)pt * 3 + d] = v;
+        }
+    }
+}
+
+static_assert(NW4 * 64 * (2 * 8 + 1) <= kStageFloats, "scatter scratch must fit the idle stage buffer");
+
+static int launch_sdfnet4(bool bwd, const nsa_grid_t* grid, const SdfNet4Args& a, hipStream_t st) {
+    const bool map = a.g_table != nullptr || a.emit != nullptr;
+    GridGeom16 geom;
+    if (int rc = make_grid_geom16(grid->offsets_host, grid->L, grid->S, grid->H, &geom)) return rc;
+    const uint32_t tiles = (a.src.P + 15) / 16;
+    const dim3 g((tiles + NW4 - 1) / NW4), b(64 * NW4);
+    launch_begin();
+    if (grid->L == 4 && grid->C == 8 && grid->n_hidden == 1) {
+        if (bwd && map) hipLaunchKernelGGL((k_sdfnet4_bwd<4, 8, 1, true>), g, b, 0, st, a, geom);
+        else if (bwd)   hipLaunchKernelGGL((k_sdfnet4_bwd<4, 8, 1, false>), g, b, 0, st, a, geom);
+        else            hipLaunchKernelGGL((k_sdfnet4_fwd<4, 8, 1>), g, b, 0, st, a, geom);
+    } else if (grid->L == 8 && grid->C == 4 && grid->n_hidden == 3) {
+        if (bwd && map) hipLaunchKernelGGL((k_sdfnet4_bwd<8, 4, 3, true>), g, b, 0, st, a, geom);
+        else if (bwd)   hipLaunchKernelGGL((k_sdfnet4_bwd<8, 4, 3, false>), g, b, 0, st, a, geom);
+        else            hipLaunchKernelGGL((k_sdfnet4_fwd<8, 4, 3>), g, b, 0, st, a, geom);
+    } else {
+        return NSA_EUNSUPPORTED_NET;
+    }
+    return launch_end();
+}
+
+}  // namespace nsa
+
+#include "quad_entries.hpp"
+
+// Internal entry points (not in the public header): render_sdfnet.hip forwards here when nsa_grid_t.tile == 16.
+extern "C" {
+
+int NSA_ENTRY(nsa_sdfnet4_forward)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, int accumulate, float* sdf,
+                                   float* grad, float* feat_hl, nsa_stream_t stream) {
+    using namespace nsa;
+    SdfNet4Args a{};
+    a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S, pts->order};
+    a.table = grid->table; a.wp = packed; a.divide_factor = grid->divide_factor; a.accumulate = accumulate;
+    a.sdf = sdf; a.grad = grad; a.feat = feat_hl;
+    return launch_sdfnet4(false, grid, a, (hipStream_t)stream);
+}
+
+int NSA_ENTRY(nsa_sdfnet4_backward)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* g_sdf,
+                                    const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x, float* g_table,
+                                    float* emit, uint32_t emit_ld, nsa_stream_t stream) {
+    using namespace nsa;
+    SdfNet4Args a{};
+    a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S, pts->order};
+    a.table = grid->table; a.wp = packed; a.divide_factor = grid->divide_factor; a.accumulate = accumulate;
+    a.g_sdf = g_sdf; a.g_feat = g_feat_hl; a.g_grad = g_grad; a.g_x = g_x;
+    a.g_table = g_table; a.emit = emit; a.emit_ld = emit_ld;
+    return launch_sdfnet4(true, grid, a, (hipStream_t)stream);
+}
+
+int NSA_ENTRY(nsa_sdfnet4_emit_rows)(uint32_t n_hidden) {
+    return n_hidden == 1 ? nsa::SE4<1>::ROWS : n_hidden == 3 ? nsa::SE4<3>::ROWS : -1;
+}
+
+}  // extern "C"

@@ -25,30 +25,35 @@ from .._native import lib, check, PointsDesc
 from ..hashencoder.backend import _timed
 from . import pack
 from .render import composite_forward_raw, composite_backward_raw, hl_size, morton_order, _stream
-from .sampler import grid_desc, packed_sdf, precision_of
+from .sampler import grid_desc, packed_sdf, precision_of, sdf_grid_desc, tile_of
 
 KCHUNK = 4096
 SORT_POINTS = True      # run the per-point kernels of a mapping iteration in Morton order (see render.morton_order)
 
 
-def se_rows(NH):
-    """Emission row map of an SDF network with NH hidden layers = struct SE<NH> of csrc/render_sdfnet.hip:
-    [H0 | TIN | DA_1.. | H_1.. | TH_1..TH_{NH-1} | AB_1..AB_NH | TH_NH | FB], regions of 72, 72, then 64 rows each."""
-    m = {"H0": 0, "TIN": 72}
+def se_rows(NH, tile=32):
+    """Emission row map of an SDF network with NH hidden layers = struct SE<NH> of csrc/render_sdfnet.hip (tile 32) resp.
+    SE4<NH> of csrc/render_sdfnet4.hip (tile 16):
+    [H0 | TIN | DA_1.. | H_1.. | TH_1..TH_{NH-1} | AB_1..AB_NH | TH_NH | FB]; H0 / TIN hold one row per first-layer slot
+    (72 resp. 96 rows, "IN"), the other regions 64 rows (hidden features in reference order)."""
+    n_in = 96 if tile == 16 else 72
+    b = 2 * n_in
+    m = {"H0": 0, "TIN": n_in, "IN": n_in}
     for k in range(1, NH + 1):
-        m[f"DA{k}"] = 144 + 64 * (k - 1)
-        m[f"H{k}"] = 144 + 64 * NH + 64 * (k - 1)
-        m[f"AB{k}"] = 144 + 128 * NH + 64 * (NH - 1) + 64 * (k - 1)
+        m[f"DA{k}"] = b + 64 * (k - 1)
+        m[f"H{k}"] = b + 64 * NH + 64 * (k - 1)
+        m[f"AB{k}"] = b + 128 * NH + 64 * (NH - 1) + 64 * (k - 1)
         if k < NH:
-            m[f"TH{k}"] = 144 + 128 * NH + 64 * (k - 1)
+            m[f"TH{k}"] = b + 128 * NH + 64 * (k - 1)
     m[f"TH{NH}"] = m["AB1"] + 64 * NH
     m["FB"] = m[f"TH{NH}"] + 64
     m["ROWS"] = m["FB"] + 64
     return m
 
 
-SE = se_rows(1)      # coarse network (464 rows); fine: se_rows(3) (976 rows)
-assert SE == dict(H0=0, TIN=72, DA1=144, H1=208, AB1=272, TH1=336, FB=400, ROWS=464)
+SE = se_rows(1)      # coarse network, 32-point tiling (464 rows); fine: se_rows(3) (976 rows); quad tiling: 512 / 1024
+assert SE == dict(H0=0, TIN=72, IN=72, DA1=144, H1=208, AB1=272, TH1=336, FB=400, ROWS=464)
+assert se_rows(1, 16)["ROWS"] == 512 and se_rows(3, 16)["ROWS"] == 1024
 CE = dict(IN=0, H1=130, H2=194, AB1=258, AB2=322, OB=386, ROWS=389)              # = enum CE_* (render_colour.hip)
 
 
@@ -57,10 +62,10 @@ def emit_ld(P):
 
 
 def new_emit(rows, P, device):
-    """Emission buffer [rows][ld]; the columns past the last 32-point tile are never written by the kernel."""
+    """Emission buffer [rows][ld]; the columns past the last (16-point) tile are never written by the kernels."""
     ld = emit_ld(P)
     buf = torch.empty(rows, ld, device=device)
-    tail = ((P + 31) // 32) * 32
+    tail = ((P + 15) // 16) * 16
     if tail < ld:
         buf[:, tail:].zero_()
     return buf
@@ -77,14 +82,22 @@ def outer_sum(A, B):
 
 
 @functools.lru_cache(maxsize=None)
-def _sdf_rows(L, C):
-    """row (2*slot + half) of the H0 / TIN regions holding reference input feature f = 0..70."""
+def _sdf_rows(L, C, tile=32):
+    """row of the H0 / TIN regions holding reference input feature f = 0..70: 2*slot + half (32-point tiling) resp.
+    4*slot + quarter (quad tiling)."""
     rows = np.full(39 + L * C, -1, dtype=np.int64)
-    for s in range(pack.SDF_IN_STEPS):
-        for h in range(2):
-            f = pack.sdf_in_feature(s, h, L, C)
-            if f >= 0:
-                rows[f] = 2 * s + h
+    if tile == 16:
+        for s in range(pack.QIN_STEPS):
+            for q in range(4):
+                f = pack.sdf_in_feature4(s, q, C)
+                if f >= 0:
+                    rows[f] = 4 * s + q
+    else:
+        for s in range(pack.SDF_IN_STEPS):
+            for h in range(2):
+                f = pack.sdf_in_feature(s, h, L, C)
+                if f >= 0:
+                    rows[f] = 2 * s + h
     assert (rows >= 0).all()
     return torch.from_numpy(rows)
 
@@ -101,15 +114,15 @@ def _col_rows():
     return torch.from_numpy(rows)
 
 
-def sdf_flat_grad(emit, g_sdf, P, L, C, NH=1):
+def sdf_flat_grad(emit, g_sdf, P, L, C, NH=1, tile=32):
     """Gradient of an SDF network's flat parameter vector [W0(64x71), b0, W1, b1, .., W_NH(65x64), b_NH, 0] from its emission
-    rows (row map and formulas: struct SE<NH>, csrc/render_sdfnet.hip)."""
-    m = se_rows(NH)
+    rows (row map and formulas: struct SE<NH>, csrc/render_sdfnet.hip; SE4<NH>, csrc/render_sdfnet4.hip)."""
+    m = se_rows(NH, tile)
     r = lambda name, n=64: emit[m[name]:m[name] + n]
     sums = emit[m["AB1"]:m["ROWS"]].sum(1)                   # AB_1..AB_NH | TH_NH | FB row sums in one reduction
     parts = []
-    M = outer_sum(r("AB1"), r("H0", 72)) + outer_sum(r("DA1"), r("TIN", 72))
-    parts += [M[:, _sdf_rows(L, C).to(emit.device)].reshape(-1), sums[:64]]
+    M = outer_sum(r("AB1"), r("H0", m["IN"])) + outer_sum(r("DA1"), r("TIN", m["IN"]))
+    parts += [M[:, _sdf_rows(L, C, tile).to(emit.device)].reshape(-1), sums[:64]]
     for k in range(1, NH):                                   # hidden layer k: value path + its share of the reverse pass
         parts += [(outer_sum(r(f"AB{k + 1}"), r(f"H{k}")) + outer_sum(r(f"DA{k + 1}"), r(f"TH{k}"))).reshape(-1),
                   sums[64 * k:64 * (k + 1)]]
@@ -192,8 +205,8 @@ class FusedSdfGradient(torch.autograd.Function):
         N = points.shape[0]
         dev = points.device
         imp = model.implicit_network
-        gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1, precision_of(model, "sdf"))
-        gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3, precision_of(model, "sdf"))
+        gc, keep_c = sdf_grid_desc(model, "coarse")
+        gf, keep_f = sdf_grid_desc(model, "fine")
         pc, pf = packed_sdf(model, "coarse"), packed_sdf(model, "fine")
         order = morton_order(PointsDesc(None, None, None, points.data_ptr(), N, 0, None), N, dev) if SORT_POINTS else None
         pts = PointsDesc(None, None, None, points.data_ptr(), N, 0, None if order is None else order.data_ptr())
@@ -219,8 +232,8 @@ class FusedSdfGradient(torch.autograd.Function):
         N = points.shape[0]
         dev = points.device
         imp = model.implicit_network
-        gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1, precision_of(model, "sdf"))
-        gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3, precision_of(model, "sdf"))
+        gc, keep_c = sdf_grid_desc(model, "coarse")
+        gf, keep_f = sdf_grid_desc(model, "fine")
         pc, pf = ctx.packs
         order = ctx.order
         pts = PointsDesc(None, None, None, points.data_ptr(), N, 0, None if order is None else order.data_ptr())
@@ -229,7 +242,8 @@ class FusedSdfGradient(torch.autograd.Function):
         need = ctx.needs_input_grad
         st = _stream()
         out = [None, None, None, None, None, None, None]
-        emit = new_emit(SE["ROWS"], N, dev) if need[1] else None
+        tile = tile_of(model)
+        emit = new_emit(se_rows(1, tile)["ROWS"], N, dev) if need[1] else None
         gt_c = torch.zeros_like(imp.coarse.encoding.embeddings) if need[2] else None
         if emit is not None or gt_c is not None:
             with _timed("k_sdfnet_bwd<coarse,eik>", 0):
@@ -240,11 +254,11 @@ class FusedSdfGradient(torch.autograd.Function):
                                                      0 if emit is None else emit.shape[1], st))
             if emit is not None:
                 enc = imp.coarse.encoding
-                out[1] = sdf_flat_grad(emit, None, N, enc.num_levels, enc.level_dim)
+                out[1] = sdf_flat_grad(emit, None, N, enc.num_levels, enc.level_dim, tile=tile)
             out[2] = gt_c
         if (need[3] or need[4]) and stage != "coarse":
             gt_f = torch.zeros_like(imp.fine.encoding.embeddings) if need[3] else None
-            emit_f = new_emit(se_rows(3)["ROWS"], N, dev) if need[4] else None
+            emit_f = new_emit(se_rows(3, tile_of(model))["ROWS"], N, dev) if need[4] else None
             with _timed("k_sdfnet_bwd<fine,eik>", 0):
                 check(lib.nsa_sdfnet_backward_params(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), None, None,
                                                      g.data_ptr(), 0, g_x.data_ptr(),
@@ -254,7 +268,7 @@ class FusedSdfGradient(torch.autograd.Function):
             out[3] = gt_f
             if emit_f is not None:
                 enc = imp.fine.encoding
-                out[4] = sdf_flat_grad(emit_f, None, N, enc.num_levels, enc.level_dim, NH=3)
+                out[4] = sdf_flat_grad(emit_f, None, N, enc.num_levels, enc.level_dim, NH=3, tile=tile_of(model))
         return tuple(out)
 
 

@@ -259,3 +259,115 @@ def pack_colour_net(net):
     packed = pack_blocks(flat, blocks)
     assert packed.numel() == COL_PACK_SIZE
     return packed
+
+
+# ====================================================================================================================
+# "Quad" layout of the SDF-network kernels (csrc/mlp16.hpp, csrc/sdf_net4.hpp): v_mfma_f32_16x16x32_bf16, a wave = 16 points,
+# FOUR lanes per point (lane = point j + 16 * quarter q).  A 64-feature activation is 16 floats per lane, index s:
+#   feature(s, q) = 16 * (s >> 2) + 4 * q + (s & 3)          (= row 4q + r of output tile t = s >> 2, r = s & 3)
+# and k-group g of the next GEMM (32 k-values, 8 per lane) takes act[8g .. 8g+7] of every lane.
+QIN_STEPS = 24          # first-layer slots per lane: 3 k-groups (positional encoding 2 groups incl. x, grid 1 group)
+
+
+def qfeat(s, q):
+    """hidden feature held at activation index s of quarter-lane q"""
+    return 16 * (s >> 2) + 4 * q + (s & 3)
+
+
+def sdf_in_feature4(s, q, C=8):
+    """reference input-feature index (base_networks.py:155-164: [x, PE6(x), grid(32)]) of first-layer slot s of quarter q,
+    or -1 (zero pad).  Slots 0..9: sin/cos of pair p = 4 (s >> 1) + q (p < 18; k = p // 3, d = p % 3); slot 10: x_q (q < 3);
+    slots 16..23: the grid levels of this quarter, level = q + 4 jl (jl < 8 / C), C channels each -- coarse (C = 8): level q;
+    fine (C = 4): levels q and q + 4 (so that the four quarters work on levels 0..3, then 4..7: dense first, hashed last)."""
+    if s < 10:
+        p = 4 * (s >> 1) + q
+        if p >= 18:
+            return -1
+        k, d = divmod(p, 3)
+        return 3 + 6 * k + d + (3 if (s & 1) else 0)
+    if s == 10:
+        return q if q < 3 else -1
+    if s < 16:
+        return -1
+    jl, c = divmod(s - 16, C)
+    return 39 + (q + 4 * jl) * C + c
+
+
+def a_block16(MT, KG, elem):
+    """int64 index block [MT][KG][64 lanes][8]; elem(mt, i, g, kq, e) -> flat parameter index or -1 (zero): the weight that
+    lane (i = lane & 15, kq = lane >> 4) contributes as A[16 mt + i][k = (g, kq, e)]."""
+    out = np.full((MT, KG, 64, 8), -1, dtype=np.int64)
+    for mt in range(MT):
+        for g in range(KG):
+            for lane in range(64):
+                for e in range(8):
+                    out[mt, g, lane, e] = elem(mt, lane & 15, g, lane >> 4, e)
+    return ("A", out.reshape(-1))
+
+
+def vec_block16(elem):
+    """activation-layout vector [q * 16 + s]; elem(feature) -> flat index."""
+    out = np.full(64, -1, dtype=np.int64)
+    for q in range(4):
+        for s in range(16):
+            out[q * 16 + s] = elem(qfeat(s, q))
+    return ("V", out)
+
+
+@functools.lru_cache(maxsize=None)
+def sdf_net_index4(NH, C):
+    """Index map of one SDF network's packed block in the quad layout (order = csrc/sdf_net4.hpp::SdfPack4<NH>); C = grid
+    channels per level (8: one level per quarter-lane, 4: two)."""
+    n_in = 71
+    offs, o = [], 0
+    shapes = [(64, n_in)] + [(64, 64)] * (NH - 1) + [(65, 64)]
+    for (a, b) in shapes:
+        offs.append((o, o + a * b))
+        o += a * b + a
+    Wo = lambda k: offs[k][0]
+    Bo = lambda k: offs[k][1]
+    hk = lambda g, kq, e: qfeat(8 * g + e, kq)            # hidden feature supplied as k-value (g, kq, e)
+    blocks = []
+    blocks.append(a_block16(4, 3, lambda mt, i, g, kq, e: (
+        Wo(0) + (16 * mt + i) * n_in + f if (f := sdf_in_feature4(8 * g + e, kq, C)) >= 0 else -1)))
+    blocks.append(vec_block16(lambda f: Bo(0) + f))
+    for k in range(1, NH):
+        blocks.append(a_block16(4, 2, lambda mt, i, g, kq, e, k=k: Wo(k) + (16 * mt + i) * 64 + hk(g, kq, e)))
+        blocks.append(vec_block16(lambda f, k=k: Bo(k) + f))
+    blocks.append(vec_block16(lambda f: Wo(NH) + f))                       # sdf row
+    bs = np.full(64, -1, dtype=np.int64)
+    bs[0] = Bo(NH)
+    blocks.append(("V", bs))
+    blocks.append(a_block16(4, 2, lambda mt, i, g, kq, e: Wo(NH) + (1 + 16 * mt + i) * 64 + hk(g, kq, e)))   # feature rows
+    blocks.append(vec_block16(lambda f: Bo(NH) + 1 + f))
+    for k in range(NH - 1, 0, -1):                                         # transposed hidden layers
+        blocks.append(a_block16(4, 2, lambda mt, i, g, kq, e, k=k: Wo(k) + hk(g, kq, e) * 64 + (16 * mt + i)))
+
+    def w0t(mt, i, g, kq, e):                                              # rows = first-layer slots: tile mt, row i = 4 q + r
+        f = sdf_in_feature4(4 * mt + (i & 3), i >> 2, C)
+        return Wo(0) + hk(g, kq, e) * n_in + f if f >= 0 else -1
+    blocks.append(a_block16(6, 2, w0t))
+    blocks.append(a_block16(4, 2, lambda mt, i, g, kq, e: Wo(NH) + (1 + hk(g, kq, e)) * 64 + (16 * mt + i)))  # feature rows^T
+    return _finish(blocks, o), o
+
+
+def a_floats16(MT, KG):
+    return MT * KG * 3 * 64 * 4
+
+
+def sdf_pack_size4(NH):
+    hh = a_floats16(4, 2)
+    return (a_floats16(4, 3) + 64 + (NH - 1) * (hh + 64) + 64 + 64 + hh + 64 + (NH - 1) * hh + a_floats16(6, 2) + hh)
+
+
+def pack_sdf_net4(net):
+    """ImplicitNetworkGrid -> packed float32 device tensor in the quad layout."""
+    NH = net.num_layers - 2
+    enc = net.encoding
+    assert enc.num_levels * enc.level_dim == 32 and enc.level_dim in (4, 8)
+    blocks, n = sdf_net_index4(NH, enc.level_dim)
+    flat = flat_params(net)
+    assert flat.numel() == n + 1, (flat.numel(), n)
+    packed = pack_blocks(flat, blocks)
+    assert packed.numel() == sdf_pack_size4(NH)
+    return packed

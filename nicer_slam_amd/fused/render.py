@@ -12,7 +12,7 @@ import torch
 from .._native import lib, check, PointsDesc
 from ..hashencoder.backend import _timed
 from . import pack
-from .sampler import grid_desc, packed_sdf, precision_of
+from .sampler import grid_desc, packed_sdf, precision_of, sdf_grid_desc, tile_of
 
 
 def hl_size(P):
@@ -76,8 +76,8 @@ def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd, sort_p
     P = R * S
     dev = z_vals.device
     imp = model.implicit_network
-    gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1, precision_of(model, "sdf"))
-    gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3, precision_of(model, "sdf"))
+    gc, keep_c = sdf_grid_desc(model, "coarse")
+    gf, keep_f = sdf_grid_desc(model, "fine")
     gr, keep_r = grid_desc(model.rendering_network.encoding, model.rendering_network.divide_factor, 2, precision_of(model, "colour"))
     pc, pf, pr = packed_sdf(model, "coarse"), packed_sdf(model, "fine"), packed_colour(model)
     order = morton_order(_pts(rays_o, rays_d, z_vals), P, dev) if sort_points else None
@@ -116,8 +116,8 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
     P = R * S
     dev = z_vals.device
     imp = model.implicit_network
-    gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1, precision_of(model, "sdf"))
-    gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3, precision_of(model, "sdf"))
+    gc, keep_c = sdf_grid_desc(model, "coarse")
+    gf, keep_f = sdf_grid_desc(model, "fine")
     gr, keep_r = grid_desc(model.rendering_network.encoding, model.rendering_network.divide_factor, 2, precision_of(model, "colour"))
     pc, pf, pr = b["packs"]
     order = b.get("order")
@@ -160,7 +160,7 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
     if want.get("flat_c") or want.get("tab_c"):
         from . import mapping
         enc = imp.coarse.encoding
-        emit = mapping.new_emit(mapping.SE["ROWS"], P, dev) if want.get("flat_c") else None
+        emit = mapping.new_emit(mapping.se_rows(1, tile_of(model))["ROWS"], P, dev) if want.get("flat_c") else None
         gt = torch.zeros_like(enc.embeddings) if want.get("tab_c") else None
         with _timed("k_sdfnet_bwd<coarse,map>", P * 3 * 4 * 8 * 8 * 4):
             check(lib.nsa_sdfnet_backward_params(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), g_sdf.data_ptr(),
@@ -168,7 +168,7 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
                                                  ptr(emit), 0 if emit is None else emit.shape[1], st))
         if emit is not None:
             g_sdf_w = g_sdf if order is None else g_sdf[order.long()]       # emission columns are work items
-            pg["flat_c"] = mapping.sdf_flat_grad(emit, g_sdf_w, P, enc.num_levels, enc.level_dim)
+            pg["flat_c"] = mapping.sdf_flat_grad(emit, g_sdf_w, P, enc.num_levels, enc.level_dim, tile=tile_of(model))
             del emit
         pg["tab_c"] = gt
     else:
@@ -180,14 +180,14 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
             from . import mapping
             enc = imp.fine.encoding
             gt = torch.zeros_like(enc.embeddings) if want.get("tab_f") else None
-            emit = mapping.new_emit(mapping.se_rows(3)["ROWS"], P, dev) if want.get("flat_f") else None
+            emit = mapping.new_emit(mapping.se_rows(3, tile_of(model))["ROWS"], P, dev) if want.get("flat_f") else None
             with _timed("k_sdfnet_bwd<fine,map>", P * 3 * 8 * 8 * 4 * 4):
                 check(lib.nsa_sdfnet_backward_params(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), g_sdf.data_ptr(),
                                                      g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(),
                                                      ptr(gt), ptr(emit), 0 if emit is None else emit.shape[1], st))
             if emit is not None:
                 g_sdf_w = g_sdf if order is None else g_sdf[order.long()]
-                pg["flat_f"] = mapping.sdf_flat_grad(emit, g_sdf_w, P, enc.num_levels, enc.level_dim, NH=3)
+                pg["flat_f"] = mapping.sdf_flat_grad(emit, g_sdf_w, P, enc.num_levels, enc.level_dim, NH=3, tile=tile_of(model))
                 del emit
             pg["tab_f"] = gt
         else:

@@ -3,6 +3,7 @@ Section 2).  Replaces ImportantSampler.get_z_vals of the composed engine (refere
 with two kernel launches; no gradient flows through the sampler (the reference runs it on detached rays under
 no_grad, ray_sampler.py:38-39,101-102)."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -34,12 +35,31 @@ def precision_of(model, which):
     return 1 if mode == "bf16" or (mode == "bf16_colour" and which == "colour") else 0
 
 
-def grid_desc(net_or_enc, divide_factor, n_hidden, precision=0):
+DEFAULT_SDF_TILE = int(os.environ.get("NSA_SDF_TILE", "16"))
+
+
+def tile_of(model):
+    """Tiling of the SDF-network kernels (nsa_grid_t.tile): 16 = quad tiling (16 points per wave, four lanes per point,
+    csrc/render_sdfnet4.hip / render_sampler4.hip), 32 = the 32-point tiling (csrc/render_sdfnet.hip).  ``model.sdf_tile``
+    overrides the default (environment NSA_SDF_TILE, else 16); both produce the same numbers (tests/test_tiling_gpu.py)."""
+    t = int(getattr(model, "sdf_tile", 0) or DEFAULT_SDF_TILE)
+    if t not in (16, 32):
+        raise ValueError(f"sdf_tile must be 16 or 32, got {t}")
+    return t
+
+
+def grid_desc(net_or_enc, divide_factor, n_hidden, precision=0, tile=0):
     enc = net_or_enc
     off = _offsets_host(enc.offsets)
     d = GridDesc(enc.embeddings.data_ptr(), off.data_ptr(), enc.num_levels, enc.level_dim,
-                 float(np.log2(enc.per_level_scale)), enc.base_resolution, float(divide_factor), n_hidden, precision)
+                 float(np.log2(enc.per_level_scale)), enc.base_resolution, float(divide_factor), n_hidden, precision, tile)
     return d, (off, enc.embeddings)
+
+
+def sdf_grid_desc(model, which):
+    """nsa_grid_t of the coarse / fine SDF network under the model's precision and tiling settings."""
+    net = getattr(model.implicit_network, which)
+    return grid_desc(net.encoding, net.divide_factor, net.num_layers - 2, precision_of(model, "sdf"), tile_of(model))
 
 
 def supported(model):
@@ -75,13 +95,14 @@ def packed_sdf(model, which, detach=True):
     """Packed parameters of the coarse/fine SDF MLP, cached on the parameters' version counters."""
     net = getattr(model.implicit_network, which)
     params = net.mlp_parameters()
-    key = tuple((p.data_ptr(), p._version) for p in params)
+    tile = tile_of(model)
+    key = (tile,) + tuple((p.data_ptr(), p._version) for p in params)
     cache = model.__dict__.setdefault("_fused_pack", {})
     hit = cache.get(which)
     if detach and hit is not None and hit[0] == key:
         return hit[1]
     with torch.set_grad_enabled(not detach):
-        packed = pack.pack_sdf_net(net)
+        packed = pack.pack_sdf_net4(net) if tile == 16 else pack.pack_sdf_net(net)
     if detach:
         cache[which] = (key, packed)
     return packed
@@ -94,9 +115,8 @@ def sampler_sdf(model, rays_o, rays_d, t_rand):
     R, E = rays_o.shape[0], samp.N_samples_eval
     dev = rays_o.device
     imp = model.implicit_network
-    prec = precision_of(model, "sdf")
-    gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1, prec)
-    gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3, prec)
+    gc, keep_c = sdf_grid_desc(model, "coarse")
+    gf, keep_f = sdf_grid_desc(model, "fine")
     pc, pf = packed_sdf(model, "coarse"), packed_sdf(model, "fine")
     z = torch.empty(R, E, device=dev)
     sdf = torch.empty(R, E, device=dev)

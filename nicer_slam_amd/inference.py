@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 from ._native import lib, check
-from .fused.sampler import grid_desc, packed_sdf, precision_of, supported as fused_supported
+from .fused.sampler import grid_desc, packed_sdf, precision_of, sdf_grid_desc, supported as fused_supported
 
 
 def split_input(model_input, total_pixels, n_pixels=10000):
@@ -71,8 +71,8 @@ def sdf_values(model, points, stage="fine", chunk=1 << 22):
     if not (points.is_cuda and fused_supported(model)):
         raise RuntimeError("sdf_values: needs CUDA points and a model configuration covered by the fused kernels")
     imp = model.implicit_network
-    gc, keep_c = grid_desc(imp.coarse.encoding, imp.coarse.divide_factor, 1, precision_of(model, "sdf"))
-    gf, keep_f = grid_desc(imp.fine.encoding, imp.fine.divide_factor, 3, precision_of(model, "sdf"))
+    gc, keep_c = sdf_grid_desc(model, "coarse")
+    gf, keep_f = sdf_grid_desc(model, "fine")
     pc, pf = packed_sdf(model, "coarse"), packed_sdf(model, "fine")
     points = points.contiguous().float()
     out = torch.empty(points.shape[0], device=points.device)

@@ -55,3 +55,38 @@ def act_to_b(acc):
 
 def xhalf_sum(v):
     return v + np.concatenate([v[32:], v[:32]])
+
+
+# ---- quad layout (csrc/mlp16.hpp): v_mfma_f32_16x16x32_bf16, lane = point j + 16 * quarter q ---------------------------
+def gemm16(block, MT, KG, b, acc):
+    """block: packed weights [MT][KG][3 pieces][64 lanes][8 bf16] as float32 words; b: [64 lanes][8*KG] fp32 k-values (lane
+    (j, kq) supplies B[k = (g, kq, e)][j] = b[lane, 8g+e]); acc: [64][MT][4] updated in place (lane (j, q), register r =
+    D[row 4q + r][col j] of each 16-row output tile).  The MFMA pairs element e of quarter kq of A with element e of
+    quarter kq of B, whatever the hardware's internal k order."""
+    blk = _bf16_words_to_f64(np.asarray(block, dtype=np.float32)).reshape(MT, KG, 3, 64, 8).sum(2)   # [mt][g][lane][e]
+    for mt in range(MT):
+        D = np.zeros((16, 16))
+        for g in range(KG):
+            for kq in range(4):
+                A = blk[mt, g, 16 * kq:16 * kq + 16, :]               # [i][e]
+                B = b[16 * kq:16 * kq + 16, 8 * g:8 * g + 8].T        # [e][j]
+                D += A @ B
+        for lane in range(64):
+            j, q = lane & 15, lane >> 4
+            for r in range(4):
+                acc[lane, mt, r] += D[4 * q + r, j]
+
+
+def load_vec16(vec):
+    """activation-layout vector [q*16 + s] -> [64 lanes][4 tiles][4]"""
+    v = np.asarray(vec, dtype=np.float64)
+    out = np.zeros((64, 4, 4))
+    for lane in range(64):
+        out[lane] = v[(lane >> 4) * 16:(lane >> 4) * 16 + 16].reshape(4, 4)
+    return out
+
+
+def quad_sum(v):
+    """sum over the four quarter-lanes of a point"""
+    s = v.reshape(4, 16).sum(0)
+    return np.tile(s, 4)

@@ -70,7 +70,7 @@ def test_feature_vector_hl_layout():
     imp = model.implicit_network
     for which, acc, nh in (("coarse", 0, 1), ("fine", 1, 3)):
         net = getattr(imp, which)
-        g, keep = fs.grid_desc(net.encoding, net.divide_factor, nh)
+        g, keep = fs.sdf_grid_desc(model, which)
         check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(g), fs.packed_sdf(model, which).data_ptr(), acc,
                                      sdf.data_ptr(), grad.data_ptr(), feat.data_ptr(), torch.cuda.current_stream().cuda_stream))
     dense = feat[fr.hl_index(P, "cuda")]

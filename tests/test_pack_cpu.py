@@ -197,3 +197,94 @@ def test_colour_net_pack():
         for q in range(80):
             f = pack.col_in_feature(q, lane >> 5) if q < 65 else -1
             assert abs(acc[lane, q // 16, q % 16] - (want[lane & 31, f] if f >= 0 else 0.0)) < 2e-6
+
+
+# ---- quad layout (16-point tiles, four lanes per point; csrc/mlp16.hpp, csrc/sdf_net4.hpp) ------------------------------
+def test_quad_slot_map_covers_every_input_feature_once():
+    for C in (8, 4):
+        seen = {}
+        for q in range(4):
+            for s in range(pack.QIN_STEPS):
+                f = pack.sdf_in_feature4(s, q, C)
+                if f >= 0:
+                    assert f not in seen
+                    seen[f] = (s, q)
+        assert sorted(seen) == list(range(71))
+    assert sorted(pack.qfeat(s, q) for q in range(4) for s in range(16)) == list(range(64))
+
+
+@pytest.mark.parametrize("NH,L,C", [(1, 4, 8), (3, 8, 4)])
+def test_sdf_net_quad_pack_forward_and_transposes(NH, L, C):
+    net = make_net(NH, L, C, seed=10 + NH)
+    packed = pack.pack_sdf_net4(net).detach().float().numpy()
+    assert packed.size == pack.sdf_pack_size4(NH)
+    rng = np.random.default_rng(3)
+    h0 = rng.standard_normal((16, 71)) * 0.5
+    Ws = [pack.effective_weight(getattr(net, f"lin{l}")).detach().double().numpy() for l in range(NH + 1)]
+    bs = [getattr(net, f"lin{l}").bias.detach().double().numpy() for l in range(NH + 1)]
+    a = [h0 @ Ws[0].T + bs[0]]
+    for k in range(1, NH):
+        a.append(softplus(a[-1]) @ Ws[k].T + bs[k])
+    out = softplus(a[-1]) @ Ws[NH].T + bs[NH]
+    o = 0
+    hh, n0, n0t = pack.a_floats16(4, 2), pack.a_floats16(4, 3), pack.a_floats16(6, 2)
+    W0 = packed[o:o + n0]; o += n0
+    B0 = packed[o:o + 64]; o += 64
+    WH = []
+    for k in range(1, NH):
+        WH.append((packed[o:o + hh], packed[o + hh:o + hh + 64])); o += hh + 64
+    WSDF = packed[o:o + 64]; o += 64
+    BSDF = packed[o]; o += 64
+    WFEAT = packed[o:o + hh]; o += hh
+    BFEAT = packed[o:o + 64]; o += 64
+    WHT = {}
+    for k in range(NH - 1, 0, -1):
+        WHT[k] = packed[o:o + hh]; o += hh
+    W0T = packed[o:o + n0t]; o += n0t
+    WFEATT = packed[o:o + hh]; o += hh
+    assert o == packed.size
+    b0 = np.zeros((64, 24))
+    for lane in range(64):
+        for s in range(24):
+            f = pack.sdf_in_feature4(s, lane >> 4, C)
+            b0[lane, s] = h0[lane & 15, f] if f >= 0 else 0.0
+    acc = emu.load_vec16(B0)
+    emu.gemm16(W0, 4, 3, b0, acc)
+    for k in range(1, NH):
+        nxt = emu.load_vec16(WH[k - 1][1])
+        emu.gemm16(WH[k - 1][0], 4, 2, softplus(acc).reshape(64, 16), nxt)
+        acc = nxt
+    act = softplus(acc)
+    sdf = emu.quad_sum((act * emu.load_vec16(WSDF)).reshape(64, -1).sum(1)) + BSDF
+    for lane in range(64):
+        assert abs(sdf[lane] - out[lane & 15, 0]) < 2e-6
+    feat = emu.load_vec16(BFEAT)
+    emu.gemm16(WFEAT, 4, 2, act.reshape(64, 16), feat)
+    for lane in range(64):
+        for s in range(16):
+            assert abs(feat[lane, s >> 2, s & 3] - out[lane & 15, 1 + pack.qfeat(s, lane >> 4)]) < 2e-6
+    gvec = rng.standard_normal((16, 64))
+    g_b = np.zeros((64, 16))
+    for lane in range(64):
+        for s in range(16):
+            g_b[lane, s] = gvec[lane & 15, pack.qfeat(s, lane >> 4)]
+    for k in range(1, NH):
+        acc = np.zeros((64, 4, 4))
+        emu.gemm16(WHT[k], 4, 2, g_b, acc)
+        want = gvec @ Ws[k]
+        for lane in range(64):
+            for s in range(16):
+                assert abs(acc[lane, s >> 2, s & 3] - want[lane & 15, pack.qfeat(s, lane >> 4)]) < 2e-6
+    acc = np.zeros((64, 6, 4))
+    emu.gemm16(W0T, 6, 2, g_b, acc)
+    want = gvec @ Ws[0]
+    for lane in range(64):
+        for s in range(24):
+            f = pack.sdf_in_feature4(s, lane >> 4, C)
+            assert abs(acc[lane, s >> 2, s & 3] - (want[lane & 15, f] if f >= 0 else 0.0)) < 2e-6, (lane, s)
+    acc = np.zeros((64, 4, 4))
+    emu.gemm16(WFEATT, 4, 2, g_b, acc)
+    want = gvec @ Ws[NH][1:, :]
+    for lane in range(64):
+        for s in range(16):
+            assert abs(acc[lane, s >> 2, s & 3] - want[lane & 15, pack.qfeat(s, lane >> 4)]) < 2e-6

@@ -1,0 +1,91 @@
+"""The two tilings of the SDF-network kernels -- quad (16 points per wave, four lanes per point: csrc/render_sdfnet4.hip,
+render_sampler4.hip; the default) and 32-point (lane pair per point: csrc/render_sdfnet.hip, render_sampler.hip) -- compute
+the same function: identical inputs, every output and every gradient compared.  (All other GPU tests run on the default
+tiling and hold it to the oracle / the reference goldens; this file keeps the 32-point kernels held to the same numbers.)"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load, tt, draws_of, golden_objective, assert_close
+from test_model_cpu import build_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(fx, tile, z=None):
+    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    model = build_model(fx).cuda()
+    model.engine = "fused"
+    model.sdf_tile = tile
+    model.tracking_param_grads = True
+    model.fine_mlp_grads = True
+    mode, stage, cstage = str(fx["meta_mode"]), str(fx["meta_stage"]), str(fx["meta_color_stage"])
+    model.train(True)
+    model.voxels = tt(fx["in_voxels"]).cuda()
+    model.draws = draws_of(fx, "cuda")
+    if z is not None:
+        model.draws["z_vals_override"] = z
+    cam = tt(fx["in_cam"]).cuda().requires_grad_(True)
+    out = model({"intrinsics": tt(fx["in_K"]).cuda(), "uv": tt(fx["in_uv"]).cuda(), "pose": get_camera_from_tensor(cam)},
+                torch.arange(cam.shape[0], device="cuda"), {}, mode=mode, stage=stage, color_stage=cstage, frame_idx=1)
+    assert model.last_engine == "fused"
+    golden_objective(out, fx, mode).backward()
+    return out, cam.grad, {n: p.grad for n, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("name", ["full_tracking_rw", "full_mapping_rw", "full_mapping_rw_coarse", "full_tracking_poisson"])
+def test_quad_and_32_point_tilings_agree(name):
+    fx = load(name)
+    o16, c16, g16 = _run(fx, 16)
+    z = o16["z_vals"].detach()
+    o32, c32, g32 = _run(fx, 32, z)
+    o16, c16, g16 = _run(fx, 16, z)
+    # free-running sampler of the quad tiling vs the reference's samples is covered by tests/test_sampler_gpu.py
+    for k in ("sdf", "weights", "rgb", "rgb_values", "depth_values", "normal_map", "entropy", "grad_theta", "grad_theta_nei"):
+        if k in o16:
+            assert_close(o16[k], o32[k].detach().cpu().numpy(), 2e-6, 1e-5, k)
+    assert_close(c16, c32.cpu().numpy(), 1e-7 + 1e-4 * float(c32.abs().max()), 1e-4, "grad_cam")
+    n = 0
+    for k, g in g32.items():
+        if g is None:
+            assert g16[k] is None, k
+            continue
+        assert_close(g16[k], g.cpu().numpy(), 1e-8 + 2e-4 * float(g.abs().max()), 1e-3, "grad " + k)
+        n += 1
+    assert n >= 10
+
+
+def test_sampler_sdf_stage_both_tilings():
+    """Coarse sampler stage (z, sdf at R*E points) and batch SDF inference, quad vs 32-point tiling, shipped grid sizes, ragged
+    point counts (the quad kernels are persistent: every tile must be visited exactly once)."""
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    from nicer_slam_amd.fused import sampler as fs
+    from nicer_slam_amd import inference
+    torch.manual_seed(0)
+    model = SLAMNetwork(replica_model_conf(94, 640, 32, use_warp_loss=False), n_images=1,
+                        colour_grid=dict(base_resolution=16, desired_resolution=64, log2_hashmap_size=12)).cuda().train()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    with torch.no_grad():
+        for enc in (model.implicit_network.coarse.encoding, model.implicit_network.fine.encoding):
+            enc.embeddings.copy_((torch.rand(enc.embeddings.shape, device="cuda", generator=g) * 2 - 1) * 0.05)
+        for n_, p in model.named_parameters():
+            if n_.startswith("implicit_network") and n_.endswith("weight_v"):
+                p.add_(0.05 * torch.randn(p.shape, device="cuda", generator=g))
+    for R in (1000, 37):
+        d = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda", generator=g), dim=-1) * 0.7
+        o = (torch.rand(R, 3, device="cuda", generator=g) - 0.5) * 0.4
+        t_rand = torch.rand(R, 640, device="cuda", generator=g)
+        res = {}
+        for tile in (16, 32):
+            model.sdf_tile = tile
+            res[tile] = fs.sampler_sdf(model, o, d, t_rand)
+        for a, b, what in zip(res[16], res[32], ("z", "sdf", "far")):
+            assert_close(a, b.cpu().numpy(), 1e-6 if what == "sdf" else 0, 1e-5 if what == "sdf" else 0, f"{what} (R={R})")
+    pts = (torch.rand(100003, 3, device="cuda", generator=g) * 2 - 1) * 1.2
+    for stage in ("fine", "coarse"):
+        vals = {}
+        for tile in (16, 32):
+            model.sdf_tile = tile
+            vals[tile] = inference.sdf_values(model, pts, stage, chunk=30011)
+        assert_close(vals[16], vals[32].cpu().numpy(), 1e-6, 1e-5, "sdf_values " + stage)

@@ -17,7 +17,13 @@ TAG = os.environ.get("NSA_BUILD_TAG", "")
 OBJ = os.path.join(HERE, "build" + ("_" + TAG if TAG else ""))
 LIB = os.path.join(HERE, "lib", "libnicer_slam_amd" + ("_" + TAG if TAG else "") + ".so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+# -fno-slp-vectorize is a CORRECTNESS flag here, not a tuning knob.  With SLP vectorisation (on at -O2/-O3) hipcc (ROCm 7.2)
+# packs adjacent fp32 multiplies / adds / fmas of the per-point code into v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, and the
+# MFMA kernels then return run-to-run DIFFERENT values on MI355X at ~1e-4 of the points (always lanes >= 16 of a wave, errors
+# up to 3e-3 in sdf) -- the same binary, the same inputs (tools/diag_determinism.py; -O1 and -fno-slp-vectorize builds are
+# bit-reproducible and equal the CPU oracle, every -O2/-O3 build with packed fp32 math is not; tests/test_tiling_gpu.py holds the
+# regression).  The packed forms are also slower beside MFMAs (MI355X_MICROARCH.md, per-instruction constants).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"] + os.environ.get("NSA_EXTRA_HIPCC_FLAGS", "").split()
 
 

@@ -6,7 +6,7 @@ files=(); extra=()
 while [ $# -gt 0 ]; do if [ "$1" == "--" ]; then shift; extra=("$@"); break; fi; files+=("$1"); shift; done
 [ ${#files[@]} -eq 0 ] && files=(render_sdfnet render_sampler render_colour)
 for f in "${files[@]}"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Rpass-analysis=kernel-resource-usage \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -munsafe-fp-atomics -Rpass-analysis=kernel-resource-usage \
      "${extra[@]}" -c nicer_slam_amd/csrc/${f%.hip}.hip -o /tmp/kr_$$.o 2>&1 | python3 -c '
 import sys,re
 cur={}

@@ -58,7 +58,8 @@ def test_random_shapes_fused_vs_composed(seed):
         model.engine = engine
         model.zero_grad(set_to_none=True)
         model.voxels = torch.zeros(64, 64, 64, device="cuda")
-        model.draws = {} if zfix is None else {"z_vals_override": zfix}
+        # (the near-surface eikonal sample is one of the ray's samples: fixed too, or a sampler ulp moves one eikonal point)
+        model.draws = {} if zfix is None else {"z_vals_override": zfix, "eik_idx": eik_fix}
         torch.manual_seed(7)
         cam = torch.tensor([1.0, 0.03, -0.02, 0.01, 0.05, 0.02, -0.1], device="cuda", requires_grad=True)
         out = model({"intrinsics": K[None], "uv": uv, "pose": get_camera_from_tensor(cam).unsqueeze(0)},
@@ -69,6 +70,7 @@ def test_random_shapes_fused_vs_composed(seed):
             # ulp of o + z d and the two engines build their rays differently) slightly inside, for BOTH engines
             zfix = out["z_vals"].detach().clone()
             zfix[:, -1] = torch.maximum(zfix[:, -1] * (1 - 2e-4), zfix[:, -2])
+            eik_fix = torch.randint(zfix.shape[1], (zfix.shape[0],), device="cuda", generator=g)
         loss = (out["rgb_values"].reshape(-1, 3) - gt).abs().mean() + 0.1 * out["depth_values"].mean() \
             + 0.05 * out["normal_map"].abs().mean()
         if "grad_theta" in out:

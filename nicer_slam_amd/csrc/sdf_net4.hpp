@@ -3,9 +3,13 @@
 // Reference: ImplicitNetworkGrid.forward / get_outputs (code/model/base_networks.py:155-221), HashEncoder.forward
 // (code/hashencoder/hashgrid.py:199-215), Embedder (code/model/embedder.py:5-37).
 //
-// First-layer slots of quarter-lane q (24 per lane = 3 k-groups; reference feature index in brackets):
-//   slots 2n, 2n+1 (n < 5) : sin, cos of 2^k x_d for the pair p = 4n + q, k = p / 3, d = p % 3   [3+6k+d], [6+6k+d]   (p < 18)
-//   slot 10                : x_q   [q]                                                                              (q < 3)
+// First-layer slots of quarter-lane q (24 per lane = 3 k-groups; reference feature index in brackets; k = frequency 2^k, d =
+// coordinate).  The map keeps every coordinate index a compile-time constant or a two-way choice (a lane-varying three-way
+// choice compiles to divergent branches):
+//   slots 2n, 2n+1, n < 3  : sin, cos of 2^q x_n                                  [3+6q+n], [6+6q+n]
+//   slots 6, 7             : sin, cos of 2^(4+(q&1)) x_d, d = (q & 2) ? 2 : 0    [3+6k+d], [6+6k+d]
+//   slots 8, 9             : q < 2: sin, cos of 2^(4+q) x_1   [27+6q+1], [30+6q+1] ;  q == 3: x_0, x_1   [0], [1] ;  q == 2: zero
+//   slot 10                : q == 3: x_2   [2] ;  else zero
 //   slots 11..15           : zero pad
 //   slots 16 + jl*C + c    : channel c of grid level q + 4 jl   [39 + (q + 4 jl) C + c]        (jl < 8/C: coarse 1, fine 2)
 // (nicer_slam_amd/fused/pack.py::sdf_in_feature4 builds the packed weights from exactly this table; with level = q + 4 jl
@@ -42,37 +46,41 @@ __device__ __forceinline__ void geom_to_lds(const GridGeom16& geom, LevelGeom* s
     if (threadIdx.x < 16) s_geom[threadIdx.x] = geom.lv[threadIdx.x];
 }
 
-struct PairInfo {      // positional-encoding pair n of quarter q: p = 4n + q -> frequency 2^k, dimension d
-    float sc;          // 2^k, or 0 for the pairs that do not exist (n = 4, q >= 2)
-    int d;
+__device__ __forceinline__ float pow2f(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }
+
+// coordinate and frequency of positional-encoding pair n (slots 2n, 2n+1) of quarter q; sc == 0: the pair does not exist
+struct PairSel {
+    float xa;     // the coordinate (or, for the tangent, the cotangent component) it reads
+    float sc;     // 2^k
 };
-__device__ __forceinline__ PairInfo pe_pair(int n, int q) {
-    const int p = 4 * n + q;
-    const int k = (p * 11) >> 5;                  // p / 3 for p < 32
-    PairInfo r;
-    r.d = p - 3 * k;
-    r.sc = p < 18 ? __uint_as_float((uint32_t)(127 + k) << 23) : 0.0f;
+__device__ __forceinline__ PairSel pe_pair(int n, int q, const float (&x)[3]) {
+    PairSel r;
+    if (n < 3) { r.xa = x[n]; r.sc = pow2f(q); }
+    else if (n == 3) { r.xa = (q & 2) ? x[2] : x[0]; r.sc = pow2f(4 + (q & 1)); }
+    else { r.xa = x[1]; r.sc = q < 2 ? pow2f(4 + q) : 0.0f; }
     return r;
 }
-__device__ __forceinline__ float pick3(const float (&x)[3], int d) { return d == 0 ? x[0] : (d == 1 ? x[1] : x[2]); }
-__device__ __forceinline__ void add3(float (&g)[3], int d, float t) {
-    g[0] += d == 0 ? t : 0.0f;
-    g[1] += d == 1 ? t : 0.0f;
-    g[2] += d == 2 ? t : 0.0f;
+// g[d(n, q)] += t
+__device__ __forceinline__ void pe_add(int n, int q, float (&g)[3], float t) {
+    if (n < 3) g[n] += t;
+    else if (n == 3) { g[0] += (q & 2) ? 0.0f : t; g[2] += (q & 2) ? t : 0.0f; }
+    else g[1] += t;                     // (t carries sc == 0 for the quarters without this pair)
 }
 
 // Position + positional-encoding slots 0..15 (identical for the coarse and the fine network).
 __device__ __forceinline__ void pe_slots4(const float (&x)[3], int q, float (&in)[QIN]) {
 #pragma unroll
     for (int n = 0; n < 5; ++n) {
-        const PairInfo pi = pe_pair(n, q);
+        const PairSel ps = pe_pair(n, q, x);
         float s, c;
-        sincos_f(pick3(x, pi.d) * pi.sc, s, c);
-        const bool valid = n < 4 || q < 2;
-        in[2 * n] = valid ? s : 0.0f;
-        in[2 * n + 1] = valid ? c : 0.0f;
+        sincos_f(ps.xa * ps.sc, s, c);
+        in[2 * n] = s;
+        in[2 * n + 1] = c;
     }
-    in[10] = q < 3 ? pick3(x, q) : 0.0f;
+    // slots 8, 9: the pair exists for q < 2 only; quarter 3 keeps x_0, x_1 there and x_2 in slot 10
+    in[8] = q < 2 ? in[8] : (q == 3 ? x[0] : 0.0f);
+    in[9] = q < 2 ? in[9] : (q == 3 ? x[1] : 0.0f);
+    in[10] = q == 3 ? x[2] : 0.0f;
 #pragma unroll
     for (int s = 11; s < 16; ++s) in[s] = 0.0f;
 }
@@ -139,12 +147,14 @@ __device__ __forceinline__ float sdf_only4(const float* __restrict__ wp, int q, 
 // Contraction of a per-slot cotangent with d(first-layer input)/dx for THIS lane's share of the slots:
 //   g[d] = sum_slots dl[slot] * d in[slot] / d x_d.   Caller adds the four quarter-lanes (quad_sum).
 __device__ __forceinline__ void pe_to_x4(int q, const float (&in)[QIN], const float (&dl)[QIN], float (&g)[3]) {
-    g[0] = g[1] = g[2] = 0.0f;
-    add3(g, q, q < 3 ? dl[10] : 0.0f);                       // (q == 3: d = 3 matches nothing)
+    g[0] = q == 3 ? dl[8] : 0.0f;
+    g[1] = q == 3 ? dl[9] : 0.0f;
+    g[2] = q == 3 ? dl[10] : 0.0f;
+    const float zero3[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int n = 0; n < 5; ++n) {
-        const PairInfo pi = pe_pair(n, q);
-        add3(g, pi.d, pi.sc * (in[2 * n + 1] * dl[2 * n] - in[2 * n] * dl[2 * n + 1]));   // 2^k (cos d_sin - sin d_cos)
+        const float sc = pe_pair(n, q, zero3).sc;
+        pe_add(n, q, g, sc * (in[2 * n + 1] * dl[2 * n] - in[2 * n] * dl[2 * n + 1]));   // 2^k (cos d_sin - sin d_cos)
     }
 }
 
@@ -201,14 +211,15 @@ __device__ __forceinline__ void pe_tangent4(int q, const float (&in)[QIN], const
     xbar[0] = xbar[1] = xbar[2] = 0.0f;
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
-        const PairInfo pi = pe_pair(m, q);
-        const float nd = pick3(n, pi.d);
-        const float s = in[2 * m], c = in[2 * m + 1];
-        tin[2 * m] = pi.sc * c * nd;
-        tin[2 * m + 1] = -pi.sc * s * nd;
-        add3(xbar, pi.d, -pi.sc * pi.sc * (s * dl[2 * m] + c * dl[2 * m + 1]) * nd);
+        const PairSel ps = pe_pair(m, q, n);                 // xa = the cotangent component n_d of this pair's coordinate
+        const float s = m == 4 && q >= 2 ? 0.0f : in[2 * m], c = m == 4 && q >= 2 ? 0.0f : in[2 * m + 1];   // (q == 3 keeps x there)
+        tin[2 * m] = ps.sc * c * ps.xa;
+        tin[2 * m + 1] = -ps.sc * s * ps.xa;
+        pe_add(m, q, xbar, -ps.sc * ps.sc * (s * dl[2 * m] + c * dl[2 * m + 1]) * ps.xa);
     }
-    tin[10] = q < 3 ? pick3(n, q) : 0.0f;
+    tin[8] = q == 3 ? n[0] : tin[8];
+    tin[9] = q == 3 ? n[1] : tin[9];
+    tin[10] = q == 3 ? n[2] : 0.0f;
 #pragma unroll
     for (int s = 11; s < 16; ++s) tin[s] = 0.0f;
 }

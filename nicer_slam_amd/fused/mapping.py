@@ -242,7 +242,7 @@ class FusedSdfGradient(torch.autograd.Function):
         need = ctx.needs_input_grad
         st = _stream()
         out = [None, None, None, None, None, None, None]
-        tile = tile_of(model)
+        tile = tile_of(model, "coarse")
         emit = new_emit(se_rows(1, tile)["ROWS"], N, dev) if need[1] else None
         gt_c = torch.zeros_like(imp.coarse.encoding.embeddings) if need[2] else None
         if emit is not None or gt_c is not None:
@@ -258,7 +258,7 @@ class FusedSdfGradient(torch.autograd.Function):
             out[2] = gt_c
         if (need[3] or need[4]) and stage != "coarse":
             gt_f = torch.zeros_like(imp.fine.encoding.embeddings) if need[3] else None
-            emit_f = new_emit(se_rows(3, tile_of(model))["ROWS"], N, dev) if need[4] else None
+            emit_f = new_emit(se_rows(3, tile_of(model, "fine"))["ROWS"], N, dev) if need[4] else None
             with _timed("k_sdfnet_bwd<fine,eik>", 0):
                 check(lib.nsa_sdfnet_backward_params(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), None, None,
                                                      g.data_ptr(), 0, g_x.data_ptr(),
@@ -268,7 +268,7 @@ class FusedSdfGradient(torch.autograd.Function):
             out[3] = gt_f
             if emit_f is not None:
                 enc = imp.fine.encoding
-                out[4] = sdf_flat_grad(emit_f, None, N, enc.num_levels, enc.level_dim, NH=3, tile=tile_of(model))
+                out[4] = sdf_flat_grad(emit_f, None, N, enc.num_levels, enc.level_dim, NH=3, tile=tile_of(model, "fine"))
         return tuple(out)
 
 

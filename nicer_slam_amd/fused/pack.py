@@ -275,18 +275,19 @@ def qfeat(s, q):
 
 
 def sdf_in_feature4(s, q, C=8):
-    """reference input-feature index (base_networks.py:155-164: [x, PE6(x), grid(32)]) of first-layer slot s of quarter q,
-    or -1 (zero pad).  Slots 0..9: sin/cos of pair p = 4 (s >> 1) + q (p < 18; k = p // 3, d = p % 3); slot 10: x_q (q < 3);
-    slots 16..23: the grid levels of this quarter, level = q + 4 jl (jl < 8 / C), C channels each -- coarse (C = 8): level q;
-    fine (C = 4): levels q and q + 4 (so that the four quarters work on levels 0..3, then 4..7: dense first, hashed last)."""
-    if s < 10:
-        p = 4 * (s >> 1) + q
-        if p >= 18:
-            return -1
-        k, d = divmod(p, 3)
-        return 3 + 6 * k + d + (3 if (s & 1) else 0)
+    """reference input-feature index (base_networks.py:155-164: [x, PE6(x), grid(32)]) of first-layer slot s of quarter q, or
+    -1 (zero pad); the table of csrc/sdf_net4.hpp.  sin / cos of 2^k x_d are features 3+6k+d / 6+6k+d."""
+    pe = lambda k, d, which: 3 + 6 * k + d + (3 if which else 0)
+    if s < 6:                                  # pairs n = 0..2: frequency q, coordinate n
+        return pe(q, s >> 1, s & 1)
+    if s < 8:                                  # pair 3: frequency 4 + (q & 1), coordinate 0 or 2
+        return pe(4 + (q & 1), 2 if (q & 2) else 0, s & 1)
+    if s < 10:                                 # pair 4: q < 2: frequency 4 + q, coordinate 1;  q == 3: x_0, x_1
+        if q < 2:
+            return pe(4 + q, 1, s & 1)
+        return (s - 8) if q == 3 else -1
     if s == 10:
-        return q if q < 3 else -1
+        return 2 if q == 3 else -1
     if s < 16:
         return -1
     jl, c = divmod(s - 16, C)

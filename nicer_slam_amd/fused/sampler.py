@@ -35,14 +35,19 @@ def precision_of(model, which):
     return 1 if mode == "bf16" or (mode == "bf16_colour" and which == "colour") else 0
 
 
-DEFAULT_SDF_TILE = int(os.environ.get("NSA_SDF_TILE", "16"))
+# Tiling of the SDF-network kernels per use (nsa_grid_t.tile): 16 = quad tiling (16 points per wave, four lanes per point,
+# csrc/render_sdfnet4.hip / render_sampler4.hip), 32 = 32-point tiling (lane pair per point, csrc/render_sdfnet.hip /
+# render_sampler.hip).  Both compute the same numbers (tests/test_tiling_gpu.py); the defaults are what measured fastest on
+# MI355X (profiles/r02_*): the fine network (three hidden layers: 256 .. 500 registers per lane at 32 points) runs the quad
+# tiling, the coarse network and the sampler's SDF-only pass the 32-point one.  NSA_SDF_TILE=16|32 or ``model.sdf_tile``
+# force one tiling everywhere.
+DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 32}
+_FORCE = int(os.environ.get("NSA_SDF_TILE", "0"))
 
 
-def tile_of(model):
-    """Tiling of the SDF-network kernels (nsa_grid_t.tile): 16 = quad tiling (16 points per wave, four lanes per point,
-    csrc/render_sdfnet4.hip / render_sampler4.hip), 32 = the 32-point tiling (csrc/render_sdfnet.hip).  ``model.sdf_tile``
-    overrides the default (environment NSA_SDF_TILE, else 16); both produce the same numbers (tests/test_tiling_gpu.py)."""
-    t = int(getattr(model, "sdf_tile", 0) or DEFAULT_SDF_TILE)
+def tile_of(model, which):
+    """``which``: "coarse" / "fine" (composite-pass kernels of that network) or "sampler" (SDF-only pass, both networks)."""
+    t = int(getattr(model, "sdf_tile", 0) or _FORCE or DEFAULT_TILES[which])
     if t not in (16, 32):
         raise ValueError(f"sdf_tile must be 16 or 32, got {t}")
     return t
@@ -56,10 +61,11 @@ def grid_desc(net_or_enc, divide_factor, n_hidden, precision=0, tile=0):
     return d, (off, enc.embeddings)
 
 
-def sdf_grid_desc(model, which):
-    """nsa_grid_t of the coarse / fine SDF network under the model's precision and tiling settings."""
+def sdf_grid_desc(model, which, use=None):
+    """nsa_grid_t of the coarse / fine SDF network under the model's precision and tiling settings; ``use`` = "sampler"
+    selects the tiling of the SDF-only pass (default: the composite-pass tiling of that network)."""
     net = getattr(model.implicit_network, which)
-    return grid_desc(net.encoding, net.divide_factor, net.num_layers - 2, precision_of(model, "sdf"), tile_of(model))
+    return grid_desc(net.encoding, net.divide_factor, net.num_layers - 2, precision_of(model, "sdf"), tile_of(model, use or which))
 
 
 def supported(model):
@@ -91,20 +97,21 @@ def sample_counts_ok(samp):
             and samp.N_samples >= 1)
 
 
-def packed_sdf(model, which, detach=True):
-    """Packed parameters of the coarse/fine SDF MLP, cached on the parameters' version counters."""
+def packed_sdf(model, which, detach=True, use=None):
+    """Packed parameters of the coarse/fine SDF MLP in the layout of the tiling used (``use``: see sdf_grid_desc), cached on
+    the parameters' version counters."""
     net = getattr(model.implicit_network, which)
     params = net.mlp_parameters()
-    tile = tile_of(model)
-    key = (tile,) + tuple((p.data_ptr(), p._version) for p in params)
+    tile = tile_of(model, use or which)
+    key = tuple((p.data_ptr(), p._version) for p in params)
     cache = model.__dict__.setdefault("_fused_pack", {})
-    hit = cache.get(which)
+    hit = cache.get((which, tile))
     if detach and hit is not None and hit[0] == key:
         return hit[1]
     with torch.set_grad_enabled(not detach):
         packed = pack.pack_sdf_net4(net) if tile == 16 else pack.pack_sdf_net(net)
     if detach:
-        cache[which] = (key, packed)
+        cache[(which, tile)] = (key, packed)
     return packed
 
 
@@ -115,9 +122,9 @@ def sampler_sdf(model, rays_o, rays_d, t_rand):
     R, E = rays_o.shape[0], samp.N_samples_eval
     dev = rays_o.device
     imp = model.implicit_network
-    gc, keep_c = sdf_grid_desc(model, "coarse")
-    gf, keep_f = sdf_grid_desc(model, "fine")
-    pc, pf = packed_sdf(model, "coarse"), packed_sdf(model, "fine")
+    gc, keep_c = sdf_grid_desc(model, "coarse", "sampler")
+    gf, keep_f = sdf_grid_desc(model, "fine", "sampler")
+    pc, pf = packed_sdf(model, "coarse", use="sampler"), packed_sdf(model, "fine", use="sampler")
     z = torch.empty(R, E, device=dev)
     sdf = torch.empty(R, E, device=dev)
     far = torch.empty(R, device=dev)

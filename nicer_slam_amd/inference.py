@@ -71,9 +71,9 @@ def sdf_values(model, points, stage="fine", chunk=1 << 22):
     if not (points.is_cuda and fused_supported(model)):
         raise RuntimeError("sdf_values: needs CUDA points and a model configuration covered by the fused kernels")
     imp = model.implicit_network
-    gc, keep_c = sdf_grid_desc(model, "coarse")
-    gf, keep_f = sdf_grid_desc(model, "fine")
-    pc, pf = packed_sdf(model, "coarse"), packed_sdf(model, "fine")
+    gc, keep_c = sdf_grid_desc(model, "coarse", "sampler")
+    gf, keep_f = sdf_grid_desc(model, "fine", "sampler")
+    pc, pf = packed_sdf(model, "coarse", use="sampler"), packed_sdf(model, "fine", use="sampler")
     points = points.contiguous().float()
     out = torch.empty(points.shape[0], device=points.device)
     st = torch.cuda.current_stream().cuda_stream

@@ -137,7 +137,13 @@ __device__ __forceinline__ void stage_issue_n(const float* __restrict__ g, int n
 }
 
 // GEMM number `opi` of the kernel's sequence Seq: wait for its block, start fetching the next one into the other buffer,
-// multiply from LDS.  All NW waves of the block must execute the same sequence.
+// multiply from LDS.  All NW waves of the block must execute the same sequence.  (A ring of three buffers, fetching two GEMMs
+// ahead behind a counted vmcnt, measured the same: the copies are not what the waves wait for -- profiles/r02_ab_experiments.txt.)
+template <class Seq, int NW>
+__device__ __forceinline__ void stage16_begin(float* stage, const float* __restrict__ wp) {
+    stage_issue_n<NW>(wp + Seq::off(0), Seq::size(0), stage);
+}
+
 template <class Seq, int NW, int KG, int MT>
 __device__ __forceinline__ void gemm16_staged(float* stage, const float* __restrict__ wp, int opi, int lane,
                                               const float (&b)[8 * KG], f32x4v (&acc)[MT]) {

@@ -134,24 +134,11 @@ __device__ __forceinline__ void mma_group(const AV (&a)[MT][3], const float (&x)
 #endif
         const bf16x8_t bh = as_bf16x8(bf.p[0]), bm = as_bf16x8(bf.p[1]), bl = as_bf16x8(bf.p[2]);
         // smallest terms first; the MT accumulators alternate so no MFMA waits on its predecessor
-#ifdef NSA_EXP_CHAIN        // hazard experiment: the six products of one accumulator back to back, tile after tile
-#define NSA_MM1(mt, AP, BV) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[mt][AP]), BV, acc[mt], 0, 0, 0);
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {
-            NSA_MM1(mt, 2, bh) NSA_MM1(mt, 0, bl) NSA_MM1(mt, 1, bm) NSA_MM1(mt, 1, bh) NSA_MM1(mt, 0, bm) NSA_MM1(mt, 0, bh)
-        }
-#undef NSA_MM1
-#else
 #define NSA_MM(AP, BV)                                                                                   \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                \
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[mt][AP]), BV, acc[mt], 0, 0, 0);
         NSA_MM(2, bh) NSA_MM(0, bl) NSA_MM(1, bm) NSA_MM(1, bh) NSA_MM(0, bm) NSA_MM(0, bh)
 #undef NSA_MM
-#endif
-#ifdef NSA_EXP_MFMA_NOP     // hazard experiment: nothing may follow the group's last MFMA for 64 cycles
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
-        __builtin_amdgcn_sched_barrier(0);
-#endif
     } else {
         const bf16x8_t b = round8_bf16(x);
 #pragma unroll
@@ -366,9 +353,6 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ vp, int h, f3
 // favoured wave run ahead; the other fills the slots it leaves and the phases become complementary (matrix beside
 // VALU).  The wave slot id (HW_REG_HW_ID[3:0]) differs between the waves of one SIMD.
 __device__ __forceinline__ void desync_simd_partners() {
-#ifdef NSA_EXP_NO_SETPRIO
-    return;
-#endif
     const unsigned slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);   // hwreg(HW_REG_HW_ID, 0, 4) = WAVE_ID
     if (slot & 1u) __builtin_amdgcn_s_setprio(1);
     else           __builtin_amdgcn_s_setprio(0);

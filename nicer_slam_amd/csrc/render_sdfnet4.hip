@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_FWD) void k_sdfnet4_fwd(SdfNet4A
     using Seq = SdfOps4<NH, false>;
     __shared__ __attribute__((aligned(16))) float stage[2 * kStageFloats];
     __shared__ LevelGeom s_geom[16];
-    stage_issue_n<NW4>(a.wp + Seq::off(0), Seq::size(0), stage);
+    stage16_begin<Seq, NW4>(stage, a.wp);
     geom_to_lds(geom, s_geom);
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
     using E = SE4<NH>;
     __shared__ __attribute__((aligned(16))) float stage[2 * kStageFloats];
     __shared__ LevelGeom s_geom[16];
-    stage_issue_n<NW4>(a.wp + Seq::off(0), Seq::size(0), stage);
+    stage16_begin<Seq, NW4>(stage, a.wp);
     geom_to_lds(geom, s_geom);
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
     float gx[3];
     slots_to_x_jac4<L, C>(a.divide_factor, jstore, q, in, hb0, gx);
     // scatter scratch: the stage buffer the last GEMM (op 4 NH, even) does NOT read; every wave passed the barrier of that
-    // GEMM, so nobody reads it any more
+    // GEMM and nothing is fetched after it, so nobody touches that buffer any more
     if (MAP && a.g_table)
         table_grad_scatter4<L, C>(x, a.divide_factor, s_geom, q, lane, live, hb0, dl, nbar, a.g_table,
                                   stage + kStageFloats + (threadIdx.x >> 6) * 64 * (2 * C + 1));

@@ -7,14 +7,7 @@ objective is a mean over the global ray batch, code/model/loss.py:57-65)."""
 import torch
 import torch.distributed as dist
 
-def _bump_version(p):
-    """The kernel wrote p behind autograd's back: advance its version counter like an in-place op would (the packed-weight
-    caches of the fused engine key on it).  Private torch API with a portable fallback for the small tensors that matter."""
-    try:
-        torch._C._autograd._unsafe_set_version_counter((p,), (p._version + 1,))
-    except Exception:                      # older / newer torch: an in-place no-op does the same for MLP-sized tensors
-        if p.numel() <= (1 << 20):
-            p.add_(0)
+from ._version import bump_version
 
 
 
@@ -98,6 +91,24 @@ class ShardedAdam(torch.optim.Optimizer):
         else:
             dist.reduce_scatter_tensor(shard, flat, group=self.group)
 
+    def _all_gather(self, flat, shard):
+        """flat[world * n] <- every rank's shard[n]; ``shard`` may be the rank's own slice of ``flat`` (in place: RCCL/NCCL
+        define that case; gloo gets a private copy of the input)."""
+        if dist.get_backend(self.group) == "gloo":
+            shard = shard.clone()
+        dist.all_gather_into_tensor(flat, shard, group=self.group)
+
+    def _sharded_state(self, p, state):
+        """Persistent buffers of one sharded tensor (allocated once, on the first step): the rank's moment slices and gradient
+        slice and -- only when numel is not a multiple of world -- one padded staging buffer whose tail stays zero."""
+        n = -(-p.numel() // self.world)
+        state.update(step=0, sharded=True, shard_numel=n, padded=n * self.world != p.numel(),
+                     exp_avg=torch.zeros(n, device=p.device, dtype=p.dtype),
+                     exp_avg_sq=torch.zeros(n, device=p.device, dtype=p.dtype),
+                     g_shard=torch.empty(n, device=p.device, dtype=p.dtype))
+        if state["padded"]:
+            state["flat"] = torch.zeros(n * self.world, device=p.device, dtype=p.dtype)
+
     @torch.no_grad()
     def step(self, weight=None):
         w = (1.0 / self.world) if weight is None else float(weight)
@@ -108,29 +119,49 @@ class ShardedAdam(torch.optim.Optimizer):
                     continue
                 state = self.state[p]
                 if not state:
-                    sharded = self.world > 1 and p.numel() >= self.shard_min_numel
-                    n = -(-p.numel() // self.world) if sharded else p.numel()
-                    state.update(step=0, sharded=sharded, shard_numel=n,
-                                 exp_avg=torch.zeros(n, device=p.device, dtype=p.dtype),
-                                 exp_avg_sq=torch.zeros(n, device=p.device, dtype=p.dtype))
+                    if self.world > 1 and p.numel() >= self.shard_min_numel:
+                        self._sharded_state(p, state)
+                    else:
+                        state.update(step=0, sharded=False, shard_numel=p.numel(),
+                                     exp_avg=torch.zeros(p.numel(), device=p.device, dtype=p.dtype),
+                                     exp_avg_sq=torch.zeros(p.numel(), device=p.device, dtype=p.dtype))
                 state["step"] += 1
                 if state["sharded"]:
-                    n = state["shard_numel"]
-                    flat = torch.zeros(n * self.world, device=p.device, dtype=p.dtype)
-                    flat[:p.numel()] = p.grad.reshape(-1) * w
-                    g_shard = torch.empty(n, device=p.device, dtype=p.dtype)
-                    self._reduce_scatter(flat, g_shard)
-                    flat[:p.numel()] = p.reshape(-1)                   # reuse as the parameter gather buffer
-                    p_shard = flat.view(self.world, n)[self.rank].clone()
-                    self.stepper(p_shard, g_shard, state["exp_avg"], state["exp_avg_sq"], state["step"], group["lr"],
+                    # reduce-scatter the (weighted) gradient -> Adam on this rank's slice of the PARAMETER, in place ->
+                    # all-gather the slices back into the parameter.  No per-step allocation: the gradient is scaled in place
+                    # (it is consumed here) and, when numel is a multiple of world, every collective runs straight on the
+                    # gradient / parameter storage; otherwise through the one persistent padded buffer.
+                    n, numel = state["shard_numel"], p.numel()
+                    if not (p.is_contiguous() and p.grad.is_contiguous()):
+                        raise RuntimeError("ShardedAdam: sharded tensors and their gradients must be contiguous")
+                    g = p.grad.view(-1).mul_(w)
+                    if state["padded"]:
+                        flat = state["flat"]
+                        flat[:numel].copy_(g)
+                        self._reduce_scatter(flat, state["g_shard"])
+                        flat[:numel].copy_(p.view(-1))
+                    else:
+                        self._reduce_scatter(g, state["g_shard"])
+                        flat = p.view(-1)
+                    p_shard = flat[self.rank * n:(self.rank + 1) * n]
+                    self.stepper(p_shard, state["g_shard"], state["exp_avg"], state["exp_avg_sq"], state["step"], group["lr"],
                                  group["betas"], group["eps"])
-                    dist.all_gather_into_tensor(flat, p_shard, group=self.group)
-                    p.copy_(flat[:p.numel()].view_as(p))
+                    self._all_gather(flat, p_shard)
+                    if state["padded"]:
+                        p.view(-1).copy_(flat[:numel])
+                    bump_version(p)
                 else:
                     small.append((p, group, state))
         if small:
             if self.world > 1 or w != 1.0:
-                bucket = torch.cat([p.grad.reshape(-1) * w for p, _, _ in small])
+                n_small = sum(p.numel() for p, _, _ in small)
+                bucket = self.__dict__.get("_bucket")
+                if bucket is None or bucket.numel() != n_small or bucket.device != small[0][0].device:
+                    bucket = self._bucket = torch.empty(n_small, device=small[0][0].device, dtype=small[0][0].dtype)
+                o = 0
+                for p, _, _ in small:
+                    torch.mul(p.grad.reshape(-1), w, out=bucket[o:o + p.numel()])
+                    o += p.numel()
                 if self.world > 1:
                     dist.all_reduce(bucket, group=self.group)
                 o = 0
@@ -141,4 +172,4 @@ class ShardedAdam(torch.optim.Optimizer):
                 flat_p = p.view(-1)
                 self.stepper(flat_p, p.grad.reshape(-1), state["exp_avg"], state["exp_avg_sq"], state["step"],
                              group["lr"], group["betas"], group["eps"])
-                _bump_version(p)
+                bump_version(p)

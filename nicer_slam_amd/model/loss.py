@@ -20,11 +20,18 @@ def _masked_mean_abs(a, b, mask=None):
     return (a - b).abs().mean()
 
 
-def scale_shift_invariant_depth_loss(pred, target, mask, alpha=0.5):
+def scale_shift_invariant_depth_loss(pred, target, mask, alpha=0.5, shard=None):
     """Least-squares (scale, shift) per image aligning ``pred`` to ``target`` on ``mask`` (closed-form 2x2 solve,
     detached), then  sum(mask (s p + t - target)^2) / (2 sum mask)  +  alpha * masked first-difference L1 of the residual
     along both pixel axes / sum mask.  Shapes [b, n, 1] (the reference feeds rays as an n x 1 'image', so only the
-    difference along n is non-empty).  MiDaS.py:6-143."""
+    difference along n is non-empty).  MiDaS.py:6-143.
+
+    ``shard`` = (group, weight): ray-sharded multi-GPU mapping.  Every rank holds a slice of each keyframe's
+    rays; the five per-image sums of the 2x2 system and the two normalisers are summed over ranks with ONE all-reduce, so every
+    rank solves the same (scale, shift) as a single process would; the returned value is this rank's share of the terms divided
+    by ``weight`` (its share of the ray batch), so that  sum_r weight_r * loss_r  -- what ShardedAdam forms from the ranks'
+    gradients -- is the single-process loss.  (The first-difference regulariser is taken inside each rank's slice: rays are
+    sharded contiguously, the one pair straddling a shard boundary is dropped.)"""
     mask = mask.to(pred.dtype)
     dims = (1, 2)
     a00 = (mask * pred * pred).sum(dims)
@@ -32,13 +39,20 @@ def scale_shift_invariant_depth_loss(pred, target, mask, alpha=0.5):
     a11 = mask.sum(dims)
     b0 = (mask * pred * target).sum(dims)
     b1 = (mask * target).sum(dims)
+    weight = 1.0
+    if shard is not None:
+        import torch.distributed as dist
+        group, weight = shard
+        sums = torch.stack([a00, a01, a11, b0, b1]).detach()          # [5, b]: the solve is detached anyway (MiDaS.py:22-26)
+        dist.all_reduce(sums, group=group)
+        a00, a01, a11, b0, b1 = sums.unbind(0)
     det = a00 * a11 - a01 * a01
     ok = det != 0
     safe = torch.where(ok, det, torch.ones_like(det))
     scale = torch.where(ok, (a11 * b0 - a01 * b1) / safe, torch.zeros_like(det)).detach()
     shift = torch.where(ok, (a00 * b1 - a01 * b0) / safe, torch.zeros_like(det)).detach()
     aligned = scale.view(-1, 1, 1) * pred + shift.view(-1, 1, 1)
-    M = mask.sum(dims)
+    M = a11 if shard is not None else mask.sum(dims)                   # global mask count per image
     res = aligned - target
     data_div = (2 * M).sum()
     total = (mask * res * res).sum() / data_div if float(data_div) != 0 else pred.new_zeros(())
@@ -49,7 +63,7 @@ def scale_shift_invariant_depth_loss(pred, target, mask, alpha=0.5):
         reg_div = M.sum()
         reg = (gx.sum() + gy.sum()) / reg_div if float(reg_div) != 0 else pred.new_zeros(())
         total = total + alpha * reg
-    return total
+    return total / weight
 
 
 class SLAMLoss(nn.Module):
@@ -88,7 +102,9 @@ class SLAMLoss(nn.Module):
         return torch.norm(unit(model_outputs["grad_theta"]) - unit(model_outputs["grad_theta_nei"]), dim=-1).mean()
 
     def get_depth_loss(self, depth_pred, depth_gt, mask, keyframe_list=None):
-        return scale_shift_invariant_depth_loss(depth_pred, depth_gt * 50 + 0.5, mask, alpha=0.5)
+        # self.depth_shard = (process group, this rank's share of the ray batch) in ray-sharded multi-GPU mapping, else None
+        return scale_shift_invariant_depth_loss(depth_pred, depth_gt * 50 + 0.5, mask, alpha=0.5,
+                                                shard=getattr(self, "depth_shard", None))
 
     def get_normal_loss(self, normal_pred, normal_gt):
         g = torch.nn.functional.normalize(normal_gt, p=2, dim=-1)

@@ -10,15 +10,7 @@ contiguous parameters only; anything else raises (no fallback).
 import torch
 
 from ._native import lib, check
-
-def _bump_version(p):
-    """The kernel wrote p behind autograd's back: advance its version counter like an in-place op would (the packed-weight
-    caches of the fused engine key on it).  Private torch API with a portable fallback for the small tensors that matter."""
-    try:
-        torch._C._autograd._unsafe_set_version_counter((p,), (p._version + 1,))
-    except Exception:                      # older / newer torch: an in-place no-op does the same for MLP-sized tensors
-        if p.numel() <= (1 << 20):
-            p.add_(0)
+from ._version import bump_version
 
 
 
@@ -57,5 +49,5 @@ class Adam(torch.optim.Optimizer):
                                               float(group["lr"]), float(b1), float(b2), float(group["eps"]), st))
                 # the kernel wrote p behind autograd's back: bump its version counter like an in-place op would
                 # (the packed-weight caches of the fused engine key on it)
-                _bump_version(p)
+                bump_version(p)
         return loss

@@ -99,7 +99,8 @@ def _rank_grads(rank, it, shapes):
     return [torch.randn(*s, generator=g) * (0.1 + it) for s in shapes]
 
 
-_SHAPES = [(37,), (70001, 2), (5, 7)]            # small, sharded (>= 65536 elements, odd size -> padded shards), small
+_SHAPES = [(37,), (70001, 3), (5, 7), (40000, 2)]   # small, sharded (odd size -> padded staging buffer), small, sharded (even:
+                                                   # collectives run straight on the gradient / parameter storage)
 _WEIGHTS = [0.25, 0.75]                          # unequal ray shares
 
 
@@ -114,12 +115,19 @@ def _map_worker(rank, world, port, out_q):
     torch.manual_seed(0)
     params = [torch.nn.Parameter(torch.randn(*s)) for s in _SHAPES]
     opt = nd.ShardedAdam([{"params": params[:2], "lr": 0.04}, {"params": params[2:], "lr": 0.002}], betas=(0.9, 0.99),
-                         eps=1e-15, stepper=_torch_math_adam)
+                         eps=1e-15, stepper=_torch_math_adam, shard_min_numel=1 << 16)
+    ptrs = None
     for it in range(3):
         for p, g in zip(params, _rank_grads(rank, it, _SHAPES)):
             p.grad = g
         opt.step(weight=_WEIGHTS[rank])
-    assert opt.state[params[1]]["sharded"] and opt.state[params[1]]["exp_avg"].numel() == 70001
+        # no buffer churn: every persistent buffer of the sharded tensors keeps its storage from the first step on
+        now = [opt.state[params[i]][k].data_ptr() for i in (1, 3) for k in ("exp_avg", "exp_avg_sq", "g_shard")]
+        now.append(opt.state[params[1]]["flat"].data_ptr())
+        assert ptrs is None or now == ptrs
+        ptrs = now
+    assert opt.state[params[1]]["sharded"] and opt.state[params[1]]["exp_avg"].numel() == 105002 and opt.state[params[1]]["padded"]
+    assert opt.state[params[3]]["sharded"] and not opt.state[params[3]]["padded"] and "flat" not in opt.state[params[3]]
     assert not opt.state[params[0]]["sharded"]
     vox0 = torch.arange(8.0).reshape(2, 2, 2)
     vox = vox0 + (rank + 1) * torch.tensor([1.0, 0, 0, 2, 0, 0, 0, 3]).reshape(2, 2, 2)
@@ -155,3 +163,61 @@ def test_two_rank_sharded_adam_matches_single_process_adam():
     expect = np.arange(8.0).reshape(2, 2, 2) + 3 * np.array([1.0, 0, 0, 2, 0, 0, 0, 3]).reshape(2, 2, 2)
     np.testing.assert_array_equal(res[0][2], expect)
     np.testing.assert_array_equal(res[1][2], expect)
+
+
+# ---------------------------------------------------------------------------------------------- SSI depth sums
+def _ssi_inputs():
+    g = torch.Generator().manual_seed(5)
+    b, n = 3, 40
+    pred = torch.rand(b, n, 1, generator=g) * 2 + 0.1
+    target = 1.7 * pred + 0.3 + 0.05 * torch.randn(b, n, 1, generator=g)
+    mask = torch.rand(b, n, 1, generator=g) > 0.3
+    return pred, target, mask
+
+
+def _ssi_worker(rank, world, port, out_q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from nicer_slam_amd.dist import shard_rays
+    from nicer_slam_amd.model.loss import scale_shift_invariant_depth_loss
+    pred, target, mask = _ssi_inputs()
+    lo, hi = shard_rays(pred.shape[1], rank, world)          # rays sharded WITHIN every keyframe (unequal: 40 = 14 + 13 + 13)
+    w = (hi - lo) / pred.shape[1]
+    p = pred[:, lo:hi].clone().requires_grad_(True)
+    loss = scale_shift_invariant_depth_loss(p, target[:, lo:hi], mask[:, lo:hi], alpha=0.0, shard=(None, w))
+    loss.backward()
+    out_q.put((rank, lo, hi, w, float(loss), p.grad.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ray_sharded_ssi_depth_loss_equals_single_process():
+    """The five per-image sums of the scale-and-shift solve (MiDaS.py:6-26) all-reduced over ranks: the weighted sum of the
+    ranks' losses and gradients is the single-process loss and gradient (data term; alpha = 0 -- the first-difference
+    regulariser drops the pairs that straddle a shard boundary by construction)."""
+    from nicer_slam_amd.model.loss import scale_shift_invariant_depth_loss
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ssi_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    pred, target, mask = _ssi_inputs()
+    pr = pred.clone().requires_grad_(True)
+    ref = scale_shift_invariant_depth_loss(pr, target, mask, alpha=0.0)
+    ref.backward()
+    total = sum(w * l for _, _, _, w, l, _ in res)
+    assert abs(total - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
+    grad = torch.cat([torch.from_numpy(g) * w for _, _, _, w, _, g in res], dim=1)
+    # (the 2x2 solve sees the five sums in another summation order: ~1e-7 relative in scale / shift)
+    np.testing.assert_allclose(grad.numpy(), pr.grad.numpy(), rtol=1e-4, atol=1e-4 * float(pr.grad.abs().max()))

@@ -172,9 +172,14 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_FWD) void k_sdfnet4_fwd(SdfNet4A
     load_point(a.src, pt, x, ray, z);
     __syncthreads();                                         // s_geom
 
+    // the grid Jacobian of this lane's levels stays in lane-private LDS (24 floats per lane): grad sdf needs no second corner
+    // gather at the end of the kernel
+    constexpr int kJac = (8 / C) * 3 * C;
+    __shared__ float jac_lds[NW4 * kJac * 64];
+    float* jstore = jac_lds + (threadIdx.x >> 6) * (kJac * 64) + lane;
     float in[QIN];
     pe_slots4(x, q, in);
-    grid_slots4<L, C>(x, a.divide_factor, a.table, s_geom, q, in);
+    grid_slots4<L, C>(x, a.divide_factor, a.table, s_geom, q, in, jstore);
     float sg[NH][QHS], hl[QHS];
     hidden_forward4<NH, Seq>(stage, 0, a.wp, lane, q, in, sg, hl);
     // outputs: sdf (row 0, VALU dot) and the 64 features (rows 1..64)
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_FWD) void k_sdfnet4_fwd(SdfNet4A
     // grad sdf
     float dh[NH > 1 ? NH - 1 : 1][QHS], dl[QIN], g[3];
     reverse_pass4<NH, Seq>(stage, NH + 1, a.wp, lane, q, sg, dh, dl);
-    slots_to_x4<L, C>(x, a.divide_factor, a.table, s_geom, q, in, dl, g);
+    slots_to_x_jac4<L, C>(a.divide_factor, jstore, q, in, dl, g);
 #pragma unroll
     for (int d = 0; d < 3; ++d) g[d] = quad_sum(g[d]);
     if (live && q == 0) {

@@ -33,8 +33,9 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak = the peak for this config'
 # Algorithmic multiply-accumulates per point of each per-point kernel (true layer sizes, no padding):
 #   SDF nets 71->64(->64->64)->65 Softplus, colour net 129->64->64->3; forward kernels include the reverse pass that
 #   yields grad sdf, backward kernels include the recomputation + tangent sweep + reverse sweep.
-# v_mfma_f32_32x32x16_bf16 instructions per 32-point wave tile (static: groups x tiles x 6 products, see csrc/): with 32
-# cycles per instruction per SIMD this gives the matrix-pipe busy time, reported beside the fp32-equivalent `frac`.
+# v_mfma_f32_32x32x16_bf16 instructions per 32 points (static: groups x tiles x 6 products, see csrc/): with 32 cycles per
+# instruction per SIMD this gives the matrix-pipe busy time, reported beside the fp32-equivalent `frac`.  The quad tiling issues
+# twice as many v_mfma_f32_16x16x32_bf16 of half the duration -- the same busy cycles (profiles/r02_pmc_per_kernel_*.csv).
 MFMA_PER_TILE = {"k_sampler_sdf": 216, "k_sdfnet_fwd<coarse>": 180, "k_sdfnet_fwd<fine>": 372, "k_sdfnet_bwd<coarse>": 288,
                  "k_sdfnet_bwd<fine>": 672, "k_colour_fwd": 156, "k_colour_bwd": 324}
 N_SIMD, NOMINAL_GHZ = 1024, 2.4

@@ -11,19 +11,20 @@ class _DS:
     data_dir = "../Datasets/processed/Replica"
 
 
-@pytest.mark.parametrize("name", ["loss_mapping_first_frame", "loss_mapping_fine"])
-def test_slam_loss_vs_reference_golden(name):
+def check_slam_loss(name, device="cpu", atol=1e-6, gtol=1e-7):
+    """shared with tests/test_loss_gpu.py (the same goldens with every tensor on the device)"""
     from nicer_slam_amd.model.loss import SLAMLoss
     fx = load(name)
-    leaf = lambda k: tt(fx[k]).clone().requires_grad_(True)
+    dv = lambda k: tt(fx[k]).to(device)
+    leaf = lambda k: dv(k).clone().requires_grad_(True)
     out = {k: leaf("in_" + k) for k in ("rgb_values", "depth_values", "normal_map", "grad_theta", "grad_theta_nei", "flow")}
-    out["sdf"] = tt(fx["in_sdf"])
+    out["sdf"] = dv("in_sdf")
     warp = {}
     for ps in (1, 5):
-        warp[ps] = (tt(fx[f"in_warp{ps}_gt"]), leaf(f"in_warp{ps}_sampled"), tt(fx[f"in_warp{ps}_mask"]).bool(),
-                    tt(fx[f"in_warp{ps}_raymask"]).bool())
+        warp[ps] = (dv(f"in_warp{ps}_gt"), leaf(f"in_warp{ps}_sampled"), dv(f"in_warp{ps}_mask").bool(),
+                    dv(f"in_warp{ps}_raymask").bool())
     out["warp_output"] = warp
-    gt = {k[3:]: tt(fx[k]) for k in fx if k.startswith("gt_")}
+    gt = {k[3:]: dv(k) for k in fx if k.startswith("gt_")}
     gt["flow_mask"] = gt["flow_mask"].bool()
     crit = SLAMLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, train_dataset=_DS(), scan_id=1,
                     assign_scale_shift_init=True, smooth_weight=0.005, warp_loss_type="l1", depth_weight=0.1,
@@ -31,17 +32,22 @@ def test_slam_loss_vs_reference_golden(name):
     res = crit(out, gt, keyframe_list=None, frame_idx=int(fx["meta_frame_idx"]), stage=str(fx["meta_stage"]))
     assert set(res) == {k[4:] for k in fx if k.startswith("out_")}
     for k, v in res.items():
-        assert_close(torch.as_tensor(float(v)), fx["out_" + k], 1e-6, 1e-5, k)
+        assert_close(torch.as_tensor(float(v)), fx["out_" + k], atol, 1e-5, k)
     res["loss"].backward()
     for k in ("rgb_values", "depth_values", "normal_map", "grad_theta", "grad_theta_nei", "flow"):
         if "grad_" + k in fx:
-            assert_close(out[k].grad, fx["grad_" + k], 1e-7, 1e-4, "d/d " + k)
+            assert_close(out[k].grad, fx["grad_" + k], gtol, 1e-4, "d/d " + k)
         else:
             assert out[k].grad is None or float(out[k].grad.abs().max()) == 0
     for ps in (1, 5):
         key = f"grad_warp{ps}_sampled"
         if key in fx:
-            assert_close(warp[ps][1].grad, fx[key], 1e-7, 1e-4, key)
+            assert_close(warp[ps][1].grad, fx[key], gtol, 1e-4, key)
+
+
+@pytest.mark.parametrize("name", ["loss_mapping_first_frame", "loss_mapping_fine"])
+def test_slam_loss_vs_reference_golden(name):
+    check_slam_loss(name)
 
 
 def test_depth_loss_degenerate_mask_is_zero():

@@ -46,7 +46,7 @@ def test_quad_and_32_point_tilings_agree(name):
             # (weights and what is composited with them: d sigma / d sdf = 1 / (2 beta^2) ~ 2400 amplifies the last-ulp
             # differences of the two summation orders)
             per_point = k in ("sdf", "rgb", "grad_theta", "grad_theta_nei")
-            assert_close(o16[k], o32[k].detach().cpu().numpy(), 2e-6 if per_point else 2e-5, 1e-5, k)
+            assert_close(o16[k], o32[k].detach().cpu().numpy(), 5e-6 if per_point else 2e-5, 1e-5, k)
     assert_close(c16, c32.cpu().numpy(), 1e-7 + 1e-4 * float(c32.abs().max()), 1e-4, "grad_cam")
     n = 0
     for k, g in g32.items():

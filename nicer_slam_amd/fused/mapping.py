@@ -103,6 +103,12 @@ def _sdf_rows(L, C, tile=32):
 
 
 @functools.lru_cache(maxsize=None)
+def _on(device, fn, *args):
+    """device-resident copy of a (cached) host index map: uploaded once, not per iteration (a pageable upload is synchronous)"""
+    return fn(*args).to(device)
+
+
+@functools.lru_cache(maxsize=None)
 def _col_rows():
     rows = np.full(129, -1, dtype=np.int64)
     for s in range(pack.COL_IN_STEPS):
@@ -122,7 +128,7 @@ def sdf_flat_grad(emit, g_sdf, P, L, C, NH=1, tile=32):
     sums = emit[m["AB1"]:m["ROWS"]].sum(1)                   # AB_1..AB_NH | TH_NH | FB row sums in one reduction
     parts = []
     M = outer_sum(r("AB1"), r("H0", m["IN"])) + outer_sum(r("DA1"), r("TIN", m["IN"]))
-    parts += [M[:, _sdf_rows(L, C, tile).to(emit.device)].reshape(-1), sums[:64]]
+    parts += [M[:, _on(emit.device, _sdf_rows, L, C, tile)].reshape(-1), sums[:64]]
     for k in range(1, NH):                                   # hidden layer k: value path + its share of the reverse pass
         parts += [(outer_sum(r(f"AB{k + 1}"), r(f"H{k}")) + outer_sum(r(f"DA{k + 1}"), r(f"TH{k}"))).reshape(-1),
                   sums[64 * k:64 * (k + 1)]]
@@ -139,7 +145,7 @@ def colour_flat_grad(emit):
     """Gradient of the colour network's flat parameter vector [W0(64x129), b0, W1, b1, W2(3x64), b2, 0]."""
     r = lambda name, n: emit[CE[name]:CE[name] + n]
     IN, AB1, H1, AB2, H2, OB = r("IN", 130), r("AB1", 64), r("H1", 64), r("AB2", 64), r("H2", 64), r("OB", 3)
-    dW0 = outer_sum(AB1, IN)[:, _col_rows().to(emit.device)]
+    dW0 = outer_sum(AB1, IN)[:, _on(emit.device, _col_rows)]
     dW1 = outer_sum(AB2, H1)
     dW2 = outer_sum(OB, H2)
     sums = emit[CE["AB1"]:CE["ROWS"]].sum(1)                 # AB1 | AB2 | OB row sums in one reduction

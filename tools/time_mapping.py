@@ -62,3 +62,37 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 print(f"mapping iteration: {R} rays, engine {model.last_engine}: {dt * 1e3:.1f} ms  ({R / dt:.0f} rays/s)  loss {float(l):.4f}")
 print("max memory GB", torch.cuda.max_memory_allocated() / 2 ** 30)
+
+if os.environ.get("NSA_SYNC_DEBUG"):
+    # where does the host wait for the device inside one iteration?  (torch's sync debug mode + python stacks), and how long
+    # does the host need to ISSUE an iteration (CPU time until the last launch returns, device still running)
+    import traceback, warnings
+    seen = {}
+
+    def show(message, category, filename, lineno, file=None, line=None):
+        st = [f for f in traceback.extract_stack()[:-2] if "nicer_slam_amd" in f.filename or "time_mapping" in f.filename]
+        key = " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in reversed(st[-4:]))
+        seen[key] = seen.get(key, 0) + 1
+
+    warnings.showwarning = show
+    warnings.simplefilter("always")
+    torch.cuda.set_sync_debug_mode(1)
+    step()
+    torch.cuda.set_sync_debug_mode(0)
+    for k, v in sorted(seen.items(), key=lambda kv: -kv[1]):
+        print(f"sync x{v}: {k}")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"host issue time {1e3 * (t1 - t0):.2f} ms, device drained after {1e3 * (t2 - t0):.2f} ms")
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(3):
+        step()
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)

@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--engine", default="auto", choices=["auto", "fused", "composed"])
     ap.add_argument("--param-grads", action="store_true",
                     help="also produce (and discard) table/MLP gradients like the reference's tracking loop")
+    ap.add_argument("--chunks", type=int, default=1,
+                    help="KernelTracker: independent ray chunks on their own HIP streams inside the graph (fork / join)")
     ap.add_argument("--no-graph", action="store_true", help="launch every op eagerly instead of replaying a hipGraph")
     ap.add_argument("--autograd", action="store_true",
                     help="drive the model through torch autograd (TrackingStepper) instead of the kernel sequence")
@@ -156,7 +158,8 @@ def main():
     from nicer_slam_amd.tracking import TrackingStepper, KernelTracker
     use_graph = not args.no_graph and not args.param_grads
     Stepper = TrackingStepper if (args.autograd or args.param_grads) else KernelTracker
-    stepper = Stepper(model, K, args.rays, cam, lr=0.005, use_graph=use_graph, world=world)
+    extra = {"chunks": args.chunks} if Stepper is KernelTracker else {}
+    stepper = Stepper(model, K, args.rays, cam, lr=0.005, use_graph=use_graph, world=world, **extra)
 
     def step(i):
         uv, gt = batches[i]
@@ -266,7 +269,7 @@ def main():
                        "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "sampler_evals_per_ray": 640,
                        "global_rays": args.rays * world,
                        "engine": "fused" if Stepper.__name__ == "KernelTracker" else model.last_engine, "param_grads": args.param_grads,
-                       "hip_graph": bool(use_graph), "driver": Stepper.__name__, "clock_prewarm_s": args.prewarm_s,
+                       "hip_graph": bool(use_graph), "driver": Stepper.__name__, "ray_chunks": getattr(stepper, "chunks", 1), "clock_prewarm_s": args.prewarm_s,
                        "parallelism": f"ray-shard x{world}" if world > 1 else "single",
                        "rccl_ranks": 0 if (world == 1 or oversub) else world,
                        "exchange": None if world == 1 else "one 9-float all-reduce (pose gradient, loss, ray count) per step",
@@ -327,10 +330,88 @@ def mapping_leg(device, rays=8192, frames=8, iters=5):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     assert model.last_engine == "fused"
-    return {"ms": round(dt * 1e3, 2), "rays": rays, "keyframes": frames, "samples_per_ray": 98,
+    # per-kernel durations of one more iteration (event pairs on the launch stream) and the roofline of its dominant kernel
+    import nicer_slam_amd.hashencoder.backend as be
+    be.PROFILE = []
+    step()
+    torch.cuda.synchronize()
+    prof, be.PROFILE = be.PROFILE, None
+    agg = {}
+    for name, _, e0, e1 in prof:
+        agg[name] = agg.get(name, 0.0) + e0.elapsed_time(e1)
+    S = 98
+    P = rays * S
+    roof = None
+    if agg:
+        name, tms = max(agg.items(), key=lambda kv: kv[1])
+        # algorithmic bytes per composite point of the MAP backward kernels: saved forward state read + table rows
+        # added (2^3 corners x levels x C floats, counted once) + emission rows written for the weight-gradient GEMMs
+        per_point = {"k_colour_bwd<map>": (512 + 16 * 8 * 2 * 4 + 389 * 4, 16 * 8),
+                     "k_sdfnet_bwd<fine,map>": (3 * 8 * 8 * 4 * 4 + 8 * 8 * 4 * 4, 8 * 8),
+                     "k_sdfnet_bwd<coarse,map>": (3 * 4 * 8 * 8 * 4 + 4 * 8 * 8 * 4 + 464 * 4, 4 * 8)}.get(name)
+        if per_point:
+            nbytes, rows = per_point[0] * P, per_point[1] * P
+            ach = nbytes / (tms * 1e-3) / 1e9
+            roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(tms * 1e3, 1),
+                    "bytes_per_launch": nbytes,
+                    "atomic_scatter": {"table_rows_per_launch": rows, "rows_per_s": round(rows / (tms * 1e-3), 0),
+                                       "measured_ceiling": "fp32 atomics retire at ~20 G requests/s chip-wide on MI355X "
+                                                           "(~41 G rows/s when two adjacent rows share a request): "
+                                                           "tools/micro/atomic_bench.hip, DESIGN.md 4b",
+                                       "frac_of_41G_rows_per_s": round(rows / (tms * 1e-3) / 41e9, 3)}}
+    return {"ms": round(dt * 1e3, 2), "rays": rays, "keyframes": frames, "samples_per_ray": S,
             "eikonal_points": 22 * rays, "rays_per_s": round(rays / dt, 1), "engine": model.last_engine,
             "optimizer": "nicer_slam_amd.optim.Adam (1.1 GiB of parameters, dense)", "iters": iters,
-            "final_loss": round(float(last), 6)}
+            "final_loss": round(float(last), 6), "kernels_ms": {k: round(v, 3) for k, v in sorted(agg.items())},
+            "roofline": roof, "cpu_baseline": cpu_mapping_baseline(model)}
+
+
+def cpu_mapping_baseline(model, n=256, frames=8):
+    """The oracle ("port") on the same mapping iteration -- forward, rgb L1 + 0.1 eikonal, backward to every trainable
+    parameter (three tables, coarse SDF MLP, colour MLP) -- on a bounded sample of n rays over `frames` keyframes."""
+    from oracle import render_ref as R
+    torch.set_num_threads(min(32, os.cpu_count()))
+    mk = R.make_grid_spec
+    cfg = R.RenderConfig(coarse=R.SdfNetSpec(mk(4, 8, 32, 32, 19), 2), fine=R.SdfNetSpec(mk(8, 4, 32, 128, 19), 4),
+                         colour_grid=mk(16, 2, 16, 2048, 24), n_samples=64, n_samples_eval=640, n_samples_extra=32)
+    frozen = "implicit_network.fine.lin"
+    params = {}
+    for k, v in model.state_dict().items():
+        v = v.detach().cpu().clone()
+        if v.is_floating_point() and k != "voxels" and not k.startswith(frozen) and "offsets" not in k:
+            v.requires_grad_(True)
+        params[k] = v
+    g = torch.Generator().manual_seed(7)
+    H, W = DS.img_res
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 600.0
+    K[0, 2], K[1, 2] = 599.5, 339.5
+    K = K[None].repeat(frames, 1, 1)
+    cams = torch.tensor([1.0, 0, 0, 0, 0.1, 0.0, -0.2]).repeat(frames, 1) + 0.01 * torch.randn(frames, 7, generator=g)
+    pose = torch.stack([R.camera_from_tensor(c) for c in cams])
+    times = []
+    for it in range(4):
+        idx = torch.randint(H * W, (frames, n // frames), generator=g)
+        uv = torch.stack([(idx % W).float(), (idx // W).float()], -1)
+        gt = torch.rand(n, 3, generator=g)
+        draws = {"t_rand": torch.rand(n, 640, generator=g), "extra_idx": torch.randperm(640, generator=g)[:32],
+                 "eik_idx": torch.randint(98, (n,), generator=g),
+                 "eik_uniform": (torch.rand(10 * n, 3, generator=g) * 2 - 1) * cfg.scene_bounding_sphere,
+                 "eik_jitter": torch.rand(11 * n, 3, generator=g)}
+        for v in params.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        out = R.render(params, cfg, uv, pose, K, torch.zeros(64, 64, 64), draws, mode="mapping", training=True)
+        loss = R.rgb_l1(out, gt) + 0.1 * ((out["grad_theta"].norm(2, dim=1) - 1) ** 2).mean()
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    timed = sorted(times[1:])
+    med = timed[len(timed) // 2]
+    return {"value": round(n / med, 1), "unit": "rays/s", "cores": max(torch.get_num_threads(), min(16, os.cpu_count() or 1)),
+            "kind": "port", "sample": f"{n} rays over {frames} keyframes x (640 sampler + 98 composite) samples + {22 * n} eikonal "
+                                      f"points, fwd+bwd to every trainable parameter (no optimizer step), median of "
+                                      f"{len(timed)} iterations after 1 warm-up ({round(sum(times), 1)} s of host time in all)"}
 
 
 def cpu_baseline(args, model, conf):

@@ -166,9 +166,10 @@ def sample_rays(model, rays_o, rays_d, z, sdf, far, extra_idx, eik_idx):
     return z_vals, (z_eik.unsqueeze(-1) if ek is not None else None)
 
 
-def get_z_vals(model, ray_dirs, cam_loc, need_eik=True):
+def get_z_vals(model, ray_dirs, cam_loc, need_eik=True, rows=None):
     """Drop-in for ImportantSampler.get_z_vals (fused engine).  ``need_eik=False`` (tracking) skips the near-surface
-    eikonal sample, which only mapping consumes."""
+    eikonal sample, which only mapping consumes.  ``rows = (lo, hi)``: these rays are rows lo..hi of a larger batch (a chunk of
+    KernelTracker) -- pinned per-ray draws (``model.draws``, tests) are sliced accordingly."""
     samp = model.ray_sampler
     rays_d = ray_dirs.detach().contiguous()
     rays_o = cam_loc.detach().contiguous()
@@ -188,6 +189,8 @@ def get_z_vals(model, ray_dirs, cam_loc, need_eik=True):
                                      torch.cuda.current_stream().cuda_stream))
         return sample_rays(model, rays_o, rays_d, z, sdf, far, extra, eik_idx)
     t_rand = model.draw("t_rand", (R, E)) if model.training else None
+    if t_rand is not None and rows is not None and t_rand.shape[0] != R:
+        t_rand = t_rand[rows[0]:rows[1]]
     z, sdf, far = sampler_sdf(model, rays_o, rays_d, t_rand)
     if n_extra > 0:
         if model.training:
@@ -197,4 +200,6 @@ def get_z_vals(model, ray_dirs, cam_loc, need_eik=True):
     else:
         extra = None
     eik_idx = model.draw("eik_idx", (S, R)) if need_eik else None
+    if eik_idx is not None and rows is not None and eik_idx.shape[0] != R:
+        eik_idx = eik_idx[rows[0]:rows[1]]
     return sample_rays(model, rays_o, rays_d, z, sdf, far, extra, eik_idx)

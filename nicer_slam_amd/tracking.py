@@ -21,10 +21,16 @@ class KernelTracker:
     (fresh Adam state, StepLR back to its first step, no candidate yet), ``step(uv, gt)`` runs one iteration, and
     ``candidate`` is the camera of the smallest loss seen -- cloned AFTER that iteration's optimizer step, like the
     reference -- which is what the frame's pose estimate is set to (:445-446).  ``lr_step=50, lr_gamma=0.95`` is the
-    reference's StepLR (:398)."""
+    reference's StepLR (:398).
+
+    ``chunks > 1`` splits the ray batch into independent contiguous chunks that run the whole kernel sequence on their own
+    HIP streams (fork / join inside the captured graph) and meet only in the 9-float message [w*g_cam, w*loss, w] that the
+    multi-GPU form already uses: rays are independent until the pose-gradient sum, and kernels of different character
+    (VALU-bound SDF networks, gather-bound colour grid, latency-bound per-ray scans) then share the CUs and fill each
+    other's tails.  Same arithmetic per ray; the ray sums are added chunk by chunk."""
 
     def __init__(self, model, intrinsics, n_rays, cam_init, lr=0.005, betas=(0.9, 0.999), eps=1e-8, lr_step=0,
-                 lr_gamma=1.0, use_graph=True, world=1, stage="fine", color_stage="highfreq"):
+                 lr_gamma=1.0, use_graph=True, world=1, stage="fine", color_stage="highfreq", chunks=1):
         from .fused import render as fr, sampler as fs
         if not fr.supported(model):
             raise RuntimeError("KernelTracker: configuration outside the fused engine's compiled set")
@@ -44,13 +50,24 @@ class KernelTracker:
         self.best[0] = 1e10                                                 # current_min_loss (volsdf_train.py:403)
         self.rays_o, self.rays_d, self.ds = z(n_rays, 3), z(n_rays, 3), z(n_rays)
         self.g_rgbv = z(n_rays, 3)
+        self.chunks = max(1, min(int(chunks), n_rays))
+        if self.chunks > 1:
+            from .dist import shard_rays
+            self.bounds = [shard_rays(n_rays, c, self.chunks) for c in range(self.chunks)]
+            self.streams = [torch.cuda.Stream() for _ in range(self.chunks)]
+            self.red_c, self.pose_c = z(self.chunks, 9), z(self.chunks, 4, 4)
         self.graph = None
         if use_graph:
             self._capture()
 
     @property
+    def message(self):
+        """the step consumes the weighted 9-float message (multi-GPU and / or chunked) instead of the plain gradient"""
+        return self.world > 1 or self.chunks > 1
+
+    @property
     def loss(self):
-        return self.red[7] / self.red[8] if self.world > 1 else self.red[7]
+        return self.red[7] / self.red[8] if self.message else self.red[7]
 
     @property
     def candidate(self):
@@ -71,30 +88,46 @@ class KernelTracker:
             self.best.zero_()
             self.best[0] = 1e10
 
-    def _iteration(self):
+    def _rays_pass(self, lo, hi, pose, red):
+        """head .. tail for the rays [lo, hi) on torch's current stream; `red` receives g_cam (and, fused, the Adam step) or the
+        weighted message"""
         from ._native import lib, check
         fr, fs, model = self.fr, self.fs, self.model
         st = torch.cuda.current_stream().cuda_stream
-        R = self.R
-        check(lib.nsa_track_head(self.uv.data_ptr(), self.K.data_ptr(), self.cam.data_ptr(), R, self.pose.data_ptr(),
-                                 self.rays_o.data_ptr(), self.rays_d.data_ptr(), self.ds.data_ptr(), st))
-        z_vals, _ = fs.get_z_vals(model, self.rays_d, self.rays_o, need_eik=False)
-        b = fr.composite_forward_raw(model, self.rays_o, self.rays_d, z_vals, self.stage, True)
-        check(lib.nsa_l1_loss(b["rgb_values"].data_ptr(), self.gt.data_ptr(), 3 * R, self.red[7:8].data_ptr(),
-                              self.g_rgbv.data_ptr(), st))
-        g_o, g_d = fr.composite_backward_raw(model, self.rays_o, self.rays_d, z_vals, b, self.stage, self.color_stage,
-                                             g_rgbv=self.g_rgbv)
-        # single GPU: the Adam step rides in the same kernel; multi-GPU: the all-reduce sits between the two
+        R = hi - lo
+        uv, gt, g_rgbv = self.uv[0, lo:hi], self.gt[lo:hi], self.g_rgbv[lo:hi]
+        rays_o, rays_d, ds = self.rays_o[lo:hi], self.rays_d[lo:hi], self.ds[lo:hi]
+        check(lib.nsa_track_head(uv.data_ptr(), self.K.data_ptr(), self.cam.data_ptr(), R, pose.data_ptr(),
+                                 rays_o.data_ptr(), rays_d.data_ptr(), ds.data_ptr(), st))
+        z_vals, _ = fs.get_z_vals(model, rays_d, rays_o, need_eik=False, rows=(lo, hi))
+        b = fr.composite_forward_raw(model, rays_o, rays_d, z_vals, self.stage, True)
+        check(lib.nsa_l1_loss(b["rgb_values"].data_ptr(), gt.data_ptr(), 3 * R, red[7:8].data_ptr(), g_rgbv.data_ptr(), st))
+        g_o, g_d = fr.composite_backward_raw(model, rays_o, rays_d, z_vals, b, self.stage, self.color_stage, g_rgbv=g_rgbv)
+        # one chunk on one GPU: the Adam step rides in the same kernel; otherwise the tail leaves the weighted message and the
+        # step follows the chunk sum / the all-reduce
         lr, b1, b2, eps, lr_step, lr_gamma = self.hyper
-        check(lib.nsa_track_tail(self.uv.data_ptr(), self.K.data_ptr(), self.cam.data_ptr(), R, g_o.data_ptr(),
-                                 g_d.data_ptr(), self.red.data_ptr(), 1 if self.world == 1 else 0,
-                                 0.0 if self.world == 1 else float(R), self.m.data_ptr(), self.v.data_ptr(),
-                                 self.t.data_ptr(), lr, b1, b2, eps, lr_step, lr_gamma,
-                                 self.red[7:8].data_ptr() if self.world == 1 else None,
-                                 self.best.data_ptr() if self.world == 1 else None, st))
+        fused = not self.message
+        check(lib.nsa_track_tail(uv.data_ptr(), self.K.data_ptr(), self.cam.data_ptr(), R, g_o.data_ptr(),
+                                 g_d.data_ptr(), red.data_ptr(), 1 if fused else 0, 0.0 if fused else float(R),
+                                 self.m.data_ptr(), self.v.data_ptr(), self.t.data_ptr(), lr, b1, b2, eps, lr_step, lr_gamma,
+                                 red[7:8].data_ptr() if fused else None, self.best.data_ptr() if fused else None, st))
+
+    def _iteration(self):
+        if self.chunks == 1:
+            return self._rays_pass(0, self.R, self.pose, self.red)
+        cur = torch.cuda.current_stream()
+        for c, side in enumerate(self.streams):          # fork
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self._rays_pass(*self.bounds[c], self.pose_c[c], self.red_c[c])
+        for side in self.streams:                        # join
+            cur.wait_stream(side)
+        torch.sum(self.red_c, 0, out=self.red)
+        if self.world == 1:
+            self._update()
 
     def _update(self):
-        """multi-GPU: Adam on the all-reduced message, gradient = red[0..6] / red[8]"""
+        """Adam on the (chunk-summed, all-reduced) message, gradient = red[0..6] / red[8]"""
         from ._native import lib, check
         lr, b1, b2, eps, lr_step, lr_gamma = self.hyper
         check(lib.nsa_adam_step_scaled(self.cam.data_ptr(), self.red.data_ptr(), self.red[8:].data_ptr(), self.m.data_ptr(),
@@ -128,8 +161,7 @@ class KernelTracker:
                 import torch.distributed as dist
                 dist.all_reduce(self.red)
                 self._update()
-                return self.red[7] / self.red[8]
-        return self.red[7]
+        return self.loss
 
 
 class TrackingStepper:

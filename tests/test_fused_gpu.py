@@ -324,6 +324,28 @@ def test_kernel_tracker_multi_gpu_message_path_single_rank_group():
     assert_close(many.cam, one.cam, 1e-6, 1e-5, "camera after 4 steps")
 
 
+@pytest.mark.parametrize("chunks", [2, 3])
+def test_kernel_tracker_chunked_streams_follow_the_single_stream_trajectory(chunks):
+    """chunks > 1: independent ray chunks on their own streams (fork / join inside the captured graph), joined through the
+    weighted 9-float message -- same arithmetic per ray, so with pinned draws the trajectory is the single-stream one."""
+    from nicer_slam_amd.tracking import KernelTracker
+    fx, model, cam, pose, _, _ = _setup("full_tracking")
+    model.train(True)
+    model.engine = "fused"
+    model.draws = draws_of(fx, "cuda")
+    K, uv, gt = tt(fx["in_K"]).cuda(), tt(fx["in_uv"]).cuda(), tt(fx["gt_rgb"]).cuda()
+    cam0 = tt(fx["in_cam"]).reshape(-1)
+    one = KernelTracker(model, K, uv.shape[1], cam0, lr=0.005, use_graph=True)
+    l1 = [float(one.step(uv, gt)) for _ in range(4)]
+    for use_graph in (False, True):
+        many = KernelTracker(model, K, uv.shape[1], cam0, lr=0.005, use_graph=use_graph, chunks=chunks)
+        l2 = [float(many.step(uv, gt)) for _ in range(4)]
+        assert float(many.red[8]) == float(uv.shape[1])
+        assert_close(torch.tensor(l2), torch.tensor(l1), 1e-6, 1e-5, "losses")
+        assert_close(many.cam, one.cam, 1e-6, 1e-5, "camera after 4 steps")
+        assert_close(many.candidate, one.candidate, 1e-6, 1e-5, "arg-min-loss camera")
+
+
 def test_composite_backward_far_from_the_surface_matches_torch_expm1_backward():
     """Regression (found by tests/test_configs_gpu.py): in empty space (sdf / beta > ~17) expm1(-|s|/beta) has rounded to
     exactly -1, so the reference's sigma is exactly 0 or one ulp of 0.5 / beta, and torch's expm1 backward -- (result + 1),

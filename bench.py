@@ -160,6 +160,7 @@ def main():
     Stepper = TrackingStepper if (args.autograd or args.param_grads) else KernelTracker
     extra = {"chunks": args.chunks} if Stepper is KernelTracker else {}
     stepper = Stepper(model, K, args.rays, cam, lr=0.005, use_graph=use_graph, world=world, **extra)
+    ray_chunks = getattr(stepper, "chunks", 1)
 
     def step(i):
         uv, gt = batches[i]
@@ -269,7 +270,7 @@ def main():
                        "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "sampler_evals_per_ray": 640,
                        "global_rays": args.rays * world,
                        "engine": "fused" if Stepper.__name__ == "KernelTracker" else model.last_engine, "param_grads": args.param_grads,
-                       "hip_graph": bool(use_graph), "driver": Stepper.__name__, "ray_chunks": getattr(stepper, "chunks", 1), "clock_prewarm_s": args.prewarm_s,
+                       "hip_graph": bool(use_graph), "driver": Stepper.__name__, "ray_chunks": ray_chunks, "clock_prewarm_s": args.prewarm_s,
                        "parallelism": f"ray-shard x{world}" if world > 1 else "single",
                        "rccl_ranks": 0 if (world == 1 or oversub) else world,
                        "exchange": None if world == 1 else "one 9-float all-reduce (pose gradient, loss, ray count) per step",

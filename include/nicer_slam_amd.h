@@ -273,6 +273,16 @@ int nsa_update_voxels(const nsa_points_t *pts, float *voxels, uint32_t res, nsa_
 int nsa_adam_table_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, uint32_t step,
                         float lr, float beta1, float beta2, float eps, nsa_stream_t stream);
 
+/* MLP weight gradients from the emission rows of the *_backward_params kernels: emit is [rows][ld] fp32 (column = point,
+ * ld a multiple of 4096, columns past the last point zero).
+ *   out[m][n] = sum_j sum_p emit[a_rows[j] + m][p] * emit[b_rows[j] + n][p],   j < pairs (1 or 2), m < M <= 64, n < N <= 159
+ * and, with row_sums, out[m][N] = sum_p emit[a_rows[0] + m][p] (the bias gradient); out is [M][N + row_sums], fp32-faithful
+ * products, deterministic (per-chunk partials in `workspace`, nsa_emit_gemm_workspace() floats, added in chunk order).
+ * replaces torch autograd's weight / bias gradients of the Linear layers (code/model/base_networks.py:195-221, 333-395). */
+int nsa_emit_gemm(const float *emit, uint64_t ld, uint32_t pairs, const uint32_t *a_rows, const uint32_t *b_rows, uint32_t M,
+                  uint32_t N, int row_sums, float *out, float *workspace, nsa_stream_t stream);
+uint64_t nsa_emit_gemm_workspace(uint64_t ld, uint32_t M, uint32_t N, int row_sums);
+
 #ifdef __cplusplus
 }
 #endif

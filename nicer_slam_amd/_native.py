@@ -120,6 +120,13 @@ lib.nsa_adam_table_step.restype = _i
 lib.nsa_adam_table_step.argtypes = [_p, _p, _p, _p, ctypes.c_uint64, _u32, _f32, _f32, _f32, _f32, _p]
 EXPORTS += ["nsa_update_voxels", "nsa_adam_table_step"]
 
+lib.nsa_emit_gemm.restype = _i
+lib.nsa_emit_gemm.argtypes = [_p, ctypes.c_uint64, _u32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), _u32,
+                              _u32, ctypes.c_int, _p, _p, _p]
+lib.nsa_emit_gemm_workspace.restype = ctypes.c_uint64
+lib.nsa_emit_gemm_workspace.argtypes = [ctypes.c_uint64, _u32, _u32, ctypes.c_int]
+EXPORTS += ["nsa_emit_gemm", "nsa_emit_gemm_workspace"]
+
 lib.nsa_sdf_points.restype = _i
 lib.nsa_sdf_points.argtypes = [_p, ctypes.c_uint64, _gp, _gp, _p, _p, _p, _p]
 EXPORTS += ["nsa_sdf_points"]

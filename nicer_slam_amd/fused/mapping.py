@@ -2,8 +2,8 @@
 
 The backward kernels of fused/render.py (run as their MAP variants, Section 2 of the C ABI) accumulate the grid-table
 gradients with run-merged atomics and write, per point, the vectors whose outer products are the MLP weight
-gradients; the weight gradients themselves are a handful of [64 x n] x [n x ~130] GEMMs over those rows, batched here
-in K-chunks so that the long reduction dimension fills the chip.
+gradients; the weight gradients themselves are a handful of [64 x n] x [n x ~130] products over those rows (nsa_emit_gemm,
+csrc/emit_gemm.hip: K-chunked so that the long reduction dimension fills the chip, bias gradients as an extra column).
 
 Trainable parameters follow the reference's optimizer list (code/training/volsdf_train.py:150-173): the three grid
 tables, the coarse SDF MLP and the colour MLP.  The fine SDF MLP is pretrained and never handed to the optimizer there, yet
@@ -71,14 +71,27 @@ def new_emit(rows, P, device):
     return buf
 
 
-def outer_sum(A, B):
-    """A[m, ld] @ B[n, ld]^T with the reduction split into ld/KCHUNK batches (strided views, no copies)."""
-    m, ld = A.shape
-    n = B.shape[0]
-    nch = ld // KCHUNK
-    A3 = A.view(m, nch, KCHUNK).transpose(0, 1)
-    B3 = B.view(n, nch, KCHUNK).transpose(0, 1)
-    return torch.bmm(A3, B3.transpose(1, 2)).sum(0)
+def emit_gemm(emit, a_rows, M, b_rows, N, sums=True, workspace=None):
+    """out[M, N + sums] = sum over the (one or two) row pairs of emit[a : a + M] @ emit[b : b + N]^T, last column = row sums of
+    the first A block: one weight gradient with its bias gradient (nsa_emit_gemm: fp32-faithful MFMA products straight from the
+    emission rows, deterministic chunk-order reduction)."""
+    rows, ld = emit.shape
+    pairs = len(a_rows)
+    b_rows = tuple(b_rows) if N else (0,) * pairs
+    assert pairs in (1, 2) and len(b_rows) == pairs and emit.is_contiguous() and emit.dtype == torch.float32
+    assert all(a + M <= rows for a in a_rows) and all(b + N <= rows for b in b_rows)
+    need = int(lib.nsa_emit_gemm_workspace(ld, M, N, int(sums)))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=emit.device)
+    out = torch.empty(M, N + int(sums), device=emit.device)
+    check(lib.nsa_emit_gemm(emit.data_ptr(), ld, pairs, (ctypes.c_uint32 * 2)(*a_rows, *([0] * (2 - pairs))),
+                            (ctypes.c_uint32 * 2)(*b_rows, *([0] * (2 - pairs))), M, N, int(sums), out.data_ptr(),
+                            workspace.data_ptr(), _stream()))
+    return out
+
+
+def _workspace(emit, M=64, N=159):
+    return torch.empty(int(lib.nsa_emit_gemm_workspace(emit.shape[1], M, N, 1)), device=emit.device)
 
 
 @functools.lru_cache(maxsize=None)
@@ -124,33 +137,32 @@ def sdf_flat_grad(emit, g_sdf, P, L, C, NH=1, tile=32):
     """Gradient of an SDF network's flat parameter vector [W0(64x71), b0, W1, b1, .., W_NH(65x64), b_NH, 0] from its emission
     rows (row map and formulas: struct SE<NH>, csrc/render_sdfnet.hip; SE4<NH>, csrc/render_sdfnet4.hip)."""
     m = se_rows(NH, tile)
-    r = lambda name, n=64: emit[m[name]:m[name] + n]
-    sums = emit[m["AB1"]:m["ROWS"]].sum(1)                   # AB_1..AB_NH | TH_NH | FB row sums in one reduction
+    IN, ws = m["IN"], _workspace(emit)
     parts = []
-    M = outer_sum(r("AB1"), r("H0", m["IN"])) + outer_sum(r("DA1"), r("TIN", m["IN"]))
-    parts += [M[:, _on(emit.device, _sdf_rows, L, C, tile)].reshape(-1), sums[:64]]
-    for k in range(1, NH):                                   # hidden layer k: value path + its share of the reverse pass
-        parts += [(outer_sum(r(f"AB{k + 1}"), r(f"H{k}")) + outer_sum(r(f"DA{k + 1}"), r(f"TH{k}"))).reshape(-1),
-                  sums[64 * k:64 * (k + 1)]]
-    row0, fb_sum = sums[64 * NH:64 * (NH + 1)], sums[64 * (NH + 1):]
+    # first layer: value path (AB_1 x H0) + its share of the reverse pass (DA_1 x TIN); the last column is the bias gradient
+    W0 = emit_gemm(emit, (m["AB1"], m["DA1"]), 64, (m["H0"], m["TIN"]), IN, workspace=ws)
+    parts += [W0[:, :IN][:, _on(emit.device, _sdf_rows, L, C, tile)].reshape(-1), W0[:, IN]]
+    for k in range(1, NH):                                   # hidden layer k, same two paths
+        Wk = emit_gemm(emit, (m[f"AB{k + 1}"], m[f"DA{k + 1}"]), 64, (m[f"H{k}"], m[f"TH{k}"]), 64, workspace=ws)
+        parts += [Wk[:, :64].reshape(-1), Wk[:, 64]]
+    row0 = emit_gemm(emit, (m[f"TH{NH}"],), 64, None, 0, workspace=ws)[:, 0]           # sdf row: row sums of TH_NH
+    Wf = emit_gemm(emit, (m["FB"],), 64, (m[f"H{NH}"],), 64, workspace=ws)               # feature rows + their biases
     dbs = emit.new_zeros(1)
     if g_sdf is not None:
-        row0 = row0 + r(f"H{NH}")[:, :P] @ g_sdf
+        row0 = row0 + emit[m[f"H{NH}"]:m[f"H{NH}"] + 64, :P] @ g_sdf
         dbs = g_sdf.sum().reshape(1)
-    parts += [row0, outer_sum(r("FB"), r(f"H{NH}")).reshape(-1), dbs, fb_sum, emit.new_zeros(1)]
+    parts += [row0, Wf[:, :64].reshape(-1), dbs, Wf[:, 64], emit.new_zeros(1)]
     return torch.cat(parts)
 
 
 def colour_flat_grad(emit):
     """Gradient of the colour network's flat parameter vector [W0(64x129), b0, W1, b1, W2(3x64), b2, 0]."""
-    r = lambda name, n: emit[CE[name]:CE[name] + n]
-    IN, AB1, H1, AB2, H2, OB = r("IN", 130), r("AB1", 64), r("H1", 64), r("AB2", 64), r("H2", 64), r("OB", 3)
-    dW0 = outer_sum(AB1, IN)[:, _on(emit.device, _col_rows)]
-    dW1 = outer_sum(AB2, H1)
-    dW2 = outer_sum(OB, H2)
-    sums = emit[CE["AB1"]:CE["ROWS"]].sum(1)                 # AB1 | AB2 | OB row sums in one reduction
-    return torch.cat([dW0.reshape(-1), sums[:64], dW1.reshape(-1), sums[64:128], dW2.reshape(-1), sums[128:],
-                      emit.new_zeros(1)])
+    ws = _workspace(emit)
+    W0 = emit_gemm(emit, (CE["AB1"],), 64, (CE["IN"],), 130, workspace=ws)
+    W1 = emit_gemm(emit, (CE["AB2"],), 64, (CE["H1"],), 64, workspace=ws)
+    W2 = emit_gemm(emit, (CE["OB"],), 3, (CE["H2"],), 64, workspace=ws)
+    return torch.cat([W0[:, :130][:, _on(emit.device, _col_rows)].reshape(-1), W0[:, 130], W1[:, :64].reshape(-1), W1[:, 64],
+                      W2[:, :64].reshape(-1), W2[:, 64], emit.new_zeros(1)])
 
 
 def _nets(model):

@@ -417,3 +417,34 @@ def test_flow_block_downstream_of_fused_function():
         if k.startswith(FROZEN):
             continue
         assert_close(res["fused"][2][k], g.cpu().numpy(), 1e-6 + 4e-4 * float(g.abs().max()), 1e-3, "grad " + k)
+
+
+@pytest.mark.parametrize("case", [dict(a=(5, 140), M=64, b=(70, 200), N=96), dict(a=(3,), M=64, b=(80,), N=130),
+                                  dict(a=(9,), M=3, b=(20,), N=64), dict(a=(11,), M=64, b=None, N=0),
+                                  dict(a=(0, 64), M=33, b=(128, 200), N=31)])
+def test_emit_gemm_vs_float64(case):
+    """nsa_emit_gemm (weight + bias gradients from emission rows) against a float64 product of the same rows: fp32-faithful
+    (error of an fp32 dot product, not of bf16 operands), deterministic, ragged M / N, one and two product pairs."""
+    from nicer_slam_amd.fused.mapping import emit_gemm, emit_ld
+    g = torch.Generator().manual_seed(3)
+    P = 3 * 4096 - 1234
+    ld = emit_ld(P)
+    emit = torch.zeros(300, ld)
+    emit[:, :P] = torch.randn(300, P, generator=g) * torch.rand(300, 1, generator=g) * 3
+    dev = emit.cuda()
+    a, b, M, N = case["a"], case["b"], case["M"], case["N"]
+    out = emit_gemm(dev, a, M, b, N)
+    again = emit_gemm(dev, a, M, b, N)
+    assert torch.equal(out, again)
+    e64 = emit.double()
+    ref = torch.zeros(M, N + 1, dtype=torch.float64)
+    scale = torch.zeros(M, N + 1, dtype=torch.float64)
+    for j, a0 in enumerate(a):
+        if N:
+            ref[:, :N] += e64[a0:a0 + M] @ e64[b[j]:b[j] + N].T
+            scale[:, :N] += e64[a0:a0 + M].abs() @ e64[b[j]:b[j] + N].abs().T
+    ref[:, N] = e64[a[0]:a[0] + M].sum(1)
+    scale[:, N] = e64[a[0]:a[0] + M].abs().sum(1)
+    err = (out.double().cpu() - ref).abs() / scale.clamp_min(1e-30)
+    print("emit_gemm max error / sum|ab|:", float(err.max()))
+    assert float(err.max()) < 1e-6, float(err.max())      # fp32 accumulation over ~11k terms (x2 pairs)

@@ -283,6 +283,32 @@ int nsa_emit_gemm(const float *emit, uint64_t ld, uint32_t pairs, const uint32_t
                   uint32_t N, int row_sums, float *out, float *workspace, nsa_stream_t stream);
 uint64_t nsa_emit_gemm_workspace(uint64_t ld, uint32_t M, uint32_t N, int row_sums);
 
+/* The per-ray terms of SLAMLoss (code/model/loss.py:113-233: rgb L1, eikonal, smooth, scale-and-shift-invariant monocular
+ * depth with its alpha = 0.5 first-difference regulariser (code/utils/MiDaS.py:6-143), gt-depth L1, normal L1 + cos) and the
+ * gradient of their WEIGHTED sum w.r.t. the model outputs, in three launches.  A weight of 0 skips a term (its value is then 0,
+ * like the reference's 0.0); the flow and patch-warp terms are not covered.  R = bs * n rays, image-major. */
+typedef struct nsa_loss {
+    uint32_t bs, n;               /* images, rays per image                                                             */
+    uint32_t S;                   /* samples per ray of `sdf`                                                           */
+    uint32_t E;                   /* eikonal points (0: no eikonal / smooth term)                                       */
+    const float *rgb, *rgb_gt;    /* [R,3] rgb_values, ground_truth['rgb']                                              */
+    const float *depth;           /* [R]   depth_values                                                                 */
+    const float *depth_mono;      /* [R]   ground_truth['depth'] (monocular; the term aligns to 50 * it + 0.5)           */
+    const float *depth_real;      /* [R]   target of the gt-depth L1 term (gt_depth, or depth * assign_scale on frame 0) */
+    const float *depth_real_mask; /* [R]   the gt-depth term covers rays with this > 0 (ground_truth['gt_depth'])        */
+    const float *mask_gt;         /* [R]   ground_truth['mask'] (foreground where > 0.5 AND the ray's sdf changes sign)  */
+    const float *sdf;             /* [R,S] */
+    const float *normal, *normal_gt;             /* [R,3] normal_map, ground_truth['normal']                            */
+    const float *grad_theta, *grad_theta_nei;    /* [E,3]; grad_theta_nei may be NULL (no smooth term)                  */
+    float w_rgb, w_eik, w_smooth, w_depth, w_gtdepth, w_nl1, w_ncos;
+    int depth_whole_image;        /* depth term over every ray instead of the foreground (Replica scan 4, loss.py:171-175) */
+    float *g_rgb, *g_depth, *g_normal, *g_theta, *g_theta_nei;   /* out: d(weighted sum) / d(input), same shapes         */
+    float *terms;                 /* out [8]: rgb, eikonal, smooth, depth, gt_depth, normal_l1, normal_cos (unweighted), sum */
+} nsa_loss_t;
+int nsa_slam_loss(const nsa_loss_t *in, float *workspace /* nsa_slam_loss_workspace() floats, 8-byte aligned */,
+                  nsa_stream_t stream);
+uint64_t nsa_slam_loss_workspace(uint32_t bs, uint32_t n, uint32_t E);
+
 #ifdef __cplusplus
 }
 #endif

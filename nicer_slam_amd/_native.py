@@ -127,6 +127,22 @@ lib.nsa_emit_gemm_workspace.restype = ctypes.c_uint64
 lib.nsa_emit_gemm_workspace.argtypes = [ctypes.c_uint64, _u32, _u32, ctypes.c_int]
 EXPORTS += ["nsa_emit_gemm", "nsa_emit_gemm_workspace"]
 
+class LossDesc(ctypes.Structure):
+    """nsa_loss_t"""
+    _fields_ = ([("bs", _u32), ("n", _u32), ("S", _u32), ("E", _u32)]
+                + [(k, _p) for k in ("rgb", "rgb_gt", "depth", "depth_mono", "depth_real", "depth_real_mask", "mask_gt", "sdf",
+                                     "normal", "normal_gt", "grad_theta", "grad_theta_nei")]
+                + [(k, _f32) for k in ("w_rgb", "w_eik", "w_smooth", "w_depth", "w_gtdepth", "w_nl1", "w_ncos")]
+                + [("depth_whole_image", ctypes.c_int)]
+                + [(k, _p) for k in ("g_rgb", "g_depth", "g_normal", "g_theta", "g_theta_nei", "terms")])
+
+
+lib.nsa_slam_loss.restype = _i
+lib.nsa_slam_loss.argtypes = [ctypes.POINTER(LossDesc), _p, _p]
+lib.nsa_slam_loss_workspace.restype = ctypes.c_uint64
+lib.nsa_slam_loss_workspace.argtypes = [_u32, _u32, _u32]
+EXPORTS += ["nsa_slam_loss", "nsa_slam_loss_workspace"]
+
 lib.nsa_sdf_points.restype = _i
 lib.nsa_sdf_points.argtypes = [_p, ctypes.c_uint64, _gp, _gp, _p, _p, _p, _p]
 EXPORTS += ["nsa_sdf_points"]

@@ -3,9 +3,11 @@
 Reference: SLAMLoss (code/model/loss.py:8-233) and the scale-and-shift-invariant monocular depth loss it uses
 (code/utils/MiDaS.py:6-143, alpha = 0.5, one scale, batch-based reduction).  Same constructor arguments, same
 ``forward(model_outputs, ground_truth, keyframe_list, frame_idx, stage) -> dict`` keys and weights, so a trainer that
-builds ``loss_class(**conf.loss, ...)`` can switch.  These are reductions over at most 8192 rays: plain torch ops on
-whatever device the model outputs live on; the tracking objective (rgb L1 only) additionally exists
-as a HIP kernel for the graph-captured tracker (csrc/track_tail.hip::k_l1_loss).
+builds ``loss_class(**conf.loss, ...)`` can switch.  On the GPU the per-ray terms and their gradients run in three HIP launches
+(fused/loss.py -> csrc/loss_terms.hip: rgb, eikonal, smooth, ssi depth, gt depth, normals); the torch restatement below is the
+same arithmetic for CPU tensors, for the ray-sharded depth reduction and for non-L1 colour losses, and carries the flow and
+patch-warp terms everywhere.  The tracking objective (rgb L1 only) additionally exists as a HIP kernel for the
+graph-captured tracker (csrc/track_tail.hip::k_l1_loss).
 """
 import torch
 from torch import nn
@@ -137,7 +139,52 @@ class SLAMLoss(nn.Module):
                 total = total + 0.05 * (1 - self._ssim[patchsize](a, b))
         return total
 
+    def _fused_ok(self, model_outputs):
+        """The HIP loss kernels (fused/loss.py) cover the per-ray terms when the outputs live on the GPU, the colour term is the
+        configured L1 mean and no ray-sharded depth reduction is requested; ``self.engine = "torch"`` forces the torch ops."""
+        if getattr(self, "engine", "auto") == "torch" or getattr(self, "depth_shard", None) is not None:
+            return False
+        from ..fused import loss as fl
+        rl = self.rgb_loss
+        return (fl.available(model_outputs["rgb_values"]) and isinstance(rl, nn.L1Loss) and rl.reduction == "mean"
+                and "normal_map" in model_outputs and model_outputs["depth_values"].dim() == 3)
+
+    def _forward_fused(self, model_outputs, ground_truth, keyframe_list, frame_idx, stage):
+        from ..fused.loss import fused_terms
+        dev = model_outputs["rgb_values"].device
+        depth_gt, depth_real_gt = ground_truth["depth"].to(dev), ground_truth["gt_depth"].to(dev)
+        warp_loss = 0.0
+        if "warp_output" in model_outputs and self.warp_loss_weight > 0 and stage == "fine" and frame_idx != 0:
+            warp_loss = self._warp_loss(model_outputs["warp_output"])
+        use_eik = self.eikonal_weight > 0 and "grad_theta" in model_outputs
+        use_smooth = self.smooth_weight > 0.0
+        depth_real = depth_real_gt
+        if self.assign_scale_shift_init:      # loss.py:179-185
+            if frame_idx == 0:
+                depth_real = depth_gt * self.assign_scale
+                self.gt_depth_weight = 10
+            else:
+                self.gt_depth_weight = 0
+        whole = (self.depth_weight > 0 and self.train_dataset is not None
+                 and "Replica" in getattr(self.train_dataset, "data_dir", "") and self.scan_id == 4)
+        normals = self.normal_l1_weight > 0 or self.normal_cos_weight > 0
+        w = (self.rgb_loss_weight, self.eikonal_weight if use_eik else 0.0, self.smooth_weight if use_smooth else 0.0,
+             self.depth_weight, self.gt_depth_weight, self.normal_l1_weight if normals else 0.0,
+             self.normal_cos_weight if normals else 0.0)
+        total, t = fused_terms(model_outputs, ground_truth["rgb"], depth_gt, depth_real, depth_real_gt, ground_truth["mask"],
+                               ground_truth["normal"], w, whole, use_eik, use_smooth)
+        flow_loss = self.get_flow_loss(model_outputs, ground_truth, keyframe_list) if self.flow_weight > 0.0 else 0.0
+        loss = total + self.flow_weight * flow_loss + self.warp_loss_weight * warp_loss
+        on = lambda flag, v: v if flag else 0.0
+        return {"loss": loss, "normal_l1": on(normals, t[5]), "depth_loss": on(self.depth_weight > 0, t[3]),
+                "normal_cos": on(normals, t[6]), "gt_depth_loss": on(self.gt_depth_weight > 0, t[4]),
+                "flow_loss": self.flow_weight * flow_loss, "rgb_loss": self.rgb_loss_weight * t[0],
+                "warp_loss": self.warp_loss_weight * warp_loss, "smooth_loss": self.smooth_weight * on(use_smooth, t[2]),
+                "eikonal_loss": self.eikonal_weight * on(use_eik, t[1])}
+
     def forward(self, model_outputs, ground_truth, keyframe_list=None, frame_idx=0, stage="coarse"):
+        if self._fused_ok(model_outputs):
+            return self._forward_fused(model_outputs, ground_truth, keyframe_list, frame_idx, stage)
         rgb_pred, depth_pred = model_outputs["rgb_values"], model_outputs["depth_values"]
         dev = rgb_pred.device
         rgb_gt, depth_gt = ground_truth["rgb"].to(dev), ground_truth["depth"].to(dev)

@@ -11,7 +11,7 @@ class _DS:
     data_dir = "../Datasets/processed/Replica"
 
 
-def check_slam_loss(name, device="cpu", atol=1e-6, gtol=1e-7):
+def check_slam_loss(name, device="cpu", atol=1e-6, gtol=1e-7, engine="auto"):
     """shared with tests/test_loss_gpu.py (the same goldens with every tensor on the device)"""
     from nicer_slam_amd.model.loss import SLAMLoss
     fx = load(name)
@@ -29,6 +29,8 @@ def check_slam_loss(name, device="cpu", atol=1e-6, gtol=1e-7):
     crit = SLAMLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, train_dataset=_DS(), scan_id=1,
                     assign_scale_shift_init=True, smooth_weight=0.005, warp_loss_type="l1", depth_weight=0.1,
                     normal_l1_weight=0.05, normal_cos_weight=0.05, flow_weight=0.001, warp_loss_weight=0.5)
+    crit.engine = engine
+    assert crit._fused_ok(out) == (device == "cuda" and engine == "auto")      # GPU: the HIP loss kernels, not the torch ops
     res = crit(out, gt, keyframe_list=None, frame_idx=int(fx["meta_frame_idx"]), stage=str(fx["meta_stage"]))
     assert set(res) == {k[4:] for k in fx if k.startswith("out_")}
     for k, v in res.items():

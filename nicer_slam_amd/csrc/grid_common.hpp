@@ -118,8 +118,9 @@ __device__ __forceinline__ uint32_t level_row(const LevelGeom& g, const uint32_t
 // `key` = destination row (relative to `table`) or 0xFFFFFFFF for lanes with nothing to add (they never merge).
 // Blocks using this are 256 threads (4 waves).
 //  3. wider spans: a request may cover at least 64 contiguous bytes (same benchmark: C lanes on one 8/16/32-byte row and
-//     2C lanes on two ADJACENT rows both retire at ~20 G requests/s, i.e. 41 G rows/s for pairs).  On a dense level the
-//     two x-neighbour corners of a cell are adjacent rows, so they are sent as one 2C-float span (scatter_row_pair).
+//     2C lanes on two ADJACENT rows both retire at ~20 G requests/s, i.e. 41 G rows/s for pairs).  The two x-neighbour
+//     corners of a cell are adjacent rows on a dense level, and on a hashed level for every cell with even x: they are sent
+//     as one 2C-float span (scatter_x_pair).
 // `elem` = float offset of the span's first channel in `table`, or 0xFFFFFFFF for lanes with nothing to add.
 // `tile` = this wave's 64*(W+1)-float LDS scratch.  Must be called by all 64 lanes (shuffles / ballots inside).
 template <int W>
@@ -147,11 +148,14 @@ __device__ __forceinline__ void scatter_span(float* __restrict__ table, uint32_t
 #pragma unroll
     for (int c = 0; c < W; ++c) tile[lane * (W + 1) + c] = val[c];     // row pitch W+1: conflict-free transposed reads
     __builtin_amdgcn_wave_barrier();                                   // LDS ops of one wave execute in order
-    const int grp = (lane / W) * W, ch = lane % W;
+    // round j sends the spans held by the CONTIGUOUS lanes [j * 64/W, (j+1) * 64/W): neighbouring lanes are neighbouring points
+    // (consecutive samples of a ray / Morton order), whose spans often share a 64-byte segment and then leave as one request
+    const int slot = lane / W, ch = lane % W;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        const uint32_t e = __shfl(send, grp + j);
-        const float v = tile[(grp + j) * (W + 1) + ch];
+        const int src = j * (64 / W) + slot;
+        const uint32_t e = __shfl(send, src);
+        const float v = tile[src * (W + 1) + ch];
         if (e != 0xFFFFFFFFu) atomicAdd(table + (size_t)e + ch, v);
     }
     __builtin_amdgcn_wave_barrier();
@@ -169,23 +173,35 @@ __device__ __forceinline__ void scatter_runs(float* __restrict__ table, uint32_t
     scatter_runs<C>(table, key, val, lane, stage[threadIdx.x >> 6]);
 }
 
-// the two x-neighbour corner rows (r0, r1) of a cell on a DENSE level: one 2C-float span when they are adjacent in memory
-// (always, except where the level's index wraps); `tile` holds 64*(2C+1) floats.
+// The two x-neighbour corner rows (r0: corner x, r1: corner x + 1) of a cell as ONE 2C-float span when they are adjacent in
+// memory: always on a dense level (r1 == r0 + 1; except where the level's index wraps), and on a HASHED level whenever the
+// cell's x is even -- the hash xors x in with prime 1, so the two rows then differ in bit 0 only (either order).  Lanes whose
+// rows are not adjacent send them as two single rows; that path is skipped when no lane of the wave needs it.
+// `tile` holds 64*(2C+1) floats.  Must be called by all 64 lanes.
 template <int C>
-__device__ __forceinline__ void scatter_row_pair(float* __restrict__ table, uint32_t r0, uint32_t r1, bool valid,
-                                                 const float (&v0)[C], const float (&v1)[C], int lane, float* tile) {
-    const bool adjacent = r1 == r0 + 1u;
-    if (valid && !adjacent) {                                          // wrap point of the level: rare, plain atomics
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            atomicAdd(table + (size_t)r0 * C + c, v0[c]);
-            atomicAdd(table + (size_t)r1 * C + c, v1[c]);
-        }
-    }
+__device__ __forceinline__ void scatter_x_pair(float* __restrict__ table, uint32_t r0, uint32_t r1, bool valid,
+                                               const float (&v0)[C], const float (&v1)[C], int lane, float* tile) {
+    const bool up = r1 == r0 + 1u, down = r0 == r1 + 1u;
+    const bool adj = valid && (up || down);
     float val[2 * C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) { val[c] = v0[c]; val[C + c] = v1[c]; }
-    scatter_span<2 * C>(table, (valid && adjacent) ? r0 * (uint32_t)C : 0xFFFFFFFFu, val, lane, tile);
+    for (int c = 0; c < C; ++c) { val[c] = down ? v1[c] : v0[c]; val[C + c] = down ? v0[c] : v1[c]; }
+    scatter_span<2 * C>(table, adj ? (down ? r1 : r0) * (uint32_t)C : 0xFFFFFFFFu, val, lane, tile);
+    const bool single = valid && !adj;
+    if (__ballot(single)) {                                            // wave-uniform
+        float a[C], b[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { a[c] = v0[c]; b[c] = v1[c]; }
+        scatter_runs<C>(table, single ? r0 : 0xFFFFFFFFu, a, lane, tile);
+        scatter_runs<C>(table, single ? r1 : 0xFFFFFFFFu, b, lane, tile);
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void scatter_x_pair(float* __restrict__ table, uint32_t r0, uint32_t r1, bool valid,
+                                               const float (&v0)[C], const float (&v1)[C], int lane) {
+    __shared__ float stage2[4][64 * (2 * C + 1)];
+    scatter_x_pair<C>(table, r0, r1, valid, v0, v1, lane, stage2[threadIdx.x >> 6]);
 }
 
 // Range test + cell/fraction split.  Returns false for a point outside [0,1]^D (NaN passes, as in the

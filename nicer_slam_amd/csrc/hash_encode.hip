@@ -116,21 +116,27 @@ __global__ __launch_bounds__(TPB) void k_grid_scatter(const float* __restrict__ 
         for (int c = 0; c < C; ++c) gy[c] = 0.0f;
         if (active) load_row<C>(grad + ((size_t)level * B + b) * C, gy);
         float* tl = grad_emb + (size_t)g.row0 * C;
+        // corners in x-neighbour pairs (2 yz, 2 yz + 1): one span per pair where the two rows are adjacent (grid_common.hpp)
 #pragma unroll
-        for (int corner = 0; corner < (1 << D); ++corner) {
-            float wt = 1.0f;
-            uint32_t q[D];
+        for (int yz = 0; yz < (1 << (D - 1)); ++yz) {
+            uint32_t r[2];
+            float v[2][C];
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const int bit = (corner >> d) & 1;
-                wt *= bit ? w[d] : 1.0f - w[d];
-                q[d] = cell[d] + bit;
+            for (int xb = 0; xb < 2; ++xb) {
+                const int corner = 2 * yz + xb;
+                float wt = 1.0f;
+                uint32_t q[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int bit = (corner >> d) & 1;
+                    wt *= bit ? w[d] : 1.0f - w[d];
+                    q[d] = cell[d] + bit;
+                }
+                r[xb] = level_row<D>(g, q);
+#pragma unroll
+                for (int c = 0; c < C; ++c) v[xb][c] = wt * gy[c];
             }
-            const uint32_t key = active ? level_row<D>(g, q) : 0xFFFFFFFFu;
-            float v[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) v[c] = wt * gy[c];
-            scatter_runs<C>(tl, key, v, lane);
+            scatter_x_pair<C>(tl, r[0], r[1], active, v[0], v[1], lane);
         }
     }
 }
@@ -238,15 +244,20 @@ __global__ __launch_bounds__(TPB) void k_grid_second_backward(const float* __res
         }
         float* tl = grad2_emb + (size_t)g.row0 * C;
 #pragma unroll
-        for (int corner = 0; corner < (1 << D); ++corner) {
-            uint32_t q[D];
+        for (int yz = 0; yz < (1 << (D - 1)); ++yz) {
+            uint32_t r[2];
+            float v[2][C];
 #pragma unroll
-            for (int d = 0; d < D; ++d) q[d] = cell[d] + ((corner >> d) & 1);
-            const uint32_t key = active ? level_row<D>(g, q) : 0xFFFFFFFFu;
-            float v[C];
+            for (int xb = 0; xb < 2; ++xb) {
+                const int corner = 2 * yz + xb;
+                uint32_t q[D];
 #pragma unroll
-            for (int c = 0; c < C; ++c) v[c] = k[corner] * gy[c];
-            scatter_runs<C>(tl, key, v, lane);
+                for (int d = 0; d < D; ++d) q[d] = cell[d] + ((corner >> d) & 1);
+                r[xb] = level_row<D>(g, q);
+#pragma unroll
+                for (int c = 0; c < C; ++c) v[xb][c] = k[corner] * gy[c];
+            }
+            scatter_x_pair<C>(tl, r[0], r[1], active, v[0], v[1], lane);
         }
     }
 }

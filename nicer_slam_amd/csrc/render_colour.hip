@@ -350,7 +350,6 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
             const bool active = locate<3>(u, lg.scale, cell, w, dw) && live;
             // scratch: stage buffer 0 -- the last GEMM part (op 5, odd) reads buffer 1, and every wave is past op 4
             float* tile = stage + (threadIdx.x >> 6) * 64 * (2 * CC + 1);
-            const bool pair_mode = !((geom.lv[2 * jl].flags | geom.lv[2 * jl + 1].flags) & LV_HASHED);   // wave-uniform
             uint32_t row[8];
             float wt8[8];
 #pragma unroll
@@ -366,25 +365,16 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
                 row[corner] = lg.row0 + level_row<3>(lg, q);
                 wt8[corner] = wt;
             }
-            if (pair_mode) {        // dense levels: the two x-neighbour corners are adjacent rows -> one 16-byte span
+            // x-neighbour corners leave as one 16-byte span wherever they are adjacent rows (dense levels; even cells of hashed ones)
 #pragma unroll
-                for (int yz = 0; yz < 4; ++yz) {
-                    float v0[CC], v1[CC];
+            for (int yz = 0; yz < 4; ++yz) {
+                float v0[CC], v1[CC];
 #pragma unroll
-                    for (int c = 0; c < CC; ++c) {
-                        v0[c] = wt8[2 * yz] * ib[49 + jl * CC + c];
-                        v1[c] = wt8[2 * yz + 1] * ib[49 + jl * CC + c];
-                    }
-                    scatter_row_pair<CC>(a.g_table, row[2 * yz], row[2 * yz + 1], active, v0, v1, lane, tile);
+                for (int c = 0; c < CC; ++c) {
+                    v0[c] = wt8[2 * yz] * ib[49 + jl * CC + c];
+                    v1[c] = wt8[2 * yz + 1] * ib[49 + jl * CC + c];
                 }
-            } else {
-#pragma unroll
-                for (int corner = 0; corner < 8; ++corner) {
-                    float v[CC];
-#pragma unroll
-                    for (int c = 0; c < CC; ++c) v[c] = wt8[corner] * ib[49 + jl * CC + c];
-                    scatter_runs<CC>(a.g_table, active ? row[corner] : 0xFFFFFFFFu, v, lane, tile);
-                }
+                scatter_x_pair<CC>(a.g_table, row[2 * yz], row[2 * yz + 1], active, v0, v1, lane, tile);
             }
         }
     }

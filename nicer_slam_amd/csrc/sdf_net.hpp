@@ -376,7 +376,6 @@ __device__ __forceinline__ void table_grad_scatter(const float (&x)[3], float di
             }
         }
         // both levels of this iteration dense (uniform across the wave): x-neighbour corners go out as row pairs
-        const bool pair_mode = !((geom.lv[2 * jl].flags | geom.lv[2 * jl + 1].flags) & LV_HASHED);
         uint32_t row[8];
         float wt8[8];
 #pragma unroll
@@ -392,25 +391,15 @@ __device__ __forceinline__ void table_grad_scatter(const float (&x)[3], float di
             row[corner] = lg.row0 + level_row<3>(lg, q);
             wt8[corner] = wt;
         }
-        if (pair_mode) {
 #pragma unroll
-            for (int yz = 0; yz < 4; ++yz) {
-                float v0[C], v1[C];
+        for (int yz = 0; yz < 4; ++yz) {
+            float v0[C], v1[C];
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    v0[c] = fmaf(wt8[2 * yz], hb[20 + jl * C + c], k[2 * yz] * dl[20 + jl * C + c]);
-                    v1[c] = fmaf(wt8[2 * yz + 1], hb[20 + jl * C + c], k[2 * yz + 1] * dl[20 + jl * C + c]);
-                }
-                scatter_row_pair<C>(g_table, row[2 * yz], row[2 * yz + 1], active, v0, v1, lane, lds_tile);
+            for (int c = 0; c < C; ++c) {
+                v0[c] = fmaf(wt8[2 * yz], hb[20 + jl * C + c], k[2 * yz] * dl[20 + jl * C + c]);
+                v1[c] = fmaf(wt8[2 * yz + 1], hb[20 + jl * C + c], k[2 * yz + 1] * dl[20 + jl * C + c]);
             }
-        } else {
-#pragma unroll
-            for (int corner = 0; corner < 8; ++corner) {
-                float v[C];
-#pragma unroll
-                for (int c = 0; c < C; ++c) v[c] = fmaf(wt8[corner], hb[20 + jl * C + c], k[corner] * dl[20 + jl * C + c]);
-                scatter_runs<C>(g_table, active ? row[corner] : 0xFFFFFFFFu, v, lane, lds_tile);
-            }
+            scatter_x_pair<C>(g_table, row[2 * yz], row[2 * yz + 1], active, v0, v1, lane, lds_tile);
         }
     }
 }

@@ -260,12 +260,14 @@ class FusedSdfGradient(torch.autograd.Function):
         need = ctx.needs_input_grad
         st = _stream()
         out = [None, None, None, None, None, None, None]
-        tile = tile_of(model, "coarse")
+        tile = tile_of(model, "coarse_map")
         emit = new_emit(se_rows(1, tile)["ROWS"], N, dev) if need[1] else None
         gt_c = torch.zeros_like(imp.coarse.encoding.embeddings) if need[2] else None
         if emit is not None or gt_c is not None:
+            gcm, keep_cm = sdf_grid_desc(model, "coarse", "coarse_map")
+            pcm = packed_sdf(model, "coarse", use="coarse_map")
             with _timed("k_sdfnet_bwd<coarse,eik>", 0):
-                check(lib.nsa_sdfnet_backward_params(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), None, None,
+                check(lib.nsa_sdfnet_backward_params(ctypes.byref(pts), ctypes.byref(gcm), pcm.data_ptr(), None, None,
                                                      g.data_ptr(), 0, g_x.data_ptr(),
                                                      None if gt_c is None else gt_c.data_ptr(),
                                                      None if emit is None else emit.data_ptr(),

@@ -160,15 +160,19 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
     if want.get("flat_c") or want.get("tab_c"):
         from . import mapping
         enc = imp.coarse.encoding
-        emit = mapping.new_emit(mapping.se_rows(1, tile_of(model, "coarse"))["ROWS"], P, dev) if want.get("flat_c") else None
+        # the MAP backward has its own tiling (the forward's results reach it in tiling-independent layouts only)
+        tile_m = tile_of(model, "coarse_map")
+        gcm, keep_cm = sdf_grid_desc(model, "coarse", "coarse_map")
+        pcm = packed_sdf(model, "coarse", use="coarse_map")
+        emit = mapping.new_emit(mapping.se_rows(1, tile_m)["ROWS"], P, dev) if want.get("flat_c") else None
         gt = torch.zeros_like(enc.embeddings) if want.get("tab_c") else None
         with _timed("k_sdfnet_bwd<coarse,map>", P * 3 * 4 * 8 * 8 * 4):
-            check(lib.nsa_sdfnet_backward_params(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), g_sdf.data_ptr(),
+            check(lib.nsa_sdfnet_backward_params(ctypes.byref(pts), ctypes.byref(gcm), pcm.data_ptr(), g_sdf.data_ptr(),
                                                  g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), ptr(gt),
                                                  ptr(emit), 0 if emit is None else emit.shape[1], st))
         if emit is not None:
             g_sdf_w = g_sdf if order is None else g_sdf[order.long()]       # emission columns are work items
-            pg["flat_c"] = mapping.sdf_flat_grad(emit, g_sdf_w, P, enc.num_levels, enc.level_dim, tile=tile_of(model, "coarse"))
+            pg["flat_c"] = mapping.sdf_flat_grad(emit, g_sdf_w, P, enc.num_levels, enc.level_dim, tile=tile_m)
             del emit
         pg["tab_c"] = gt
     else:

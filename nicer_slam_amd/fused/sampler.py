@@ -39,14 +39,18 @@ def precision_of(model, which):
 # csrc/render_sdfnet4.hip / render_sampler4.hip), 32 = 32-point tiling (lane pair per point, csrc/render_sdfnet.hip /
 # render_sampler.hip).  Both compute the same numbers (tests/test_tiling_gpu.py); the defaults are what measured fastest on
 # MI355X (profiles/r02_*): the fine network (three hidden layers: 256 .. 500 registers per lane at 32 points) runs the quad
-# tiling, the coarse network and the sampler's SDF-only pass the 32-point one.  NSA_SDF_TILE=16|32 or ``model.sdf_tile``
-# force one tiling everywhere.
-DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 32}
+# tiling, the coarse network and the sampler's SDF-only pass the 32-point one -- except the coarse network's MAP backward
+# (parameter gradients: one wave per SIMD at 32 points, two in quad form: 969 -> 748 us per launch at 8192 rays) and the sampler
+# on mapping-sized batches (the persistent quad sampler with LDS-resident weights: 1739 -> 1645 us at 8192 rays, equal at 1024).
+# NSA_SDF_TILE=16|32 or ``model.sdf_tile`` force one tiling everywhere.
+DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 32, "coarse_map": 16, "sampler_large": 16}
+SAMPLER_LARGE_RAYS = 4096
 _FORCE = int(os.environ.get("NSA_SDF_TILE", "0"))
 
 
 def tile_of(model, which):
-    """``which``: "coarse" / "fine" (composite-pass kernels of that network) or "sampler" (SDF-only pass, both networks)."""
+    """``which``: "coarse" / "fine" (composite-pass kernels of that network), "coarse_map" (the coarse network's MAP backward),
+    "sampler" / "sampler_large" (SDF-only pass, both networks; by batch size)."""
     t = int(getattr(model, "sdf_tile", 0) or _FORCE or DEFAULT_TILES[which])
     if t not in (16, 32):
         raise ValueError(f"sdf_tile must be 16 or 32, got {t}")
@@ -122,9 +126,10 @@ def sampler_sdf(model, rays_o, rays_d, t_rand):
     R, E = rays_o.shape[0], samp.N_samples_eval
     dev = rays_o.device
     imp = model.implicit_network
-    gc, keep_c = sdf_grid_desc(model, "coarse", "sampler")
-    gf, keep_f = sdf_grid_desc(model, "fine", "sampler")
-    pc, pf = packed_sdf(model, "coarse", use="sampler"), packed_sdf(model, "fine", use="sampler")
+    use = "sampler_large" if R >= SAMPLER_LARGE_RAYS else "sampler"
+    gc, keep_c = sdf_grid_desc(model, "coarse", use)
+    gf, keep_f = sdf_grid_desc(model, "fine", use)
+    pc, pf = packed_sdf(model, "coarse", use=use), packed_sdf(model, "fine", use=use)
     z = torch.empty(R, E, device=dev)
     sdf = torch.empty(R, E, device=dev)
     far = torch.empty(R, device=dev)

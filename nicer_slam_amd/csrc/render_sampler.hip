@@ -47,8 +47,11 @@ __device__ __forceinline__ float cube_far(const float (&o)[3], const float (&d)[
     return fminf(farv, far_cap);
 }
 
+#ifndef NSA_OCC_SAMPLER
+#define NSA_OCC_SAMPLER 2      // (asks for <= 256 registers; the kernel needs 167: three waves per SIMD.  4 = 128 registers spills 60+)
+#endif
 template <int LC, int CC, int NHC, int LF, int CF, int NHF>
-__global__ __launch_bounds__(256, 2) void k_sampler_sdf(SamplerArgs a, GridGeom16 gc, GridGeom16 gf) {
+__global__ __launch_bounds__(256, NSA_OCC_SAMPLER) void k_sampler_sdf(SamplerArgs a, GridGeom16 gc, GridGeom16 gf) {
     desync_simd_partners();
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;

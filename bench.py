@@ -67,6 +67,9 @@ def parse():
                     help="also produce (and discard) table/MLP gradients like the reference's tracking loop")
     ap.add_argument("--chunks", type=int, default=1,
                     help="KernelTracker: independent ray chunks on their own HIP streams inside the graph (fork / join)")
+    ap.add_argument("--graph-collective", action="store_true",
+                    help="N > 1: capture the 9-float all-reduce and the Adam step into the hipGraph too (default: env "
+                         "NSA_GRAPH_COLLECTIVE; off)")
     ap.add_argument("--no-graph", action="store_true", help="launch every op eagerly instead of replaying a hipGraph")
     ap.add_argument("--autograd", action="store_true",
                     help="drive the model through torch autograd (TrackingStepper) instead of the kernel sequence")
@@ -158,9 +161,10 @@ def main():
     from nicer_slam_amd.tracking import TrackingStepper, KernelTracker
     use_graph = not args.no_graph and not args.param_grads
     Stepper = TrackingStepper if (args.autograd or args.param_grads) else KernelTracker
-    extra = {"chunks": args.chunks} if Stepper is KernelTracker else {}
+    extra = {"chunks": args.chunks, "graph_collective": True if args.graph_collective else None} if Stepper is KernelTracker else {}
     stepper = Stepper(model, K, args.rays, cam, lr=0.005, use_graph=use_graph, world=world, **extra)
     ray_chunks = getattr(stepper, "chunks", 1)
+    collective_in_graph = bool(getattr(stepper, "collective_in_graph", False))
 
     def step(i):
         uv, gt = batches[i]
@@ -273,7 +277,8 @@ def main():
                        "hip_graph": bool(use_graph), "driver": Stepper.__name__, "ray_chunks": ray_chunks, "clock_prewarm_s": args.prewarm_s,
                        "parallelism": f"ray-shard x{world}" if world > 1 else "single",
                        "rccl_ranks": 0 if (world == 1 or oversub) else world,
-                       "exchange": None if world == 1 else "one 9-float all-reduce (pose gradient, loss, ray count) per step",
+                       "exchange": None if world == 1 else "one 9-float all-reduce (pose gradient, loss, ray count) per step"
+                                   + (", captured in the hipGraph" if collective_in_graph else ", between graph replay and Adam launch"),
                        "oversubscribed": oversub or None},
             "final_loss": round(last, 6),
             "roofline": roof, "cpu_baseline": cpu, "dropin": dropin, "mapping_iteration": mapping,

@@ -30,7 +30,7 @@ class KernelTracker:
     other's tails.  Same arithmetic per ray; the ray sums are added chunk by chunk."""
 
     def __init__(self, model, intrinsics, n_rays, cam_init, lr=0.005, betas=(0.9, 0.999), eps=1e-8, lr_step=0,
-                 lr_gamma=1.0, use_graph=True, world=1, stage="fine", color_stage="highfreq", chunks=1):
+                 lr_gamma=1.0, use_graph=True, world=1, stage="fine", color_stage="highfreq", chunks=1, graph_collective=None):
         from .fused import render as fr, sampler as fs
         if not fr.supported(model):
             raise RuntimeError("KernelTracker: configuration outside the fused engine's compiled set")
@@ -50,6 +50,13 @@ class KernelTracker:
         self.best[0] = 1e10                                                 # current_min_loss (volsdf_train.py:403)
         self.rays_o, self.rays_d, self.ds = z(n_rays, 3), z(n_rays, 3), z(n_rays)
         self.g_rgbv = z(n_rays, 3)
+        # multi-GPU: capture the 9-float all-reduce and the Adam step into the graph as well (RCCL collectives can be captured;
+        # every rank captures the same sequence).  Opt-in (NSA_GRAPH_COLLECTIVE=1 or graph_collective=True): the build boxes have
+        # one GPU, so only the 1-rank form of the captured collective could be exercised (tests/test_fused_gpu.py).
+        import os
+        if graph_collective is None:
+            graph_collective = os.environ.get("NSA_GRAPH_COLLECTIVE", "0") == "1"
+        self.collective_in_graph = bool(graph_collective and use_graph and world > 1)
         self.chunks = max(1, min(int(chunks), n_rays))
         if self.chunks > 1:
             from .dist import shard_rays
@@ -114,7 +121,10 @@ class KernelTracker:
 
     def _iteration(self):
         if self.chunks == 1:
-            return self._rays_pass(0, self.R, self.pose, self.red)
+            self._rays_pass(0, self.R, self.pose, self.red)
+            if self.collective_in_graph:
+                self._exchange()
+            return
         cur = torch.cuda.current_stream()
         for c, side in enumerate(self.streams):          # fork
             side.wait_stream(cur)
@@ -125,6 +135,14 @@ class KernelTracker:
         torch.sum(self.red_c, 0, out=self.red)
         if self.world == 1:
             self._update()
+        elif self.collective_in_graph:
+            self._exchange()
+
+    def _exchange(self):
+        """weighted mean over the global ray batch: the tail kernel(s) left the 9-float message"""
+        import torch.distributed as dist
+        dist.all_reduce(self.red)
+        self._update()
 
     def _update(self):
         """Adam on the (chunk-summed, all-reduced) message, gradient = red[0..6] / red[8]"""
@@ -157,10 +175,8 @@ class KernelTracker:
                 self.graph.replay()
             else:
                 self._iteration()
-            if self.world > 1:      # weighted mean over the global ray batch: the tail kernel left the 9-float message
-                import torch.distributed as dist
-                dist.all_reduce(self.red)
-                self._update()
+            if self.world > 1 and not self.collective_in_graph:
+                self._exchange()
         return self.loss
 
 

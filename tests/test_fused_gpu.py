@@ -318,10 +318,16 @@ def test_kernel_tracker_multi_gpu_message_path_single_rank_group():
         many = KernelTracker(model, K, uv.shape[1], cam0, lr=0.005, use_graph=True, world=2)   # forces the message path
         l2 = [float(many.step(uv, gt)) for _ in range(4)]
         assert float(many.red[8]) == float(uv.shape[1])
+        # the same with the all-reduce and the Adam step captured into the hipGraph (opt-in)
+        cap = KernelTracker(model, K, uv.shape[1], cam0, lr=0.005, use_graph=True, world=2, graph_collective=True)
+        assert cap.collective_in_graph
+        l3 = [float(cap.step(uv, gt)) for _ in range(4)]
     finally:
         dist.destroy_process_group()
     assert_close(torch.tensor(l2), torch.tensor(l1), 1e-6, 1e-5, "losses")
     assert_close(many.cam, one.cam, 1e-6, 1e-5, "camera after 4 steps")
+    assert_close(torch.tensor(l3), torch.tensor(l1), 1e-6, 1e-5, "losses, captured collective")
+    assert_close(cap.cam, one.cam, 1e-6, 1e-5, "camera after 4 steps, captured collective")
 
 
 @pytest.mark.parametrize("chunks", [2, 3])

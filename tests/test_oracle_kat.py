@@ -71,3 +71,96 @@ def test_level_geometry_matches_python_layout(name):
         frac = scale - np.floor(scale)
         assert frac == 0.0 or 1e-3 < frac < 1 - 1e-3, (lv, scale)
     assert spec.n_rows == {"coarse": 131072, "fine": 2333247, "colour": 133023682}[name]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# An independent restatement of kernel_grid (hashencoder.cu:131-283) in pure Python: arbitrary-precision ints masked to 32 bits
+# for the index rule (:35-73), numpy float32 scalars for the interpolation.  It shares no code with oracle/hashenc_oracle.c and
+# pins the C oracle on HASHED levels (and on the wrapped dense level) beyond the hand-computed vectors above: a wrong index picks
+# a different random table row, so any disagreement is O(1), not a rounding matter.
+M32 = 0xFFFFFFFF
+PRIMES = (1, 2654435761, 805459861)
+
+
+def _py_index(cell, rows, res):
+    stride, index, d = 1, 0, 0
+    while d < 3 and stride <= rows:                      # get_grid_index :56-62, uint32 arithmetic
+        index = (index + cell[d] * stride) & M32
+        stride = (stride * res) & M32
+        d += 1
+    if stride > rows:                                    # :65-67
+        index = 0
+        for c, p in zip(cell, PRIMES):
+            index ^= (c * p) & M32
+    return index % rows
+
+
+def _py_level(x, level, offsets, S, H, table, C, hashed_seen):
+    f32 = np.float32
+    rows = int(offsets[level + 1] - offsets[level])
+    # :180  exp2f of the float32 product; evaluated in float64 and rounded once (= a correctly rounded exp2f, which glibc's is to
+    # within the last ulp -- numpy's own float32 exp2 is not, and one ulp of scale moves a coordinate of ~2000 cells by 1e-4)
+    scale = f32(np.exp2(np.float64(f32(level) * f32(S)))) * f32(H) - f32(1.0)
+    res = int(np.ceil(scale)) + 1                                                  # :181
+    pos = [f32(v) * scale for v in x]
+    cell = [int(np.floor(p)) for p in pos]
+    t = [p - f32(c) for p, c in zip(pos, cell)]
+    w = [v * v * (f32(3.0) - f32(2.0) * v) for v in t]                             # smoothstep
+    dw = [f32(6.0) * v * (f32(1.0) - v) for v in t]
+    stride, d = 1, 0
+    while d < 3 and stride <= rows:
+        stride = (stride * res) & M32
+        d += 1
+    hashed_seen.append(stride > rows)
+    out = np.zeros(C, dtype=np.float32)
+    corner_val = {}
+    for idx in range(8):
+        wt, q = f32(1.0), []
+        for dd in range(3):
+            bit = (idx >> dd) & 1
+            wt = wt * (w[dd] if bit else f32(1.0) - w[dd])
+            q.append(cell[dd] + bit)
+        v = table[int(offsets[level]) + _py_index(q, rows, res)]
+        corner_val[idx] = v
+        out = out + wt * v
+    jac = np.zeros((3, C), dtype=np.float32)                                       # :239-282
+    for gd in range(3):
+        for face in range(4):
+            wt, lo, nd = scale, 0, 0
+            for dd in range(3):
+                if dd == gd:
+                    continue
+                if (face >> nd) & 1:
+                    wt = wt * w[dd]
+                    lo |= 1 << dd
+                else:
+                    wt = wt * (f32(1.0) - w[dd])
+                nd += 1
+            jac[gd] += wt * (corner_val[lo | (1 << gd)] - corner_val[lo]) * dw[gd]
+    return out, jac
+
+
+@pytest.mark.parametrize("name,L,C,base,desired,log2", [("colour-like, 2^15 rows", 16, 2, 16, 2048, 15),
+                                                        ("fine SDF grid", 8, 4, 32, 128, 19)])
+def test_hashed_levels_vs_pure_python_restatement(name, L, C, base, desired, log2):
+    import torch
+    from nicer_slam_amd.hashencoder.hashgrid import level_layout
+    per_level_scale = np.exp2(np.log2(desired / base) / (L - 1))
+    offsets = np.asarray(level_layout(3, L, per_level_scale, base, log2), dtype=np.int64)
+    S = float(np.log2(per_level_scale))
+    rng = np.random.default_rng(7)
+    table = rng.uniform(-1, 1, size=(int(offsets[-1]), C)).astype(np.float32)
+    B = 48
+    x = rng.uniform(0.02, 0.98, size=(B, 3)).astype(np.float32)
+    out = torch.zeros(L, B, C)
+    dy = torch.zeros(B, L * 3 * C)
+    hashenc.OracleBackend.hash_encode_forward(torch.from_numpy(x), torch.from_numpy(table), torch.from_numpy(offsets.astype(np.int32)),
+                                              out, B, 3, C, L, S, base, True, dy)
+    dy = dy.view(B, L, 3, C).numpy()
+    hashed = []
+    for b in range(B):
+        for level in range(L):
+            ref, jac = _py_level(x[b], level, offsets, S, base, table, C, hashed)
+            np.testing.assert_allclose(out[level, b].numpy(), ref, rtol=2e-5, atol=2e-6, err_msg=f"{name}: point {b} level {level}")
+            np.testing.assert_allclose(dy[b, level], jac, rtol=2e-4, atol=2e-4 * float(np.abs(jac).max() + 1), err_msg=f"{name}: J {b} {level}")
+    assert any(hashed) and not all(hashed)           # the case covers hashed AND dense levels

@@ -333,6 +333,36 @@ __device__ __forceinline__ void gemm_op(const float* __restrict__ wp, int lane, 
     gemm_run<KS, MT>(wp, lane, f, b, acc);
 }
 
+// The same for T point tiles per wave: one weight fragment stream feeds T independent accumulator sets, so the fragment traffic
+// (3 KiB per slot group and output tile, the L1's whole 64 B/clk when the wave is MFMA-bound) is paid once per T tiles, and the
+// operand split of tile t + 1 issues while the matrix cores work on tile t.
+template <int KS, int MT, int T>
+__device__ __forceinline__ void gemm_op_tiles(const float* __restrict__ wp, int lane, const float (&b)[T][KS], f32x16 (&acc)[T][MT]) {
+    constexpr int KS8 = (KS + 7) / 8;
+    const uint4* __restrict__ w4 = reinterpret_cast<const uint4*>(wp) + lane;
+    AFrag<MT> f;
+    gemm_preload<KS, MT>(wp, lane, f);
+#pragma unroll
+    for (int g = 0; g < KS8; ++g) {
+        uint4 a[MT][3];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int pc = 0; pc < kPieces; ++pc) {
+                a[mt][pc] = f.g[mt][pc];
+                if (g + 1 < KS8) f.g[mt][pc] = w4[((mt * KS8 + g + 1) * 3 + pc) * 64];
+            }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? b[t][8 * g + e] : 0.0f;
+            mma_group<MT>(a, x, acc[t]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // Load a packed per-feature vector (bias) for MT tiles into accumulator layout.
 template <int MT>
 __device__ __forceinline__ void load_vec(const float* __restrict__ vp, int h, f32x16 (&acc)[MT]) {

@@ -50,29 +50,20 @@ __device__ __forceinline__ float cube_far(const float (&o)[3], const float (&d)[
 #ifndef NSA_OCC_SAMPLER
 #define NSA_OCC_SAMPLER 2      // (asks for <= 256 registers; the kernel needs 167: three waves per SIMD.  4 = 128 registers spills 60+)
 #endif
-template <int LC, int CC, int NHC, int LF, int CF, int NHF>
-__global__ __launch_bounds__(256, NSA_OCC_SAMPLER) void k_sampler_sdf(SamplerArgs a, GridGeom16 gc, GridGeom16 gf) {
-    desync_simd_partners();
-    const int lane = threadIdx.x & 63;
-    const int h = lane >> 5;
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint64_t total = (uint64_t)a.R * a.E;
-    uint64_t pid = (uint64_t)wave * 32 + (lane & 31);
-    const bool live = pid < total;
-    if (!live) pid = total - 1;                 // keep the wave converged for the MFMAs; store is predicated
-    const uint32_t ray = (uint32_t)(pid / a.E);
-    const uint32_t i = (uint32_t)(pid - (uint64_t)ray * a.E);
 
+// sample position i of ray `ray`: stratified z and the point (ray_sampler.py:49-59); every product rounded separately, as the
+// reference's elementwise torch ops do (see mul_rn)
+__device__ __forceinline__ void sampler_point(const SamplerArgs& a, uint64_t pid, uint32_t ray, uint32_t i, float (&x)[3], float& zi,
+                                              float& farv) {
     float o[3], d[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { o[k] = a.rays_o[ray * 3 + k]; d[k] = a.rays_d[ray * 3 + k]; }
-    const float farv = cube_far(o, d, a.bound, a.far_cap, a.near);
+    farv = cube_far(o, d, a.bound, a.far_cap, a.near);
     const float nearv = a.near;
-    // z_lin(i) = near (1 - t_i) + far t_i ; stratified: lower + (upper - lower) * rand   (ray_sampler.py:49-59)
+    // z_lin(i) = near (1 - t_i) + far t_i ; stratified: lower + (upper - lower) * rand
     const uint32_t E = a.E;
     const float ti = a.t_lin[i];
-    // every product rounded separately, as the reference's elementwise torch ops do (see mul_rn)
-    float zi = mul_rn(nearv, 1.0f - ti) + mul_rn(farv, ti);
+    zi = mul_rn(nearv, 1.0f - ti) + mul_rn(farv, ti);
     if (a.t_rand) {
         const float tp = a.t_lin[i + 1 < E ? i + 1 : i], tm = a.t_lin[i > 0 ? i - 1 : 0];
         const float zp = mul_rn(nearv, 1.0f - tp) + mul_rn(farv, tp);
@@ -81,20 +72,47 @@ __global__ __launch_bounds__(256, NSA_OCC_SAMPLER) void k_sampler_sdf(SamplerArg
         const float lower = i > 0 ? 0.5f * (zi + zm) : zi;
         zi = lower + mul_rn(upper - lower, a.t_rand[pid]);
     }
-    float x[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) x[k] = o[k] + mul_rn(zi, d[k]);
+}
 
-    float in[SDF_IN_STEPS];
-    pe_slots(x, h, in);                         // shared by both networks
-    grid_slots<LC, CC>(x, a.df_c, a.table_c, gc, h, in);
-    float sdf = sdf_only<NHC>(a.wp_c, lane, h, in);
-    grid_slots<LF, CF>(x, a.df_f, a.table_f, gf, h, in);
-    sdf += sdf_only<NHF>(a.wp_f, lane, h, in);
-    if (live && h == 0) {
-        a.z[pid] = zi;
-        a.sdf[pid] = sdf;
-        if (i == 0) a.far[ray] = farv;
+// T = point tiles (of 32 points) per wave.  T = 1: the round-1 form, 167 registers, three waves per SIMD.  T = 2: one weight
+// fragment stream serves both tiles (sdf_only_tiles), two waves per SIMD.
+template <int LC, int CC, int NHC, int LF, int CF, int NHF, int T>
+__global__ __launch_bounds__(256, NSA_OCC_SAMPLER) void k_sampler_sdf(SamplerArgs a, GridGeom16 gc, GridGeom16 gf) {
+    desync_simd_partners();
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t total = (uint64_t)a.R * a.E;
+    uint64_t pid[T];
+    bool live[T];
+    uint32_t ray[T], idx[T];
+    float x[T][3], zi[T], farv[T];
+    float in[T][SDF_IN_STEPS];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        pid[t] = ((uint64_t)wave * T + t) * 32 + (lane & 31);
+        live[t] = pid[t] < total;
+        if (!live[t]) pid[t] = total - 1;       // keep the wave converged for the MFMAs; store is predicated
+        ray[t] = (uint32_t)(pid[t] / a.E);
+        idx[t] = (uint32_t)(pid[t] - (uint64_t)ray[t] * a.E);
+        sampler_point(a, pid[t], ray[t], idx[t], x[t], zi[t], farv[t]);
+        pe_slots(x[t], h, in[t]);               // shared by both networks
+        grid_slots<LC, CC>(x[t], a.df_c, a.table_c, gc, h, in[t]);
+    }
+    float sdf[T], sdf_f[T];
+    sdf_only_tiles<NHC, T>(a.wp_c, lane, h, in, sdf);
+#pragma unroll
+    for (int t = 0; t < T; ++t) grid_slots<LF, CF>(x[t], a.df_f, a.table_f, gf, h, in[t]);
+    sdf_only_tiles<NHF, T>(a.wp_f, lane, h, in, sdf_f);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        if (live[t] && h == 0) {
+            a.z[pid[t]] = zi[t];
+            a.sdf[pid[t]] = sdf[t] + sdf_f[t];
+            if (idx[t] == 0) a.far[ray[t]] = farv[t];
+        }
     }
 }
 
@@ -412,10 +430,13 @@ int NSA_ENTRY(nsa_sampler_sdf)(const float* rays_o, const float* rays_d, uint32_
     SamplerArgs a{rays_o, rays_d, t_lin, t_rand, z, sdf, far, R, E, near, bound, far_cap,
                   coarse->table, fine->table, packed_coarse, packed_fine, coarse->divide_factor, fine->divide_factor};
     const uint64_t total = (uint64_t)R * E;
-    const uint32_t waves = (uint32_t)((total + 31) / 32);
+    const bool two = coarse->tile == 64;                  // 64: 32-point tiling, two tiles per wave
+    if (two != (fine->tile == 64)) return NSA_EBADARG;
+    const uint32_t waves = (uint32_t)((total + (two ? 63 : 31)) / (two ? 64 : 32));
     const uint32_t blocks = (waves + 3) / 4;
     launch_begin();
-    hipLaunchKernelGGL((k_sampler_sdf<4, 8, 1, 8, 4, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, gc, gf);
+    if (two) hipLaunchKernelGGL((k_sampler_sdf<4, 8, 1, 8, 4, 3, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, gc, gf);
+    else     hipLaunchKernelGGL((k_sampler_sdf<4, 8, 1, 8, 4, 3, 1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, gc, gf);
     return launch_end();
 }
 

@@ -143,6 +143,42 @@ __device__ __forceinline__ float sdf_only(const float* __restrict__ wp, int lane
     return xhalf_sum(part) + wp[P::kBSDF];
 }
 
+// The same for T point tiles per wave (gemm_op_tiles): in[t] / the result of tile t.
+template <int NH, int T>
+__device__ __forceinline__ void sdf_only_tiles(const float* __restrict__ wp, int lane, int h, const float (&in)[T][SDF_IN_STEPS],
+                                               float (&sdf)[T]) {
+    using P = SdfPack<NH>;
+    f32x16 acc[T][2];
+#pragma unroll
+    for (int t = 0; t < T; ++t) load_vec<2>(wp + P::kB0, h, acc[t]);
+    gemm_op_tiles<SDF_IN_STEPS, 2, T>(wp + P::kW0, lane, in, acc);
+    float act[T][HS];
+#pragma unroll
+    for (int k = 1; k < NH; ++k) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) act[t][16 * mt + r] = softplus100(acc[t][mt][r]);
+            load_vec<2>(wp + P::bh(k), h, acc[t]);
+        }
+        gemm_op_tiles<HS, 2, T>(wp + P::wh(k), lane, act, acc);
+    }
+    f32x16 ws[2];
+    load_vec<2>(wp + P::kWSDF, h, ws);
+    const float bias = wp[P::kBSDF];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        float part = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part = fmaf(softplus100(acc[t][mt][r]), ws[mt][r], part);
+        sdf[t] = xhalf_sum(part) + bias;
+    }
+}
+
 }  // namespace nsa
 
 namespace nsa {

@@ -43,17 +43,23 @@ def precision_of(model, which):
 # (parameter gradients: one wave per SIMD at 32 points, two in quad form: 969 -> 748 us per launch at 8192 rays) and the sampler
 # on mapping-sized batches (the persistent quad sampler with LDS-resident weights: 1739 -> 1645 us at 8192 rays, equal at 1024).
 # NSA_SDF_TILE=16|32 or ``model.sdf_tile`` force one tiling everywhere.
-DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 32, "coarse_map": 16, "sampler_large": 16}
+# "sampler": 64 = the 32-point tiling with TWO point tiles per wave: one weight-fragment stream feeds both tiles and the
+# operand split of one overlaps the matrix instructions of the other; bit-identical results, 2 waves per SIMD instead of 3,
+# 208-214 -> 206 us (profiles/r02_ab_experiments.txt r3b).
+DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 64, "coarse_map": 16, "sampler_large": 16}
 SAMPLER_LARGE_RAYS = 4096
 _FORCE = int(os.environ.get("NSA_SDF_TILE", "0"))
+_FORCE_SAMPLER = int(os.environ.get("NSA_SAMPLER_TILE", "0"))      # A/B runs of the sampler pass alone: 16 | 32 | 64
 
 
 def tile_of(model, which):
     """``which``: "coarse" / "fine" (composite-pass kernels of that network), "coarse_map" (the coarse network's MAP backward),
     "sampler" / "sampler_large" (SDF-only pass, both networks; by batch size)."""
     t = int(getattr(model, "sdf_tile", 0) or _FORCE or DEFAULT_TILES[which])
-    if t not in (16, 32):
-        raise ValueError(f"sdf_tile must be 16 or 32, got {t}")
+    if which.startswith("sampler") and _FORCE_SAMPLER and not getattr(model, "sdf_tile", 0):
+        t = _FORCE_SAMPLER
+    if t not in (16, 32) and not (t == 64 and which.startswith("sampler")):
+        raise ValueError(f"sdf_tile must be 16 or 32 (64 = 32-point tiling with two tiles per wave, sampler only), got {t}")
     return t
 
 

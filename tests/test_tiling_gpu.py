@@ -80,11 +80,13 @@ def test_sampler_sdf_stage_both_tilings():
         o = (torch.rand(R, 3, device="cuda", generator=g) - 0.5) * 0.4
         t_rand = torch.rand(R, 640, device="cuda", generator=g)
         res = {}
-        for tile in (16, 32):
+        for tile in (16, 32, 64):               # 64 = 32-point tiling, two point tiles per wave (the tracking default)
             model.sdf_tile = tile
             res[tile] = fs.sampler_sdf(model, o, d, t_rand)
         for a, b, what in zip(res[16], res[32], ("z", "sdf", "far")):
             assert_close(a, b.cpu().numpy(), 1e-6 if what == "sdf" else 0, 1e-5 if what == "sdf" else 0, f"{what} (R={R})")
+        for a, b, what in zip(res[64], res[32], ("z", "sdf", "far")):
+            assert torch.equal(a, b), f"two tiles per wave: {what} differs from one tile per wave (R={R})"
     pts = (torch.rand(100003, 3, device="cuda", generator=g) * 2 - 1) * 1.2
     for stage in ("fine", "coarse"):
         vals = {}

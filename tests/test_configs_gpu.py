@@ -20,11 +20,23 @@ class _DS:
 
 @pytest.mark.parametrize("poisson", [False, True])
 def test_config0_256_rays_64_samples_vs_oracle(poisson):
+    _check_shape(256, 64, poisson)
+
+
+@pytest.mark.parametrize("Rn,S,what", [(128, 128, "configs[1] / [2]: 128 samples per ray (the bench shape), reduced ray count"),
+                                       (96, 192, "configs[4]: 192 samples per ray, reduced ray count")])
+def test_other_config_sample_counts_vs_oracle(Rn, S, what):
+    """The per-ray kernels' shapes depend on S (LDS tiles, wave-scan lengths, sort width), not on the ray count: the remaining
+    BASELINE sample counts at a ray count the oracle renders in about a second."""
+    _check_shape(Rn, S, False)
+
+
+def _check_shape(Rn, S, poisson):
     from nicer_slam_amd.model.network import SLAMNetwork
     from nicer_slam_amd.utils.conf import replica_model_conf
     from nicer_slam_amd.utils.general import get_camera_from_tensor
     from oracle import render_ref as R
-    Rn, S, E, NX = 256, 64, 640, 32
+    E, NX = 640, 32
     torch.manual_seed(0)
     model = SLAMNetwork(replica_model_conf(S - 2 - NX, E, NX, use_warp_loss=False), dataset=_DS(), n_images=1).cuda().train()
     g = torch.Generator(device="cuda").manual_seed(3)

@@ -16,8 +16,47 @@ def quad2rotation(quad):
     return torch.stack([r0, r1, r2], 1)
 
 
+class _CamToPose(torch.autograd.Function):
+    """cam[b,7] -> pose[b,4,4] and its backward as ONE kernel each (csrc/track_tail.hip: k_cam_to_pose / k_pose_grad_to_cam,
+    C ABI nsa_cam_to_pose / nsa_pose_grad_to_cam) instead of the ~45 + ~90 element-wise launches torch makes of quad2rotation and
+    its autograd graph -- per iteration of the reference's tracking loop that is a third of all launches."""
+
+    @staticmethod
+    def forward(ctx, cam):
+        from .._native import lib, check
+        cam = cam.contiguous()
+        pose = torch.empty(cam.shape[0], 4, 4, device=cam.device, dtype=torch.float32)
+        check(lib.nsa_cam_to_pose(cam.data_ptr(), cam.shape[0], pose.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        ctx.save_for_backward(cam)
+        return pose
+
+    @staticmethod
+    def backward(ctx, g_pose):
+        from .._native import lib, check
+        (cam,) = ctx.saved_tensors
+        g_pose = g_pose.contiguous()
+        g_cam = torch.empty_like(cam)
+        check(lib.nsa_pose_grad_to_cam(cam.data_ptr(), g_pose.data_ptr(), cam.shape[0], g_cam.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream))
+        return g_cam
+
+
 def get_camera_from_tensor(inputs):
-    """7-vector (quaternion wxyz, translation) -> 4x4 camera-to-world (general.py:79-100)."""
+    """7-vector (quaternion wxyz, translation) -> 4x4 camera-to-world (general.py:79-100).  Device float32 tensors go through the
+    HIP kernel pair (forward + backward); anything else through the torch restatement below."""
+    single = inputs.dim() == 1
+    if single:
+        inputs = inputs.unsqueeze(0)
+    if inputs.is_cuda and inputs.dtype == torch.float32 and inputs.shape[-1] == 7:
+        RT = _CamToPose.apply(inputs)
+        return RT[0] if single else RT
+    return camera_from_tensor_torch(inputs[0] if single else inputs)
+
+
+def camera_from_tensor_torch(inputs):
+    """The same map with torch ops in the reference's operation order (general.py:52-100), on any device.  The kernel agrees with it
+    to the last ulps; where a test needs the pose bit-for-bit as the reference's ops build it (a ray's far sample sits exactly on
+    the cube face), it asks for this one."""
     single = inputs.dim() == 1
     if single:
         inputs = inputs.unsqueeze(0)

@@ -28,6 +28,24 @@ def test_a17_cam_to_pose_kernel(fx):
     assert_close(pose, fx["a17_pose"], 1e-6, 1e-6, "pose")
 
 
+def test_a17_get_camera_from_tensor_on_the_device_is_the_kernel_pair(fx):
+    """nicer_slam_amd.utils.general.get_camera_from_tensor on a device tensor = one HIP kernel forward, one backward: the value
+    against the reference golden, the gradient against torch autograd through the restated quad2rotation (non-unit quaternions)."""
+    from nicer_slam_amd.utils import general as G
+    cam = tt(fx["a17_cam"]).cuda().contiguous().requires_grad_(True)
+    pose = G.get_camera_from_tensor(cam)
+    assert pose.grad_fn is not None and "CamToPose" in type(pose.grad_fn).__name__
+    assert_close(pose, fx["a17_pose"], 1e-6, 1e-6, "pose")
+    g = torch.randn(pose.shape, generator=torch.Generator().manual_seed(0)).cuda()
+    (pose * g).sum().backward()
+    cam_c = tt(fx["a17_cam"]).clone().requires_grad_(True)
+    (G.get_camera_from_tensor(cam_c) * g.cpu()).sum().backward()          # CPU tensors: the torch restatement
+    assert_close(cam.grad, cam_c.grad, 1e-6, 1e-5, "d/d cam")
+    one = G.get_camera_from_tensor(cam.detach()[0])                       # single 7-vector -> [4,4]
+    assert one.shape == (4, 4)
+    assert_close(one, fx["a17_pose"][0], 1e-6, 1e-6, "single pose")
+
+
 def test_a1_rays_kernel(fx):
     from nicer_slam_amd._native import lib, check
     uv, K, pose = tt(fx["a1_uv"]).cuda().contiguous(), tt(fx["a1_K"]).cuda().contiguous(), tt(fx["a1_pose"]).cuda().contiguous()

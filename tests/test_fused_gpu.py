@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _setup(name):
-    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    from nicer_slam_amd.utils.general import camera_from_tensor_torch as get_camera_from_tensor   # the reference's op order: golden comparison (on-face far samples)
     from nicer_slam_amd.utils import rend_util
     fx = load(name)
     model = build_model(fx).cuda()

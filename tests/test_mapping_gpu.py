@@ -14,7 +14,7 @@ FROZEN = "implicit_network.fine.lin"     # fine SDF MLP: pretrained, not in the 
 
 
 def _run(fx, engine, ground_truth=None):
-    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    from nicer_slam_amd.utils.general import camera_from_tensor_torch as get_camera_from_tensor   # the reference's op order: golden comparison (on-face far samples)
     model = build_model(fx).cuda()
     model.freeze_fine_mlp()
     model.engine = engine
@@ -75,7 +75,7 @@ def test_fused_engine_every_parameter_gradient_like_the_reference(name):
     skip-policies switched off (tracking_param_grads, fine_mlp_grads): the fused engine then produces what the reference's
     autograd produces, tracking and mapping alike, incl. the fine SDF MLP (976 emission rows from k_sdfnet_bwd<fine, MAP>).
     Every named parameter's gradient vs the reference golden."""
-    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    from nicer_slam_amd.utils.general import camera_from_tensor_torch as get_camera_from_tensor   # the reference's op order: golden comparison (on-face far samples, DESIGN 5)
     fx = load(name)
     model = build_model(fx).cuda()
     assert all(p.requires_grad for p in model.parameters())

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_mapping", "full_mapping_coarse_base",
                                   "full_vis_eval", "full_tracking_rw", "full_mapping_rw", "full_mapping_rw_coarse"])
 def test_forward_and_grads_vs_reference_goldens(name, engine):
-    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    from nicer_slam_amd.utils.general import camera_from_tensor_torch as get_camera_from_tensor   # the reference's op order: golden comparison (on-face far samples)
     fx = load(name)
     model = build_model(fx).cuda()
     model.engine = engine
@@ -48,7 +48,7 @@ def test_forward_and_grads_vs_reference_goldens(name, engine):
 
 def test_patch_warp_block_on_gpu():
     """Mapping mode incl. the patch-warp gather (composed engine on the GPU) vs the reference golden."""
-    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    from nicer_slam_amd.utils.general import camera_from_tensor_torch as get_camera_from_tensor   # the reference's op order: golden comparison (on-face far samples, DESIGN 5)
     fx = load("full_mapping_warp")
     model = build_model(fx).cuda()
     model.train(True)

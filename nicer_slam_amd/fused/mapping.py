@@ -198,6 +198,7 @@ class FusedCompositeParams(torch.autograd.Function):
         ctx.bufs, ctx.model, ctx.stage, ctx.color_stage = b, model, stage, color_stage
         sdf_o, rgb_o, grad_o = b["sdf"].view(R, S), b["rgb"].view(R, S, 3), b["grad"]
         ctx.mark_non_differentiable(sdf_o, rgb_o, grad_o)
+        ctx.set_materialize_grads(False)      # outputs the loss does not use arrive as None (a NULL cotangent), not as zero fills
         return b["rgb_values"], b["depth"].unsqueeze(-1), b["nmap"], b["weights"], b["entropy"], sdf_o, rgb_o, grad_o
 
     @staticmethod

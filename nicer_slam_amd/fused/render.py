@@ -217,6 +217,7 @@ class FusedComposite(torch.autograd.Function):
         b = composite_forward_raw(model, rays_o, rays_d, z_vals, stage, any(ctx.needs_input_grad[:2]))
         ctx.save_for_backward(rays_o, rays_d, z_vals)
         ctx.bufs, ctx.model, ctx.stage, ctx.color_stage = b, model, stage, color_stage
+        ctx.set_materialize_grads(False)      # outputs the loss does not use arrive as None (a NULL cotangent), not as zero fills
         sdf_o, rgb_o, grad_o = b["sdf"].view(R, S), b["rgb"].view(R, S, 3), b["grad"]
         ctx.mark_non_differentiable(sdf_o, rgb_o, grad_o)
         return b["rgb_values"], b["depth"].unsqueeze(-1), b["nmap"], b["weights"], b["entropy"], sdf_o, rgb_o, grad_o

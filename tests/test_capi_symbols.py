@@ -51,6 +51,18 @@ def test_argument_validation_needs_no_gpu():
     assert lib.nsa_draw_picks(None, 640, 32, 8, 98, None, None, None) == NSA_EBADARG
     assert lib.nsa_track_head(None, None, None, 0, None, None, None, None, None) == NSA_EBADARG
     assert lib.nsa_sdf_points(None, 8, None, None, None, None, None, None) == NSA_EBADARG
+    # round-2 entry points: weight-gradient GEMM over emission rows, fused loss terms
+    from nicer_slam_amd._native import LossDesc
+    a_rows = (ctypes.c_uint32 * 2)(0, 0)
+    assert lib.nsa_emit_gemm(None, 4096, 1, a_rows, a_rows, 64, 64, 1, None, None, None) == NSA_EBADARG          # NULL buffers
+    fake = ctypes.c_void_p(4096)                                                      # never dereferenced: rejected on sizes
+    assert lib.nsa_emit_gemm(fake, 4096, 3, a_rows, a_rows, 64, 64, 1, fake, fake, None) == NSA_EBADARG          # pairs > 2
+    assert lib.nsa_emit_gemm(fake, 4096, 1, a_rows, a_rows, 65, 64, 1, fake, fake, None) == NSA_EBADARG          # M > 64
+    assert lib.nsa_emit_gemm(fake, 1000, 1, a_rows, a_rows, 64, 64, 1, fake, fake, None) == NSA_EBADARG          # ld not a multiple of 256
+    assert lib.nsa_emit_gemm_workspace(8192, 64, 130, 1) == (8192 // 256) * 64 * 131
+    assert lib.nsa_slam_loss(None, None, None) == NSA_EBADARG
+    assert lib.nsa_slam_loss(ctypes.byref(LossDesc()), fake, None) == NSA_EBADARG     # zero sizes / NULL tensors
+    assert lib.nsa_slam_loss_workspace(8, 1024, 0) > 8 * 1024
     # empty work is a no-op, not an error (reference: a zero-size launch is never issued either)
     assert lib.nsa_sdf_points(None, 0, None, None, None, None, None, None) == 0
     assert lib.nsa_sampler_sdf(None, None, 0, 640, None, None, 0.0, 1.0, 3.5, None, None, None, None, None, None, None, None) == 0

@@ -15,7 +15,7 @@ cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.c
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/f1 -- $BE > /tmp/f1.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/f2 -- $BE > /tmp/f2.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d /tmp/f3 -- $BE > /tmp/f3.log 2>&1
-timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT TCC_MISS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS --output-format csv -d /tmp/f4 -- $BE > /tmp/f4.log 2>&1
+timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT TCC_MISS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d /tmp/f4 -- $BE > /tmp/f4.log 2>&1
 python $R/tools/pmc_summary.py /tmp/f1 /tmp/f2 /tmp/f3 /tmp/f4 > $OUT/pmc_per_kernel.csv
 python $R/tools/traffic_json.py $OUT/pmc_per_kernel.csv > $OUT/hbm_traffic.json
 tail -1 $OUT/bench_line.json | cut -c1-200

@@ -136,20 +136,114 @@ __device__ __forceinline__ void stage_issue_n(const float* __restrict__ g, int n
                                          (__attribute__((address_space(3))) void*)(lds_dst + ch * 256), 16, 0, 0);
 }
 
-// GEMM number `opi` of the kernel's sequence Seq: wait for its block, start fetching the next one into the other buffer,
-// multiply from LDS.  All NW waves of the block must execute the same sequence.  (A ring of three buffers, fetching two GEMMs
-// ahead behind a counted vmcnt, measured the same: the copies are not what the waves wait for -- profiles/r02_ab_experiments.txt.)
-template <class Seq, int NW>
-__device__ __forceinline__ void stage16_begin(float* stage, const float* __restrict__ wp) {
-    stage_issue_n<NW>(wp + Seq::off(0), Seq::size(0), stage);
+// ---- staged GEMMs, part by part --------------------------------------------------------------------------------------------
+// A kernel's GEMM sequence Seq lists logical ops (Seq::n; Seq::off(i) = packed block, Seq::mt(i) output tiles, Seq::kg(i)
+// k-groups).  A block larger than the stage buffer (BUF floats) is staged in PARTS of whole k-groups -- the part "groups
+// g0 .. g0+ng-1 of every tile" is MT strided segments in global memory, laid out in LDS as [mt][ng][piece][lane] -- so that the
+// buffers can be small enough for two workgroups per CU.  Parts are numbered through the whole sequence; part p uses buffer p & 1
+// and fetches part p + 1 while it multiplies.  With BUF >= the largest block every op is one part (the round-2 layout).
+struct StagePart {
+    int off, mt, kg, g0, ng;
+};
+
+template <int BUF>
+__host__ __device__ constexpr int max_groups(int mt) { return BUF / (mt * 768) < 1 ? 1 : BUF / (mt * 768); }
+
+template <class Seq, int BUF>
+__host__ __device__ constexpr int parts_of(int op) {
+    const int m = max_groups<BUF>(Seq::mt(op));
+    return (Seq::kg(op) + m - 1) / m;
 }
 
-template <class Seq, int NW, int KG, int MT>
+template <class Seq, int BUF>
+__host__ __device__ constexpr int first_part(int op) {
+    int p = 0;
+    for (int i = 0; i < op; ++i) p += parts_of<Seq, BUF>(i);
+    return p;
+}
+
+template <class Seq, int BUF>
+__host__ __device__ constexpr StagePart part_at(int p) {
+    int op = 0;
+    while (op < Seq::n && p >= parts_of<Seq, BUF>(op)) { p -= parts_of<Seq, BUF>(op); ++op; }
+    if (op >= Seq::n) return StagePart{0, 0, 0, 0, 0};
+    const int m = max_groups<BUF>(Seq::mt(op));
+    const int g0 = p * m;
+    const int ng = Seq::kg(op) - g0 < m ? Seq::kg(op) - g0 : m;
+    return StagePart{Seq::off(op), Seq::mt(op), Seq::kg(op), g0, ng};
+}
+
+template <int NW>
+__device__ __forceinline__ void stage_issue_part(const float* __restrict__ wp, const StagePart o, float* lds_dst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per_tile = o.ng * 3;                 // 1 KiB chunks per tile in this part
+    const int chunks = o.mt * per_tile;
+    for (int ch = wave; ch < chunks; ch += NW) {
+        const int mt = ch / per_tile, rem = ch - mt * per_tile;
+        const float* src = wp + o.off + ((mt * o.kg + o.g0) * 3 + rem) * 256 + lane * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds_dst + ch * 256), 16, 0, 0);
+    }
+}
+
+template <class Seq, int NW, int BUF>
+__device__ __forceinline__ void stage16_begin(float* stage, const float* __restrict__ wp) {
+    stage_issue_part<NW>(wp, part_at<Seq, BUF>(0), stage);
+}
+
+// groups G0 .. G0+NG-1 of a KG-group GEMM from a staged part laid out [mt][NG][piece][lane]
+template <int KG, int MT, int G0, int NG>
+__device__ __forceinline__ void gemm16_lds_part(const float* lds_block, int lane, const float (&b)[8 * KG], f32x4v (&acc)[MT]) {
+    const lds_u4* w4 = (const lds_u4*)lds_block + lane;
+    constexpr int TC = MT <= 4 ? MT : (MT % 3 == 0 ? 3 : 4);
+    static_assert(MT % TC == 0, "tile chunking");
+#pragma unroll
+    for (int gl = 0; gl < NG; ++gl) {
+        const int g = G0 + gl;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = b[8 * g + e];
+        bf16x8_t bh, bm, bl;
+        if constexpr (kPieces == 3) {
+            BFrag bf;
+            split8(x, bf);
+            bh = as_bf16x8(bf.p[0]); bm = as_bf16x8(bf.p[1]); bl = as_bf16x8(bf.p[2]);
+        } else {
+            bh = round8_bf16(x); bm = bh; bl = bh;
+        }
+#pragma unroll
+        for (int c = 0; c < MT / TC; ++c) {
+            u32x4 a[TC][3];
+#pragma unroll
+            for (int t = 0; t < TC; ++t)
+#pragma unroll
+                for (int pc = 0; pc < kPieces; ++pc) a[t][pc] = w4[(((c * TC + t) * NG + gl) * 3 + pc) * 64];
+            mma16_tiles<TC>(a, bh, bm, bl, &acc[c * TC]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep later layers' LDS reads from being hoisted above this GEMM
+}
+
+template <class Seq, int NW, int BUF, int KG, int MT, int P0, int G0, int NG>
+__device__ __forceinline__ void gemm16_staged_part(float* stage, const float* __restrict__ wp, int part, int lane,
+                                                   const float (&b)[8 * KG], f32x4v (&acc)[MT]) {
+    stage_wait();
+    const StagePart nxt = part_at<Seq, BUF>(part + 1);
+    if (nxt.mt) stage_issue_part<NW>(wp, nxt, stage + ((part + 1) & 1) * BUF);
+    gemm16_lds_part<KG, MT, G0, NG>(stage + (part & 1) * BUF, lane, b, acc);
+}
+
+// logical GEMM `opi` of Seq (KG k-groups, MT output tiles): all its parts (at most two)
+template <class Seq, int NW, int BUF, int KG, int MT>
 __device__ __forceinline__ void gemm16_staged(float* stage, const float* __restrict__ wp, int opi, int lane,
                                               const float (&b)[8 * KG], f32x4v (&acc)[MT]) {
-    stage_wait();
-    if (opi + 1 < Seq::n) stage_issue_n<NW>(wp + Seq::off(opi + 1), Seq::size(opi + 1), stage + ((opi + 1) & 1) * kStageFloats);
-    gemm16_lds<KG, MT>(stage + (opi & 1) * kStageFloats, lane, b, acc);
+    constexpr int M = max_groups<BUF>(MT);
+    constexpr int NP = (KG + M - 1) / M;
+    static_assert(NP <= 3, "a staged GEMM is split into at most three parts");
+    const int p0 = first_part<Seq, BUF>(opi);
+    gemm16_staged_part<Seq, NW, BUF, KG, MT, 0, 0, (KG < M ? KG : M)>(stage, wp, p0, lane, b, acc);
+    if constexpr (NP > 1) gemm16_staged_part<Seq, NW, BUF, KG, MT, 1, M, (KG - M < M ? KG - M : M)>(stage, wp, p0 + 1, lane, b, acc);
+    if constexpr (NP > 2) gemm16_staged_part<Seq, NW, BUF, KG, MT, 2, 2 * M, KG - 2 * M>(stage, wp, p0 + 2, lane, b, acc);
 }
 
 // packed per-feature vector (activation layout [q*16 + s]) -> this lane's 16 values as 4 tiles x 4

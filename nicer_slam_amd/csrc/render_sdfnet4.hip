@@ -14,6 +14,10 @@ namespace nsa {
 #define NSA_NW4 8               // waves per workgroup: 128 points share one staged copy of every weight block
 #endif
 constexpr int NW4 = NSA_NW4;
+// Stage buffer (floats) of the double-buffered weight staging.  8 waves: 36 KiB, every weight block in one piece (123 KB of LDS,
+// one workgroup per CU).  Fewer waves: 24 KiB -- the two first-layer blocks arrive in two parts (mlp16.hpp) -- so that two
+// workgroups fit a CU (2 x 24 KiB + 24 KiB of grid Jacobians = 72 KB each): two independent barrier domains per CU.
+constexpr int kStage4 = NW4 >= 8 ? 9216 : 6144;
 
 struct SdfNet4Args {
     PointSrc src;
@@ -73,10 +77,9 @@ struct SdfOps4 {
         if (!BWD) return i < NH ? fwd(i) : i == NH ? P::kWFEAT : rev(i - NH - 1);
         return i < NH ? fwd(i) : i < 2 * NH ? rev(i - NH) : i < 3 * NH ? fwd(i - 2 * NH) : i == 3 * NH ? P::kWFEATT : rev(i - 3 * NH - 1);
     }
-    __host__ __device__ static constexpr int size(int i) {
-        const int o = off(i);
-        return o == P::kW0 ? a16_floats(4, QIN_G) : o == P::kW0T ? a16_floats(6, 2) : P::kHH;
-    }
+    __host__ __device__ static constexpr int mt(int i) { return off(i) == P::kW0T ? 6 : 4; }
+    __host__ __device__ static constexpr int kg(int i) { return off(i) == P::kW0 ? QIN_G : 2; }
+    __host__ __device__ static constexpr int n_parts() { return first_part<SdfOps4<NH, BWD>, kStage4>(n); }
 };
 
 template <int NH, class Seq>
@@ -86,7 +89,7 @@ __device__ __forceinline__ void hidden_forward4(float* stage, int op0, const flo
     using P = SdfPack4<NH>;
     f32x4v acc[4];
     load_vec16(wp + P::kB0, q, acc);
-    gemm16_staged<Seq, NW4, QIN_G, 4>(stage, wp, op0, lane, in, acc);
+    gemm16_staged<Seq, NW4, kStage4, QIN_G, 4>(stage, wp, op0, lane, in, acc);
 #pragma unroll
     for (int k = 1; k <= NH; ++k) {
         float d2;
@@ -98,7 +101,7 @@ __device__ __forceinline__ void hidden_forward4(float* stage, int op0, const flo
         }
         if (k < NH) {
             load_vec16(wp + P::bh(k), q, acc);
-            gemm16_staged<Seq, NW4, 2, 4>(stage, wp, op0 + k, lane, hlast, acc);
+            gemm16_staged<Seq, NW4, kStage4, 2, 4>(stage, wp, op0 + k, lane, hlast, acc);
         }
     }
 }
@@ -123,7 +126,7 @@ __device__ __forceinline__ void reverse_pass4(float* stage, int op0, const float
         f32x4v acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        gemm16_staged<Seq, NW4, 2, 4>(stage, wp, op0 + (NH - 1 - k), lane, da, acc);
+        gemm16_staged<Seq, NW4, kStage4, 2, 4>(stage, wp, op0 + (NH - 1 - k), lane, da, acc);
 #pragma unroll
         for (int s = 0; s < QHS; ++s) {
             dh[k - 1][s] = acc[s >> 2][s & 3];
@@ -137,7 +140,7 @@ __device__ __forceinline__ void reverse_pass4(float* stage, int op0, const float
     f32x4v a6[6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) a6[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-    gemm16_staged<Seq, NW4, 2, 6>(stage, wp, op0 + NH - 1, lane, da, a6);
+    gemm16_staged<Seq, NW4, kStage4, 2, 6>(stage, wp, op0 + NH - 1, lane, da, a6);
 #pragma unroll
     for (int s = 0; s < QIN; ++s) dl[s] = a6[s >> 2][s & 3];
 }
@@ -153,9 +156,9 @@ template <int L, int C, int NH>
 __global__ __launch_bounds__(64 * NW4, NSA_OCC4_FWD) void k_sdfnet4_fwd(SdfNet4Args a, GridGeom16 geom) {
     using P = SdfPack4<NH>;
     using Seq = SdfOps4<NH, false>;
-    __shared__ __attribute__((aligned(16))) float stage[2 * kStageFloats];
+    __shared__ __attribute__((aligned(16))) float stage[2 * kStage4];
     __shared__ LevelGeom s_geom[16];
-    stage16_begin<Seq, NW4>(stage, a.wp);
+    stage16_begin<Seq, NW4, kStage4>(stage, a.wp);
     geom_to_lds(geom, s_geom);
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_FWD) void k_sdfnet4_fwd(SdfNet4A
     for (int s = 0; s < QHS; ++s) part = fmaf(hl[s], ws[s >> 2][s & 3], part);
     float sdf = quad_sum(part) + a.wp[P::kBSDF];
     load_vec16(a.wp + P::kBFEAT, q, fo);
-    gemm16_staged<Seq, NW4, 2, 4>(stage, a.wp, NH, lane, hl, fo);
+    gemm16_staged<Seq, NW4, kStage4, 2, 4>(stage, a.wp, NH, lane, hl, fo);
     if (wave_live) {
         float* fdst = a.feat + hl_base4(tile, j, q);
 #pragma unroll
@@ -223,9 +226,9 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
     using P = SdfPack4<NH>;
     using Seq = SdfOps4<NH, true>;
     using E = SE4<NH>;
-    __shared__ __attribute__((aligned(16))) float stage[2 * kStageFloats];
+    __shared__ __attribute__((aligned(16))) float stage[2 * kStage4];
     __shared__ LevelGeom s_geom[16];
-    stage16_begin<Seq, NW4>(stage, a.wp);
+    stage16_begin<Seq, NW4, kStage4>(stage, a.wp);
     geom_to_lds(geom, s_geom);
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
         f32x4v acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        gemm16_staged<Seq, NW4, QIN_G, 4>(stage, a.wp, 2 * NH, lane, tin, acc);
+        gemm16_staged<Seq, NW4, kStage4, QIN_G, 4>(stage, a.wp, 2 * NH, lane, tin, acc);
         f32x4v ws[4];
         load_vec16(a.wp + P::kWSDF, q, ws);
         float th[QHS];
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
             if (k < NH) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-                gemm16_staged<Seq, NW4, 2, 4>(stage, a.wp, 2 * NH + k, lane, th, acc);
+                gemm16_staged<Seq, NW4, kStage4, 2, 4>(stage, a.wp, 2 * NH + k, lane, th, acc);
             }
         }
     }
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
         load_vec16(a.wp + P::kWSDF, q, ws);
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = sbar * ws[t];
-        gemm16_staged<Seq, NW4, 2, 4>(stage, a.wp, 3 * NH, lane, fb, acc);
+        gemm16_staged<Seq, NW4, kStage4, 2, 4>(stage, a.wp, 3 * NH, lane, fb, acc);
 #pragma unroll
         for (int s = 0; s < QHS; ++s) ab[s] = sg[NH - 1][s] * acc[s >> 2][s & 3] + e[NH - 1][s];
     }
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
         f32x4v acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        gemm16_staged<Seq, NW4, 2, 4>(stage, a.wp, 3 * NH + 1 + (NH - 1 - k), lane, ab, acc);
+        gemm16_staged<Seq, NW4, kStage4, 2, 4>(stage, a.wp, 3 * NH + 1 + (NH - 1 - k), lane, ab, acc);
 #pragma unroll
         for (int s = 0; s < QHS; ++s) ab[s] = sg[k - 1][s] * acc[s >> 2][s & 3] + e[k - 1][s];
     }
@@ -341,17 +344,18 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
         f32x4v a6[6];
 #pragma unroll
         for (int t = 0; t < 6; ++t) a6[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        gemm16_staged<Seq, NW4, 2, 6>(stage, a.wp, 4 * NH, lane, ab, a6);
+        gemm16_staged<Seq, NW4, kStage4, 2, 6>(stage, a.wp, 4 * NH, lane, ab, a6);
 #pragma unroll
         for (int s = 0; s < QIN; ++s) hb0[s] = a6[s >> 2][s & 3];
     }
     float gx[3];
     slots_to_x_jac4<L, C>(a.divide_factor, jstore, q, in, hb0, gx);
-    // scatter scratch: the stage buffer the last GEMM (op 4 NH, even) does NOT read; every wave passed the barrier of that
-    // GEMM and nothing is fetched after it, so nobody touches that buffer any more
+    // scatter scratch: the stage buffer the last GEMM part does NOT read; every wave passed the barrier of that part and
+    // nothing is fetched after it, so nobody touches that buffer any more
+    constexpr int kIdle = (Seq::n_parts() - 1) & 1 ? 0 : 1;
     if (MAP && a.g_table)
         table_grad_scatter4<L, C>(x, a.divide_factor, s_geom, q, lane, live, hb0, dl, nbar, a.g_table,
-                                  stage + kStageFloats + (threadIdx.x >> 6) * 64 * (2 * C + 1));
+                                  stage + kIdle * kStage4 + (threadIdx.x >> 6) * 64 * (2 * C + 1));
 #pragma unroll
     for (int d = 0; d < 3; ++d) gx[d] = quad_sum(gx[d] + xb2[d]);
     if (live && q == 0) {
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
     }
 }
 
-static_assert(NW4 * 64 * (2 * 8 + 1) <= kStageFloats, "scatter scratch must fit the idle stage buffer");
+static_assert(NW4 * 64 * (2 * 8 + 1) <= kStage4, "scatter scratch must fit the idle stage buffer");
 
 static int launch_sdfnet4(bool bwd, const nsa_grid_t* grid, const SdfNet4Args& a, hipStream_t st) {
     const bool map = a.g_table != nullptr || a.emit != nullptr;

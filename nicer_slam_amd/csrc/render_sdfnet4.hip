@@ -10,14 +10,18 @@
 
 namespace nsa {
 
-#ifndef NSA_NW4
-#define NSA_NW4 8               // waves per workgroup: 128 points share one staged copy of every weight block
+// Waves per workgroup, per kernel.  8 waves: 128 points share one staged copy of every weight block, 36-KiB stage buffers (every
+// block in one piece), 123 KB of LDS = one workgroup per CU.  4 waves: 24-KiB buffers -- the two first-layer blocks arrive in two
+// parts (mlp16.hpp) -- and 2 x 24 KiB + 24 KiB of grid Jacobians = 74 KB, so TWO workgroups (two independent barrier domains)
+// share a CU.  Measured (profiles/r02_ab_experiments.txt r3j): the forward is 3.5 % faster with 4 waves, the backward 7 % slower
+// (two more barriers per tile, 7 spilled registers) -- hence the split default.
+#ifndef NSA_NW4_FWD
+#define NSA_NW4_FWD 4
 #endif
-constexpr int NW4 = NSA_NW4;
-// Stage buffer (floats) of the double-buffered weight staging.  8 waves: 36 KiB, every weight block in one piece (123 KB of LDS,
-// one workgroup per CU).  Fewer waves: 24 KiB -- the two first-layer blocks arrive in two parts (mlp16.hpp) -- so that two
-// workgroups fit a CU (2 x 24 KiB + 24 KiB of grid Jacobians = 72 KB each): two independent barrier domains per CU.
-constexpr int kStage4 = NW4 >= 8 ? 9216 : 6144;
+#ifndef NSA_NW4_BWD
+#define NSA_NW4_BWD 8
+#endif
+constexpr int stage_floats4(int nw) { return nw >= 8 ? 9216 : 6144; }
 
 struct SdfNet4Args {
     PointSrc src;
@@ -70,6 +74,8 @@ struct Emitter4 {
 template <int NH, bool BWD>
 struct SdfOps4 {
     using P = SdfPack4<NH>;
+    static constexpr int NW = BWD ? NSA_NW4_BWD : NSA_NW4_FWD;        // waves per workgroup
+    static constexpr int BUF = stage_floats4(NW);                      // stage buffer, floats
     static constexpr int n = BWD ? 4 * NH + 1 : 2 * NH + 1;
     __host__ __device__ static constexpr int rev(int j) { return j < NH - 1 ? P::wht(NH - 1 - j) : P::kW0T; }
     __host__ __device__ static constexpr int fwd(int j) { return j == 0 ? P::kW0 : P::wh(j); }
@@ -79,7 +85,7 @@ struct SdfOps4 {
     }
     __host__ __device__ static constexpr int mt(int i) { return off(i) == P::kW0T ? 6 : 4; }
     __host__ __device__ static constexpr int kg(int i) { return off(i) == P::kW0 ? QIN_G : 2; }
-    __host__ __device__ static constexpr int n_parts() { return first_part<SdfOps4<NH, BWD>, kStage4>(n); }
+    __host__ __device__ static constexpr int n_parts() { return first_part<SdfOps4<NH, BWD>, BUF>(n); }
 };
 
 template <int NH, class Seq>
@@ -89,7 +95,7 @@ __device__ __forceinline__ void hidden_forward4(float* stage, int op0, const flo
     using P = SdfPack4<NH>;
     f32x4v acc[4];
     load_vec16(wp + P::kB0, q, acc);
-    gemm16_staged<Seq, NW4, kStage4, QIN_G, 4>(stage, wp, op0, lane, in, acc);
+    gemm16_staged<Seq, Seq::NW, Seq::BUF, QIN_G, 4>(stage, wp, op0, lane, in, acc);
 #pragma unroll
     for (int k = 1; k <= NH; ++k) {
         float d2;
@@ -101,7 +107,7 @@ __device__ __forceinline__ void hidden_forward4(float* stage, int op0, const flo
         }
         if (k < NH) {
             load_vec16(wp + P::bh(k), q, acc);
-            gemm16_staged<Seq, NW4, kStage4, 2, 4>(stage, wp, op0 + k, lane, hlast, acc);
+            gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, wp, op0 + k, lane, hlast, acc);
         }
     }
 }
@@ -126,7 +132,7 @@ __device__ __forceinline__ void reverse_pass4(float* stage, int op0, const float
         f32x4v acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        gemm16_staged<Seq, NW4, kStage4, 2, 4>(stage, wp, op0 + (NH - 1 - k), lane, da, acc);
+        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, wp, op0 + (NH - 1 - k), lane, da, acc);
 #pragma unroll
         for (int s = 0; s < QHS; ++s) {
             dh[k - 1][s] = acc[s >> 2][s & 3];
@@ -140,7 +146,7 @@ __device__ __forceinline__ void reverse_pass4(float* stage, int op0, const float
     f32x4v a6[6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) a6[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-    gemm16_staged<Seq, NW4, kStage4, 2, 6>(stage, wp, op0 + NH - 1, lane, da, a6);
+    gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 6>(stage, wp, op0 + NH - 1, lane, da, a6);
 #pragma unroll
     for (int s = 0; s < QIN; ++s) dl[s] = a6[s >> 2][s & 3];
 }
@@ -153,16 +159,16 @@ __device__ __forceinline__ void reverse_pass4(float* stage, int op0, const float
 #endif
 
 template <int L, int C, int NH>
-__global__ __launch_bounds__(64 * NW4, NSA_OCC4_FWD) void k_sdfnet4_fwd(SdfNet4Args a, GridGeom16 geom) {
+__global__ __launch_bounds__(64 * NSA_NW4_FWD, NSA_OCC4_FWD) void k_sdfnet4_fwd(SdfNet4Args a, GridGeom16 geom) {
     using P = SdfPack4<NH>;
     using Seq = SdfOps4<NH, false>;
-    __shared__ __attribute__((aligned(16))) float stage[2 * kStage4];
+    __shared__ __attribute__((aligned(16))) float stage[2 * Seq::BUF];
     __shared__ LevelGeom s_geom[16];
-    stage16_begin<Seq, NW4, kStage4>(stage, a.wp);
+    stage16_begin<Seq, Seq::NW, Seq::BUF>(stage, a.wp);
     geom_to_lds(geom, s_geom);
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
-    uint32_t tile = blockIdx.x * NW4 + (threadIdx.x >> 6);
+    uint32_t tile = blockIdx.x * Seq::NW + (threadIdx.x >> 6);
     const uint32_t n_tiles = (a.src.P + 15) / 16;
     const bool wave_live = tile < n_tiles;                  // a wave without points still takes part in the barriers
     if (!wave_live) tile = n_tiles - 1;
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_FWD) void k_sdfnet4_fwd(SdfNet4A
     // the grid Jacobian of this lane's levels stays in lane-private LDS (24 floats per lane): grad sdf needs no second corner
     // gather at the end of the kernel
     constexpr int kJac = (8 / C) * 3 * C;
-    __shared__ float jac_lds[NW4 * kJac * 64];
+    __shared__ float jac_lds[Seq::NW * kJac * 64];
     float* jstore = jac_lds + (threadIdx.x >> 6) * (kJac * 64) + lane;
     float in[QIN];
     pe_slots4(x, q, in);
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_FWD) void k_sdfnet4_fwd(SdfNet4A
     for (int s = 0; s < QHS; ++s) part = fmaf(hl[s], ws[s >> 2][s & 3], part);
     float sdf = quad_sum(part) + a.wp[P::kBSDF];
     load_vec16(a.wp + P::kBFEAT, q, fo);
-    gemm16_staged<Seq, NW4, kStage4, 2, 4>(stage, a.wp, NH, lane, hl, fo);
+    gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, a.wp, NH, lane, hl, fo);
     if (wave_live) {
         float* fdst = a.feat + hl_base4(tile, j, q);
 #pragma unroll
@@ -222,17 +228,17 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_FWD) void k_sdfnet4_fwd(SdfNet4A
 }
 
 template <int L, int C, int NH, bool MAP>
-__global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4Args a, GridGeom16 geom) {
+__global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4Args a, GridGeom16 geom) {
     using P = SdfPack4<NH>;
     using Seq = SdfOps4<NH, true>;
     using E = SE4<NH>;
-    __shared__ __attribute__((aligned(16))) float stage[2 * kStage4];
+    __shared__ __attribute__((aligned(16))) float stage[2 * Seq::BUF];
     __shared__ LevelGeom s_geom[16];
-    stage16_begin<Seq, NW4, kStage4>(stage, a.wp);
+    stage16_begin<Seq, Seq::NW, Seq::BUF>(stage, a.wp);
     geom_to_lds(geom, s_geom);
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
-    uint32_t tile = blockIdx.x * NW4 + (threadIdx.x >> 6);
+    uint32_t tile = blockIdx.x * Seq::NW + (threadIdx.x >> 6);
     const uint32_t n_tiles = (a.src.P + 15) / 16;
     const bool wave_live = tile < n_tiles;
     if (!wave_live) tile = n_tiles - 1;
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
     __syncthreads();                                         // s_geom
     // the grid Jacobian of this lane's levels stays in lane-private LDS: the backward needs no second and third corner gather
     constexpr int kJac = (8 / C) * 3 * C;                    // 24 floats per lane
-    __shared__ float jac_lds[NW4 * kJac * 64];
+    __shared__ float jac_lds[Seq::NW * kJac * 64];
     float* jstore = jac_lds + (threadIdx.x >> 6) * (kJac * 64) + lane;
     float in[QIN];
     pe_slots4(x, q, in);
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
         f32x4v acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        gemm16_staged<Seq, NW4, kStage4, QIN_G, 4>(stage, a.wp, 2 * NH, lane, tin, acc);
+        gemm16_staged<Seq, Seq::NW, Seq::BUF, QIN_G, 4>(stage, a.wp, 2 * NH, lane, tin, acc);
         f32x4v ws[4];
         load_vec16(a.wp + P::kWSDF, q, ws);
         float th[QHS];
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
             if (k < NH) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-                gemm16_staged<Seq, NW4, kStage4, 2, 4>(stage, a.wp, 2 * NH + k, lane, th, acc);
+                gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, a.wp, 2 * NH + k, lane, th, acc);
             }
         }
     }
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
         load_vec16(a.wp + P::kWSDF, q, ws);
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = sbar * ws[t];
-        gemm16_staged<Seq, NW4, kStage4, 2, 4>(stage, a.wp, 3 * NH, lane, fb, acc);
+        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, a.wp, 3 * NH, lane, fb, acc);
 #pragma unroll
         for (int s = 0; s < QHS; ++s) ab[s] = sg[NH - 1][s] * acc[s >> 2][s & 3] + e[NH - 1][s];
     }
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
         f32x4v acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        gemm16_staged<Seq, NW4, kStage4, 2, 4>(stage, a.wp, 3 * NH + 1 + (NH - 1 - k), lane, ab, acc);
+        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, a.wp, 3 * NH + 1 + (NH - 1 - k), lane, ab, acc);
 #pragma unroll
         for (int s = 0; s < QHS; ++s) ab[s] = sg[k - 1][s] * acc[s >> 2][s & 3] + e[k - 1][s];
     }
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
         f32x4v a6[6];
 #pragma unroll
         for (int t = 0; t < 6; ++t) a6[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        gemm16_staged<Seq, NW4, kStage4, 2, 6>(stage, a.wp, 4 * NH, lane, ab, a6);
+        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 6>(stage, a.wp, 4 * NH, lane, ab, a6);
 #pragma unroll
         for (int s = 0; s < QIN; ++s) hb0[s] = a6[s >> 2][s & 3];
     }
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
     constexpr int kIdle = (Seq::n_parts() - 1) & 1 ? 0 : 1;
     if (MAP && a.g_table)
         table_grad_scatter4<L, C>(x, a.divide_factor, s_geom, q, lane, live, hb0, dl, nbar, a.g_table,
-                                  stage + kIdle * kStage4 + (threadIdx.x >> 6) * 64 * (2 * C + 1));
+                                  stage + kIdle * Seq::BUF + (threadIdx.x >> 6) * 64 * (2 * C + 1));
 #pragma unroll
     for (int d = 0; d < 3; ++d) gx[d] = quad_sum(gx[d] + xb2[d]);
     if (live && q == 0) {
@@ -368,14 +374,15 @@ __global__ __launch_bounds__(64 * NW4, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4A
     }
 }
 
-static_assert(NW4 * 64 * (2 * 8 + 1) <= kStage4, "scatter scratch must fit the idle stage buffer");
+static_assert(NSA_NW4_BWD * 64 * (2 * 8 + 1) <= stage_floats4(NSA_NW4_BWD), "scatter scratch must fit the idle stage buffer");
 
 static int launch_sdfnet4(bool bwd, const nsa_grid_t* grid, const SdfNet4Args& a, hipStream_t st) {
     const bool map = a.g_table != nullptr || a.emit != nullptr;
     GridGeom16 geom;
     if (int rc = make_grid_geom16(grid->offsets_host, grid->L, grid->S, grid->H, &geom)) return rc;
     const uint32_t tiles = (a.src.P + 15) / 16;
-    const dim3 g((tiles + NW4 - 1) / NW4), b(64 * NW4);
+    const int nw = bwd ? NSA_NW4_BWD : NSA_NW4_FWD;
+    const dim3 g((tiles + nw - 1) / nw), b(64 * nw);
     launch_begin();
     if (grid->L == 4 && grid->C == 8 && grid->n_hidden == 1) {
         if (bwd && map) hipLaunchKernelGGL((k_sdfnet4_bwd<4, 8, 1, true>), g, b, 0, st, a, geom);

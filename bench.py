@@ -176,13 +176,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    probe_tflops = None
     if args.prewarm_s > 0:          # bring the clocks up with work that touches none of the tracker's state or caches
         a = torch.randn(4096, 4096, device=device)
-        t_pre = time.perf_counter()
+        t_pre, n_mm = time.perf_counter(), 0
         while time.perf_counter() - t_pre < args.prewarm_s:
             for _ in range(8):
                 a @ a
             torch.cuda.synchronize()
+            n_mm += 8
+        # the same loop doubles as a probe of the box's clock / power state (library fp32 GEMM rate): boxes of this pool differ
+        # by up to 1.3x with identical binaries, and every kernel of the iteration scales with it
+        probe_tflops = round(n_mm * 2 * 4096 ** 3 / (time.perf_counter() - t_pre) / 1e12, 1)
         del a
     for i in range(args.warmup):
         step(i)
@@ -274,7 +279,7 @@ def main():
                        "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "sampler_evals_per_ray": 640,
                        "global_rays": args.rays * world,
                        "engine": "fused" if Stepper.__name__ == "KernelTracker" else model.last_engine, "param_grads": args.param_grads,
-                       "hip_graph": bool(use_graph), "driver": Stepper.__name__, "ray_chunks": ray_chunks, "clock_prewarm_s": args.prewarm_s,
+                       "hip_graph": bool(use_graph), "driver": Stepper.__name__, "ray_chunks": ray_chunks, "clock_prewarm_s": args.prewarm_s, "box_probe_fp32_gemm_tflops": probe_tflops,
                        "parallelism": f"ray-shard x{world}" if world > 1 else "single",
                        "rccl_ranks": 0 if (world == 1 or oversub) else world,
                        "exchange": None if world == 1 else "one 9-float all-reduce (pose gradient, loss, ray count) per step"

@@ -13,11 +13,6 @@ from ..hashencoder.hashgrid import HashEncoder
 from .embedder import get_embedder
 
 
-def _make_linear(d_in, d_out, weight_norm):
-    lin = nn.Linear(d_in, d_out)
-    return lin
-
-
 class ImplicitNetworkGrid(nn.Module):
     """Hash-grid feature (+) positional encoding -> weight-normalised Softplus(beta=100) MLP -> [sdf, feature]."""
 

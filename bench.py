@@ -294,15 +294,22 @@ def main():
 
 
 def mapping_leg(device, rays=8192, frames=8, iters=5):
-    """Context number, not `value`: one MAPPING iteration (SURVEY 8a rows a1-a15 with parameter gradients, eikonal
-    samples, voxel counter; Adam over the three tables + two MLPs as volsdf_train.py:150-174) at the shipped sizes:
-    8192 rays over 8 keyframes, 98 samples/ray, fused engine, nicer_slam_amd.optim.Adam."""
+    """Context number, not `value`: one MAPPING iteration as the shipped Replica configuration runs it
+    (code/confs/replica/runconf_replica_1.conf; volsdf_train.py:548-576): SLAMNetwork.forward(mode="mapping", stage "fine",
+    colour stage "highfreq", use_warp_loss = true, mapping_patchsizes = [1], flow edges between neighbouring keyframes) ->
+    SLAMLoss with that conf's weights (rgb L1, eikonal 0.1, smooth 0.005, ssi depth 0.1, normal L1/cos 0.05, patch warp 0.5,
+    flow 0.001) -> backward to the three tables + coarse SDF MLP + colour MLP -> Adam (lr x20 / x20 / x5 for the grids,
+    volsdf_train.py:150-174).  8192 rays over 8 keyframes, 98 samples/ray, 180 k eikonal points; frames resident in HBM
+    (feed.py); fused engine, nicer_slam_amd.optim.Adam."""
+    from nicer_slam_amd.feed import FrameFeed
+    from nicer_slam_amd.model.loss import SLAMLoss
     from nicer_slam_amd.model.network import SLAMNetwork
     from nicer_slam_amd.optim import Adam
     from nicer_slam_amd.utils.conf import replica_model_conf
     from nicer_slam_amd.utils.general import get_camera_from_tensor
     torch.manual_seed(0)
-    model = SLAMNetwork(replica_model_conf(64, 640, 32, use_warp_loss=False), dataset=DS(), n_images=2000).to(device)
+    model = SLAMNetwork(replica_model_conf(64, 640, 32, use_warp_loss=True, mapping_patchsizes=[1]), dataset=DS(),
+                        n_images=2000).to(device)
     model.train().freeze_fine_mlp()
     groups = [{"params": list(model.implicit_network.fine.grid_parameters()), "lr": 0.04},
               {"params": list(model.implicit_network.coarse.grid_parameters()), "lr": 0.04},
@@ -310,24 +317,47 @@ def mapping_leg(device, rays=8192, frames=8, iters=5):
               {"params": list(model.rendering_network.mlp_parameters()), "lr": 0.002},
               {"params": list(model.implicit_network.coarse.mlp_parameters()), "lr": 0.002}]
     opt = Adam(groups, betas=(0.9, 0.99), eps=1e-15)
+
+    class TrainDS:
+        data_dir = "../Datasets/processed/Replica"
+    crit = SLAMLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, train_dataset=TrainDS(), scan_id=1,
+                    assign_scale_shift_init=True, smooth_weight=0.005, warp_loss_type="l1", depth_weight=0.1,
+                    normal_l1_weight=0.05, normal_cos_weight=0.05, flow_weight=0.001, warp_loss_weight=0.5)
     g = torch.Generator(device=device).manual_seed(1)
     K = torch.eye(4, device=device)
     K[0, 0] = K[1, 1] = 600.0
     K[0, 2], K[1, 2] = 599.5, 339.5
-    K = K[None].repeat(frames, 1, 1)
     cams = torch.tensor([1.0, 0, 0, 0, 0.1, 0.0, -0.2], device=device).repeat(frames, 1)
     cams = cams + 0.01 * torch.randn(frames, 7, device=device, generator=g)
     H, W = DS.img_res
+    feed = FrameFeed((H, W), device=device, capacity=frames)
+    key_ids = [10 * i for i in range(frames)]
+    with torch.no_grad():
+        poses = get_camera_from_tensor(cams)
+    for i, fid in enumerate(key_ids):                       # synthetic frames, uploaded once (smooth depth, random colour)
+        feed.add_frame(fid, rgb=torch.rand(H * W, 3, device=device, generator=g),
+                       depth=0.02 + 0.01 * torch.rand(H * W, 1, device=device, generator=g),
+                       normal=torch.nn.functional.normalize(torch.randn(H * W, 3, device=device, generator=g), dim=-1),
+                       gt_depth=1.0 + 0.5 * torch.rand(H * W, 1, device=device, generator=g), intrinsics=K, pose=poses[i])
+    # flow graph as build_graph makes it (volsdf_train.py:312-324): keyframes at most 30 frames apart, both directions
+    pairs = [(a, b) for a in range(frames) for b in range(frames) if a != b and abs(key_ids[a] - key_ids[b]) <= 30]
+    idii = torch.tensor([a for a, _ in pairs], device=device)
+    idjj = torch.tensor([b for _, b in pairs], device=device)
+    edges = (idii, idjj, None, None)
+    n = rays // frames
+    flow_images = (torch.randn(len(pairs), H * W, 2, device=device, generator=g) * 5,
+                   torch.rand(len(pairs), H * W, device=device, generator=g) > 0.2)
 
     def step():
-        idx = torch.randint(H * W, (frames, rays // frames), device=device, generator=g)
-        uv = torch.stack([(idx % W).float(), (idx // W).float()], -1)
-        gt = torch.rand(rays, 3, device=device, generator=g)
+        sel = feed.change_sampling_idx(n, generator=g)
+        indices, inp, gt = feed.batch(key_ids, full="store")
+        gt["edges"] = edges
+        # select_flow_uv (volsdf_train.py:348-361): the GT flow of the sampled pixels of every edge
+        gt["flow"], gt["flow_mask"] = flow_images[0].index_select(1, sel), flow_images[1].index_select(1, sel)
         opt.zero_grad()
-        out = model({"intrinsics": K, "uv": uv, "pose": get_camera_from_tensor(cams)}, torch.arange(frames, device=device),
-                    {}, mode="mapping", stage="fine", color_stage="highfreq", frame_idx=5)
-        loss = (out["rgb_values"].reshape(-1, 3) - gt).abs().mean()
-        loss = loss + 0.1 * ((out["grad_theta"].norm(2, dim=1) - 1) ** 2).mean()
+        out = model(inp, indices.to(device), gt, keyframe_list=key_ids, mode="mapping", stage="fine", color_stage="highfreq",
+                    frame_idx=key_ids[-1])
+        loss = crit(out, gt, key_ids, frame_idx=key_ids[-1], stage="fine")["loss"]
         loss.backward()
         opt.step()
         return loss
@@ -372,6 +402,8 @@ def mapping_leg(device, rays=8192, frames=8, iters=5):
                                                            "tools/micro/atomic_bench.hip, DESIGN.md 4b",
                                        "frac_of_41G_rows_per_s": round(rows / (tms * 1e-3) / 41e9, 3)}}
     return {"ms": round(dt * 1e3, 2), "rays": rays, "keyframes": frames, "samples_per_ray": S,
+            "objective": "SLAMLoss with the weights of code/confs/replica/runconf_replica_1.conf (rgb, eikonal, smooth, ssi depth, "
+                         "normals, patch warp [patch 1], flow over %d edges); stage fine / highfreq" % len(pairs),
             "eikonal_points": 22 * rays, "rays_per_s": round(rays / dt, 1), "engine": model.last_engine,
             "optimizer": "nicer_slam_amd.optim.Adam (1.1 GiB of parameters, dense)", "iters": iters,
             "final_loss": round(float(last), 6), "kernels_ms": {k: round(v, 3) for k, v in sorted(agg.items())},

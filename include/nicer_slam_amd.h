@@ -286,7 +286,7 @@ uint64_t nsa_emit_gemm_workspace(uint64_t ld, uint32_t M, uint32_t N, int row_su
 /* The per-ray terms of SLAMLoss (code/model/loss.py:113-233: rgb L1, eikonal, smooth, scale-and-shift-invariant monocular
  * depth with its alpha = 0.5 first-difference regulariser (code/utils/MiDaS.py:6-143), gt-depth L1, normal L1 + cos) and the
  * gradient of their WEIGHTED sum w.r.t. the model outputs, in three launches.  A weight of 0 skips a term (its value is then 0,
- * like the reference's 0.0); the flow and patch-warp terms are not covered.  R = bs * n rays, image-major. */
+ * like the reference's 0.0); the flow and patch-warp terms are Section 5.  R = bs * n rays, image-major. */
 typedef struct nsa_loss {
     uint32_t bs, n;               /* images, rays per image                                                             */
     uint32_t S;                   /* samples per ray of `sdf`                                                           */
@@ -308,6 +308,60 @@ typedef struct nsa_loss {
 int nsa_slam_loss(const nsa_loss_t *in, float *workspace /* nsa_slam_loss_workspace() floats, 8-byte aligned */,
                   nsa_stream_t stream);
 uint64_t nsa_slam_loss_workspace(uint32_t bs, uint32_t n, uint32_t E);
+
+/* ---- Section 5: keyframe re-projection blocks of a mapping iteration (patch warp, flow) and their masked-L1 terms ---- */
+
+/* Shared description of a mapping batch: b keyframes x n sampled pixels.  `images` / `depths` are the resident full frames
+ * ([frames,H,W,3] / [frames,H,W] fp32, pixel (y,x) at y*W+x -- the reference's ground_truth['full_rgb'] / ['full_depth'],
+ * code/datasets/scene_dataset.py:248-257); batch entry i uses frame frame_index[i] of that store (NULL: frame i), so a
+ * batch needs no per-iteration stacking copy of the frames. */
+typedef struct nsa_warp {
+    uint32_t b, n;              /* keyframes in the batch, sampled pixels per keyframe                                  */
+    uint32_t H, W;              /* image size                                                                           */
+    const float *uv;            /* [b,n,2] pixel coordinates                                                            */
+    const float *pose;          /* [b,4,4] camera-to-world                                                              */
+    const float *w2c;           /* [b,4,4] its inverse (the caller forms it with torch.linalg.inv like network.py:157,191) */
+    const float *K;             /* [b,4,4] intrinsics                                                                   */
+    const float *depth;         /* [b,n]   rendered depth along the ray, BEFORE the depth_scale factor (network.py:147-150) */
+    const float *images;        /* [frames,H,W,3]                                                                       */
+    const float *depths;        /* [frames,H,W]   (patch > 1 only; may be NULL otherwise)                               */
+    const int32_t *frame_index; /* [b] device, or NULL                                                                  */
+} nsa_warp_t;
+
+/* Patch warp, forward: for every (target t, source s, pixel i, patch cell c) the reference's warp_output[patch] tensors
+ *   sampled[t,s,i,c,3] = bilinear sample (zeros padding, align_corners=True) of image t at the projection of the lifted cell,
+ *   gt_rgb [t,s,i,c,3] = image s at the cell's own pixel (ones outside the image), replicated over t,
+ *   mask   [t,s,i,c]   = projection strictly inside image t and in front of it  &  cell inside image s  &  (patch > 1) flat[s,i],
+ *   flat   [s,i]       = biased variance of the patch's ground-truth depths < 0.01 (patch > 1; else untouched, may be NULL).
+ * Cell order c = ix * patch + iy with offsets (ix - patch/2, iy - patch/2) on (u,v) (general.py:139-144); patch must be odd.
+ * replaces code/model/network.py:167-279 (one patch size per call) + uv2patch (code/utils/general.py:129-145). */
+int nsa_patch_warp_forward(const nsa_warp_t *in, uint32_t patch, float *sampled, uint8_t *mask, float *gt_rgb, uint8_t *flat,
+                           nsa_stream_t stream);
+
+/* Backward of the above: g_sampled[t,s,i,c,3] -> g_depth[b,n] (overwritten); when g_pose and g_w2c are non-NULL also the
+ * gradients of the source poses (through ray origin and direction) and of the target world-to-camera matrices, both [b,4,4]
+ * (overwritten, bottom row zero) -- bundle adjustment (volsdf_train.py:521-528).  Deterministic (fixed-order sums).
+ * workspace: nsa_patch_warp_workspace() floats (may be NULL when that is 0). */
+int nsa_patch_warp_backward(const nsa_warp_t *in, uint32_t patch, const float *g_sampled, float *g_depth, float *g_pose,
+                            float *g_w2c, float *workspace, nsa_stream_t stream);
+uint64_t nsa_patch_warp_workspace(uint32_t b, uint32_t n, uint32_t patch, int want_pose);
+
+/* Flow: flow[e,i,2] = projection into frame idjj[e] of the rendered point of pixel i of frame idii[e], minus that pixel.
+ * idii / idjj: [ne] int64 on the device (the reference's `edges`, volsdf_train.py:312-324).  replaces network.py:153-165.
+ * (`images`, `depths` of nsa_warp_t are not used.) */
+int nsa_flow_forward(const nsa_warp_t *in, const int64_t *idii, const int64_t *idjj, uint32_t ne, float *flow,
+                     nsa_stream_t stream);
+int nsa_flow_backward(const nsa_warp_t *in, const int64_t *idii, const int64_t *idjj, uint32_t ne, const float *g_flow,
+                      float *g_depth, float *g_pose, float *g_w2c, float *workspace, nsa_stream_t stream);
+uint64_t nsa_flow_workspace(uint32_t b, uint32_t n, uint32_t ne, int want_pose);
+
+/* loss[0] = mean over the selected items and their `channels` values of |pred - target| (NaN for an empty selection, like
+ * torch); g_pred (optional, [items,channels]) = its gradient, 0 outside the mask.  mask: [items] bytes or NULL (all).
+ * replaces `(sampled[mask] - gt[mask]).abs().mean()` (code/model/loss.py:136-142) and the flow L1 on flow_mask (:106-111).
+ * workspace: nsa_masked_l1_workspace() floats, 8-byte aligned.  Deterministic. */
+int nsa_masked_l1(const float *pred, const float *target, const uint8_t *mask, uint64_t items, uint32_t channels, float *loss,
+                  float *g_pred, float *workspace, nsa_stream_t stream);
+uint64_t nsa_masked_l1_workspace(uint64_t items);
 
 #ifdef __cplusplus
 }

@@ -165,3 +165,30 @@ EXPORTS += ["nsa_morton_keys"]
 lib.nsa_adam_step_scaled.restype = _i
 lib.nsa_adam_step_scaled.argtypes = [_p, _p, _p, _p, _p, _p, _u32, _f32, _f32, _f32, _f32, _u32, _f32, _p, _p, _p]
 EXPORTS += ["nsa_adam_step_scaled"]
+
+
+class WarpDesc(ctypes.Structure):
+    """nsa_warp_t"""
+    _fields_ = ([("b", _u32), ("n", _u32), ("H", _u32), ("W", _u32)]
+                + [(k, _p) for k in ("uv", "pose", "w2c", "K", "depth", "images", "depths", "frame_index")])
+
+
+_wp, _u64 = ctypes.POINTER(WarpDesc), ctypes.c_uint64
+lib.nsa_patch_warp_forward.restype = _i
+lib.nsa_patch_warp_forward.argtypes = [_wp, _u32, _p, _p, _p, _p, _p]
+lib.nsa_patch_warp_backward.restype = _i
+lib.nsa_patch_warp_backward.argtypes = [_wp, _u32, _p, _p, _p, _p, _p, _p]
+lib.nsa_patch_warp_workspace.restype = _u64
+lib.nsa_patch_warp_workspace.argtypes = [_u32, _u32, _u32, _i]
+lib.nsa_flow_forward.restype = _i
+lib.nsa_flow_forward.argtypes = [_wp, _p, _p, _u32, _p, _p]
+lib.nsa_flow_backward.restype = _i
+lib.nsa_flow_backward.argtypes = [_wp, _p, _p, _u32, _p, _p, _p, _p, _p, _p]
+lib.nsa_flow_workspace.restype = _u64
+lib.nsa_flow_workspace.argtypes = [_u32, _u32, _u32, _i]
+lib.nsa_masked_l1.restype = _i
+lib.nsa_masked_l1.argtypes = [_p, _p, _p, _u64, _u32, _p, _p, _p, _p]
+lib.nsa_masked_l1_workspace.restype = _u64
+lib.nsa_masked_l1_workspace.argtypes = [_u64]
+EXPORTS += ["nsa_patch_warp_forward", "nsa_patch_warp_backward", "nsa_patch_warp_workspace", "nsa_flow_forward",
+            "nsa_flow_backward", "nsa_flow_workspace", "nsa_masked_l1", "nsa_masked_l1_workspace"]

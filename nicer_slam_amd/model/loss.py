@@ -5,8 +5,9 @@ Reference: SLAMLoss (code/model/loss.py:8-233) and the scale-and-shift-invariant
 ``forward(model_outputs, ground_truth, keyframe_list, frame_idx, stage) -> dict`` keys and weights, so a trainer that
 builds ``loss_class(**conf.loss, ...)`` can switch.  On the GPU the per-ray terms and their gradients run in three HIP launches
 (fused/loss.py -> csrc/loss_terms.hip: rgb, eikonal, smooth, ssi depth, gt depth, normals); the torch restatement below is the
-same arithmetic for CPU tensors, for the ray-sharded depth reduction and for non-L1 colour losses, and carries the flow and
-patch-warp terms everywhere.  The tracking objective (rgb L1 only) additionally exists as a HIP kernel for the
+same arithmetic for CPU tensors, for the ray-sharded depth reduction and for non-L1 colour losses; the flow and patch-warp terms
+are masked-L1 means (fused/warp.py::masked_l1 -> csrc/warp_terms.hip on the GPU) over the tensors the model's re-projection
+kernels produce.  The tracking objective (rgb L1 only) additionally exists as a HIP kernel for the
 graph-captured tracker (csrc/track_tail.hip::k_l1_loss).
 """
 import torch
@@ -113,18 +114,29 @@ class SLAMLoss(nn.Module):
         p = torch.nn.functional.normalize(normal_pred, p=2, dim=-1)
         return (p - g).abs().sum(dim=-1).mean(), (1.0 - (p * g).sum(dim=-1)).mean()
 
+    def _kernels(self, t):
+        """masked-L1 terms as HIP launches (fused/warp.py::masked_l1) for device tensors, unless engine == "torch"."""
+        return getattr(self, "engine", "auto") != "torch" and t.is_cuda and t.dtype == torch.float32
+
     def get_flow_loss(self, model_outputs, ground_truth, keyframe_list=None):
         if "flow" not in model_outputs:
             return 0.0
         m = ground_truth["flow_mask"]
         flow = model_outputs["flow"]
+        if self._kernels(flow):
+            from ..fused.warp import masked_l1
+            return masked_l1(flow, ground_truth["flow"], m, 2)
         return (flow[m] - ground_truth["flow"].to(flow.device)[m]).abs().mean()
 
     def _warp_loss(self, warp_output):
         total = 0.0
         for patchsize, (gt_rgb, sampled, mask, _ray_mask) in warp_output.items():
             if patchsize == 1 or self.warp_loss_type == "l1":
-                total = total + (sampled[mask] - gt_rgb[mask]).abs().mean()
+                if self._kernels(sampled):
+                    from ..fused.warp import masked_l1
+                    total = total + masked_l1(sampled, gt_rgb, mask, 3)
+                else:
+                    total = total + (sampled[mask] - gt_rgb[mask]).abs().mean()
             else:   # "ssim": needs pytorch_msssim, exactly as the reference does
                 try:
                     from pytorch_msssim import SSIM

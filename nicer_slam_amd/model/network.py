@@ -71,6 +71,7 @@ class SLAMNetwork(nn.Module):
         #  * fine SDF MLP: pretrained, never in the optimizer (:140-173), but left requires_grad=True.
         self.tracking_param_grads = False
         self.fine_mlp_grads = False
+        self.warp_engine = "auto"   # "auto": flow / patch-warp blocks as HIP kernels on the fused engine; "torch": model/warp.py
 
     # ------------------------------------------------------------------ plumbing
     def _share_voxels(self):
@@ -201,16 +202,23 @@ class SLAMNetwork(nn.Module):
             depth = torch.sum(weights * z_vals, 1, keepdims=True) / (weights.sum(dim=1, keepdims=True) + 1e-8)
 
         output = {}
+        # keyframe re-projection blocks: HIP kernels on the fused engine (fused/warp.py), torch ops otherwise (model/warp.py)
+        warp_kernels = False
+        if fused and self.warp_engine != "torch":
+            from ..fused import warp as fused_warp
+            warp_kernels = fused_warp.available(depth, uv, pose)
         if "edges" in ground_truth:   # optical-flow reprojection (network.py:153-165)
-            pts = (cam_flat.unsqueeze(1) + depth.unsqueeze(2) * dirs.unsqueeze(1)).reshape(bs, -1, 3).permute(0, 2, 1)
-            idii, idjj, _, _ = ground_truth["edges"]
-            w2c = torch.linalg.inv(pose[idjj])
-            cam_pts = w2c[:, :3, :3] @ pts[idii] + w2c[:, :3, 3:]
-            proj = (intrinsics[idjj][:, :3, :3] @ cam_pts).permute(0, 2, 1)
-            output["flow"] = proj[..., :2] / (proj[..., 2:] + 1e-8) - uv[idii]
+            if warp_kernels:
+                output["flow"] = fused_warp.flow(self, uv, pose, intrinsics, depth, ground_truth["edges"])
+            else:
+                from .warp import flow_reproject
+                output["flow"] = flow_reproject(uv, pose, intrinsics, depth, ground_truth["edges"])
         if self.use_warp_loss and ("vis" not in mode) and ("tracking" not in mode):
-            from .warp import patch_warp
-            output["warp_output"] = patch_warp(self, uv, pose, intrinsics, depth.unsqueeze(2), ground_truth, bs)
+            if warp_kernels:
+                output["warp_output"] = fused_warp.patch_warp(self, uv, pose, intrinsics, depth, ground_truth, bs)
+            else:
+                from .warp import patch_warp
+                output["warp_output"] = patch_warp(self, uv, pose, intrinsics, depth.unsqueeze(2), ground_truth, bs)
 
         depth_values = depth_scale * depth.reshape(bs, -1, 1)
         if self.white_bkgd:

@@ -23,8 +23,9 @@ def uv2patch(uv, patchsize):
 
 def patch_warp(model, uv, pose, intrinsics, rendered_depth, ground_truth, batch_size):
     H, W = model.H, model.W
-    full_rgb = ground_truth["full_rgb"].reshape(batch_size, H, W, 3)
-    full_depth = ground_truth["full_depth"].reshape(batch_size, H, W, 1)
+    stacked = lambda t: t.stacked() if hasattr(t, "stacked") else t       # fused/warp.py::FrameStore (feed.py) or a plain tensor
+    full_rgb = stacked(ground_truth["full_rgb"]).reshape(batch_size, H, W, 3)
+    full_depth = stacked(ground_truth["full_depth"]).reshape(batch_size, H, W, 1)
     depth = rendered_depth.reshape(batch_size, -1, 1, 1)          # z of the centre ray, shared by its patch
     w2c = torch.linalg.inv(pose)
     out = {}
@@ -62,3 +63,16 @@ def patch_warp(model, uv, pose, intrinsics, rendered_depth, ground_truth, batch_
             total = total & flat_ok[None, :, :, None].expand(batch_size, -1, -1, p2)
         out[ps] = (gt_rgbs, sampled, total, ray_level)
     return out
+
+
+def flow_reproject(uv, pose, intrinsics, rendered_depth, edges):
+    """Optical-flow reprojection (network.py:150-165): the rendered 3-D point of every pixel of frame idii[e], projected into
+    frame idjj[e], minus the pixel.  [n_edges, n, 2]."""
+    bs = uv.shape[0]
+    dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
+    pts = (cam_loc.unsqueeze(1) + rendered_depth.reshape(bs, -1, 1) * dirs).permute(0, 2, 1)        # [b, 3, n]
+    idii, idjj = edges[0], edges[1]
+    w2c = torch.linalg.inv(pose[idjj])
+    cam_pts = w2c[:, :3, :3] @ pts[idii] + w2c[:, :3, 3:]
+    proj = (intrinsics[idjj][:, :3, :3] @ cam_pts).permute(0, 2, 1)
+    return proj[..., :2] / (proj[..., 2:] + 1e-8) - uv[idii]

@@ -404,6 +404,115 @@ def warp_case(name, seed, bs=2, n_pix=6):
     print(name, float(loss), {k: tuple(v.shape) for k, v in rec.items() if k.startswith("out_warp")})
 
 
+class _CutDepth(torch.overrides.TorchFunctionMode):
+    """Replaces the result of `rendered_depth = depth_values.unsqueeze(2)` (network.py:149) by a fresh leaf holding the same
+    values: the re-projection blocks downstream (flow :153-165, patch warp :167-279) are then a function of (depth leaf, pose)
+    alone, so their gradients can be recorded separately from the renderer's."""
+
+    def __init__(self, n_rays):
+        super().__init__()
+        self.n_rays, self.leaf = n_rays, None
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        if (self.leaf is None and func is torch.Tensor.unsqueeze and len(args) == 2 and args[1] == 2
+                and tuple(args[0].shape) == (self.n_rays, 1) and args[0].requires_grad):
+            self.leaf = out.detach().clone().requires_grad_(True)
+            return self.leaf
+        return out
+
+
+def reproj_case(name, seed, bs=3, n_pix=10):
+    """The keyframe re-projection blocks of a mapping iteration under bundle adjustment (camera tensors require grad,
+    volsdf_train.py:521-528): flow (network.py:153-165) and patch warp with patch sizes 1 and 5 (:167-279) on 40x60 frames.
+    Run twice on the reference: (A) as is -- forward tensors, total camera gradient; (B) with the rendered depth cut into a
+    leaf (_CutDepth) -- d/d(rendered depth) and the DIRECT camera gradient of the masked-L1 terms (loss.py:106-111,136-142)."""
+    coarse_grid, fine_grid, colour_grid = (4, 4, 8, 4, 8), (4, 32, 10, 8, 4), (4, 64, 10)
+    samples = (10, 32, 6)
+    H, W = _SmallDS.img_res
+    g = torch.Generator().manual_seed(seed + 1)
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 30.0
+    K[0, 2], K[1, 2] = 29.5, 19.5
+    K[0, 1] = 0.3                                  # skew
+    idx = torch.randint(H * W, (bs, n_pix), generator=g)
+    uv = torch.stack([(idx % W).float(), (idx // W).float()], -1)
+    uv[0, 0] = torch.tensor([1.0, 1.0])            # patch partly outside the image
+    uv[1, 1] = torch.tensor([float(W - 1), float(H - 2)])
+    cam0 = torch.zeros(bs, 7)
+    cam0[:, 0] = 1.0
+    cam0[:, :4] += 0.03 * torch.randn(bs, 4, generator=g)
+    cam0[:, 4:] = torch.tensor([0.1, 0.0, -0.2]) + 0.03 * torch.randn(bs, 3, generator=g)
+    Kb = K[None].repeat(bs, 1, 1)
+    full_rgb = torch.rand(bs, H * W, 3, generator=g)
+    full_depth = 1.0 + 0.02 * torch.rand(bs, H * W, 1, generator=g)
+    full_depth[:, : H * W // 3] += torch.rand(bs, H * W // 3, 1, generator=g)
+    gt_rgb = torch.rand(bs * n_pix, 3, generator=g)
+    edges = (torch.tensor([0, 1, 1, 2]), torch.tensor([1, 0, 2, 1]), torch.tensor([0, 10, 10, 20]), torch.tensor([10, 0, 20, 10]))
+    gt_flow = (torch.rand(4, n_pix, 2, generator=g) - 0.5) * 6
+    flow_mask = torch.rand(4, n_pix, generator=g) > 0.3
+    rec = {"in_uv": uv, "in_cam": cam0, "in_K": Kb, "in_voxels": torch.zeros(64, 64, 64), "in_full_rgb": full_rgb,
+           "in_full_depth": full_depth, "gt_rgb": gt_rgb, "in_idii": edges[0], "in_idjj": edges[1], "gt_flow": gt_flow,
+           "gt_flow_mask": flow_mask, "meta_mode": "mapping", "meta_stage": "fine", "meta_color_stage": "highfreq",
+           "meta_training": 1, "meta_samples": np.array(samples), "meta_coarse_grid": np.array(coarse_grid),
+           "meta_fine_grid": np.array(fine_grid), "meta_colour_grid": np.array(colour_grid), "meta_img_res": np.array([H, W])}
+
+    def reproj_terms(out):
+        terms = []
+        for ps, (gt_w, samp, mask, ray_mask) in out["warp_output"].items():
+            terms.append((samp[mask] - gt_w[mask]).abs().mean())                              # loss.py:136-142
+        fl = (out["flow"][flow_mask] - gt_flow[flow_mask]).abs().mean()                         # loss.py:106-111
+        return terms, fl
+
+    for run in ("A", "B"):
+        model, conf = build_model(seed, coarse_grid, fine_grid, colour_grid, *samples, emb_scale=(0.05, 0.05, 0.5),
+                                  warp=True, ds=_SmallDS())
+        model.train(True)
+        cam = cam0.clone().requires_grad_(True)
+        pose = ref_general.get_camera_from_tensor(cam)
+        pose.retain_grad()
+        log = DrawLog()
+        torch.manual_seed(seed + 3)
+        cut = _CutDepth(bs * n_pix) if run == "B" else contextlib.nullcontext()
+        with capture_draws(log), cut:
+            out = model({"intrinsics": Kb, "uv": uv, "pose": pose}, torch.arange(bs),
+                        {"full_rgb": full_rgb, "full_depth": full_depth, "edges": edges}, mode="mapping", stage="fine",
+                        color_stage="highfreq", frame_idx=20)
+        terms, fl = reproj_terms(out)
+        if run == "A":
+            rec["in_pose"] = pose.detach()
+            rec["draw_t_rand"], rec["draw_extra_idx"] = log.draws[0][1], log.draws[1][1][: samples[2]]
+            rec["draw_eik_idx"], rec["draw_eik_uniform"], rec["draw_eik_jitter"] = (log.draws[2][1], log.draws[3][1],
+                                                                                     log.draws[4][1])
+            for k, v in model.state_dict().items():
+                rec["param_" + k] = v
+            rec["out_flow"] = out["flow"]
+            for ps, (gt_w, samp, mask, ray_mask) in out["warp_output"].items():
+                rec[f"out_warp{ps}_gt"], rec[f"out_warp{ps}_sampled"], rec[f"out_warp{ps}_mask"] = gt_w, samp, mask
+                if ray_mask is not None:
+                    rec[f"out_warp{ps}_raymask"] = ray_mask
+            rec["out_z_vals"], rec["out_rgb_values"], rec["out_depth_values"] = (out["z_vals"], out["rgb_values"],
+                                                                                  out["depth_values"])
+            rec["out_warp_terms"], rec["out_flow_term"] = torch.stack(terms), fl
+            loss = (out["rgb_values"].reshape(-1, 3) - gt_rgb).abs().mean() + 0.5 * sum(terms) + 0.1 * fl
+            loss.backward()
+            rec["out_loss"], rec["grad_cam"], rec["grad_pose"] = loss, cam.grad, pose.grad
+        else:
+            leaf = cut.leaf
+            assert leaf is not None
+            rec["in_rendered_depth"] = leaf.detach().reshape(bs, n_pix)
+            # one backward per term: d term / d depth and the direct d term / d pose
+            for tag, term in [(f"warp{ps}", t) for ps, t in zip(out["warp_output"].keys(), terms)] + [("flow", fl)]:
+                leaf.grad = None
+                pose.grad = None
+                term.backward(retain_graph=True)
+                rec[f"grad_depth_{tag}"] = leaf.grad.reshape(bs, n_pix).clone()
+                rec[f"grad_pose_{tag}"] = pose.grad.clone()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **t2n(rec))
+    print(name, float(rec["out_loss"]), [float(t) for t in rec["out_warp_terms"]], float(rec["out_flow_term"]),
+          {k: tuple(v.shape) for k, v in rec.items() if k.startswith("grad_")})
+
+
 def loss_case(name, seed, frame_idx, stage, bs=2, n=12, S=6):
     """SLAMLoss.forward (model/loss.py:113-233 + utils/MiDaS.py) with the shipped Replica weights
     (confs/replica/runconf_replica_1.conf:45-56) on random model outputs: every term and d loss / d output."""
@@ -580,6 +689,9 @@ if __name__ == "__main__":
     if "--rw-only" in sys.argv:
         rw_cases()
         sys.exit(0)
+    if "--reproj-only" in sys.argv:
+        reproj_case("reproj_blocks", 51)
+        sys.exit(0)
     if "--feed-only" in sys.argv:
         feed_case("feed_batches", 41)
         sys.exit(0)
@@ -591,6 +703,7 @@ if __name__ == "__main__":
     if "--loss-only" in sys.argv:
         sys.exit(0)
     warp_case("full_mapping_warp", 15)
+    reproj_case("reproj_blocks", 51)
     encoder_case("enc_coarse", 1, L=4, C=8, base=8, end=8, logmap=19, n_pts=64)
     encoder_case("enc_fine", 2, L=8, C=4, base=4, end=40, logmap=10, n_pts=64)
     encoder_case("enc_colour", 3, L=16, C=2, base=4, end=128, logmap=11, n_pts=64)

@@ -63,6 +63,23 @@ def test_argument_validation_needs_no_gpu():
     assert lib.nsa_slam_loss(None, None, None) == NSA_EBADARG
     assert lib.nsa_slam_loss(ctypes.byref(LossDesc()), fake, None) == NSA_EBADARG     # zero sizes / NULL tensors
     assert lib.nsa_slam_loss_workspace(8, 1024, 0) > 8 * 1024
+    # round-3 entry points: keyframe re-projection blocks and their masked-L1 terms
+    from nicer_slam_amd._native import WarpDesc
+    assert lib.nsa_patch_warp_forward(None, 1, None, None, None, None, None) == NSA_EBADARG
+    w = WarpDesc(2, 8, 40, 60, 4096, 4096, 4096, 4096, 4096, 4096, None, None)       # pointers never dereferenced
+    assert lib.nsa_patch_warp_forward(ctypes.byref(w), 4, fake, fake, fake, fake, None) == NSA_EBADARG      # even patch size
+    assert lib.nsa_patch_warp_forward(ctypes.byref(w), 5, fake, fake, fake, fake, None) == NSA_EBADARG      # patch > 1 without depth frames
+    assert lib.nsa_patch_warp_backward(ctypes.byref(w), 1, fake, fake, fake, None, None, None) == NSA_EBADARG   # pose gradient without w2c gradient
+    assert lib.nsa_patch_warp_backward(ctypes.byref(w), 5, fake, fake, None, None, None, None) == NSA_EBADARG   # patch > 1 needs the workspace
+    assert lib.nsa_patch_warp_workspace(8, 1024, 1, 0) == 0
+    assert lib.nsa_patch_warp_workspace(8, 1024, 5, 0) == 8 * 1024 * 25
+    assert lib.nsa_flow_forward(ctypes.byref(w), None, None, 3, None, None) == NSA_EBADARG
+    assert lib.nsa_flow_forward(ctypes.byref(w), None, None, 0, None, None) == 0                                # no edges: no-op
+    assert lib.nsa_flow_backward(None, None, None, 0, None, None, None, None, None, None) == NSA_EBADARG
+    assert lib.nsa_flow_workspace(8, 1024, 12, 0) == 0 and lib.nsa_flow_workspace(8, 1024, 12, 1) > 0
+    assert lib.nsa_masked_l1(None, None, None, 16, 3, None, None, None, None) == NSA_EBADARG
+    assert lib.nsa_masked_l1(fake, fake, None, 16, 0, fake, None, fake, None) == NSA_EBADARG                    # zero channels
+    assert lib.nsa_masked_l1_workspace(1 << 20) >= 4
     # empty work is a no-op, not an error (reference: a zero-size launch is never issued either)
     assert lib.nsa_sdf_points(None, 0, None, None, None, None, None, None) == 0
     assert lib.nsa_sampler_sdf(None, None, 0, 640, None, None, 0.0, 1.0, 3.5, None, None, None, None, None, None, None, None) == 0

@@ -16,6 +16,9 @@ constexpr uint32_t LV_HASHED = 1u;    // index = xor-prime hash of the cell
 constexpr uint32_t LV_POW2 = 2u;      // rows is a power of two: modulo == mask
 constexpr uint32_t LV_SUBONCE = 4u;   // dense and idx < 2*rows guaranteed: modulo == one conditional subtract
 constexpr uint32_t LV_GENERIC = 8u;   // neither: needs a true uint32 modulo (never the case for the shipped grids)
+// fast corner addressing of the fused kernels (gather_corners, D = 3): byte offsets, three adds for the eight corners
+constexpr uint32_t LV_FASTDENSE = 16u;  // dense, no uint32 stride wrap, idx < 2*rows, all byte offsets < 2^31
+constexpr uint32_t LV_FASTHASH = 32u;   // hashed with a power-of-two row count, all byte offsets < 2^32
 
 struct LevelGeom {
     float scale;     // exp2f(level*S)*H - 1   (float32, hashencoder.cu:180)
@@ -25,6 +28,11 @@ struct LevelGeom {
     uint32_t s2;     // dense stride of dim 2 (= res*res, uint32 wrap)
     uint32_t flags;
     uint32_t mask;   // rows-1 when rows is a power of two, else 0xFFFFFFFF (so `idx & mask` is always legal)
+    // byte-scaled copies for the fast corner addressing of the fused kernels (corner_offsets; B = C * 4 bytes per row)
+    uint32_t row0B;  // row0 * B
+    uint32_t s1B;    // s1 * B
+    uint32_t s2B;    // s2 * B
+    uint32_t limB;   // LV_FASTDENSE: (row0 + rows) * B - (s2B + s1B + B): corner (0,0,0) below it <=> all eight rows inside the level
     uint32_t pad;
 };
 
@@ -33,8 +41,10 @@ struct GridGeom {
 };
 
 // Host: emulate get_grid_index's stride loop (hashencoder.cu:56-70) in uint32 to classify the level.
-inline int make_grid_geom(const int32_t* offsets_host, uint32_t L, uint32_t D, float S, uint32_t H, GridGeom* out) {
+inline int make_grid_geom(const int32_t* offsets_host, uint32_t L, uint32_t D, float S, uint32_t H, GridGeom* out,
+                          uint32_t C = 8) {
     if (L > NSA_MAX_LEVELS) return NSA_ETOO_MANY_LEVELS;
+    const uint64_t table_bytes = (uint64_t)(uint32_t)offsets_host[L] * C * 4;
     for (uint32_t l = 0; l < L; ++l) {
         LevelGeom g;
         g.scale = exp2f((float)l * S) * (float)H - 1.0f;
@@ -61,6 +71,20 @@ inline int make_grid_geom(const int32_t* offsets_host, uint32_t L, uint32_t D, f
         else g.flags |= LV_GENERIC;
         g.mask = (g.flags & LV_POW2) ? g.rows - 1u : 0xFFFFFFFFu;
         g.pad = 0;
+        const uint32_t B = C * 4;
+        g.row0B = g.row0 * B;
+        g.s1B = g.s1 * B;
+        g.s2B = g.s2 * B;
+        g.limB = 0;
+        if (D == 3 && table_bytes < (1ull << 32)) {
+            const uint64_t end_bytes = ((uint64_t)g.row0 + g.rows) * B;
+            if (!(g.flags & LV_HASHED) && !wrapped && max_idx < 2ull * g.rows && end_bytes < (1ull << 31) &&
+                (uint64_t)g.s2 * B < (1ull << 24) && res < (1u << 20)) {
+                g.flags |= LV_FASTDENSE;
+                g.limB = (uint32_t)end_bytes - (g.s2B + g.s1B + B);
+            }
+            if ((g.flags & LV_HASHED) && (g.flags & LV_POW2)) g.flags |= LV_FASTHASH;
+        }
         out->lv[l] = g;
     }
     return NSA_OK;
@@ -87,6 +111,15 @@ __device__ __forceinline__ float mul_rn(float a, float b) {
 }
 
 // ---- device side -------------------------------------------------------------------------------
+// [-1,1] -> [0,1] map of HashEncoder.forward: (x / divide_factor + 1) / 2 (hashgrid.py:203, size = 1).  x / 1.0f == x exactly,
+// and every shipped configuration has divide_factor = 1 (a kernel argument, uniform): the ~10-instruction IEEE division
+// sequence is skipped by a scalar branch in that case, bit-identically.
+__device__ __forceinline__ float to_unit(float x, float divide_factor) {
+    float y = x;
+    if (__builtin_expect(divide_factor != 1.0f, 0)) y = x / divide_factor;
+    return (y + 1.0f) / 2.0f;
+}
+
 template <int D>
 __device__ __forceinline__ uint32_t level_row(const LevelGeom& g, const uint32_t (&q)[D]) {
     uint32_t idx;
@@ -214,9 +247,11 @@ __device__ __forceinline__ bool locate(const float (&x)[D], float scale, uint32_
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         const float p = x[d] * scale;
-        const float fl = floorf(p);
-        cell[d] = (uint32_t)fl;
-        const float t = p - (float)cell[d];
+        // cell = (uint32_t)floorf(p), t = p - (float)cell (hashencoder.cu:188-195).  For every in-range point p >= 0, so the
+        // truncating conversion IS the floor and p - floor(p) is v_fract_f32 (the subtraction is exact in fp32); results of
+        // out-of-range points are discarded by every caller (`inside`).
+        cell[d] = (uint32_t)p;
+        const float t = __builtin_amdgcn_fractf(p);
         dw[d] = 6.0f * t * (1.0f - t);
         w[d] = t * t * (3.0f - 2.0f * t);
     }
@@ -261,14 +296,16 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&v
 }
 
 // Gather the 2^D corner rows of the cell into registers: corner bit d set <=> +1 along dim d.
-// Branch-free (the level, hence hashed/dense, differs between the two half-waves): per dimension the two candidate
-// index terms (cell, cell+1) are formed once -- (q * prime) for hashed levels, (q * stride) for dense ones -- and the
-// 2^D corners combine them with xor resp. add; `& mask` and one conditional subtract implement the modulo for every
-// level class except LV_GENERIC, which only a pathological geometry produces: the stand-alone operator compiles the
-// slow path in (GENERIC = true), the fused kernels refuse such a grid on the host (has_generic_level).
+//
+// Generic form (stand-alone operator, and the fall-back of the fast form): branch-free -- the level, hence hashed/dense, may
+// differ between the lanes of a wave -- per dimension the two candidate index terms (cell, cell+1) are formed once, (q * prime)
+// for hashed levels, (q * stride) for dense ones, and the 2^D corners combine them with xor resp. add; `& mask` and one
+// conditional subtract implement the modulo for every level class except LV_GENERIC, which only a pathological geometry
+// produces: the stand-alone operator compiles the slow path in (GENERIC = true), the fused kernels refuse such a grid on the
+// host (has_generic_level).
 template <int D, int C, bool GENERIC = false>
-__device__ __forceinline__ void gather_corners(const float* __restrict__ table, const LevelGeom& g,
-                                               const uint32_t (&cell)[D], float (&v)[1 << D][C]) {
+__device__ __forceinline__ void gather_corners_generic(const float* __restrict__ table, const LevelGeom& g,
+                                                       const uint32_t (&cell)[D], float (&v)[1 << D][C]) {
     const bool hashed = (g.flags & LV_HASHED) != 0;
     uint32_t term[D][2];
     term[0][0] = cell[0];
@@ -305,19 +342,90 @@ __device__ __forceinline__ void gather_corners(const float* __restrict__ table, 
     }
 }
 
+// Fast form of the fused kernels (D = 3, levels classified by make_grid_geom): the BYTE offsets of the eight corner rows from
+// the table base, then eight loads with the table pointer in SGPRs and the 32-bit offset in a VGPR (global_load ... saddr) --
+// no 64-bit address arithmetic per corner.  A lane takes the path of ITS level (the lanes of a wave may hold different levels; a
+// path no lane needs is skipped; only offsets are formed inside the branches, so the loads stay one vector instruction per row):
+//   LV_FASTDENSE  offset of corner (0,0,0) by a shift-add and two 24-bit multiply-adds with the level's byte strides, the
+//                 other corners by seven adds.  The only modulo a dense level ever needs is at its upper boundary (cell + 1 ==
+//                 resolution, i.e. a coordinate of exactly 1.0): such a lane takes the generic path;
+//   LV_FASTHASH   power-of-two hashed level: the four (y, z) prime-term combinations once, then xor / and / shift-add per corner;
+//   otherwise     the generic index arithmetic.
+template <int C>
+__device__ __forceinline__ void corner_offsets(const LevelGeom& g, const uint32_t (&cell)[3], uint32_t (&off)[8]) {
+    constexpr uint32_t B = C * 4;
+    // every corner row inside the level <=> the last one is; all byte offsets then stay below 2^31 (no wrap-around), and a
+    // garbage cell of an out-of-range point -- whose result is discarded -- cannot address outside the table either
+    uint32_t o00 = __umul24(cell[1], g.s1B) + (cell[0] * B + g.row0B);
+    o00 = __umul24(cell[2], g.s2B) + o00;
+    if ((g.flags & LV_FASTDENSE) && o00 < g.limB) {
+        const uint32_t o10 = o00 + g.s1B, o01 = o00 + g.s2B, o11 = o01 + g.s1B;
+        off[0] = o00; off[1] = o00 + B; off[2] = o10; off[3] = o10 + B;
+        off[4] = o01; off[5] = o01 + B; off[6] = o11; off[7] = o11 + B;
+    } else if (g.flags & LV_FASTHASH) {
+        const uint32_t y0 = cell[1] * 2654435761u, y1 = y0 + 2654435761u;
+        const uint32_t z0 = cell[2] * 805459861u, z1 = z0 + 805459861u;
+        const uint32_t yz[4] = {y0 ^ z0, y1 ^ z0, y0 ^ z1, y1 ^ z1};
+        const uint32_t x0 = cell[0], x1 = cell[0] + 1u;
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner)
+            off[corner] = ((((corner & 1) ? x1 : x0) ^ yz[corner >> 1]) & g.mask) * B + g.row0B;
+    } else {
+        const bool hashed = (g.flags & LV_HASHED) != 0;
+        const uint32_t m1 = hashed ? 2654435761u : g.s1, m2 = hashed ? 805459861u : g.s2;
+        const uint32_t t0[2] = {cell[0], cell[0] + 1u}, t1[2] = {cell[1] * m1, cell[1] * m1 + m1}, t2[2] = {cell[2] * m2, cell[2] * m2 + m2};
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const uint32_t a0 = t0[corner & 1], a1 = t1[(corner >> 1) & 1], a2 = t2[corner >> 2];
+            uint32_t idx = (hashed ? (a0 ^ a1 ^ a2) : (a0 + a1 + a2)) & g.mask;
+            idx = idx >= g.rows ? idx - g.rows : idx;
+            idx = idx < g.rows ? idx : g.rows - 1u;        // (garbage cell of a far out-of-range point: stay inside the level)
+            off[corner] = idx * B + g.row0B;
+        }
+    }
+}
+
+template <int D, int C, bool GENERIC = false>
+__device__ __forceinline__ void gather_corners(const float* __restrict__ table, const LevelGeom& g,
+                                               const uint32_t (&cell)[D], float (&v)[1 << D][C]) {
+#ifdef NSA_ABL_NOGATHER
+    gather_corners_generic<D, C, GENERIC>(table, g, cell, v);
+#else
+    if constexpr (D != 3 || GENERIC) {
+        gather_corners_generic<D, C, GENERIC>(table, g, cell, v);
+    } else {
+        uint32_t off[8];
+        corner_offsets<C>(g, cell, off);
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner)
+            load_row<C>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + (size_t)off[corner]), v[corner]);
+    }
+#endif
+}
+
 // Smoothstep-weighted multilinear blend, corner order/product order as kernel_grid (:203-229).
 template <int D, int C>
 __device__ __forceinline__ void blend(const float (&v)[1 << D][C], const float (&w)[D], float (&out)[C]) {
 #pragma unroll
     for (int c = 0; c < C; ++c) out[c] = 0.0f;
+    float wt[1 << D];
+    if constexpr (D == 3) {       // ((wx wy) wz), the association of the reference's running product, with the xy products shared
+        const float nx = 1.0f - w[0], ny = 1.0f - w[1], nz = 1.0f - w[2];
+        const float xy[4] = {nx * ny, w[0] * ny, nx * w[1], w[0] * w[1]};
 #pragma unroll
-    for (int corner = 0; corner < (1 << D); ++corner) {
-        float wt = 1.0f;
+        for (int corner = 0; corner < 8; ++corner) wt[corner] = xy[corner & 3] * ((corner & 4) ? w[2] : nz);
+    } else {
 #pragma unroll
-        for (int d = 0; d < D; ++d) wt *= ((corner >> d) & 1) ? w[d] : 1.0f - w[d];
+        for (int corner = 0; corner < (1 << D); ++corner) {
+            wt[corner] = 1.0f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) out[c] += wt * v[corner][c];
+            for (int d = 0; d < D; ++d) wt[corner] *= ((corner >> d) & 1) ? w[d] : 1.0f - w[d];
+        }
     }
+#pragma unroll
+    for (int corner = 0; corner < (1 << D); ++corner)
+#pragma unroll
+        for (int c = 0; c < C; ++c) out[c] += wt[corner] * v[corner][c];
 }
 
 // Jacobian row d out/d x[gd] from the SAME corner values (kernel_grid :239-282 re-gathers them).

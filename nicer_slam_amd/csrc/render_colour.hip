@@ -118,7 +118,7 @@ __device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeo
     }
     float u[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) u[d] = (x[d] / a.divide_factor + 1.0f) / 2.0f;
+    for (int d = 0; d < 3; ++d) u[d] = to_unit(x[d], a.divide_factor);
     float* sv = (a.save && wave_live) ? a.save + (size_t)tile * 64 * 64 + lane : nullptr;   // clamped waves write nothing
 #pragma unroll
     for (int jl = 0; jl < CL / 2; ++jl) {
@@ -163,7 +163,7 @@ __device__ __forceinline__ void colour_mlp(float* stage, const float* __restrict
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h1[16 * t + r] = fmaxf(a1[t][r], 0.0f);
+        for (int r = 0; r < 16; ++r) h1[16 * t + r] = relu_f(a1[t][r]);
     load_vec<2>(wp + ColPack::kB1, h, a2);
     if (STAGED) gemm_staged_part<Seq, kColStage, HS, 2, 0, 4>(stage, wp, 2, lane, h1, a2);
     else        gemm_op<HS, 2>(wp + ColPack::kW1, lane, h1, a2);
@@ -175,7 +175,7 @@ __device__ __forceinline__ void colour_mlp(float* stage, const float* __restrict
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) part = fmaf(fmaxf(a2[t][r], 0.0f), wv[t][r], part);
+            for (int r = 0; r < 16; ++r) part = fmaf(relu_f(a2[t][r]), wv[t][r], part);
         const float o = xhalf_sum(part) + wp[ColPack::kB2 + j];
         rgb[j] = 1.0f / (1.0f + expf(-o));
     }
@@ -244,8 +244,8 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
         for (int s = 0; s < COL_IN_STEPS; ++s) em.slot(CE_IN, s, h, in[s]);
 #pragma unroll
         for (int q = 0; q < HS; ++q) {
-            em.hid(CE_H1, q, h, fmaxf(a1[q >> 4][q & 15], 0.0f));
-            em.hid(CE_H2, q, h, fmaxf(a2[q >> 4][q & 15], 0.0f));
+            em.hid(CE_H1, q, h, relu_f(a1[q >> 4][q & 15]));
+            em.hid(CE_H2, q, h, relu_f(a2[q >> 4][q & 15]));
         }
     }
     // d/d(pre-sigmoid), d/d h2 = sum_j ob_j W2[j,:], relu masks (torch: grad * (a > 0))
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
     if (MAP && a.grid_grad && a.g_table) {   // colour-table gradient: w_corner * fbar, run-merged (kernel_grid_backward)
         float u[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) u[d] = (x[d] / a.divide_factor + 1.0f) / 2.0f;
+        for (int d = 0; d < 3; ++d) u[d] = to_unit(x[d], a.divide_factor);
 #pragma unroll
         for (int jl = 0; jl < CL / 2; ++jl) {
             const LevelGeom lg = geom.lv[2 * jl + h];
@@ -407,7 +407,7 @@ static int colour_common(const nsa_points_t* pts, const nsa_grid_t* grid, nsa::C
     if (!pts || !grid) return NSA_EBADARG;
     if (pts->points || !pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0) return NSA_EBADARG;   // needs view dirs
     if (!(grid->L == 16 && grid->C == 2)) return NSA_EUNSUPPORTED_NET;
-    if (int rc = make_grid_geom16(grid->offsets_host, grid->L, grid->S, grid->H, geom)) return rc;
+    if (int rc = make_grid_geom16(grid->offsets_host, grid->L, grid->S, grid->H, geom, grid->C)) return rc;
     a->src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, nullptr, pts->P, pts->S, pts->order};
     a->table = grid->table;
     a->divide_factor = grid->divide_factor;

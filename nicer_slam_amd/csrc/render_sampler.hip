@@ -425,8 +425,8 @@ int NSA_ENTRY(nsa_sampler_sdf)(const float* rays_o, const float* rays_d, uint32_
                                            packed_fine, z, sdf, far, stream);
     }
     GridGeom16 gc, gf;
-    if (int rc = make_grid_geom16(coarse->offsets_host, coarse->L, coarse->S, coarse->H, &gc)) return rc;
-    if (int rc = make_grid_geom16(fine->offsets_host, fine->L, fine->S, fine->H, &gf)) return rc;
+    if (int rc = make_grid_geom16(coarse->offsets_host, coarse->L, coarse->S, coarse->H, &gc, coarse->C)) return rc;
+    if (int rc = make_grid_geom16(fine->offsets_host, fine->L, fine->S, fine->H, &gf, fine->C)) return rc;
     SamplerArgs a{rays_o, rays_d, t_lin, t_rand, z, sdf, far, R, E, near, bound, far_cap,
                   coarse->table, fine->table, packed_coarse, packed_fine, coarse->divide_factor, fine->divide_factor};
     const uint64_t total = (uint64_t)R * E;
@@ -455,8 +455,8 @@ int NSA_ENTRY(nsa_sdf_points)(const float* points, uint64_t N, const nsa_grid_t*
         return NSA_ENTRY(nsa_sdf4_points)(points, N, coarse, fine, packed_coarse, packed_fine, sdf, stream);
     }
     GridGeom16 gc, gf{};
-    if (int rc = make_grid_geom16(coarse->offsets_host, coarse->L, coarse->S, coarse->H, &gc)) return rc;
-    if (fine) if (int rc = make_grid_geom16(fine->offsets_host, fine->L, fine->S, fine->H, &gf)) return rc;
+    if (int rc = make_grid_geom16(coarse->offsets_host, coarse->L, coarse->S, coarse->H, &gc, coarse->C)) return rc;
+    if (fine) if (int rc = make_grid_geom16(fine->offsets_host, fine->L, fine->S, fine->H, &gf, fine->C)) return rc;
     SdfPointsArgs a{points, sdf, N, coarse->table, fine ? fine->table : nullptr, packed_coarse, fine ? packed_fine : nullptr,
                     coarse->divide_factor, fine ? fine->divide_factor : 1.0f};
     const uint64_t waves = (N + 31) / 32;

@@ -207,8 +207,8 @@ int NSA_ENTRY(nsa_sampler4_sdf)(const float* rays_o, const float* rays_d, uint32
                                 float* far, nsa_stream_t stream) {
     using namespace nsa;
     GridGeom16 gc, gf;
-    if (int rc = make_grid_geom16(coarse->offsets_host, coarse->L, coarse->S, coarse->H, &gc)) return rc;
-    if (int rc = make_grid_geom16(fine->offsets_host, fine->L, fine->S, fine->H, &gf)) return rc;
+    if (int rc = make_grid_geom16(coarse->offsets_host, coarse->L, coarse->S, coarse->H, &gc, coarse->C)) return rc;
+    if (int rc = make_grid_geom16(fine->offsets_host, fine->L, fine->S, fine->H, &gf, fine->C)) return rc;
     Sampler4Args a{rays_o, rays_d, t_lin, t_rand, z, sdf, far, R, E, near, bound, far_cap,
                    coarse->table, fine->table, packed_coarse, packed_fine, coarse->divide_factor, fine->divide_factor};
     const uint64_t total = (uint64_t)R * E;
@@ -224,8 +224,8 @@ int NSA_ENTRY(nsa_sdf4_points)(const float* points, uint64_t N, const nsa_grid_t
                                const float* packed_coarse, const float* packed_fine, float* sdf, nsa_stream_t stream) {
     using namespace nsa;
     GridGeom16 gc, gf{};
-    if (int rc = make_grid_geom16(coarse->offsets_host, coarse->L, coarse->S, coarse->H, &gc)) return rc;
-    if (fine) if (int rc = make_grid_geom16(fine->offsets_host, fine->L, fine->S, fine->H, &gf)) return rc;
+    if (int rc = make_grid_geom16(coarse->offsets_host, coarse->L, coarse->S, coarse->H, &gc, coarse->C)) return rc;
+    if (fine) if (int rc = make_grid_geom16(fine->offsets_host, fine->L, fine->S, fine->H, &gf, fine->C)) return rc;
     SdfPoints4Args a{points, sdf, N, coarse->table, fine ? fine->table : nullptr, packed_coarse, fine ? packed_fine : nullptr,
                      coarse->divide_factor, fine ? fine->divide_factor : 1.0f};
     const uint64_t tiles = (N + 15) / 16;

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256, (NH == 1 ? (MAP ? 1 : NSA_OCC_BWD_COARSE) : NS
 static int launch_sdfnet(bool bwd, const nsa_grid_t* grid, const SdfNetArgs& a, hipStream_t st) {
     const bool map = a.g_table != nullptr || a.emit != nullptr;
     GridGeom16 geom;
-    if (int rc = make_grid_geom16(grid->offsets_host, grid->L, grid->S, grid->H, &geom)) return rc;
+    if (int rc = make_grid_geom16(grid->offsets_host, grid->L, grid->S, grid->H, &geom, grid->C)) return rc;
     const uint32_t tiles = (a.src.P + 31) / 32;
     const dim3 g((tiles + 3) / 4), b(256);
     launch_begin();

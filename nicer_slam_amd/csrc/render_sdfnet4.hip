@@ -379,7 +379,7 @@ static_assert(NSA_NW4_BWD * 64 * (2 * 8 + 1) <= stage_floats4(NSA_NW4_BWD), "sca
 static int launch_sdfnet4(bool bwd, const nsa_grid_t* grid, const SdfNet4Args& a, hipStream_t st) {
     const bool map = a.g_table != nullptr || a.emit != nullptr;
     GridGeom16 geom;
-    if (int rc = make_grid_geom16(grid->offsets_host, grid->L, grid->S, grid->H, &geom)) return rc;
+    if (int rc = make_grid_geom16(grid->offsets_host, grid->L, grid->S, grid->H, &geom, grid->C)) return rc;
     const uint32_t tiles = (a.src.P + 15) / 16;
     const int nw = bwd ? NSA_NW4_BWD : NSA_NW4_FWD;
     const dim3 g((tiles + nw - 1) / nw), b(64 * nw);

@@ -19,10 +19,10 @@ struct GridGeom16 {
     LevelGeom lv[16];
 };
 
-inline int make_grid_geom16(const int32_t* offsets_host, uint32_t L, float S, uint32_t H, GridGeom16* out) {
+inline int make_grid_geom16(const int32_t* offsets_host, uint32_t L, float S, uint32_t H, GridGeom16* out, uint32_t C) {
     if (L > 16) return NSA_ETOO_MANY_LEVELS;
     GridGeom g;
-    if (int rc = make_grid_geom(offsets_host, L, 3, S, H, &g)) return rc;
+    if (int rc = make_grid_geom(offsets_host, L, 3, S, H, &g, C)) return rc;
     for (uint32_t l = 0; l < L; ++l) out->lv[l] = g.lv[l];
     if (has_generic_level(out->lv, L)) return NSA_EUNSUPPORTED_NET;   // fused kernels carry no generic-modulo path
     return NSA_OK;
@@ -70,7 +70,7 @@ __device__ __forceinline__ void grid_slots(const float (&x)[3], float divide_fac
                                            const GridGeom16& geom, int h, float (&in)[SDF_IN_STEPS], float* jstore = nullptr) {
     float u[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) u[d] = (x[d] / divide_factor + 1.0f) / 2.0f;   // hashgrid.py:203 (size = 1)
+    for (int d = 0; d < 3; ++d) u[d] = to_unit(x[d], divide_factor);   // hashgrid.py:203 (size = 1)
 #ifdef NSA_ABL_NOGRID       // timing experiment only: no grid encoder at all
     if (!jstore) {
 #pragma unroll
@@ -208,7 +208,7 @@ __device__ __forceinline__ void slots_to_x(const float (&x)[3], float divide_fac
     }
     float u[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) u[d] = (x[d] / divide_factor + 1.0f) / 2.0f;
+    for (int d = 0; d < 3; ++d) u[d] = to_unit(x[d], divide_factor);
     const float chain = 1.0f / (2.0f * divide_factor);
 #pragma unroll
     for (int jl = 0; jl < L / 2; ++jl) {
@@ -271,7 +271,7 @@ __device__ __forceinline__ void x_to_slots_tangent(const float (&x)[3], float di
     }
     float u[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) u[d] = (x[d] / divide_factor + 1.0f) / 2.0f;
+    for (int d = 0; d < 3; ++d) u[d] = to_unit(x[d], divide_factor);
     const float chain = 1.0f / (2.0f * divide_factor);
 #pragma unroll
     for (int jl = 0; jl < L / 2; ++jl) {
@@ -383,7 +383,7 @@ __device__ __forceinline__ void table_grad_scatter(const float (&x)[3], float di
                                                    const float (&n)[3], float* __restrict__ g_table, float* lds_tile) {
     float u[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) u[d] = (x[d] / divide_factor + 1.0f) / 2.0f;
+    for (int d = 0; d < 3; ++d) u[d] = to_unit(x[d], divide_factor);
     const float chain = 1.0f / (2.0f * divide_factor);
 #pragma unroll
     for (int jl = 0; jl < L / 2; ++jl) {

@@ -94,7 +94,7 @@ __device__ __forceinline__ void grid_slots4(const float (&x)[3], float divide_fa
     static_assert(L * C == 32 && (C == 4 || C == 8), "quad layout: 32 grid features, 8 per quarter-lane");
     float u[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) u[d] = (x[d] / divide_factor + 1.0f) / 2.0f;   // hashgrid.py:203 (size = 1)
+    for (int d = 0; d < 3; ++d) u[d] = to_unit(x[d], divide_factor);   // hashgrid.py:203 (size = 1)
 #pragma unroll
     for (int jl = 0; jl < 8 / C; ++jl) {
         const LevelGeom g = s_geom[q + 4 * jl];
@@ -166,7 +166,7 @@ __device__ __forceinline__ void slots_to_x4(const float (&x)[3], float divide_fa
     pe_to_x4(q, in, dl, g);
     float u[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) u[d] = (x[d] / divide_factor + 1.0f) / 2.0f;
+    for (int d = 0; d < 3; ++d) u[d] = to_unit(x[d], divide_factor);
     const float chain = 1.0f / (2.0f * divide_factor);
 #pragma unroll
     for (int jl = 0; jl < 8 / C; ++jl) {
@@ -231,7 +231,7 @@ __device__ __forceinline__ void x_to_slots_tangent4(const float (&x)[3], float d
     pe_tangent4(q, in, n, dl, tin, xbar);
     float u[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) u[d] = (x[d] / divide_factor + 1.0f) / 2.0f;
+    for (int d = 0; d < 3; ++d) u[d] = to_unit(x[d], divide_factor);
     const float chain = 1.0f / (2.0f * divide_factor);
 #pragma unroll
     for (int jl = 0; jl < 8 / C; ++jl) {
@@ -316,7 +316,7 @@ __device__ __forceinline__ void table_grad_scatter4(const float (&x)[3], float d
                                                     const float (&n)[3], float* __restrict__ g_table, float* lds_tile) {
     float u[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) u[d] = (x[d] / divide_factor + 1.0f) / 2.0f;
+    for (int d = 0; d < 3; ++d) u[d] = to_unit(x[d], divide_factor);
     const float chain = 1.0f / (2.0f * divide_factor);
 #pragma unroll
     for (int jl = 0; jl < 8 / C; ++jl) {

@@ -502,7 +502,7 @@ __global__ __launch_bounds__(WT) void k_l1_grad(L1Args a) {
 static inline uint32_t waves_per_image(uint32_t per_image) { return ((per_image + WT - 1) / WT) * (WT / 64); }
 
 static inline bool warp_ok(const nsa_warp_t* in) {
-    return in && in->b && in->n && in->H > 1 && in->W > 1 && in->uv && in->pose && in->w2c && in->K && in->depth;
+    return in && in->b && in->n && in->uv && in->pose && in->w2c && in->K && in->depth;     // (H, W: patch warp only)
 }
 
 }  // namespace nsa
@@ -512,7 +512,7 @@ extern "C" {
 int nsa_patch_warp_forward(const nsa_warp_t* in, uint32_t patch, float* sampled, uint8_t* mask, float* gt_rgb, uint8_t* flat,
                            nsa_stream_t stream) {
     using namespace nsa;
-    if (!warp_ok(in) || !in->images || !patch || !(patch & 1) || !sampled || !mask || !gt_rgb) return NSA_EBADARG;
+    if (!warp_ok(in) || in->H < 2 || in->W < 2 || !in->images || !patch || !(patch & 1) || !sampled || !mask || !gt_rgb) return NSA_EBADARG;
     if (patch > 1 && (!in->depths || !flat)) return NSA_EBADARG;
     WarpArgs a{};
     a.in = *in;
@@ -544,7 +544,7 @@ uint64_t nsa_patch_warp_workspace(uint32_t b, uint32_t n, uint32_t patch, int wa
 int nsa_patch_warp_backward(const nsa_warp_t* in, uint32_t patch, const float* g_sampled, float* g_depth, float* g_pose,
                             float* g_w2c, float* workspace, nsa_stream_t stream) {
     using namespace nsa;
-    if (!warp_ok(in) || !in->images || !patch || !(patch & 1) || !g_sampled || !g_depth) return NSA_EBADARG;
+    if (!warp_ok(in) || in->H < 2 || in->W < 2 || !in->images || !patch || !(patch & 1) || !g_sampled || !g_depth) return NSA_EBADARG;
     const int want_pose = g_pose != nullptr || g_w2c != nullptr;
     if (want_pose && (!g_pose || !g_w2c)) return NSA_EBADARG;
     if ((patch > 1 || want_pose) && !workspace) return NSA_EBADARG;

@@ -111,14 +111,10 @@ __device__ __forceinline__ float mul_rn(float a, float b) {
 }
 
 // ---- device side -------------------------------------------------------------------------------
-// [-1,1] -> [0,1] map of HashEncoder.forward: (x / divide_factor + 1) / 2 (hashgrid.py:203, size = 1).  x / 1.0f == x exactly,
-// and every shipped configuration has divide_factor = 1 (a kernel argument, uniform): the ~10-instruction IEEE division
-// sequence is skipped by a scalar branch in that case, bit-identically.
-__device__ __forceinline__ float to_unit(float x, float divide_factor) {
-    float y = x;
-    if (__builtin_expect(divide_factor != 1.0f, 0)) y = x / divide_factor;
-    return (y + 1.0f) / 2.0f;
-}
+// [-1,1] -> [0,1] map of HashEncoder.forward: (x / divide_factor + 1) / 2 (hashgrid.py:203, size = 1).  (A scalar branch that skips
+// the IEEE division sequence when divide_factor == 1 -- every shipped configuration -- was measured: no gain in any kernel, +4 us in
+// the colour forward, whose first gathers then wait behind the branch; profiles/r03_ab_experiments.txt.)
+__device__ __forceinline__ float to_unit(float x, float divide_factor) { return (x / divide_factor + 1.0f) / 2.0f; }
 
 template <int D>
 __device__ __forceinline__ uint32_t level_row(const LevelGeom& g, const uint32_t (&q)[D]) {
@@ -385,13 +381,18 @@ __device__ __forceinline__ void corner_offsets(const LevelGeom& g, const uint32_
     }
 }
 
-template <int D, int C, bool GENERIC = false>
+// FAST = true: corner_offsets (per-lane branches on the level class).  Measured on MI355X, same box (profiles/r03_ab_experiments
+// .txt): it removes 17 % of the sampler's VALU instructions and 11 us (210 -> 199) of its time, but in the kernels that live on
+// memory-level parallelism (colour forward: HBM gather) or run two networks' worth of barriers (SDF forward / backward) the branch
+// regions keep the compiler from hoisting the next level's loads above the current level's arithmetic, and those got 1-4 us
+// SLOWER with 3-15 % fewer VALU instructions -- so only the sampler-side callers ask for it.
+template <int D, int C, bool GENERIC = false, bool FAST = false>
 __device__ __forceinline__ void gather_corners(const float* __restrict__ table, const LevelGeom& g,
                                                const uint32_t (&cell)[D], float (&v)[1 << D][C]) {
 #ifdef NSA_ABL_NOGATHER
     gather_corners_generic<D, C, GENERIC>(table, g, cell, v);
 #else
-    if constexpr (D != 3 || GENERIC) {
+    if constexpr (D != 3 || GENERIC || !FAST) {
         gather_corners_generic<D, C, GENERIC>(table, g, cell, v);
     } else {
         uint32_t off[8];

@@ -400,16 +400,12 @@ constexpr float SP_K = 100.0f * 1.4426950408889634f;       // beta * log2(e)
 constexpr float SP_LIN = 20.0f * 1.4426950408889634f;      // threshold in the same units
 constexpr float SP_OUT = 0.01f * 0.6931471805599453f;      // ln(2) / beta
 
-// max(a, 0) as ONE instruction: a signed-integer max on the bit pattern (negative floats, including -0, are negative integers).
-// fmaxf(a, 0.0f) -- and the compare-select and med3 forms, which the compiler turns back into it -- costs two: IEEE mode makes
-// v_max_f32 quiet signalling NaNs, so a canonicalising v_max_f32 a, a is put in front of every one whose input (an MFMA result)
-// is not provably canonical.  (Not inline asm either: the hazard recogniser cannot see an asm operand, and a VALU read of a
-// fresh MFMA result without the required wait states returns stale data -- measured: wrong colours.)  A NaN keeps its sign rule
-// (positive-signed NaN stays NaN, negative-signed becomes 0); 128 of these per 32 sampler points.
-__device__ __forceinline__ float relu_f(float a) {
-    const int i = __float_as_int(a);
-    return __int_as_float(i > 0 ? i : 0);
-}
+// max(a, 0).  fmaxf compiles to TWO v_max_f32 (a canonicalising v_max a, a in front: IEEE-mode signalling-NaN quieting the
+// compiler cannot prove unnecessary for an MFMA result).  One-instruction forms were measured (profiles/r03_ab_experiments.txt):
+// inline asm -- WRONG results, the hazard recogniser cannot see an asm operand and a VALU read of a fresh MFMA result without
+// its wait states returns stale data; integer max on the bit pattern -- correct, 128 fewer VALU per 32 sampler points, no time
+// gained there and +9 us in the colour forward.  So: fmaxf.
+__device__ __forceinline__ float relu_f(float a) { return fmaxf(a, 0.0f); }
 
 // value only (sampler): the overflow-free form max(a,0) + ln(1 + e^{-|beta a|})/beta -- no compare/select, and equal to
 // torch's thresholded softplus to the last ulp (for beta a > 20 the log term is < 2e-9 relative and rounds away).

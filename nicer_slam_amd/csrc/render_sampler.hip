@@ -99,12 +99,12 @@ __global__ __launch_bounds__(256, NSA_OCC_SAMPLER) void k_sampler_sdf(SamplerArg
         idx[t] = (uint32_t)(pid[t] - (uint64_t)ray[t] * a.E);
         sampler_point(a, pid[t], ray[t], idx[t], x[t], zi[t], farv[t]);
         pe_slots(x[t], h, in[t]);               // shared by both networks
-        grid_slots<LC, CC>(x[t], a.df_c, a.table_c, gc, h, in[t]);
+        grid_slots<LC, CC, true>(x[t], a.df_c, a.table_c, gc, h, in[t]);
     }
     float sdf[T], sdf_f[T];
     sdf_only_tiles<NHC, T>(a.wp_c, lane, h, in, sdf);
 #pragma unroll
-    for (int t = 0; t < T; ++t) grid_slots<LF, CF>(x[t], a.df_f, a.table_f, gf, h, in[t]);
+    for (int t = 0; t < T; ++t) grid_slots<LF, CF, true>(x[t], a.df_f, a.table_f, gf, h, in[t]);
     sdf_only_tiles<NHF, T>(a.wp_f, lane, h, in, sdf_f);
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -144,10 +144,10 @@ __global__ __launch_bounds__(256, 2) void k_sdf_points(SdfPointsArgs a, GridGeom
     for (int k = 0; k < 3; ++k) x[k] = a.points[pid * 3 + k];
     float in[SDF_IN_STEPS];
     pe_slots(x, h, in);
-    grid_slots<LC, CC>(x, a.df_c, a.table_c, gc, h, in);
+    grid_slots<LC, CC, true>(x, a.df_c, a.table_c, gc, h, in);
     float sdf = sdf_only<NHC>(a.wp_c, lane, h, in);
     if (a.table_f) {                            // uniform branch
-        grid_slots<LF, CF>(x, a.df_f, a.table_f, gf, h, in);
+        grid_slots<LF, CF, true>(x, a.df_f, a.table_f, gf, h, in);
         sdf += sdf_only<NHF>(a.wp_f, lane, h, in);
     }
     if (live && h == 0) a.sdf[pid] = sdf;

@@ -65,7 +65,7 @@ __device__ __forceinline__ void pe_slots(const float (&x)[3], int h, float (&in)
 // jstore != nullptr: also keeps d feature / d u (the 3 x C Jacobian rows of every level of this lane, zero outside the
 // grid) in a lane-private LDS column, jstore[((jl*3 + d)*C + c) * 64] -- the backward then needs no second and third
 // corner gather (slots_to_x_jac / tangent_from_jac below).
-template <int L, int C>
+template <int L, int C, bool FAST = false>
 __device__ __forceinline__ void grid_slots(const float (&x)[3], float divide_factor, const float* __restrict__ table,
                                            const GridGeom16& geom, int h, float (&in)[SDF_IN_STEPS], float* jstore = nullptr) {
     float u[3];
@@ -85,7 +85,7 @@ __device__ __forceinline__ void grid_slots(const float (&x)[3], float divide_fac
         float w[3], dw[3];
         const bool inside = locate<3>(u, g.scale, cell, w, dw);
         float v[8][C];
-        gather_corners<3, C>(table, g, cell, v);
+        gather_corners<3, C, false, FAST>(table, g, cell, v);
         float f[C];
         blend<3, C>(v, w, f);
 #pragma unroll

@@ -237,6 +237,7 @@ __device__ __forceinline__ void gemm16_staged_part(float* stage, const float* __
 template <class Seq, int NW, int BUF, int KG, int MT>
 __device__ __forceinline__ void gemm16_staged(float* stage, const float* __restrict__ wp, int opi, int lane,
                                               const float (&b)[8 * KG], f32x4v (&acc)[MT]) {
+
     constexpr int M = max_groups<BUF>(MT);
     constexpr int NP = (KG + M - 1) / M;
     static_assert(NP <= 3, "a staged GEMM is split into at most three parts");

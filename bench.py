@@ -79,7 +79,44 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mapping", action="store_true", help="skip the (untimed-for-value) mapping-iteration leg")
     ap.add_argument("--cpu-rays", type=int, default=1024)
-    return ap.parse_args()
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 4],
+                    help="BASELINE.json configs[i] as a preset: 1 = 1024 rays x 128 samples, one GPU, fp32 (the default); "
+                         "2 = --gpus 8 --global-rays 4096 --precision bf16; 4 = --gpus 8 --global-rays 8192 --samples 192 "
+                         "--precision bf16_colour (bf16 MLPs with the SDF head in fp32).  Explicit flags given with it must agree.")
+    args = ap.parse_args()
+    preset = {1: dict(gpus=1, global_rays=0, samples=128, precision="fp32"),
+              2: dict(gpus=8, global_rays=4096, samples=128, precision="bf16"),
+              4: dict(gpus=8, global_rays=8192, samples=192, precision="bf16_colour")}.get(args.config)
+    if preset:
+        defaults = dict(gpus=1, global_rays=0, samples=128, precision="fp32")
+        for k, v in preset.items():
+            if getattr(args, k) != defaults[k] and getattr(args, k) != v:
+                ap.error(f"--config {args.config} means --{k.replace('_', '-')} {v}, got {getattr(args, k)}")
+            setattr(args, k, v)
+    return args
+
+
+def workload_label(args, world, oversub):
+    """config.workload from the arguments actually run (never a fixed string), and the BASELINE.json config it is, if any."""
+    g_rays = args.rays * world
+    prec = {"fp32": "fp32", "bf16": "bf16 MLP operands", "bf16_colour": "bf16 colour MLP + fp32 SDF head"}[args.precision]
+    where = ("single MI355X" if world == 1 else
+             f"{world} ranks ray-sharded ({args.rays} rays/rank, {'strong' if args.global_rays else 'weak'} scaling), one 9-float "
+             + ("gloo all-reduce per step, ranks OVERSUBSCRIBED on fewer GPUs (smoke mode, not a scaling number)" if oversub
+                else "RCCL all-reduce per step, one MI355X per rank"))
+    which = "no BASELINE config (custom shape)"
+    if world == 1 and args.rays == 1024 and args.samples == 128 and args.precision == "fp32":
+        which = "BASELINE configs[1]"
+    elif world == 8 and g_rays == 4096 and args.samples == 128 and args.precision == "bf16":
+        which = "BASELINE configs[2]"
+    elif world == 8 and g_rays == 8192 and args.samples == 192 and args.precision == "bf16_colour":
+        which = "BASELINE configs[4] (sample counts; synthetic Replica-sized scene)"
+    elif args.rays == 1024 and args.samples == 128 and args.precision == "fp32" and not args.global_rays:
+        which = f"BASELINE configs[1] per GPU x {world} (weak scaling of the metric's 1/2/4/8-GPU row)"
+    elif g_rays == 1024 and args.samples == 128 and args.precision == "fp32":
+        which = f"BASELINE configs[1] spread over {world} GPUs (strong scaling)"
+    return (f"Replica room0 tracking iteration, {g_rays} rays x {args.samples} samples (+640 sampler evaluations/ray), {where}, "
+            f"{prec} [{which}]")
 
 
 class DS:
@@ -208,8 +245,13 @@ def main():
     torch.cuda.synchronize()
     prof, be.PROFILE = be.PROFILE, None
     t = torch.tensor([dt], device=device, dtype=torch.float64)
+    rccl_ranks = 0
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)                      # the number of ranks that actually took part in a collective
+        rccl_ranks = 0 if oversub else int(ones.item())
+        assert int(ones.item()) == dist.get_world_size() == world
     dt = float(t.item())
 
     if rank == 0:
@@ -274,14 +316,13 @@ def main():
             "higher_is_better": True, "scaling": "strong" if args.global_rays else "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16": "bf16 MLP operands (f32 accumulate, encoders and compositing f32)",
                       "bf16_colour": "bf16 colour-MLP operands, f32 SDF head"}[args.precision], "data": "synthetic",
-            "config": {"workload": f"Replica room0 tracking iteration, {args.rays} rays x {args.samples} samples "
-                                   f"(+640 sampler evaluations/ray), single MI355X fp32 [BASELINE configs[1]]",
+            "config": {"workload": workload_label(args, world, oversub), "baseline_config_preset": args.config or None,
                        "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "sampler_evals_per_ray": 640,
                        "global_rays": args.rays * world,
                        "engine": "fused" if Stepper.__name__ == "KernelTracker" else model.last_engine, "param_grads": args.param_grads,
                        "hip_graph": bool(use_graph), "driver": Stepper.__name__, "ray_chunks": ray_chunks, "clock_prewarm_s": args.prewarm_s, "box_probe_fp32_gemm_tflops": probe_tflops,
                        "parallelism": f"ray-shard x{world}" if world > 1 else "single",
-                       "rccl_ranks": 0 if (world == 1 or oversub) else world,
+                       "rccl_ranks": rccl_ranks,
                        "exchange": None if world == 1 else "one 9-float all-reduce (pose gradient, loss, ray count) per step"
                                    + (", captured in the hipGraph" if collective_in_graph else ", between graph replay and Adam launch"),
                        "oversubscribed": oversub or None},
@@ -497,7 +538,9 @@ def cpu_baseline(args, model, conf):
             "threads": {"torch_intraop": torch.get_num_threads(), "c_hash_kernels_openmp": omp}, "host_cores": os.cpu_count(),
             "kind": "port",
             "sample": f"{n} rays x (640 sampler + {args.samples} composite) samples, fwd+bwd to pose grad, "
-                      f"median of {len(timed)} iterations after 2 warm-ups ({round(sum(times), 1)} s of host time in all)"}
+                      f"median of {len(timed)} iterations after 2 warm-ups ({round(sum(times), 1)} s of host time in all); "
+                      f"{torch.get_num_threads()} torch + {omp} OpenMP threads of {os.cpu_count()} host cores: more threads only "
+                      f"slow this sample's [n x 768, 64] GEMMs down (all {os.cpu_count()} cores measured ~1 ray/s on this box type)"}
 
 
 def dropin_leg(args, device, K, batches, steps=60):
@@ -506,18 +549,19 @@ def dropin_leg(args, device, K, batches, steps=60):
     autograd around the fused autograd.Functions, no KernelTracker.  Two rows:
       faithful   every model parameter requires grad, exactly as volsdf_train.py builds the model (the reference computes and
                  discards all parameter gradients in tracking, :547 zeroes them before any use);
-      pose_only  model.tracking_param_grads = False -- one attribute -- skips that discarded work.
+      pose_only  model.tracking_param_grads = False -- one attribute -- skips that discarded work; hipGraph-captured;
+      pose_only_eager  the same launched eagerly, i.e. the reference's unmodified loop shape (it captures nothing).
     Context numbers; `value` stays the KernelTracker iteration."""
     from nicer_slam_amd.tracking import TrackingStepper
     out = {"driver": "SLAMNetwork.forward + torch autograd + torch.optim.Adam (TrackingStepper)"}
-    for row, flag in (("pose_only", False), ("faithful", True)):
+    for row, flag, graph in (("pose_only", False, True), ("pose_only_eager", False, False), ("faithful", True, False)):
         a = argparse.Namespace(**vars(args))
         a.param_grads = True                        # make_model leaves requires_grad as constructed
         model, _ = make_model(a, device)
         model.tracking_param_grads = flag
         cam = torch.tensor([1.0, 0, 0, 0, 0.1, 0.0, -0.2], device=device)
         try:
-            st = TrackingStepper(model, K, args.rays, cam, lr=0.005, use_graph=not flag, world=1)
+            st = TrackingStepper(model, K, args.rays, cam, lr=0.005, use_graph=graph, world=1)
             n = min(steps, len(batches))
             for i in range(min(5, n)):
                 st.step(*batches[i])
@@ -528,7 +572,7 @@ def dropin_leg(args, device, K, batches, steps=60):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
             out[row] = {"ms_per_step": round(dt * 1e3, 4), "rays_per_s": round(args.rays / dt, 1), "engine": model.last_engine,
-                        "hip_graph": not flag, "steps": n}
+                        "hip_graph": graph, "steps": n}
         except Exception as e:      # a context leg must never take the headline down
             out[row] = {"error": f"{type(e).__name__}: {e}"[:300]}
         del model

@@ -150,7 +150,7 @@ int nsa_colour_backward(const nsa_points_t *pts, const nsa_grid_t *grid, const f
  * 333-395; code/hashencoder/hashgrid.py:64-141) for the trainable parameters of volsdf_train.py:150-173:
  *   g_table  gradient of the grid table (same shape as grid->table), ATOMICALLY ACCUMULATED (caller zeroes it):
  *            value path + (SDF grids) the table's share of the double backward through grad sdf; may be NULL.
- *   emit     [nsa_*_emit_rows()][emit_ld] per-point vectors, column = point index (emit_ld >= ceil(P/32)*32, columns
+ *   emit     [nsa_*_emit_rows()][emit_ld] per-point vectors, column = point index (emit_ld >= ceil(P/32)*32 -- the quad tiling writes 16-point tiles, so its padding starts at ceil(P/16)*16 --, columns
  *            of padding points are written as 0).  The weight gradients are GEMMs over these rows (row map: the
  *            SE_* / CE_* enums in csrc/render_sdfnet.hip, csrc/render_colour.hip; host side fused/mapping.py).
  *            SDF: nsa_sdfnet_emit_rows_nh(grid->n_hidden) rows (464 for the coarse network, 976 for the fine one, whose
@@ -275,7 +275,7 @@ int nsa_adam_table_step(float *param, const float *grad, float *exp_avg, float *
 
 /* MLP weight gradients from the emission rows of the *_backward_params kernels: emit is [rows][ld] fp32 (column = point,
  * ld a multiple of 4096, columns past the last point zero).
- *   out[m][n] = sum_j sum_p emit[a_rows[j] + m][p] * emit[b_rows[j] + n][p],   j < pairs (1 or 2), m < M <= 64, n < N <= 159
+ *   out[m][n] = sum_j sum_p emit[a_rows[j] + m][p] * emit[b_rows[j] + n][p],   j < pairs (1 or 2), m < M <= 64, n < N <= 192
  * and, with row_sums, out[m][N] = sum_p emit[a_rows[0] + m][p] (the bias gradient); out is [M][N + row_sums], fp32-faithful
  * products, deterministic (per-chunk partials in `workspace`, nsa_emit_gemm_workspace() floats, added in chunk order).
  * replaces torch autograd's weight / bias gradients of the Linear layers (code/model/base_networks.py:195-221, 333-395). */

@@ -27,6 +27,19 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-f
          "-Wall", "-Wno-unused-function"] + os.environ.get("NSA_EXTRA_HIPCC_FLAGS", "").split()
 
 
+def _check_flags():
+    """The product library (no NSA_BUILD_TAG) must be the product: timing-ablation / experiment macros (NSA_ABL_*, NSA_EXP_*,
+    NSA_X_*) compute wrong numbers or change kernels and are only accepted for a tagged side-by-side build; and the correctness
+    flag -fno-slp-vectorize (above) cannot be dropped or overridden in any build."""
+    extra = os.environ.get("NSA_EXTRA_HIPCC_FLAGS", "").split()
+    bad = [f for f in extra if any(f.startswith("-D" + p) for p in ("NSA_ABL_", "NSA_EXP_", "NSA_X_"))]
+    if bad and not TAG:
+        raise SystemExit(f"build.py: {bad} are experiment macros; set NSA_BUILD_TAG=<tag> for a side-by-side build "
+                         "(the untagged library is the product)")
+    if any(f in ("-fslp-vectorize", "-fvectorize") for f in extra) or "-fno-slp-vectorize" not in FLAGS:
+        raise SystemExit("build.py: -fno-slp-vectorize is a correctness flag on gfx950 (see the comment above FLAGS)")
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -35,6 +48,7 @@ def _stale(target, deps):
 
 
 def build_native(force=False, verbose=False):
+    _check_flags()
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))

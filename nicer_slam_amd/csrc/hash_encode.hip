@@ -108,7 +108,7 @@ __global__ __launch_bounds__(TPB) void k_grid_scatter(const float* __restrict__ 
     for (int d = 0; d < D; ++d) x[d] = have ? inputs[(size_t)b * D + d] : -1.0f;
     for (uint32_t level = wave; level < L; level += NWAVE) {
         const LevelGeom g = geom.lv[level];
-        uint32_t cell[D];
+        uint32_t cell[D] = {};               // (lanes without a point skip locate(): keep the row arithmetic below defined)
         float w[D], dw[D];
         const bool active = have && locate<D>(x, g.scale, cell, w, dw);     // out-of-range points add nothing (:313-317)
         float gy[C];
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(TPB) void k_grid_second_backward(const float* __res
             store_row<C>(grad_grad + ((size_t)level * B + b) * C, r);
         }
         if (!SCATTER) continue;
-        uint32_t cell[D];
+        uint32_t cell[D] = {};
         float w[D], dw[D];
         const bool active = have && locate<D>(x, g.scale, cell, w, dw);
         float gy[C];
@@ -267,9 +267,11 @@ static inline uint32_t point_tiles(uint32_t B) { return (B + TILE - 1) / TILE; }
 static inline int launch_status() { return launch_end(); }
 // LDS bytes of the dy_dx tile, or 0 when it would not fit the default 64 KiB dynamic allocation (the kernels then touch the
 // row pieces in global memory directly)
-static inline size_t jac_tile_bytes(uint32_t L, int D, int C) {
+// `static_lds`: what the kernel allocates statically on top (the scatter variant of the second backward keeps scatter_x_pair's
+// stage2[4][64 * (2C + 1)] floats): both together must fit the 64 KiB a launch may ask for without opting into more.
+static inline size_t jac_tile_bytes(uint32_t L, int D, int C, size_t static_lds = 0) {
     const size_t n = TILE * ((size_t)L * D * C + 1) * sizeof(float);
-    return n <= 64 * 1024 ? n : 0;
+    return n + static_lds <= 64 * 1024 ? n : 0;
 }
 
 template <int D, int C>
@@ -298,7 +300,7 @@ static int second_dc(const float* grad, const float* in, const float* dy_dx, con
     const dim3 grid(point_tiles(B)), block(TPB);
     // reading: a (point, level) piece of D*C*4 = 96 bytes (C = 8) is fetched whole anyway and the tile only costs occupancy
     // (coarse SDF grid: 327 us direct, 463 us staged); 24- and 48-byte pieces gain from arriving as complete rows
-    const size_t lds = D * C * sizeof(float) < 64 ? jac_tile_bytes(L, D, C) : 0;
+    const size_t lds = D * C * sizeof(float) < 64 ? jac_tile_bytes(L, D, C, g2emb ? 4 * 64 * (2 * C + 1) * sizeof(float) : 0) : 0;
     launch_begin();
     if (g2emb) hipLaunchKernelGGL((k_grid_second_backward<D, C, true>), grid, block, lds, st, grad, in, dy_dx, ggi, gg, g2emb, B, L, geom, lds != 0);
     else       hipLaunchKernelGGL((k_grid_second_backward<D, C, false>), grid, block, lds, st, grad, in, dy_dx, ggi, gg, g2emb, B, L, geom, lds != 0);

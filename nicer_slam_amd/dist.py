@@ -75,6 +75,14 @@ class ShardedAdam(torch.optim.Optimizer):
     the SUM so that ranks with different ray counts still produce the gradient of the global mean.
     Hyper-parameters/semantics as nicer_slam_amd.optim.Adam / torch.optim.Adam (no weight decay, no amsgrad).
     ``stepper`` = callable(p, g, exp_avg, exp_avg_sq, step, lr, betas, eps) updating p in place; default: the HIP kernel.
+
+    ``p.grad`` is CONSUMED by ``step()``: it is scaled by ``weight`` in place and the collectives run on its storage (the
+    reduce-scatter reads it; under gloo the fallback all-reduces into it), so after the step it no longer holds this rank's
+    local gradient -- call ``zero_grad()`` before the next backward as usual, and read local gradients before ``step()``.
+    Branches that have never run with more than one rank on real hardware (no multi-GPU box was available to any build round):
+    the ``nccl`` in-place forms ``dist.reduce_scatter_tensor`` / ``dist.all_gather_into_tensor`` on views of the gradient /
+    parameter storage (``_reduce_scatter`` / ``_all_gather``); the gloo tests (world 2 and 3) take the all-reduce / all-gather
+    list fallbacks of the same methods, and a 1-rank RCCL group exercises the in-place forms with world = 1 only.
     """
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, shard_min_numel=1 << 16, stepper=None):

@@ -119,7 +119,48 @@ class KernelTracker:
                                  self.m.data_ptr(), self.v.data_ptr(), self.t.data_ptr(), lr, b1, b2, eps, lr_step, lr_gamma,
                                  red[7:8].data_ptr() if fused else None, self.best.data_ptr() if fused else None, st))
 
+    # ---- packed MLP parameters (fused/pack.py) ---------------------------------------------------------------------------
+    # The kernels read the weight-normed MLP parameters from packed snapshots cached on (data_ptr, _version) of the parameters.
+    # A captured graph holds the snapshots' ADDRESSES: when a mapping step between two tracked frames changes the MLPs, the
+    # next cache miss would allocate a new snapshot (and free the captured one) while the graph kept replaying on the stale --
+    # possibly recycled -- memory.  The tracker therefore owns the snapshots its sequence reads: before every iteration it
+    # compares the parameters' keys with those of its snapshots and, on a change, re-packs INTO the same tensors.
+    def _pack_specs(self):
+        fs, model = self.fs, self.model
+        use = "sampler_large" if self.R // self.chunks >= fs.SAMPLER_LARGE_RAYS else "sampler"
+        specs = []
+        for which in ("coarse", "fine"):
+            for u in (use, None):
+                specs.append(((which, fs.tile_of(model, u or which)), which, u))
+        return specs
+
+    def _ensure_packs(self):
+        """Fresh packed blocks for every tiling the sequence uses, on the current stream (so forked chunk streams never race a
+        cache miss), re-packed in place when the tracker already owns them."""
+        fs, fr, model = self.fs, self.fr, self.model
+        owned = self.__dict__.setdefault("_packs", {})
+        cache = model.__dict__.setdefault("_fused_pack", {})
+        jobs = [(k, (lambda w=w, u=u: fs.packed_sdf(model, w, use=u)),
+                 getattr(model.implicit_network, w).mlp_parameters()) for k, w, u in self._pack_specs()]
+        jobs.append(("colour", lambda: fr.packed_colour(model), model.rendering_network.mlp_parameters()))
+        for k, pack_fn, params in jobs:
+            key = tuple((p.data_ptr(), p._version) for p in params)
+            mine = owned.get(k)
+            if mine is not None and mine[0] == key and cache.get(k, (None, None))[1] is mine[1]:
+                continue
+            if mine is not None:
+                cache.pop(k, None)                     # force a re-pack, then move it into the tensor the graph knows
+                fresh = pack_fn()
+                mine[1].copy_(fresh)
+                cache[k] = (key, mine[1])
+                owned[k] = (key, mine[1])
+            else:
+                owned[k] = (key, pack_fn())
+                cache[k] = owned[k]
+
     def _iteration(self):
+        if self.graph is None or not torch.cuda.is_current_stream_capturing():
+            self._ensure_packs()
         if self.chunks == 1:
             self._rays_pass(0, self.R, self.pose, self.red)
             if self.collective_in_graph:
@@ -172,6 +213,7 @@ class KernelTracker:
         self.gt.copy_(gt)
         with torch.no_grad():
             if self.graph is not None:
+                self._ensure_packs()               # the graph reads the tracker-owned snapshots: refresh them in place
                 self.graph.replay()
             else:
                 self._iteration()

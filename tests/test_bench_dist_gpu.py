@@ -22,3 +22,26 @@ def test_bench_under_torchrun_single_rank():
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"] is not None
     for key in ("metric", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config"):
         assert key in line
+
+
+def test_bench_self_launch_two_ranks_oversubscribed():
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run; on a one-GPU box the two ranks
+    share device 0 over gloo (smoke mode): the ray-sharded step, the max-over-ranks timing and the labels of an N > 1 line."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm-s", "0",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    cfg = line["config"]
+    assert cfg["global_rays"] == 2048 and cfg["rays_per_gpu"] == 1024
+    assert "2 ranks ray-sharded" in cfg["workload"] and "single MI355X" not in cfg["workload"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert cfg["oversubscribed"] is True and cfg["rccl_ranks"] == 0 and "OVERSUBSCRIBED" in cfg["workload"]
+    else:
+        assert cfg["rccl_ranks"] == 2
+    assert line["dropin"] is None and line["mapping_iteration"] is None          # context legs are N = 1 only

@@ -261,6 +261,40 @@ def test_kernel_tracker_matches_autograd_stepper():
     assert abs(ref_l[0] - float(fx["out_loss"])) < 5e-5
 
 
+@pytest.mark.parametrize("chunks", [1, 2])
+def test_kernel_tracker_graph_follows_mlp_updates_between_frames(chunks):
+    """A mapping step between two tracked frames changes the MLPs (version bump -> the packed-weight cache misses -> a new
+    snapshot, the old one freed).  A captured graph knows only the old snapshot's address: the tracker owns its snapshots and
+    re-packs into them, so the replayed graph renders with the CURRENT weights (tracking.py).  Graph vs a fresh
+    eager tracker after an optimizer-like in-place update of every MLP and of a table; also the eager chunked path (packs made
+    on the launching stream before the fork)."""
+    from nicer_slam_amd.tracking import KernelTracker
+    fx, model, cam, pose, _, _ = _setup("full_tracking")
+    model.train(True)
+    model.engine = "fused"
+    model.draws = draws_of(fx, "cuda")
+    K, uv, gt = tt(fx["in_K"]).cuda(), tt(fx["in_uv"]).cuda(), tt(fx["gt_rgb"]).cuda()
+    cam0 = tt(fx["in_cam"]).reshape(-1)
+    n = uv.shape[1]
+    kt = KernelTracker(model, K, n, cam0, lr=0.005, use_graph=True, chunks=chunks)
+    before = [float(kt.step(uv, gt)) for _ in range(2)]
+    g = torch.Generator(device="cuda").manual_seed(11)
+    with torch.no_grad():                                     # what optimizer.step() of a mapping iteration does: in place
+        for name, p in model.named_parameters():
+            if ".lin" in name or "embeddings" in name:
+                p.add_(0.05 * float(p.abs().mean()) * torch.randn(p.shape, device="cuda", generator=g))
+    torch.cuda.empty_cache()                                  # freed snapshots really go away
+    junk = [torch.randn(1 << 16, device="cuda") for _ in range(32)]     # ... and their memory gets recycled
+    kt.reset(cam0)
+    got = [float(kt.step(uv, gt)) for _ in range(3)]
+    fresh = KernelTracker(model, K, n, cam0, lr=0.005, use_graph=False, chunks=chunks)
+    want = [float(fresh.step(uv, gt)) for _ in range(3)]
+    assert abs(want[0] - before[0]) > 1e-4, "the update must change the rendering for this test to mean anything"
+    assert_close(torch.tensor(got), torch.tensor(want), 2e-6, 1e-5, "losses after the update (graph vs fresh eager)")
+    assert_close(kt.cam, fresh.cam, 2e-6, 1e-4, "camera")
+    del junk
+
+
 def test_kernel_tracker_steplr_and_min_loss_candidate():
     """The reference's per-frame tracking protocol (volsdf_train.py:396-403,425-446): Adam + StepLR, and the frame's result
     is the camera cloned AFTER the step of the arg-min-loss iteration.  KernelTracker (schedule and candidate inside the

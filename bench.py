@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mapping", action="store_true", help="skip the (untimed-for-value) mapping-iteration leg")
     ap.add_argument("--cpu-rays", type=int, default=1024)
+    ap.add_argument("--only-mapping", type=int, default=0, metavar="ITERS",
+                    help="profiling aid: run ONLY the mapping-iteration leg with this many timed iterations and print its dict")
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 4],
                     help="BASELINE.json configs[i] as a preset: 1 = 1024 rays x 128 samples, one GPU, fp32 (the default); "
                          "2 = --gpus 8 --global-rays 4096 --precision bf16; 4 = --gpus 8 --global-rays 8192 --samples 192 "
@@ -161,6 +163,10 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.only_mapping:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X"
+        print(json.dumps(mapping_leg(torch.device("cuda", 0), iters=args.only_mapping, cpu=not args.no_cpu_baseline)))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -334,7 +340,7 @@ def main():
         dist.destroy_process_group()
 
 
-def mapping_leg(device, rays=8192, frames=8, iters=5):
+def mapping_leg(device, rays=8192, frames=8, iters=5, cpu=True):
     """Context number, not `value`: one MAPPING iteration as the shipped Replica configuration runs it
     (code/confs/replica/runconf_replica_1.conf; volsdf_train.py:548-576): SLAMNetwork.forward(mode="mapping", stage "fine",
     colour stage "highfreq", use_warp_loss = true, mapping_patchsizes = [1], flow edges between neighbouring keyframes) ->
@@ -448,7 +454,7 @@ def mapping_leg(device, rays=8192, frames=8, iters=5):
             "eikonal_points": 22 * rays, "rays_per_s": round(rays / dt, 1), "engine": model.last_engine,
             "optimizer": "nicer_slam_amd.optim.Adam (1.1 GiB of parameters, dense)", "iters": iters,
             "final_loss": round(float(last), 6), "kernels_ms": {k: round(v, 3) for k, v in sorted(agg.items())},
-            "roofline": roof, "cpu_baseline": cpu_mapping_baseline(model)}
+            "roofline": roof, "cpu_baseline": cpu_mapping_baseline(model) if cpu else None}
 
 
 def cpu_mapping_baseline(model, n=256, frames=8):

@@ -238,18 +238,26 @@ __global__ __launch_bounds__(LT) void k_loss_terms(LossArgs a) {
 
 // terms[0..6] = rgb, eikonal, smooth, depth, gt_depth, normal_l1, normal_cos (unweighted, as SLAMLoss.get_* return them),
 // terms[7] = their weighted sum
-__global__ void k_loss_final(LossArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one wave: lane j adds the partials of blocks j, j + 64, ... (in that order), then a fixed butterfly adds the 64 lane sums --
+// deterministic, and ~700 dependent loads (a single thread took 84 us at the mapping shape) become 11 per lane
+__global__ __launch_bounds__(64) void k_loss_final(LossArgs a) {
     const nsa_loss_t& L = a.in;
     double s[NTERM] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t k = 0; k < a.term_blocks; ++k)
+    for (uint32_t k = threadIdx.x; k < a.term_blocks; k += 64)
         for (int j = 0; j < NTERM; ++j) s[j] += a.term_part[(size_t)k * NTERM + j];
     double M_all = 0.0, cnt_gt = 0.0;
-    for (uint32_t b = 0; b < L.bs; ++b)
-        for (uint32_t k = 0; k < a.blocks_per_image; ++k) {
-            M_all += a.stat_part[((size_t)b * a.blocks_per_image + k) * NSTAT + 2];
-            cnt_gt += a.stat_part[((size_t)b * a.blocks_per_image + k) * NSTAT + 6];
-        }
+    for (uint32_t i = threadIdx.x; i < L.bs * a.blocks_per_image; i += 64) {
+        M_all += a.stat_part[(size_t)i * NSTAT + 2];
+        cnt_gt += a.stat_part[(size_t)i * NSTAT + 6];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int j = 0; j < NTERM; ++j) s[j] += __shfl_xor(s[j], off);
+        M_all += __shfl_xor(M_all, off);
+        cnt_gt += __shfl_xor(cnt_gt, off);
+    }
+    if (threadIdx.x != 0) return;
     const double R = (double)L.bs * L.n;
     const float rgb = (float)(s[0] / (3.0 * R));
     const float eik = L.w_eik > 0.0f && L.E ? (float)(s[1] / L.E) : 0.0f;

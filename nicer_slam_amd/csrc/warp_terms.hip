@@ -477,10 +477,12 @@ __global__ __launch_bounds__(WT) void k_l1_part(L1Args a) {
     }
 }
 
-__global__ void k_l1_final(L1Args a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void k_l1_final(L1Args a) {          // one wave, fixed order (deterministic)
     double s = 0.0, cnt = 0.0;
-    for (uint32_t k = 0; k < a.blocks; ++k) { s += a.part[2 * k]; cnt += a.part[2 * k + 1]; }
+    for (uint32_t k = threadIdx.x; k < a.blocks; k += 64) { s += a.part[2 * k]; cnt += a.part[2 * k + 1]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); cnt += __shfl_xor(cnt, off); }
+    if (threadIdx.x != 0) return;
     a.part[2 * a.blocks] = s;
     a.part[2 * a.blocks + 1] = cnt;
     a.loss[0] = (float)(s / (cnt * (double)a.ch));         // an empty selection gives NaN, like torch's mean of nothing

@@ -51,7 +51,14 @@ def _random_batch(bs, n, seed, H=680, W=1200, frames=None):
     uv[0, :4] = torch.tensor([[0.0, 0.0], [2.0, 3.0], [W - 1.0, H - 1.0], [W - 3.0, 4.0]], device="cuda")   # patches leave the image
     cam = torch.tensor([1.0, 0, 0, 0, 0.1, 0.0, -0.2], device="cuda").repeat(bs, 1)
     cam = cam + 0.02 * torch.randn(bs, 7, device="cuda", generator=g)
-    rgb = torch.rand(frames, H * W, 3, device="cuda", generator=g)
+    # smooth frames + 2 % noise: |sampled - gt| and the bilinear sample are only piecewise differentiable (a projected coordinate
+    # within the evaluation-order noise of an integer picks the neighbouring texel cell: same value, different slope); on
+    # white-noise frames those kinks carry O(1) slope jumps and dominate the summed camera gradient of the 11 x 11 patches
+    i = torch.arange(H * W, device="cuda")
+    uu, vv = (i % W).float(), (i // W).float()
+    ph = torch.rand(frames, 1, 3, device="cuda", generator=g) * 6.28
+    rgb = 0.5 + 0.35 * torch.sin(uu[None, :, None] * 0.021 + ph) * torch.cos(vv[None, :, None] * 0.017 + 0.5 * ph)
+    rgb = rgb + 0.02 * torch.rand(frames, H * W, 3, device="cuda", generator=g)
     dep = 1.0 + 0.05 * torch.rand(frames, H * W, 1, device="cuda", generator=g)
     dep[:, : H * W // 2] += 0.4 * torch.rand(frames, H * W // 2, 1, device="cuda", generator=g)
     depth = 0.5 + 2.0 * torch.rand(bs, n, device="cuda", generator=g)

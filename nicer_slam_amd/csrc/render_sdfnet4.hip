@@ -186,6 +186,20 @@ __global__ __launch_bounds__(64 * NSA_NW4_FWD, NSA_OCC4_FWD) void k_sdfnet4_fwd(
     constexpr int kJac = (8 / C) * 3 * C;
     __shared__ float jac_lds[Seq::NW * kJac * 64];
     float* jstore = jac_lds + (threadIdx.x >> 6) * (kJac * 64) + lane;
+    // Second network of the COMBINE (accumulate): what it adds to -- the first network's 16 features of this lane, sdf and grad
+    // sdf -- is requested NOW, not where it is consumed after the MLP: the workgroup barriers of the staged GEMMs are fences the
+    // compiler never moves a load across, and at two waves per SIMD nothing else hides a 1-2 us HBM round trip in mid-kernel.
+    float facc[QHS], sacc = 0.0f, gacc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < QHS; ++s) facc[s] = 0.0f;
+    if (a.accumulate) {
+        const float* fsrc = a.feat + hl_base4(tile, j, q);
+#pragma unroll
+        for (int s = 0; s < QHS; ++s) facc[s] = fsrc[hl_step4(s)];
+        sacc = a.sdf[pt];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gacc[d] = a.grad[(size_t)pt * 3 + d];
+    }
     float in[QIN];
     pe_slots4(x, q, in);
     grid_slots4<L, C>(x, a.divide_factor, a.table, s_geom, q, in, jstore);
@@ -203,11 +217,7 @@ __global__ __launch_bounds__(64 * NSA_NW4_FWD, NSA_OCC4_FWD) void k_sdfnet4_fwd(
     if (wave_live) {
         float* fdst = a.feat + hl_base4(tile, j, q);
 #pragma unroll
-        for (int s = 0; s < QHS; ++s) {
-            float v = fo[s >> 2][s & 3];
-            if (a.accumulate) v += fdst[hl_step4(s)];
-            fdst[hl_step4(s)] = v;
-        }
+        for (int s = 0; s < QHS; ++s) fdst[hl_step4(s)] = fo[s >> 2][s & 3] + facc[s];
     }
     // grad sdf
     float dh[NH > 1 ? NH - 1 : 1][QHS], dl[QIN], g[3];
@@ -216,14 +226,9 @@ __global__ __launch_bounds__(64 * NSA_NW4_FWD, NSA_OCC4_FWD) void k_sdfnet4_fwd(
 #pragma unroll
     for (int d = 0; d < 3; ++d) g[d] = quad_sum(g[d]);
     if (live && q == 0) {
-        if (a.accumulate) {
-            sdf += a.sdf[pt];
+        a.sdf[pt] = sdf + sacc;
 #pragma unroll
-            for (int d = 0; d < 3; ++d) g[d] += a.grad[(size_t)pt * 3 + d];
-        }
-        a.sdf[pt] = sdf;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) a.grad[(size_t)pt * 3 + d] = g[d];
+        for (int d = 0; d < 3; ++d) a.grad[(size_t)pt * 3 + d] = g[d] + gacc[d];
     }
 }
 

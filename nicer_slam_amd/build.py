@@ -56,7 +56,8 @@ def build_native(force=False, verbose=False):
     jobs = []
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
-        if force or _stale(o, [s] + hdrs):
+        # (every .hip counts as a dependency of every object: the *_bf16.hip units #include other .hip files)
+        if force or _stale(o, srcs + hdrs):
             jobs.append((s, o))
 
     def cc(job):

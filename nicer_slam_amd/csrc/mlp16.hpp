@@ -230,7 +230,13 @@ __device__ __forceinline__ void gemm16_staged_part(float* stage, const float* __
     stage_wait();
     const StagePart nxt = part_at<Seq, BUF>(part + 1);
     if (nxt.mt) stage_issue_part<NW>(wp, nxt, stage + ((part + 1) & 1) * BUF);
+#ifdef NSA_X_TS
+    const unsigned long long tg = ts_now();
+#endif
     gemm16_lds_part<KG, MT, G0, NG>(stage + (part & 1) * BUF, lane, b, acc);
+#ifdef NSA_X_TS
+    ts_add(3, ts_now() - tg);
+#endif
 }
 
 // logical GEMM `opi` of Seq (KG k-groups, MT output tiles): all its parts (at most two)

@@ -213,9 +213,27 @@ __device__ __forceinline__ void stage_issue(const float* __restrict__ g, int nfl
     }
 }
 
+#ifdef NSA_X_TS       // profiling build only (tools/ts_profile.py): where a wave's cycles go, accumulated per wave in LDS
+static __shared__ unsigned long long nsa_ts_lds[16][16];
+__device__ __forceinline__ void ts_add(int slot, unsigned long long dt) {
+    if ((threadIdx.x & 63) == 0) nsa_ts_lds[threadIdx.x >> 6][slot] += dt;
+}
+__device__ __forceinline__ unsigned long long ts_now() { return __builtin_readcyclecounter(); }
+#endif
 __device__ __forceinline__ void stage_wait() {
+#ifdef NSA_X_TS
+    const unsigned long long t0 = ts_now();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const unsigned long long t1 = ts_now();
+    __syncthreads();
+    const unsigned long long t2 = ts_now();
+    ts_add(0, t1 - t0);
+    ts_add(1, t2 - t1);
+    ts_add(2, 1);
+#else
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this wave's async copies (and older global loads) have landed
     __syncthreads();                         // ... and so have everyone else's; all waves are done with the other buffer
+#endif
 }
 
 template <int KS, int MT>

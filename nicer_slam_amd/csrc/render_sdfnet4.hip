@@ -158,10 +158,24 @@ __device__ __forceinline__ void reverse_pass4(float* stage, int op0, const float
 #define NSA_OCC4_BWD 2
 #endif
 
+#ifdef NSA_X_TS
+static __device__ unsigned long long* g_ts4 = nullptr;
+#define TS_BEGIN const unsigned long long ts_start = ts_now(); unsigned long long ts_prev = ts_start; \
+    if ((threadIdx.x & 63) == 0) for (int i = 0; i < 16; ++i) nsa_ts_lds[threadIdx.x >> 6][i] = 0;
+#define TS_MARK(slot) { const unsigned long long t_ = ts_now(); ts_add(slot, t_ - ts_prev); ts_prev = t_; }
+#define TS_END { ts_add(15, ts_now() - ts_start); if (g_ts4 && (threadIdx.x & 63) == 0) { \
+    unsigned long long* o_ = g_ts4 + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16; \
+    for (int i = 0; i < 16; ++i) o_[i] = nsa_ts_lds[threadIdx.x >> 6][i]; } }
+#else
+#define TS_BEGIN
+#define TS_MARK(slot)
+#define TS_END
+#endif
 template <int L, int C, int NH>
 __global__ __launch_bounds__(64 * NSA_NW4_FWD, NSA_OCC4_FWD) void k_sdfnet4_fwd(SdfNet4Args a, GridGeom16 geom) {
     using P = SdfPack4<NH>;
     using Seq = SdfOps4<NH, false>;
+    TS_BEGIN
     __shared__ __attribute__((aligned(16))) float stage[2 * Seq::BUF];
     __shared__ LevelGeom s_geom[16];
     stage16_begin<Seq, Seq::NW, Seq::BUF>(stage, a.wp);
@@ -180,6 +194,7 @@ __global__ __launch_bounds__(64 * NSA_NW4_FWD, NSA_OCC4_FWD) void k_sdfnet4_fwd(
     uint32_t ray;
     load_point(a.src, pt, x, ray, z);
     __syncthreads();                                         // s_geom
+    TS_MARK(4)
 
     // the grid Jacobian of this lane's levels stays in lane-private LDS (24 floats per lane): grad sdf needs no second corner
     // gather at the end of the kernel
@@ -203,8 +218,10 @@ __global__ __launch_bounds__(64 * NSA_NW4_FWD, NSA_OCC4_FWD) void k_sdfnet4_fwd(
     float in[QIN];
     pe_slots4(x, q, in);
     grid_slots4<L, C>(x, a.divide_factor, a.table, s_geom, q, in, jstore);
+    TS_MARK(5)
     float sg[NH][QHS], hl[QHS];
     hidden_forward4<NH, Seq>(stage, 0, a.wp, lane, q, in, sg, hl);
+    TS_MARK(6)
     // outputs: sdf (row 0, VALU dot) and the 64 features (rows 1..64)
     f32x4v ws[4], fo[4];
     load_vec16(a.wp + P::kWSDF, q, ws);
@@ -219,9 +236,11 @@ __global__ __launch_bounds__(64 * NSA_NW4_FWD, NSA_OCC4_FWD) void k_sdfnet4_fwd(
 #pragma unroll
         for (int s = 0; s < QHS; ++s) fdst[hl_step4(s)] = fo[s >> 2][s & 3] + facc[s];
     }
+    TS_MARK(7)
     // grad sdf
     float dh[NH > 1 ? NH - 1 : 1][QHS], dl[QIN], g[3];
     reverse_pass4<NH, Seq>(stage, NH + 1, a.wp, lane, q, sg, dh, dl);
+    TS_MARK(8)
     slots_to_x_jac4<L, C>(a.divide_factor, jstore, q, in, dl, g);
 #pragma unroll
     for (int d = 0; d < 3; ++d) g[d] = quad_sum(g[d]);
@@ -230,6 +249,8 @@ __global__ __launch_bounds__(64 * NSA_NW4_FWD, NSA_OCC4_FWD) void k_sdfnet4_fwd(
 #pragma unroll
         for (int d = 0; d < 3; ++d) a.grad[(size_t)pt * 3 + d] = g[d] + gacc[d];
     }
+    TS_MARK(9)
+    TS_END
 }
 
 template <int L, int C, int NH, bool MAP>
@@ -431,6 +452,12 @@ int NSA_ENTRY(nsa_sdfnet4_backward)(const nsa_points_t* pts, const nsa_grid_t* g
     a.g_table = g_table; a.emit = emit; a.emit_ld = emit_ld;
     return launch_sdfnet4(true, grid, a, (hipStream_t)stream);
 }
+
+#ifdef NSA_X_TS
+int NSA_ENTRY(nsa_debug_set_ts)(unsigned long long* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(nsa::g_ts4), &p, sizeof(p)) == hipSuccess ? 0 : 3;
+}
+#endif
 
 int NSA_ENTRY(nsa_sdfnet4_emit_rows)(uint32_t n_hidden) {
     return n_hidden == 1 ? nsa::SE4<1>::ROWS : n_hidden == 3 ? nsa::SE4<3>::ROWS : -1;

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Where do a wave's cycles go?  Needs the profiling build (NSA_BUILD_TAG=ts NSA_EXTRA_HIPCC_FLAGS=-DNSA_X_TS python -m
+nicer_slam_amd.build; run with NSA_LIB_TAG=ts): the quad SDF forward kernel keeps per-wave cycle counts (s_memtime) of its
+phases and of every staged-GEMM wait in LDS and writes them out at the end.  Prints the mean over all waves of the fine-network
+forward launch at the bench shape.  Development tool."""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SLOTS = {0: "stage_wait: vmcnt(0)", 1: "stage_wait: barrier", 2: "stage_wait count", 3: "GEMM bodies (LDS reads + split + MFMA)",
+         4: "point load + geometry barrier", 5: "PE + grid gather/blend/Jacobian", 6: "hidden layers (incl. their GEMMs and waits)",
+         7: "sdf dot + feature GEMM + feature store", 8: "reverse pass (incl. GEMMs and waits)", 9: "grad assembly + output",
+         15: "whole kernel"}
+
+
+def main():
+    import bench
+    from nicer_slam_amd._native import lib
+    from nicer_slam_amd.tracking import KernelTracker
+    dev = torch.device("cuda", 0)
+    bargs = argparse.Namespace(samples=128, engine="auto", precision="fp32", param_grads=False)
+    model, conf = bench.make_model(bargs, dev)
+    K = torch.eye(4, device=dev)
+    K[0, 0] = K[1, 1] = 600.0
+    K[0, 2], K[1, 2] = 599.5, 339.5
+    gen = torch.Generator(device=dev).manual_seed(1)
+    batches = [bench.synth_batch(gen, 1024, dev) for _ in range(6)]
+    cam = torch.tensor([1.0, 0, 0, 0, 0.1, 0.0, -0.2], device=dev)
+    tr = KernelTracker(model, K[None], 1024, cam, use_graph=False)
+    n_waves = 131072 // 16 + 64
+    buf = torch.zeros(n_waves * 16, dtype=torch.int64, device=dev)
+    lib.nsa_debug_set_ts.argtypes = [ctypes.c_void_p]
+    for i in range(3):
+        tr.step(*batches[i])
+    torch.cuda.synchronize()
+    assert lib.nsa_debug_set_ts(buf.data_ptr()) == 0
+    tr.step(*batches[3])                  # the LAST forward launch of the step (fine network) overwrites the coarse one's rows
+    torch.cuda.synchronize()
+    lib.nsa_debug_set_ts(None)
+    t = buf.view(n_waves, 16)[:131072 // 16].double()
+    tot = t[:, 15].mean().item()
+    print(f"waves {t.shape[0]}  mean wave lifetime {tot:.0f} cycles")
+    for k, name in SLOTS.items():
+        v = t[:, k].mean().item()
+        print(f"  slot {k:2d}  {v:9.0f}  {100 * v / tot:5.1f} %   {name}")
+
+
+if __name__ == "__main__":
+    main()

@@ -440,14 +440,39 @@ def mapping_leg(device, rays=8192, frames=8, iters=5, cpu=True):
         if per_point:
             nbytes, rows = per_point[0] * P, per_point[1] * P
             ach = nbytes / (tms * 1e-3) / 1e9
-            roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(tms * 1e3, 1),
-                    "bytes_per_launch": nbytes,
-                    "atomic_scatter": {"table_rows_per_launch": rows, "rows_per_s": round(rows / (tms * 1e-3), 0),
-                                       "measured_ceiling": "fp32 atomics retire at ~20 G requests/s chip-wide on MI355X "
-                                                           "(~41 G rows/s when two adjacent rows share a request): "
-                                                           "tools/micro/atomic_bench.hip, DESIGN.md 4b",
-                                       "frac_of_41G_rows_per_s": round(rows / (tms * 1e-3) / 41e9, 3)}}
+            # The binding quantity of the MAP kernels is the ATOMIC REQUEST rate, not bytes: fp32 atomics retire at ~20 G requests/s
+            # chip-wide on MI355X whatever the table size or contention (tools/micro/atomic_bench.hip; a request = the lanes of one
+            # instruction that fall into one 64-byte segment).  Requests per launch come from the TCC_ATOMIC counter of a separate
+            # `rocprofv3 --pmc` pass over this same leg (tools/profile_mapping.sh -> profiles/rNN_mapping_pmc_per_kernel.csv;
+            # counters cannot be read from inside the run, so the newest committed summary is quoted and named).
+            pmc_key = {"k_colour_bwd<map>": "k_colour_bwd<true>", "k_sdfnet_bwd<fine,map>": "k_sdfnet4_bwd<8, 4, 3, true>",
+                       "k_sdfnet_bwd<coarse,map>": "k_sdfnet4_bwd<4, 8, 1, true>"}[name]
+            reqs, req_src = None, None
+            import csv
+            import glob
+            for ppath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mapping_pmc_per_kernel.csv")), reverse=True):
+                for row in csv.DictReader(open(ppath)):
+                    if pmc_key in row["kernel"] and row["counter"] == "TCC_ATOMIC_sum" and float(row["mean_per_dispatch"]) > 0:
+                        reqs, req_src = float(row["mean_per_dispatch"]), os.path.relpath(ppath, ROOT)
+                if reqs:
+                    break
+            if reqs and "sdfnet" in name:      # the counter's per-dispatch mean covers this kernel's two launches per iteration
+                reqs = reqs * 2 * P / (P + 22 * rays)      # (composite points and eikonal points): the composite launch's share
+            launches = sum(1 for n_, _, _, _ in prof if n_ == name)
+            per_launch_s = tms * 1e-3 / max(launches, 1)
+            ATOMIC_CEILING = 20e9
+            atomic = {"table_rows_per_launch": rows // max(launches, 1), "atomic_requests_per_launch": reqs,
+                      "requests_source": req_src, "rows_per_request": round(rows / max(launches, 1) / reqs, 2) if reqs else None,
+                      "requests_per_s": round(reqs / per_launch_s, 0) if reqs else None,
+                      "ceiling_requests_per_s": ATOMIC_CEILING,
+                      "frac_of_ceiling": round(reqs / per_launch_s / ATOMIC_CEILING, 3) if reqs else None,
+                      "measured_ceiling": "fp32 atomics retire at ~20 G requests/s chip-wide on MI355X, independent of table size "
+                                          "and contention (tools/micro/atomic_bench.hip, DESIGN.md 4b)"}
+            roof = {"kernel": name, "bound": "atomic requests (memory-side RMW)", "achieved": atomic["requests_per_s"],
+                    "peak": ATOMIC_CEILING, "unit": "requests/s", "frac": atomic["frac_of_ceiling"],
+                    "traffic": None, "launches_per_iteration": launches, "avg_launch_us": round(per_launch_s * 1e6, 1),
+                    "algorithmic_bytes_per_iteration": nbytes, "algorithmic_GBps": round(ach, 1),
+                    "algorithmic_frac_of_hbm": round(ach / HBM_PEAK_GBS, 4), "atomic_scatter": atomic}
     return {"ms": round(dt * 1e3, 2), "rays": rays, "keyframes": frames, "samples_per_ray": S,
             "objective": "SLAMLoss with the weights of code/confs/replica/runconf_replica_1.conf (rgb, eikonal, smooth, ssi depth, "
                          "normals, patch warp [patch 1], flow over %d edges); stage fine / highfreq" % len(pairs),

@@ -191,6 +191,7 @@ __device__ __forceinline__ void stage16_begin(float* stage, const float* __restr
     stage_issue_part<NW>(wp, part_at<Seq, BUF>(0), stage);
 }
 
+
 // groups G0 .. G0+NG-1 of a KG-group GEMM from a staged part laid out [mt][NG][piece][lane]
 template <int KG, int MT, int G0, int NG>
 __device__ __forceinline__ void gemm16_lds_part(const float* lds_block, int lane, const float (&b)[8 * KG], f32x4v (&acc)[MT]) {
@@ -230,6 +231,7 @@ __device__ __forceinline__ void gemm16_staged_part(float* stage, const float* __
     stage_wait();
     const StagePart nxt = part_at<Seq, BUF>(part + 1);
     if (nxt.mt) stage_issue_part<NW>(wp, nxt, stage + ((part + 1) & 1) * BUF);
+
 #ifdef NSA_X_TS
     const unsigned long long tg = ts_now();
 #endif

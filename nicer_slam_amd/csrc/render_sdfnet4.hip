@@ -258,6 +258,7 @@ __global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd(
     using P = SdfPack4<NH>;
     using Seq = SdfOps4<NH, true>;
     using E = SE4<NH>;
+    TS_BEGIN
     __shared__ __attribute__((aligned(16))) float stage[2 * Seq::BUF];
     __shared__ LevelGeom s_geom[16];
     stage16_begin<Seq, Seq::NW, Seq::BUF>(stage, a.wp);
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd(
     uint32_t ray;
     load_point(a.src, pt, x, ray, z);
     __syncthreads();                                         // s_geom
+    TS_MARK(4)
     // the grid Jacobian of this lane's levels stays in lane-private LDS: the backward needs no second and third corner gather
     constexpr int kJac = (8 / C) * 3 * C;                    // 24 floats per lane
     __shared__ float jac_lds[Seq::NW * kJac * 64];
@@ -286,9 +288,12 @@ __global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd(
     const bool emit = MAP && a.emit != nullptr && wave_live;   // (a clamped wave must not touch the last tile's rows)
     const Emitter4 em{emit ? a.emit + (size_t)tile * 16 + j : nullptr, a.emit_ld, live};
     float sg[NH][QHS], hl[QHS];
+    TS_MARK(5)
     hidden_forward4<NH, Seq>(stage, 0, a.wp, lane, q, in, sg, hl, emit ? &em : nullptr);
+    TS_MARK(6)
     float dh[NH > 1 ? NH - 1 : 1][QHS], dl[QIN];
     reverse_pass4<NH, Seq>(stage, NH, a.wp, lane, q, sg, dh, dl, emit ? &em : nullptr);
+    TS_MARK(7)
     if (emit) {
 #pragma unroll
         for (int s = 0; s < QIN; ++s) em.slot(E::H0, s, q, in[s]);
@@ -335,6 +340,7 @@ __global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd(
             }
         }
     }
+    TS_MARK(8)
     // ---- reverse sweep ----
     float ab[QHS];
     {
@@ -371,6 +377,7 @@ __global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd(
 #pragma unroll
         for (int s = 0; s < QHS; ++s) em.hid(E::AB(1), s, q, ab[s]);
     }
+    TS_MARK(9)
     float hb0[QIN];
     {
         f32x4v a6[6];
@@ -398,6 +405,8 @@ __global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd(
             a.g_x[(size_t)pt * 3 + d] = v;
         }
     }
+    TS_MARK(10)
+    TS_END
 }
 
 static_assert(NSA_NW4_BWD * 64 * (2 * 8 + 1) <= stage_floats4(NSA_NW4_BWD), "scatter scratch must fit the idle stage buffer");

@@ -13,6 +13,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+SLOTS_BWD = {0: "stage_wait: vmcnt(0)", 1: "stage_wait: barrier", 2: "stage_wait count", 3: "GEMM bodies (LDS reads + split + MFMA)",
+             4: "point load + geometry barrier", 5: "PE + grid gather/blend/Jacobian", 6: "forward recompute (hidden layers)",
+             7: "reverse pass (recompute)", 8: "cotangent loads + tangent sweep", 9: "feature-cotangent load + reverse sweep",
+             10: "first-layer transposed GEMM + d/dx + output", 15: "whole kernel"}
 SLOTS = {0: "stage_wait: vmcnt(0)", 1: "stage_wait: barrier", 2: "stage_wait count", 3: "GEMM bodies (LDS reads + split + MFMA)",
          4: "point load + geometry barrier", 5: "PE + grid gather/blend/Jacobian", 6: "hidden layers (incl. their GEMMs and waits)",
          7: "sdf dot + feature GEMM + feature store", 8: "reverse pass (incl. GEMMs and waits)", 9: "grad assembly + output",
@@ -40,13 +44,14 @@ def main():
         tr.step(*batches[i])
     torch.cuda.synchronize()
     assert lib.nsa_debug_set_ts(buf.data_ptr()) == 0
-    tr.step(*batches[3])                  # the LAST forward launch of the step (fine network) overwrites the coarse one's rows
+    tr.step(*batches[3])                  # fwd: the fine launch overwrites the coarse one's rows; bwd (quad, fine only) runs later
+                                          # in the step and overwrites the forward's -> `--fwd` profiles a forward-only call
     torch.cuda.synchronize()
     lib.nsa_debug_set_ts(None)
     t = buf.view(n_waves, 16)[:131072 // 16].double()
     tot = t[:, 15].mean().item()
-    print(f"waves {t.shape[0]}  mean wave lifetime {tot:.0f} cycles")
-    for k, name in SLOTS.items():
+    print(f"waves {t.shape[0]}  mean wave lifetime {tot:.0f} cycles   (last instrumented launch of the step: the fine backward)")
+    for k, name in SLOTS_BWD.items():
         v = t[:, k].mean().item()
         print(f"  slot {k:2d}  {v:9.0f}  {100 * v / tot:5.1f} %   {name}")
 

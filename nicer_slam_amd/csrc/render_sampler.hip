@@ -78,8 +78,22 @@ __device__ __forceinline__ void sampler_point(const SamplerArgs& a, uint64_t pid
 
 // T = point tiles (of 32 points) per wave.  T = 1: the round-1 form, 167 registers, three waves per SIMD.  T = 2: one weight
 // fragment stream serves both tiles (sdf_only_tiles), two waves per SIMD.
+#ifdef NSA_X_TS
+static __device__ unsigned long long* g_ts_s = nullptr;
+#define STS_BEGIN const unsigned long long ts_start = ts_now(); unsigned long long ts_prev = ts_start; \
+    if ((threadIdx.x & 63) == 0) for (int i = 0; i < 16; ++i) nsa_ts_lds[threadIdx.x >> 6][i] = 0;
+#define STS_MARK(slot) { const unsigned long long t_ = ts_now(); ts_add(slot, t_ - ts_prev); ts_prev = t_; }
+#define STS_END { ts_add(15, ts_now() - ts_start); if (g_ts_s && (threadIdx.x & 63) == 0) { \
+    unsigned long long* o_ = g_ts_s + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16; \
+    for (int i = 0; i < 16; ++i) o_[i] = nsa_ts_lds[threadIdx.x >> 6][i]; } }
+#else
+#define STS_BEGIN
+#define STS_MARK(slot)
+#define STS_END
+#endif
 template <int LC, int CC, int NHC, int LF, int CF, int NHF, int T>
 __global__ __launch_bounds__(256, NSA_OCC_SAMPLER) void k_sampler_sdf(SamplerArgs a, GridGeom16 gc, GridGeom16 gf) {
+    STS_BEGIN
     desync_simd_partners();
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
@@ -98,14 +112,20 @@ __global__ __launch_bounds__(256, NSA_OCC_SAMPLER) void k_sampler_sdf(SamplerArg
         ray[t] = (uint32_t)(pid[t] / a.E);
         idx[t] = (uint32_t)(pid[t] - (uint64_t)ray[t] * a.E);
         sampler_point(a, pid[t], ray[t], idx[t], x[t], zi[t], farv[t]);
+        STS_MARK(4 + 3 * 0)
         pe_slots(x[t], h, in[t]);               // shared by both networks
+        STS_MARK(5)
         grid_slots<LC, CC, true>(x[t], a.df_c, a.table_c, gc, h, in[t]);
+        STS_MARK(6)
     }
     float sdf[T], sdf_f[T];
     sdf_only_tiles<NHC, T>(a.wp_c, lane, h, in, sdf);
+    STS_MARK(7)
 #pragma unroll
     for (int t = 0; t < T; ++t) grid_slots<LF, CF, true>(x[t], a.df_f, a.table_f, gf, h, in[t]);
+    STS_MARK(8)
     sdf_only_tiles<NHF, T>(a.wp_f, lane, h, in, sdf_f);
+    STS_MARK(9)
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         if (live[t] && h == 0) {
@@ -114,6 +134,8 @@ __global__ __launch_bounds__(256, NSA_OCC_SAMPLER) void k_sampler_sdf(SamplerArg
             if (idx[t] == 0) a.far[ray[t]] = farv[t];
         }
     }
+    STS_MARK(10)
+    STS_END
 }
 
 
@@ -466,6 +488,12 @@ int NSA_ENTRY(nsa_sdf_points)(const float* points, uint64_t N, const nsa_grid_t*
     hipLaunchKernelGGL((k_sdf_points<4, 8, 1, 8, 4, 3>), dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, a, gc, gf);
     return launch_end();
 }
+
+#ifdef NSA_X_TS
+int NSA_ENTRY(nsa_debug_set_ts_sampler)(unsigned long long* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(nsa::g_ts_s), &p, sizeof(p)) == hipSuccess ? 0 : 3;
+}
+#endif
 
 int NSA_ENTRY(nsa_draw_picks)(const float* u, uint32_t E, uint32_t n_extra, uint32_t R, uint32_t S, int32_t* extra_idx,
                    int32_t* eik_idx, nsa_stream_t stream) {

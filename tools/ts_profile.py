@@ -54,6 +54,22 @@ def main():
     for k, name in SLOTS_BWD.items():
         v = t[:, k].mean().item()
         print(f"  slot {k:2d}  {v:9.0f}  {100 * v / tot:5.1f} %   {name}")
+    # the sampler (two 32-point tiles per wave)
+    n_s = 1024 * 640 // 64
+    buf2 = torch.zeros((n_s + 64) * 16, dtype=torch.int64, device=dev)
+    lib.nsa_debug_set_ts_sampler.argtypes = [ctypes.c_void_p]
+    assert lib.nsa_debug_set_ts_sampler(buf2.data_ptr()) == 0
+    tr.step(*batches[4])
+    torch.cuda.synchronize()
+    lib.nsa_debug_set_ts_sampler(None)
+    t = buf2.view(-1, 16)[:n_s].double()
+    tot = t[:, 15].mean().item()
+    print(f"sampler: waves {n_s}  mean wave lifetime {tot:.0f} cycles")
+    for k, name in {4: "ray + stratified z + point (both tiles)", 5: "positional encoding", 6: "coarse grid gather + blend",
+                    7: "coarse MLP (W0 GEMM, softplus, sdf dot)", 8: "fine grid gather + blend", 9: "fine MLP (3 GEMMs)",
+                    10: "stores", 15: "whole kernel"}.items():
+        v = t[:, k].mean().item()
+        print(f"  slot {k:2d}  {v:9.0f}  {100 * v / tot:5.1f} %   {name}")
 
 
 if __name__ == "__main__":

@@ -1,7 +1,9 @@
 """B2 drop-in check: the reference's tracking + mapping loops (code/training/volsdf_train.py:393-446 and :451-576), restated
 call for call around a model built EXACTLY as the reference builds it (no freeze_fine_mlp(), no requires_grad_ edits, default
 engine), with the reference's optimizer groups (torch.optim.Adam, :150-174), its two SLAMLoss instances (confs: loss /
-tracking_loss), StepLR(50, 0.95) on the camera and the arg-min-loss candidate.  Every forward must run on the fused engine."""
+tracking_loss) with the shipped weights incl. patch warp and flow (use_warp_loss = true, mapping_patchsizes = [1]), flow edges between
+the keyframes, bundle adjustment in the last 30 % of a mapping round, StepLR(50, 0.95) on the camera and the arg-min-loss candidate.
+Every forward must run on the fused engine (the re-projection blocks on the kernels of C ABI section 5)."""
 import pytest
 import torch
 
@@ -21,7 +23,7 @@ def _world():
     from nicer_slam_amd.model.network import SLAMNetwork
     from nicer_slam_amd.utils.conf import replica_model_conf
     torch.manual_seed(0)
-    model = SLAMNetwork(conf=replica_model_conf(use_warp_loss=False), dataset=_DS(), n_images=3,
+    model = SLAMNetwork(conf=replica_model_conf(use_warp_loss=True, mapping_patchsizes=[1]), dataset=_DS(), n_images=3,   # the shipped confs
                         colour_grid=dict(base_resolution=16, desired_resolution=256, log2_hashmap_size=15))
     model.train_dataset, model.keyframe_every = None, 10
     model.cuda()
@@ -35,8 +37,9 @@ def _world():
         {"name": "coarse_mlp_parameters", "params": list(model.implicit_network.coarse.mlp_parameters()), "lr": lr},
     ]
     optimizer = torch.optim.Adam(para_list, betas=(0.9, 0.99), eps=1e-15)
-    loss = SLAMLoss(model=model, rgb_loss="torch.nn.L1Loss", assign_scale_shift_init=True, eikonal_weight=0.1,
-                    smooth_weight=0.005, depth_weight=0.1, normal_l1_weight=0.05, normal_cos_weight=0.05)
+    loss = SLAMLoss(model=model, rgb_loss="torch.nn.L1Loss", assign_scale_shift_init=True, eikonal_weight=0.1,     # confs/replica/
+                    smooth_weight=0.005, depth_weight=0.1, normal_l1_weight=0.05, normal_cos_weight=0.05,          # runconf_replica_1.conf:45-57
+                    warp_loss_weight=0.5, warp_loss_type="l1", flow_weight=0.001)
     tracking_loss = SLAMLoss(model=model, rgb_loss="torch.nn.L1Loss", eikonal_weight=0, smooth_weight=0, depth_weight=0,
                              normal_l1_weight=0, normal_cos_weight=0)
     feed = FrameFeed((H, W), device="cuda")
@@ -48,7 +51,8 @@ def _world():
         pose = torch.eye(4)
         pose[:3, 3] = torch.tensor([0.1 + 0.01 * idx, 0.0, -0.2])
         feed.add_frame(idx, rgb=torch.rand(H * W, 3, generator=g), depth=torch.rand(H * W, 1, generator=g) + 0.5,
-                       normal=torch.nn.functional.normalize(torch.randn(H * W, 3, generator=g), dim=-1), intrinsics=K, pose=pose)
+                       normal=torch.nn.functional.normalize(torch.randn(H * W, 3, generator=g), dim=-1),
+                       gt_depth=1.0 + 0.3 * torch.rand(H * W, 1, generator=g), intrinsics=K, pose=pose)
     return model, optimizer, loss, tracking_loss, feed
 
 
@@ -59,11 +63,30 @@ def test_reference_loops_run_on_the_fused_engine_unmodified():
     engines = []
     before = {n: p.detach().clone() for n, p in model.named_parameters()}
 
+    seen = {"warp": 0, "flow": 0, "ba": 0}
+
     def mapping(frame_idx, keyframe_list, iters):
         out_losses = []
+        edges = None
+        if len(keyframe_list) >= 2:                                  # build_graph (:312-324) for two neighbouring keyframes
+            edges = (torch.tensor([0, 1], device="cuda"), torch.tensor([1, 0], device="cuda"), None, None)
+            flow_img = torch.randn(2, H * W, 2, device="cuda") * 2
+            flow_occ = torch.rand(2, H * W, device="cuda") > 0.2
         for it in range(iters):                                      # :451-576
-            feed.change_sampling_idx(512 // len(keyframe_list))
-            indices, model_input, ground_truth = feed.batch(keyframe_list)
+            sel = feed.change_sampling_idx(512 // len(keyframe_list))
+            # frames handed over as resident stores on even iterations, as the reference's stacked tensors on odd ones
+            indices, model_input, ground_truth = feed.batch(keyframe_list, full="store" if it % 2 == 0 else "stack")
+            ba = frame_idx != 0 and it > int(iters * 0.7)            # :455, :521-528: camera tensors join the optimisation
+            if ba:
+                cams = torch.stack([get_tensor_from_camera(feed.frames[k]["pose"].cpu()) for k in keyframe_list])
+                cams = cams.cuda().requires_grad_(True)
+                opt_ba = torch.optim.Adam([cams], lr=0.001)
+                model_input["pose"] = get_camera_from_tensor(cams)
+                opt_ba.zero_grad()
+                seen["ba"] += 1
+            if edges is not None:                                    # :541-546 (select_flow_uv)
+                ground_truth["edges"] = edges
+                ground_truth["flow"], ground_truth["flow_mask"] = flow_img.index_select(1, sel), flow_occ.index_select(1, sel)
             optimizer.zero_grad()
             if frame_idx > 1:
                 stage = "coarse" if it < int(iters * 0.25) else "fine"
@@ -73,9 +96,16 @@ def test_reference_loops_run_on_the_fused_engine_unmodified():
             out = model(model_input, indices, ground_truth, keyframe_list=keyframe_list, frame_idx=frame_idx, mode="mapping",
                         stage=stage, color_stage=color_stage, iter=it)
             engines.append(("mapping", stage, color_stage, model.last_engine))
-            l = loss_fn(out, ground_truth, keyframe_list, frame_idx=frame_idx, stage=stage)["loss"]
+            assert "warp_output" in out and set(out["warp_output"]) == {1}
+            terms = loss_fn(out, ground_truth, keyframe_list, frame_idx=frame_idx, stage=stage)
+            l = terms["loss"]
+            seen["warp"] += int(float(terms["warp_loss"]) > 0)
+            seen["flow"] += int("flow" in out and float(terms["flow_loss"]) > 0)
             l.backward()
             optimizer.step()
+            if ba:
+                assert cams.grad is not None and bool(torch.isfinite(cams.grad).all()) and float(cams.grad.abs().max()) > 0
+                opt_ba.step()
             out_losses.append(float(l))
         return out_losses
 
@@ -105,6 +135,7 @@ def test_reference_loops_run_on_the_fused_engine_unmodified():
     assert all(e[-1] == "fused" for e in engines), [e for e in engines if e[-1] != "fused"]
     assert {e[1] for e in engines} == {"coarse", "fine"} and {e[2] for e in engines} == {"base", "highfreq"}
     assert all(l == l and abs(l) < 1e6 for l in m0 + m1)
+    assert seen["warp"] >= 4 and seen["flow"] >= 6 and seen["ba"] >= 2, seen      # the shipped terms were really in the objective
     moved = {n for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n])}
     assert any("rendering_network.lin" in n for n in moved) and any("coarse.lin" in n for n in moved)
     assert any(n.endswith("encoding.embeddings") for n in moved)

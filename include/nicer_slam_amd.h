@@ -200,7 +200,7 @@ int nsa_sampler_sdf(const float *rays_o, const float *rays_d, uint32_t R, uint32
 /* Per-ray importance stage: density -> weights -> cdf -> N inverse-CDF samples, merged with near, far and
  * n_extra of the coarse samples, sorted.  replaces ImportantSampler.get_z_vals (ray_sampler.py:104-159) and
  * GridPredefineDensity (code/model/density.py:37-67).  z_vals[R, N+2+n_extra]; z_eik[R] = z_vals[r, eik_idx[r]]
- * (optional). */
+ * (optional).  One workgroup per ray; N+2+n_extra <= 256, voxel_res <= 1024. */
 int nsa_sample_rays(const float *rays_o, const float *rays_d, const float *z, const float *sdf, const float *far,
                     const float *voxels, uint32_t voxel_res, uint32_t R, uint32_t E, uint32_t N, const float *u_lin,
                     const int32_t *extra_idx, uint32_t n_extra, float near, const int32_t *eik_idx, float *z_vals,
@@ -252,6 +252,27 @@ int nsa_track_tail(const float *uv, const float *K, float *cam, uint32_t n, cons
 /* Multi-GPU form: reduce_weight = this rank's ray count > 0 turns g_cam into the 9-float message
  * [w*g_cam(7), w*loss (slot 7 as left by nsa_l1_loss), w] that is summed over ranks with ONE all-reduce; the step is then
  * nsa_adam_step_scaled(cam, msg, msg + 8, ...) = Adam on msg[0..6] / msg[8]. */
+/* The same iteration with the per-ray neighbours folded in (one ray chunk; what the graph-captured tracker runs):
+ *   nsa_track_begin     = copy of the frame's pixel batch (uv_in [n,2], gt_in [n,3]) into the resident buffers uv / gt that the
+ *                         captured sequence reads + nsa_track_head -- one launch in front of the graph replay;
+ *   nsa_composite_track = nsa_composite_forward (rendered colour only) + nsa_l1_loss + nsa_composite_backward(g_rgb_values) in
+ *                         one pass per ray; ray_loss[r] = sum_c |rgb_values[r,c] - gt[r,c]|, the cotangent is sign / (3 n_total);
+ *                         g_grad is zero-filled (the tracking objective has no normal-map term)
+ *                         (code/model/network.py:349-370, loss.py:57-65,131);
+ *   nsa_track_finish    = nsa_rays_backward + nsa_track_tail, the loss (slot 7 of g_cam) formed as sum(ray_loss) / (3 n) from
+ *                         fixed-order block partials by the last block to arrive: deterministic.  `workspace`:
+ *                         nsa_track_finish_workspace(n) floats, zero-filled ONCE by the caller (the kernel leaves its ticket zero).
+ *                         `best` compares g_cam[7]. */
+int nsa_track_begin(const float *uv_in, const float *gt_in, float *uv, float *gt, const float *K, const float *cam, uint32_t n,
+                    float *pose, float *rays_o, float *rays_d, float *depth_scale, nsa_stream_t stream);
+int nsa_composite_track(const float *rays_o, const float *rays_d, const float *z_vals, const float *sdf, const float *rgb,
+                        const float *voxels, uint32_t voxel_res, uint32_t R, uint32_t S, const float *gt, uint32_t n_total,
+                        float *rgb_values, float *ray_loss, float *g_sdf, float *g_rgb, float *g_grad, nsa_stream_t stream);
+int nsa_track_finish(const float *uv, const float *K, float *cam, uint32_t n, uint32_t S, const float *z_vals, const float *g_x,
+                     const float *g_dir, const float *ray_loss, float *g_cam, int do_adam, float reduce_weight, float *exp_avg,
+                     float *exp_avg_sq, float *step, float lr, float beta1, float beta2, float eps, uint32_t lr_step,
+                     float lr_gamma, float *best, float *workspace, nsa_stream_t stream);
+uint64_t nsa_track_finish_workspace(uint32_t n);
 int nsa_adam_step_scaled(float *param, const float *grad, const float *grad_div, float *exp_avg, float *exp_avg_sq,
                          float *step, uint32_t n, float lr, float beta1, float beta2, float eps, uint32_t lr_step,
                          float lr_gamma, const float *loss, float *best, nsa_stream_t stream);

@@ -157,6 +157,16 @@ lib.nsa_track_tail.restype = _i
 lib.nsa_track_tail.argtypes = [_p, _p, _p, _u32, _p, _p, _p, _i, _f32, _p, _p, _p, _f32, _f32, _f32, _f32, _u32, _f32, _p, _p,
                                _p]
 EXPORTS += ["nsa_track_head", "nsa_track_tail"]
+lib.nsa_track_begin.restype = _i
+lib.nsa_track_begin.argtypes = [_p, _p, _p, _p, _p, _p, _u32, _p, _p, _p, _p, _p]
+lib.nsa_composite_track.restype = _i
+lib.nsa_composite_track.argtypes = [_p, _p, _p, _p, _p, _p, _u32, _u32, _u32, _p, _u32, _p, _p, _p, _p, _p, _p]
+lib.nsa_track_finish.restype = _i
+lib.nsa_track_finish.argtypes = [_p, _p, _p, _u32, _u32, _p, _p, _p, _p, _p, _i, _f32, _p, _p, _p, _f32, _f32, _f32, _f32, _u32,
+                                 _f32, _p, _p, _p]
+lib.nsa_track_finish_workspace.restype = ctypes.c_uint64
+lib.nsa_track_finish_workspace.argtypes = [_u32]
+EXPORTS += ["nsa_track_begin", "nsa_composite_track", "nsa_track_finish", "nsa_track_finish_workspace"]
 
 lib.nsa_morton_keys.restype = _i
 lib.nsa_morton_keys.argtypes = [_pp, _p, _p]

@@ -7,9 +7,9 @@
 //                 the positional encoding and evaluates coarse+fine SDF MLPs on the matrix cores (fp32-faithful
 //                 split GEMM, mlp_common.hpp) with all activations in registers
 //                 (the reference's redundant second coarse evaluation, base_networks.py:31, is not repeated).
-// k_sample_rays   one wave per ray: SDF -> Laplace density (beta from the visit counter) -> alpha/transmittance
-//                 weights via a wave-shuffle scan -> pdf/cdf in LDS -> inverse-CDF samples by binary search ->
-//                 merge with near/far/extras -> in-LDS bitonic sort.
+// k_sample_rays   one workgroup per ray: SDF -> Laplace density (beta from the visit counter) -> alpha/transmittance
+//                 weights via a workgroup scan -> pdf/cdf in LDS -> inverse-CDF samples by binary search ->
+//                 merge with near/far/extras -> rank sort out of LDS.
 #include "sdf_net.hpp"
 
 namespace nsa {
@@ -247,7 +247,7 @@ __device__ __forceinline__ float beta_of(const float* __restrict__ voxels, uint3
             int v = (int)((x[k] + 1.0f) / 2.0f * (float)res);   // .long() truncation
             idx[k] = v < 0 ? 0 : (v >= (int)res ? (int)res - 1 : v);
         }
-        count = voxels[((size_t)idx[0] * res + idx[1]) * res + idx[2]];
+        count = voxels[((uint32_t)idx[0] * res + (uint32_t)idx[1]) * res + (uint32_t)idx[2]];     // res <= 1024 (entry check)
     }
     return 0.01207724805f * expf(-0.0116544676f * 0.0001f * count * 5.37538f) + 0.0023639156f;
 }
@@ -258,62 +258,57 @@ __device__ __forceinline__ float laplace_density(float sdf, float beta) {
     return (1.0f / beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(sdf) / beta));
 }
 
-__device__ __forceinline__ float wave_excl_scan(float v, int lane, float& total) {
+constexpr int MAX_S = 256;    // final samples per ray supported by the sort buffer
+
+// Exclusive prefix of v over the 256 threads of the workgroup (thread order) and the workgroup total: wave-shuffle scan, the
+// four wave totals through LDS, added in wave order.  `red`: 4 floats of LDS, free again on return.
+__device__ __forceinline__ float block_excl_scan(float v, int lane, int wv, float* red, float& total) {
     float incl = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const float n = __shfl_up(incl, off);
         if (lane >= off) incl += n;
     }
-    total = __shfl(incl, 63);
-    // exclusive = inclusive of the previous lane (NOT incl - v: the last sample's free energy is ~1e10 * sigma and
-    // the subtraction would cancel the whole prefix)
+    if (lane == 63) red[wv] = incl;
+    // exclusive = inclusive of the previous lane (NOT incl - v: the last sample's free energy is ~1e10 * sigma and the
+    // subtraction would cancel the whole prefix)
     const float prev = __shfl_up(incl, 1);
-    return lane == 0 ? 0.0f : prev;
+    __syncthreads();
+    float base = 0.0f;
+    for (int w = 0; w < wv; ++w) base += red[w];
+    total = ((red[0] + red[1]) + red[2]) + red[3];
+    __syncthreads();
+    return lane == 0 ? base : base + prev;
 }
 
-constexpr int MAX_S = 256;    // final samples per ray supported by the sort buffer
-
-__device__ __forceinline__ uint32_t next_pow2(uint32_t v) {
-    uint32_t p = 1;
-    while (p < v) p <<= 1;
-    return p;
-}
-
-// The four rays of a workgroup never touch each other's LDS region, and the LDS operations of ONE wave execute in
-// program order, so phases are separated by a compiler-level wave barrier only (no workgroup barrier: the 30+ sort
-// stages would otherwise run in lock-step across four unrelated rays).
-__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
-
-// One wave per ray, 4 rays per 256-thread workgroup; LDS per ray: pdf[E], cdf[E], z[E], sort[MAX_S].
+// One 256-thread workgroup per ray (round 3; rounds 1-2 ran one WAVE per ray: at 1024 rays that is a single wave per SIMD, every
+// load latency and every dependent instruction exposed -- 21 us of which 19 were on the iteration's critical path).  LDS per ray:
+// pdf[E], cdf[E], z[E], keys[MAX_S + 4].  Four workgroups share a CU.
 __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t E = a.E, N = a.N;
     const uint32_t S = N + 2 + a.n_extra;
-    const uint32_t ray_raw = blockIdx.x * 4 + wv;
-    const bool live = ray_raw < a.R;
-    const uint32_t ray = live ? ray_raw : a.R - 1;        // dead waves shadow the last ray (no early exit: barriers)
-    float* pdf = smem + (size_t)wv * (3 * E + MAX_S);
+    const uint32_t ray = blockIdx.x;
+    const uint32_t E4 = (E + 3) & ~3u;
+    float* pdf = smem;
     float* cdf = pdf + E;
     float* zb = cdf + E;
-    float* sb = zb + E;
+    float* sb = smem + 3 * (size_t)E4;                  // 16-byte aligned: the sort reads it four keys at a time
+    STS_BEGIN
 
     float o[3], d[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { o[k] = a.rays_o[ray * 3 + k]; d[k] = a.rays_d[ray * 3 + k]; }
     const float* zr = a.z + (size_t)ray * E;
     const float* sr = a.sdf + (size_t)ray * E;
-    const uint32_t per = (E + 63) / 64;
-    const uint32_t i0 = lane * per;
 
     // free energy sigma_i * delta_i (last delta = 1e10)                       ray_sampler.py:105-108
-    // Phase 1 is lane-strided (element i = lane + 64 k: coalesced loads, the ten independent iterations -- each a z load,
-    // an sdf load and a dependent visit-counter gather -- are all in flight at once); the scans below are lane-blocked
-    // (lane owns elements i0 .. i0+per-1) and read what phase 1 left in LDS.
-#pragma unroll 10
-    for (uint32_t i = lane; i < E; i += 64) {
+    // thread-strided (coalesced loads; a thread's iterations -- each a z load, an sdf load and a dependent visit-counter
+    // gather -- are all in flight at once); the scans below are thread-blocked and read what this phase left in LDS.
+#pragma unroll 3
+    for (uint32_t i = tid; i < E; i += 256) {
         const float zi = zr[i];
         const float zn = i + 1 < E ? zr[i + 1] : 0.0f;
         float x[3];
@@ -323,14 +318,18 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
         zb[i] = zi;
         pdf[i] = (i + 1 < E ? zn - zi : 1e10f) * sigma;
     }
-    wave_sync();
+    __syncthreads();
+    STS_MARK(1)
+    const uint32_t per = (E + 255) / 256;
+    const uint32_t i0 = tid * per;
     float esum = 0.0f;
     for (uint32_t k = 0; k < per; ++k) {
         const uint32_t i = i0 + k;
         if (i < E) esum += pdf[i];
     }
     float tot;
-    float run = wave_excl_scan(esum, lane, tot);
+    float run = block_excl_scan(esum, lane, wv, red, tot);
+    STS_MARK(2)
     // w_i = (1 - exp(-E_i)) exp(-sum_{j<i} E_j);  pdf_i = w_i + 1e-5 for i < E-1      :109-117
     float psum = 0.0f;
     for (uint32_t k = 0; k < per; ++k) {
@@ -344,28 +343,35 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
             psum += p;
         }
     }
+    STS_MARK(3)
     float ptot;
-    (void)wave_excl_scan(psum, lane, ptot);
+    (void)block_excl_scan(psum, lane, wv, red, ptot);
+    STS_MARK(4)
     // cdf = [0, cumsum(pdf / sum)]                                                     :118-121
     float nsum = 0.0f;
     for (uint32_t k = 0; k < per; ++k) {
         const uint32_t i = i0 + k;
-        if (i + 1 < E) nsum += pdf[i] / ptot;
+        if (i + 1 < E) {
+            const float q = pdf[i] / ptot;
+            pdf[i] = q;                                  // (thread-private elements: no barrier needed before the re-read)
+            nsum += q;
+        }
     }
     float ntot;
-    float nrun = wave_excl_scan(nsum, lane, ntot);
+    float nrun = block_excl_scan(nsum, lane, wv, red, ntot);
     for (uint32_t k = 0; k < per; ++k) {
         const uint32_t i = i0 + k;
         if (i + 1 < E) {
-            nrun += pdf[i] / ptot;
+            nrun += pdf[i];
             cdf[i + 1] = nrun;
         }
     }
-    if (lane == 0) cdf[0] = 0.0f;
-    wave_sync();
+    if (tid == 0) cdf[0] = 0.0f;
+    __syncthreads();
+    STS_MARK(5)
 
     // inverse CDF at u_j = linspace(0,1,N)_j: searchsorted(right=True)                 :124-139
-    for (uint32_t j = lane; j < N; j += 64) {
+    for (uint32_t j = tid; j < N; j += 256) {
         const float u = a.u_lin[j];
         uint32_t lo = 0, hi = E;                     // first index with cdf > u
         while (lo < hi) {
@@ -381,9 +387,9 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
         sb[j] = b0 + mul_rn((u - c0) / den, b1 - b0);
     }
     // extras: near, far, n_extra of the coarse samples                                  :146-153
-    const uint32_t P2 = next_pow2(S);
-    for (uint32_t j = N + lane; j < P2; j += 64) {
-        float v = INFINITY;
+    const uint32_t S4 = (S + 3) & ~3u;
+    for (uint32_t j = N + tid; j < S4; j += 256) {
+        float v = INFINITY;                               // padding of the last group of four keys
         if (j == N) v = a.near;
         else if (j == N + 1) v = a.far[ray];
         else if (j < S) {                                 // caller-supplied pick: clamped to the ray's E coarse samples
@@ -392,27 +398,43 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
         }
         sb[j] = v;
     }
-    wave_sync();
-    // bitonic sort of P2 <= 256 keys in LDS                                             :155
-    for (uint32_t k = 2; k <= P2; k <<= 1) {
-        for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
-            for (uint32_t t = lane; t < P2 / 2; t += 64) {
-                const uint32_t i = 2 * t - (t & (jj - 1));      // index with bit jj clear
-                const uint32_t p = i + jj;
-                const bool up = (i & k) == 0;
-                const float x0 = sb[i], x1 = sb[p];
-                if ((x0 > x1) == up) { sb[i] = x1; sb[p] = x0; }
-            }
-            wave_sync();
-        }
+    __syncthreads();
+    STS_MARK(6)
+    // sort (:155) by rank: key t goes to position #{j : key_j < key_t} + #{j < t : key_j == key_t}.  Every thread reads the
+    // same four keys per step (an LDS broadcast), no exchanges, no barriers -- S <= 256 keys cost S/4 steps.
+    uint32_t e_pick = S;
+    if (a.z_eik) {
+        const uint32_t e = (uint32_t)a.eik_idx[ray];
+        e_pick = e < S ? e : S - 1;
     }
-    if (live) {
-        for (uint32_t j = lane; j < S; j += 64) a.z_vals[(size_t)ray * S + j] = sb[j];
-        if (a.z_eik && lane == 0) {
-            const uint32_t e = (uint32_t)a.eik_idx[ray];
-            a.z_eik[ray] = sb[e < S ? e : S - 1];
+    // S <= 128 (the shipped 98): two threads per key, each counts over half of the keys; the halves meet in LDS (the unused
+    // upper half of the key buffer).
+    const bool two = S <= 128;
+    const uint32_t t0 = two ? (uint32_t)tid & 127u : (uint32_t)tid;
+    const uint32_t half = two ? (uint32_t)tid >> 7 : 0u;
+    const uint32_t jmid = two ? ((S4 >> 1) + 3) & ~3u : S4;
+    const uint32_t jlo = half ? jmid : 0u, jhi = half ? S4 : jmid;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(sb + S4);       // two: S4 + 128 <= MAX_S
+    const float key = t0 < S ? sb[t0] : 0.0f;
+    uint32_t rank = 0;
+    if (t0 < S) {
+        for (uint32_t j = jlo; j < jhi; j += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(sb + j);
+            rank += (v.x < key || (v.x == key && j + 0 < t0)) ? 1u : 0u;
+            rank += (v.y < key || (v.y == key && j + 1 < t0)) ? 1u : 0u;
+            rank += (v.z < key || (v.z == key && j + 2 < t0)) ? 1u : 0u;
+            rank += (v.w < key || (v.w == key && j + 3 < t0)) ? 1u : 0u;
         }
+        if (half) cnt[t0] = rank;
     }
+    if (two) __syncthreads();
+    if (t0 < S && !half) {
+        if (two) rank += cnt[t0];
+        a.z_vals[(size_t)ray * S + rank] = key;
+        if (rank == e_pick) a.z_eik[ray] = key;
+    }
+    STS_MARK(7)
+    STS_END
 }
 
 }  // namespace nsa
@@ -514,14 +536,14 @@ int NSA_ENTRY(nsa_sample_rays)(const float* rays_o, const float* rays_d, const f
         (z_eik && !eik_idx))
         return NSA_EBADARG;
     const uint32_t S = N + 2 + n_extra;
-    if (S > MAX_S || E < 2 || (3 * E + MAX_S) * 4 * 4 > 160 * 1024) return NSA_EBADARG;
+    if (S > MAX_S || E < 2 || voxel_res == 0 || voxel_res > 1024 || (3 * E + MAX_S) * 4 * 4 > 160 * 1024) return NSA_EBADARG;
     RaySampleArgs a{rays_o, rays_d, z, sdf, far, voxels, u_lin, extra_idx, eik_idx, z_vals, z_eik, R, E, N, n_extra,
                     voxel_res, near};
-    const size_t lds = (size_t)(3 * E + MAX_S) * 4 * sizeof(float);
+    const size_t lds = (size_t)(3 * ((E + 3) & ~3u) + MAX_S + 4) * sizeof(float);
     launch_begin();
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)k_sample_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_sample_rays, dim3((R + 3) / 4), dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_sample_rays, dim3(R), dim3(256), lds, (hipStream_t)stream, a);
     return launch_end();
 }
 

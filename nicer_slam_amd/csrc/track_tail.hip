@@ -243,6 +243,155 @@ __global__ __launch_bounds__(1024) void k_track_tail(TrackArgs a) {
     }
 }
 
+// ---- the same head and tail with the neighbouring per-ray work folded in (graph-captured tracker, one ray chunk) ---------------
+// begin:  the frame's pixel batch is copied into the buffers the captured graph reads (uv, gt) by the kernel that lifts the
+//         rays -- one eager launch in front of the replay instead of two copies + a graph node.
+// finish: k_rays_bwd (wave per ray) + the per-ray pose-gradient terms of k_track_tail; block partials (fixed order) go to
+//         `part`, and the LAST block to arrive (ticket) adds them in a fixed order, forms the loss from the rays' L1 sums and runs
+//         the backward of cam -> pose and the Adam step: deterministic, one launch instead of two and no 1024-ray serial block.
+struct FinishArgs {
+    TrackArgs t;
+    const float* z_vals;  // [n,S]
+    const float* g_x;     // [n,S,3]
+    const float* g_dir;   // [n,S,3]
+    const float* ray_loss;  // [n] sum_c |rgb_c - gt_c| (k_composite_track)
+    uint32_t S;
+    float inv_n;          // 1 / (3 n): the loss is the mean over the pass's 3 n colour values
+    float* part;          // [blocks][16] workspace
+    unsigned* ticket;     // zero before the first launch; the kernel leaves it zero
+};
+
+constexpr int FIN_Q = 13;   // 12 pose-gradient entries (rows 0..2 of the 4x4) + the L1 sum
+
+__global__ __launch_bounds__(256) void k_track_begin(TrackArgs a, const float* uv_in, const float* gt_in, float* uv, float* gt) {
+    // (uv_in / gt_in may BE uv / gt: every thread reads its own elements before it writes them)
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    float P[16];
+    cam_to_pose(a.cam, P);
+    if (r == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a.pose[i] = P[i];
+    }
+    if (r >= a.n) return;
+    const float pu = uv_in[2 * r], pv = uv_in[2 * r + 1];
+    uv[2 * r] = pu;
+    uv[2 * r + 1] = pv;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gt[3 * r + k] = gt_in[3 * r + k];
+    float c[3];
+    lift_pixel_k(a.K, pu, pv, c);
+    float v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float w = P[4 * k] * c[0] + P[4 * k + 1] * c[1] + P[4 * k + 2] * c[2] + P[4 * k + 3];
+        v[k] = w - P[4 * k + 3];
+        a.rays_o[3 * r + k] = P[4 * k + 3];
+    }
+    const float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.rays_d[3 * r + k] = v[k] / s;
+    a.depth_scale[r] = c[2] / (c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+}
+
+__global__ __launch_bounds__(256) void k_track_finish(FinishArgs f) {
+    __shared__ float rp[4][FIN_Q];
+    __shared__ float G[16];
+    __shared__ unsigned last;
+    const TrackArgs& a = f.t;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t ray = blockIdx.x * 4 + wv;
+    float P[16];
+    cam_to_pose(a.cam, P);
+    float vals[FIN_Q];
+#pragma unroll
+    for (int q = 0; q < FIN_Q; ++q) vals[q] = 0.0f;
+    if (ray < a.n) {
+        float acc[6] = {0, 0, 0, 0, 0, 0};          // g_o, g_d of the ray: render_composite.hip::k_rays_bwd
+        for (uint32_t i = lane; i < f.S; i += 64) {
+            const size_t p = (size_t)ray * f.S + i;
+            const float z = f.z_vals[p];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float gx = f.g_x[p * 3 + c];
+                acc[c] += gx;
+                acc[3 + c] += z * gx + f.g_dir[p * 3 + c];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_xor(acc[q], off);
+        }
+        float c[3], v[3];
+        lift_pixel_k(a.K, a.uv[2 * ray], a.uv[2 * ray + 1], c);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float w = P[4 * k] * c[0] + P[4 * k + 1] * c[1] + P[4 * k + 2] * c[2] + P[4 * k + 3];
+            v[k] = w - P[4 * k + 3];
+        }
+        const float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+        const float vg = v[0] * acc[3] + v[1] * acc[4] + v[2] * acc[5];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float vb = acc[3 + k] / s - 2.0f * v[k] * vg / (s * s);     // d = v / (v.v)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) vals[4 * k + j] = vb * c[j];
+            vals[4 * k + 3] = acc[k];
+        }
+        vals[12] = f.ray_loss[ray];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < FIN_Q; ++q) rp[wv][q] = vals[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < FIN_Q) {
+        const int q = threadIdx.x;
+        const float x = ((rp[0][q] + rp[1][q]) + rp[2][q]) + rp[3][q];
+        __hip_atomic_store(f.part + (size_t)blockIdx.x * 16 + q, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();                        // the partials are visible device-wide before the ticket is taken
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(f.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    // 16 threads per quantity, each adds every 16th block's partial in block order, then a 16-lane butterfly
+    {
+        const int q = threadIdx.x >> 4, j = threadIdx.x & 15;
+        float x = 0.0f;
+        if (q < FIN_Q)
+            for (uint32_t b = j; b < gridDim.x; b += 16)
+                x += __hip_atomic_load(f.part + (size_t)b * 16 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        if (j == 0 && q < FIN_Q) G[q] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        f.ticket[0] = 0u;
+        float o[7];
+        pose_grad_to_cam(a.cam, G, o);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) a.g_cam[i] = o[i];
+        a.g_cam[7] = G[12] * f.inv_n;
+        if (a.reduce_weight > 0.0f) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a.g_cam[i] *= a.reduce_weight;
+            a.g_cam[8] = a.reduce_weight;
+        }
+    }
+    __syncthreads();
+    if (a.adam.p) {
+        const float t = a.adam.step[0] + 1.0f;
+        if (threadIdx.x < 7) adam_one(a.adam, threadIdx.x, t);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a.adam.step[0] = t;
+            keep_best(a.adam);
+        }
+    }
+}
 
 }  // namespace nsa
 
@@ -323,6 +472,42 @@ int nsa_track_tail(const float* uv, const float* K, float* cam, uint32_t n, cons
                                     best, loss, nullptr};
     launch_begin();
     hipLaunchKernelGGL(k_track_tail, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    return launch_end();
+}
+
+int nsa_track_begin(const float* uv_in, const float* gt_in, float* uv, float* gt, const float* K, const float* cam, uint32_t n,
+                    float* pose, float* rays_o, float* rays_d, float* depth_scale, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!uv_in || !gt_in || !uv || !gt || !K || !cam || !pose || !rays_o || !rays_d || !depth_scale || n == 0) return NSA_EBADARG;
+    TrackArgs a{};
+    a.K = K; a.cam = const_cast<float*>(cam); a.pose = pose; a.n = n;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.depth_scale = depth_scale;
+    launch_begin();
+    hipLaunchKernelGGL(k_track_begin, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, uv_in, gt_in, uv, gt);
+    return launch_end();
+}
+
+uint64_t nsa_track_finish_workspace(uint32_t n) { return ((uint64_t)(n + 3) / 4) * 16 + 4; }
+
+int nsa_track_finish(const float* uv, const float* K, float* cam, uint32_t n, uint32_t S, const float* z_vals, const float* g_x,
+                     const float* g_dir, const float* ray_loss, float* g_cam, int do_adam, float reduce_weight, float* exp_avg,
+                     float* exp_avg_sq, float* step, float lr, float beta1, float beta2, float eps, uint32_t lr_step,
+                     float lr_gamma, float* best, float* workspace, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!uv || !K || !cam || !z_vals || !g_x || !g_dir || !ray_loss || !g_cam || !workspace || n == 0 || S == 0) return NSA_EBADARG;
+    if (do_adam && (!exp_avg || !exp_avg_sq || !step)) return NSA_EBADARG;
+    if (best && !do_adam) return NSA_EBADARG;
+    FinishArgs f{};
+    f.t.uv = uv; f.t.K = K; f.t.cam = cam; f.t.n = n; f.t.g_cam = g_cam; f.t.reduce_weight = reduce_weight;
+    if (do_adam) f.t.adam = AdamArgs{cam, g_cam, exp_avg, exp_avg_sq, step, nullptr, 7, lr, beta1, beta2, eps, lr_gamma, lr_step,
+                                      best, g_cam + 7, nullptr};
+    f.z_vals = z_vals; f.g_x = g_x; f.g_dir = g_dir; f.ray_loss = ray_loss; f.S = S;
+    f.inv_n = 1.0f / (float)(3 * (uint64_t)n);
+    const uint32_t blocks = (n + 3) / 4;
+    f.ticket = reinterpret_cast<unsigned*>(workspace);       // first 4 floats: the ticket (zero-filled by the caller once)
+    f.part = workspace + 4;
+    launch_begin();
+    hipLaunchKernelGGL(k_track_finish, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f);
     return launch_end();
 }
 

@@ -68,8 +68,9 @@ def morton_order(pts_desc, P, device):
     return torch.sort(keys).indices.to(torch.int32)
 
 
-def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd, sort_points=False):
+def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd, sort_points=False, composite=True):
     """Launch the forward kernels of the composite pass.  Returns a dict of device buffers.
+    ``composite=False`` stops after the per-point kernels (the tracker's nsa_composite_track forms the ray sums itself).
     ``sort_points``: run the per-point kernels in Morton order (mapping: the table-gradient scatter merges far more
     rows and the colour-table gathers share cache lines; the sort costs more than it saves for a 1024-ray tracking step)."""
     R, S = z_vals.shape
@@ -99,6 +100,8 @@ def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd, sort_p
         check(lib.nsa_colour_forward(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
                                      b["feat"].data_ptr(), b["rgb"].data_ptr(),
                                      b["save"].data_ptr() if need_bwd else None, st))
+    if not composite:
+        return b
     with _timed("k_composite_fwd", P * 32):
         check(lib.nsa_composite_forward(rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(), b["sdf"].data_ptr(),
                                         b["rgb"].data_ptr(), b["grad"].data_ptr(), b["vox"].data_ptr(), model.voxel_res,
@@ -108,10 +111,13 @@ def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd, sort_p
 
 
 def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage, g_rgbv=None, g_depth=None, g_nmap=None,
-                           g_ent=None, g_w=None, params=None):
+                           g_ent=None, g_w=None, params=None, track=None, reduce_rays=True):
     """Launch the backward kernels.  Returns (g_rays_o[R,3], g_rays_d[R,3]); with ``params`` (dict of wanted parameter
     gradients: flat_c, flat_r, tab_c, tab_f, tab_r -- see fused/mapping.py) the MAP kernels run instead and a third
-    value, the dict of those gradients, is returned."""
+    value, the dict of those gradients, is returned.
+    ``track`` = dict(gt [R,3], ray_loss [R]): the tracking objective -- nsa_composite_track forms the ray colours, the L1 cotangent
+    and the composite backward in one launch (after composite_forward_raw(composite=False)).  ``reduce_rays=False`` returns the
+    per-sample (g_x, g_dir) instead of the ray sums (the tracker's nsa_track_finish adds them)."""
     R, S = z_vals.shape
     P = R * S
     dev = z_vals.device
@@ -128,11 +134,18 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
     g_sdf = torch.empty(P, device=dev)
     g_rgb = torch.empty(P, 3, device=dev)
     g_grad = torch.empty(P, 3, device=dev)
-    with _timed("k_composite_bwd", P * 60):
-        check(lib.nsa_composite_backward(rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(), b["sdf"].data_ptr(),
-                                         b["rgb"].data_ptr(), b["grad"].data_ptr(), b["vox"].data_ptr(), model.voxel_res,
-                                         R, S, ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gs[4]),
-                                         g_sdf.data_ptr(), g_rgb.data_ptr(), g_grad.data_ptr(), st))
+    if track is not None:
+        with _timed("k_composite_track", P * 60):
+            check(lib.nsa_composite_track(rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(), b["sdf"].data_ptr(),
+                                          b["rgb"].data_ptr(), b["vox"].data_ptr(), model.voxel_res, R, S, track["gt"].data_ptr(),
+                                          R, b["rgb_values"].data_ptr(), track["ray_loss"].data_ptr(), g_sdf.data_ptr(),
+                                          g_rgb.data_ptr(), g_grad.data_ptr(), st))
+    else:
+        with _timed("k_composite_bwd", P * 60):
+            check(lib.nsa_composite_backward(rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(), b["sdf"].data_ptr(),
+                                             b["rgb"].data_ptr(), b["grad"].data_ptr(), b["vox"].data_ptr(), model.voxel_res,
+                                             R, S, ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gs[4]),
+                                             g_sdf.data_ptr(), g_rgb.data_ptr(), g_grad.data_ptr(), st))
     g_feat = torch.empty(hl_size(P), device=dev)
     g_x = torch.empty(P, 3, device=dev)
     g_dir = torch.empty(P, 3, device=dev)
@@ -200,6 +213,8 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
                                               g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))
     if "_keep" in b:      # diagnostics (tools/diag_config0.py): per-point cotangents of the stages
         b["_keep"].update(g_x=g_x, g_dir=g_dir, g_sdf=g_sdf, g_rgb=g_rgb, g_grad=g_grad, g_feat=g_feat)
+    if not reduce_rays:
+        return g_x, g_dir
     g_o = torch.empty(R, 3, device=dev)
     g_d = torch.empty(R, 3, device=dev)
     check(lib.nsa_rays_backward(z_vals.data_ptr(), g_x.data_ptr(), g_dir.data_ptr(), R, S, g_o.data_ptr(),

@@ -94,7 +94,7 @@ def supported(model):
 
 
 MAX_S = 256                      # = MAX_S of csrc/render_sampler.hip / MAX_PER*64 of csrc/render_composite.hip
-LDS_BYTES = 160 * 1024           # per-workgroup LDS of k_sample_rays: 4 rays x (3 E + MAX_S) floats
+LDS_BYTES = 160 * 1024           # bound on E kept from the wave-per-ray k_sample_rays of rounds 1-2: 4 x (3 E + MAX_S) floats
 
 
 def sample_counts_ok(samp):

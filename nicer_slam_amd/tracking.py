@@ -63,6 +63,13 @@ class KernelTracker:
             self.bounds = [shard_rays(n_rays, c, self.chunks) for c in range(self.chunks)]
             self.streams = [torch.cuda.Stream() for _ in range(self.chunks)]
             self.red_c, self.pose_c = z(self.chunks, 9), z(self.chunks, 4, 4)
+        # one ray chunk: the per-ray neighbours of head and tail are folded into them (nsa_track_begin in front of the graph,
+        # nsa_composite_track, nsa_track_finish): 5 fewer launches per iteration.  NSA_TRACK_FOLD=0 keeps the plain sequence (A/B).
+        self.folded = self.chunks == 1 and os.environ.get("NSA_TRACK_FOLD", "1") != "0"
+        if self.folded:
+            from ._native import lib
+            self.ray_loss = z(n_rays)
+            self.fin_ws = z(int(lib.nsa_track_finish_workspace(n_rays)))      # ticket + block partials; zero once
         self.graph = None
         if use_graph:
             self._capture()
@@ -104,6 +111,19 @@ class KernelTracker:
         R = hi - lo
         uv, gt, g_rgbv = self.uv[0, lo:hi], self.gt[lo:hi], self.g_rgbv[lo:hi]
         rays_o, rays_d, ds = self.rays_o[lo:hi], self.rays_d[lo:hi], self.ds[lo:hi]
+        lr, b1, b2, eps, lr_step, lr_gamma = self.hyper
+        fused = not self.message
+        if self.folded:                                # (the rays were lifted by _begin, in front of the graph)
+            z_vals, _ = fs.get_z_vals(model, rays_d, rays_o, need_eik=False, rows=(lo, hi))
+            b = fr.composite_forward_raw(model, rays_o, rays_d, z_vals, self.stage, True, composite=False)
+            g_x, g_dir = fr.composite_backward_raw(model, rays_o, rays_d, z_vals, b, self.stage, self.color_stage,
+                                                   track=dict(gt=gt, ray_loss=self.ray_loss), reduce_rays=False)
+            check(lib.nsa_track_finish(uv.data_ptr(), self.K.data_ptr(), self.cam.data_ptr(), R, z_vals.shape[1],
+                                       z_vals.data_ptr(), g_x.data_ptr(), g_dir.data_ptr(), self.ray_loss.data_ptr(),
+                                       red.data_ptr(), 1 if fused else 0, 0.0 if fused else float(R), self.m.data_ptr(),
+                                       self.v.data_ptr(), self.t.data_ptr(), lr, b1, b2, eps, lr_step, lr_gamma,
+                                       self.best.data_ptr() if fused else None, self.fin_ws.data_ptr(), st))
+            return
         check(lib.nsa_track_head(uv.data_ptr(), self.K.data_ptr(), self.cam.data_ptr(), R, pose.data_ptr(),
                                  rays_o.data_ptr(), rays_d.data_ptr(), ds.data_ptr(), st))
         z_vals, _ = fs.get_z_vals(model, rays_d, rays_o, need_eik=False, rows=(lo, hi))
@@ -112,8 +132,6 @@ class KernelTracker:
         g_o, g_d = fr.composite_backward_raw(model, rays_o, rays_d, z_vals, b, self.stage, self.color_stage, g_rgbv=g_rgbv)
         # one chunk on one GPU: the Adam step rides in the same kernel; otherwise the tail leaves the weighted message and the
         # step follows the chunk sum / the all-reduce
-        lr, b1, b2, eps, lr_step, lr_gamma = self.hyper
-        fused = not self.message
         check(lib.nsa_track_tail(uv.data_ptr(), self.K.data_ptr(), self.cam.data_ptr(), R, g_o.data_ptr(),
                                  g_d.data_ptr(), red.data_ptr(), 1 if fused else 0, 0.0 if fused else float(R),
                                  self.m.data_ptr(), self.v.data_ptr(), self.t.data_ptr(), lr, b1, b2, eps, lr_step, lr_gamma,
@@ -194,12 +212,26 @@ class KernelTracker:
                                        self.red[7:8].data_ptr(), self.best.data_ptr(),
                                        torch.cuda.current_stream().cuda_stream))
 
+    def _begin(self, uv, gt):
+        """The frame's pixel batch into the resident buffers + camera -> pose -> rays, one launch (folded sequence)."""
+        from ._native import lib, check
+        dev = self.uv.device
+        uv = uv.detach().to(device=dev, dtype=torch.float32).reshape(-1, 2).contiguous()
+        gt = gt.detach().to(device=dev, dtype=torch.float32).reshape(-1, 3).contiguous()
+        if uv.shape[0] != self.R or gt.shape[0] != self.R:
+            raise ValueError(f"KernelTracker.step: expected {self.R} rays, got uv {tuple(uv.shape)} / gt {tuple(gt.shape)}")
+        check(lib.nsa_track_begin(uv.data_ptr(), gt.data_ptr(), self.uv.data_ptr(), self.gt.data_ptr(), self.K.data_ptr(),
+                                  self.cam.data_ptr(), self.R, self.pose.data_ptr(), self.rays_o.data_ptr(),
+                                  self.rays_d.data_ptr(), self.ds.data_ptr(), torch.cuda.current_stream().cuda_stream))
+
     def _capture(self):
         cam0 = self.cam.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(2):
+                if self.folded:
+                    self._begin(self.uv, self.gt)
                 self._iteration()
         torch.cuda.current_stream().wait_stream(side)
         self.reset(cam0)                           # the warm-up iterations stepped the camera: undo
@@ -209,8 +241,11 @@ class KernelTracker:
         self.reset(cam0)                           # (capture does not execute, but keep the state explicit)
 
     def step(self, uv, gt):
-        self.uv.copy_(uv)
-        self.gt.copy_(gt)
+        if self.folded:
+            self._begin(uv, gt)
+        else:
+            self.uv.copy_(uv)
+            self.gt.copy_(gt)
         with torch.no_grad():
             if self.graph is not None:
                 self._ensure_packs()               # the graph reads the tracker-owned snapshots: refresh them in place

@@ -80,6 +80,16 @@ def test_argument_validation_needs_no_gpu():
     assert lib.nsa_masked_l1(None, None, None, 16, 3, None, None, None, None) == NSA_EBADARG
     assert lib.nsa_masked_l1(fake, fake, None, 16, 0, fake, None, fake, None) == NSA_EBADARG                    # zero channels
     assert lib.nsa_masked_l1_workspace(1 << 20) >= 4
+    # the folded tracking sequence (one launch each for begin / composite + L1 / ray reduction + tail)
+    assert lib.nsa_track_begin(None, None, None, None, None, None, 8, None, None, None, None, None) == NSA_EBADARG
+    assert lib.nsa_composite_track(fake, fake, fake, fake, fake, fake, 64, 8, 257, fake, 8, fake, fake, fake, fake, fake, None) == NSA_EBADARG   # > 256 samples per ray
+    assert lib.nsa_composite_track(fake, fake, fake, fake, fake, fake, 64, 8, 128, fake, 4, fake, fake, fake, fake, fake, None) == NSA_EBADARG   # n_total < R
+    assert lib.nsa_composite_track(None, None, None, None, None, None, 64, 0, 128, None, 0, None, None, None, None, None, None) == 0            # no rays
+    assert lib.nsa_track_finish(fake, fake, fake, 8, 128, fake, fake, fake, fake, fake, 1, 0.0, None, None, None, 0.1, 0.9, 0.999, 1e-8, 0, 1.0,
+                                None, fake, None) == NSA_EBADARG                                                                                 # Adam without its state
+    assert lib.nsa_track_finish(fake, fake, fake, 8, 128, fake, fake, fake, fake, fake, 0, 8.0, None, None, None, 0.1, 0.9, 0.999, 1e-8, 0, 1.0,
+                                fake, fake, None) == NSA_EBADARG                                                                                 # candidate without the step
+    assert lib.nsa_track_finish_workspace(1024) == 256 * 16 + 4
     # empty work is a no-op, not an error (reference: a zero-size launch is never issued either)
     assert lib.nsa_sdf_points(None, 0, None, None, None, None, None, None) == 0
     assert lib.nsa_sampler_sdf(None, None, 0, 640, None, None, 0.0, 1.0, 3.5, None, None, None, None, None, None, None, None) == 0

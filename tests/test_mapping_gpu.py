@@ -182,7 +182,11 @@ def test_fused_mapping_larger_batch_vs_composed():
     K = torch.eye(4, device="cuda")[None].clone()
     K[0, 0, 0] = K[0, 1, 1] = 600.0
     K[0, 0, 2], K[0, 1, 2] = 599.5, 339.5
-    draws = {}
+    # the two engines are compared from ONE sample set: z_vals of the first run are handed to the second, and the index of the
+    # near-surface eikonal sample is pinned so that it is the same element of that set (two correct samplers differ where the
+    # inverse CDF is ill-conditioned; the samplers themselves are compared in CDF space in test_sampler_gpu.py)
+    samp = model.ray_sampler
+    draws = {"eik_idx": torch.randint(samp.N_samples + 2 + samp.N_samples_extra, (R,), device="cuda")}
     vox0 = torch.randint(0, 50, (64, 64, 64), device="cuda").float()
     res = {}
     for engine in ("composed", "fused"):

@@ -70,6 +70,15 @@ def main():
                     10: "stores", 15: "whole kernel"}.items():
         v = t[:, k].mean().item()
         print(f"  slot {k:2d}  {v:9.0f}  {100 * v / tot:5.1f} %   {name}")
+    # the per-ray sampling kernel ran after the sampler in the same step and overwrote the first 4 x 1024 rows
+    t = buf2.view(-1, 16)[:4096].double()
+    tot = t[:, 15].mean().item()
+    print(f"k_sample_rays: waves 4096  mean wave lifetime {tot:.0f} cycles")
+    for k, name in {1: "ray / z / sdf loads, voxel gather, density, free energy -> LDS", 2: "block sums + scan of the free energy",
+                    3: "weights, pdf", 4: "pdf total", 5: "cdf scan", 6: "inverse-CDF search + extras", 7: "rank sort + store",
+                    15: "whole kernel"}.items():
+        v = t[:, k].mean().item()
+        print(f"  slot {k:2d}  {v:9.0f}  {100 * v / tot:5.1f} %   {name}")
 
 
 if __name__ == "__main__":

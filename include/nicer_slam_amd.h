@@ -114,6 +114,15 @@ typedef struct nsa_points {
 int nsa_sdfnet_forward(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, int accumulate,
                        float *sdf, float *grad, float *feat_hl, nsa_stream_t stream);
 
+/* Both networks of the COMBINE in one launch: what nsa_sdfnet_forward(coarse, accumulate 0) followed by
+ * nsa_sdfnet_forward(fine, accumulate 1) leaves in sdf / grad / feat_hl, bit for bit, for the quad tiling (both descriptors
+ * tile == 16 with their quad packs, the same precision).  Point, positional encoding, level geometry and outputs are handled
+ * once; the coarse results stay in registers.  replaces ImplicitNetworkGrid_COMBINE.get_outputs
+ * (code/model/base_networks.py:7-47) in the "fine" stage. */
+int nsa_sdfnet_forward_pair(const nsa_points_t *pts, const nsa_grid_t *coarse, const nsa_grid_t *fine,
+                            const float *packed_coarse, const float *packed_fine, float *sdf, float *grad, float *feat_hl,
+                            nsa_stream_t stream);
+
 /* Backward of the above for the DATA path: given d/d(sdf)[P], d/d(feat) (HL), d/d(grad sdf)[P,3] (any may be
  * NULL = zero) produce d/dx [P,3] -- value path + double backward through the reverse pass, with exactly the terms
  * of the reference graph (the grid-Hessian term is dropped, code/hashencoder/hashgrid.py:134). */

@@ -144,7 +144,19 @@ __device__ __forceinline__ void stage_issue_n(const float* __restrict__ g, int n
 // and fetches part p + 1 while it multiplies.  With BUF >= the largest block every op is one part (the round-2 layout).
 struct StagePart {
     int off, mt, kg, g0, ng;
+    int net;      // 0 / 1: which of the (at most two) packed blocks of the sequence `off` is relative to (Seq::net, optional)
 };
+
+// Seq::net(op) is optional: sequences over ONE packed block do not define it
+template <class Seq, class = void>
+struct seq_has_net { static constexpr bool value = false; };
+template <class Seq>
+struct seq_has_net<Seq, decltype((void)Seq::net(0))> { static constexpr bool value = true; };
+template <class Seq>
+__host__ __device__ constexpr int seq_net(int op) {
+    if constexpr (seq_has_net<Seq>::value) return Seq::net(op);
+    else return 0;
+}
 
 template <int BUF>
 __host__ __device__ constexpr int max_groups(int mt) { return BUF / (mt * 768) < 1 ? 1 : BUF / (mt * 768); }
@@ -166,21 +178,23 @@ template <class Seq, int BUF>
 __host__ __device__ constexpr StagePart part_at(int p) {
     int op = 0;
     while (op < Seq::n && p >= parts_of<Seq, BUF>(op)) { p -= parts_of<Seq, BUF>(op); ++op; }
-    if (op >= Seq::n) return StagePart{0, 0, 0, 0, 0};
+    if (op >= Seq::n) return StagePart{0, 0, 0, 0, 0, 0};
     const int m = max_groups<BUF>(Seq::mt(op));
     const int g0 = p * m;
     const int ng = Seq::kg(op) - g0 < m ? Seq::kg(op) - g0 : m;
-    return StagePart{Seq::off(op), Seq::mt(op), Seq::kg(op), g0, ng};
+    return StagePart{Seq::off(op), Seq::mt(op), Seq::kg(op), g0, ng, seq_net<Seq>(op)};
 }
 
 template <int NW>
-__device__ __forceinline__ void stage_issue_part(const float* __restrict__ wp, const StagePart o, float* lds_dst) {
+__device__ __forceinline__ void stage_issue_part(const float* __restrict__ wp, const StagePart o, float* lds_dst,
+                                                 const float* __restrict__ wp1 = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per_tile = o.ng * 3;                 // 1 KiB chunks per tile in this part
     const int chunks = o.mt * per_tile;
+    const float* base = o.net ? wp1 : wp;
     for (int ch = wave; ch < chunks; ch += NW) {
         const int mt = ch / per_tile, rem = ch - mt * per_tile;
-        const float* src = wp + o.off + ((mt * o.kg + o.g0) * 3 + rem) * 256 + lane * 4;
+        const float* src = base + o.off + ((mt * o.kg + o.g0) * 3 + rem) * 256 + lane * 4;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(lds_dst + ch * 256), 16, 0, 0);
     }
@@ -227,10 +241,10 @@ __device__ __forceinline__ void gemm16_lds_part(const float* lds_block, int lane
 
 template <class Seq, int NW, int BUF, int KG, int MT, int P0, int G0, int NG>
 __device__ __forceinline__ void gemm16_staged_part(float* stage, const float* __restrict__ wp, int part, int lane,
-                                                   const float (&b)[8 * KG], f32x4v (&acc)[MT]) {
+                                                   const float (&b)[8 * KG], f32x4v (&acc)[MT], const float* __restrict__ wp1 = nullptr) {
     stage_wait();
     const StagePart nxt = part_at<Seq, BUF>(part + 1);
-    if (nxt.mt) stage_issue_part<NW>(wp, nxt, stage + ((part + 1) & 1) * BUF);
+    if (nxt.mt) stage_issue_part<NW>(wp, nxt, stage + ((part + 1) & 1) * BUF, wp1);
 
 #ifdef NSA_X_TS
     const unsigned long long tg = ts_now();
@@ -241,18 +255,19 @@ __device__ __forceinline__ void gemm16_staged_part(float* stage, const float* __
 #endif
 }
 
-// logical GEMM `opi` of Seq (KG k-groups, MT output tiles): all its parts (at most two)
+// logical GEMM `opi` of Seq (KG k-groups, MT output tiles): all its parts (at most two).  `wp1`: base of the second packed block
+// of a sequence that runs two networks (Seq::net).
 template <class Seq, int NW, int BUF, int KG, int MT>
 __device__ __forceinline__ void gemm16_staged(float* stage, const float* __restrict__ wp, int opi, int lane,
-                                              const float (&b)[8 * KG], f32x4v (&acc)[MT]) {
+                                              const float (&b)[8 * KG], f32x4v (&acc)[MT], const float* __restrict__ wp1 = nullptr) {
 
     constexpr int M = max_groups<BUF>(MT);
     constexpr int NP = (KG + M - 1) / M;
     static_assert(NP <= 3, "a staged GEMM is split into at most three parts");
     const int p0 = first_part<Seq, BUF>(opi);
-    gemm16_staged_part<Seq, NW, BUF, KG, MT, 0, 0, (KG < M ? KG : M)>(stage, wp, p0, lane, b, acc);
-    if constexpr (NP > 1) gemm16_staged_part<Seq, NW, BUF, KG, MT, 1, M, (KG - M < M ? KG - M : M)>(stage, wp, p0 + 1, lane, b, acc);
-    if constexpr (NP > 2) gemm16_staged_part<Seq, NW, BUF, KG, MT, 2, 2 * M, KG - 2 * M>(stage, wp, p0 + 2, lane, b, acc);
+    gemm16_staged_part<Seq, NW, BUF, KG, MT, 0, 0, (KG < M ? KG : M)>(stage, wp, p0, lane, b, acc, wp1);
+    if constexpr (NP > 1) gemm16_staged_part<Seq, NW, BUF, KG, MT, 1, M, (KG - M < M ? KG - M : M)>(stage, wp, p0 + 1, lane, b, acc, wp1);
+    if constexpr (NP > 2) gemm16_staged_part<Seq, NW, BUF, KG, MT, 2, 2 * M, KG - 2 * M>(stage, wp, p0 + 2, lane, b, acc, wp1);
 }
 
 // packed per-feature vector (activation layout [q*16 + s]) -> this lane's 16 values as 4 tiles x 4

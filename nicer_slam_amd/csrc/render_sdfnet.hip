@@ -461,6 +461,21 @@ int NSA_ENTRY(nsa_sdfnet_forward)(const nsa_points_t* pts, const nsa_grid_t* gri
     return launch_sdfnet(false, grid, a, (hipStream_t)stream);
 }
 
+int NSA_ENTRY(nsa_sdfnet_forward_pair)(const nsa_points_t* pts, const nsa_grid_t* coarse, const nsa_grid_t* fine,
+                            const float* packed_coarse, const float* packed_fine, float* sdf, float* grad, float* feat_hl,
+                            nsa_stream_t stream) {
+#if NSA_PIECES == 3
+    if (coarse && fine && coarse->precision == 1 && fine->precision == 1)
+        return nsa_sdfnet_forward_pair_bf16(pts, coarse, fine, packed_coarse, packed_fine, sdf, grad, feat_hl, stream);
+#endif
+    using namespace nsa;
+    if (!pts || !coarse || !fine || !packed_coarse || !packed_fine || !sdf || !grad || !feat_hl) return NSA_EBADARG;
+    if (pts->P == 0) return NSA_OK;
+    if (!pts->points && (!pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0)) return NSA_EBADARG;
+    if (coarse->tile != 16 || fine->tile != 16 || coarse->precision != fine->precision) return NSA_EBADARG;   // quad packs, one precision
+    return NSA_ENTRY(nsa_sdfnet4_forward_pair)(pts, coarse, fine, packed_coarse, packed_fine, sdf, grad, feat_hl, stream);
+}
+
 int NSA_ENTRY(nsa_sdfnet_backward)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* g_sdf,
                         const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x, nsa_stream_t stream) {
 #if NSA_PIECES == 3

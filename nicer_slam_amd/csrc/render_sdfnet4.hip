@@ -88,14 +88,33 @@ struct SdfOps4 {
     __host__ __device__ static constexpr int n_parts() { return first_part<SdfOps4<NH, BWD>, BUF>(n); }
 };
 
+// `wp`: this network's packed block (per-feature vectors).  A sequence over TWO networks (SdfOpsPair) stages from `s0` / `s1`, the
+// blocks of its net 0 / net 1; a one-network sequence leaves them null and stages from `wp`.
+// Forward of BOTH networks of the COMBINE in one kernel: the coarse network's ops, then the fine network's, one staging chain
+// (the last coarse GEMM prefetches the fine network's first block).  off() is relative to the packed block of net(i).
+template <int NHA, int NHB>
+struct SdfOpsPair {
+    using A = SdfOps4<NHA, false>;
+    using B = SdfOps4<NHB, false>;
+    static constexpr int NW = NSA_NW4_FWD;
+    static constexpr int BUF = stage_floats4(NW);
+    static constexpr int n = A::n + B::n;
+    __host__ __device__ static constexpr int net(int i) { return i < A::n ? 0 : 1; }
+    __host__ __device__ static constexpr int off(int i) { return i < A::n ? A::off(i) : B::off(i - A::n); }
+    __host__ __device__ static constexpr int mt(int i) { return i < A::n ? A::mt(i) : B::mt(i - A::n); }
+    __host__ __device__ static constexpr int kg(int i) { return i < A::n ? A::kg(i) : B::kg(i - A::n); }
+};
+
 template <int NH, class Seq>
 __device__ __forceinline__ void hidden_forward4(float* stage, int op0, const float* __restrict__ wp, int lane, int q,
                                                 const float (&in)[QIN], float (&sg)[NH][QHS], float (&hlast)[QHS],
-                                                const Emitter4* em = nullptr) {
+                                                const Emitter4* em = nullptr, const float* __restrict__ s0 = nullptr,
+                                                const float* __restrict__ s1 = nullptr) {
     using P = SdfPack4<NH>;
+    if (!s0) s0 = wp;
     f32x4v acc[4];
     load_vec16(wp + P::kB0, q, acc);
-    gemm16_staged<Seq, Seq::NW, Seq::BUF, QIN_G, 4>(stage, wp, op0, lane, in, acc);
+    gemm16_staged<Seq, Seq::NW, Seq::BUF, QIN_G, 4>(stage, s0, op0, lane, in, acc, s1);
 #pragma unroll
     for (int k = 1; k <= NH; ++k) {
         float d2;
@@ -107,7 +126,7 @@ __device__ __forceinline__ void hidden_forward4(float* stage, int op0, const flo
         }
         if (k < NH) {
             load_vec16(wp + P::bh(k), q, acc);
-            gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, wp, op0 + k, lane, hlast, acc);
+            gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, s0, op0 + k, lane, hlast, acc, s1);
         }
     }
 }
@@ -116,8 +135,10 @@ __device__ __forceinline__ void hidden_forward4(float* stage, int op0, const flo
 template <int NH, class Seq>
 __device__ __forceinline__ void reverse_pass4(float* stage, int op0, const float* __restrict__ wp, int lane, int q,
                                               const float (&sg)[NH][QHS], float (&dh)[NH > 1 ? NH - 1 : 1][QHS], float (&dl)[QIN],
-                                              const Emitter4* em = nullptr) {
+                                              const Emitter4* em = nullptr, const float* __restrict__ s0 = nullptr,
+                                              const float* __restrict__ s1 = nullptr) {
     using P = SdfPack4<NH>;
+    if (!s0) s0 = wp;
     f32x4v ws[4];
     load_vec16(wp + P::kWSDF, q, ws);
     float da[QHS];
@@ -132,7 +153,7 @@ __device__ __forceinline__ void reverse_pass4(float* stage, int op0, const float
         f32x4v acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, wp, op0 + (NH - 1 - k), lane, da, acc);
+        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, s0, op0 + (NH - 1 - k), lane, da, acc, s1);
 #pragma unroll
         for (int s = 0; s < QHS; ++s) {
             dh[k - 1][s] = acc[s >> 2][s & 3];
@@ -146,7 +167,7 @@ __device__ __forceinline__ void reverse_pass4(float* stage, int op0, const float
     f32x4v a6[6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) a6[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-    gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 6>(stage, wp, op0 + NH - 1, lane, da, a6);
+    gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 6>(stage, s0, op0 + NH - 1, lane, da, a6, s1);
 #pragma unroll
     for (int s = 0; s < QIN; ++s) dl[s] = a6[s >> 2][s & 3];
 }
@@ -251,6 +272,93 @@ __global__ __launch_bounds__(64 * NSA_NW4_FWD, NSA_OCC4_FWD) void k_sdfnet4_fwd(
     }
     TS_MARK(9)
     TS_END
+}
+
+// ---- both networks in one pass (ImplicitNetworkGrid_COMBINE.get_outputs, base_networks.py:7-47) ---------------------------------
+// What two launches of k_sdfnet4_fwd (coarse, then fine with accumulate) compute, with the point, the positional encoding, the
+// level geometry and the outputs handled once and the coarse network's results (16 features per lane, sdf, grad sdf) carried in
+// registers instead of through the feature buffer: bit-identical results, one kernel tail instead of two.
+struct SdfNet4PairArgs {
+    PointSrc src;
+    const float* table_c; const float* table_f;
+    const float* wp_c; const float* wp_f;
+    float df_c, df_f;
+    float* sdf; float* grad; float* feat;
+};
+
+template <int NH, class Seq>
+__device__ __forceinline__ void net_forward4(float* stage, int op0, const float* __restrict__ wp, const float* __restrict__ s0,
+                                             const float* __restrict__ s1, int lane, int q, const float (&in)[QIN], float& sdf,
+                                             f32x4v (&fo)[4], float (&dl)[QIN]) {
+    using P = SdfPack4<NH>;
+    float sg[NH][QHS], hl[QHS];
+    hidden_forward4<NH, Seq>(stage, op0, wp, lane, q, in, sg, hl, nullptr, s0, s1);
+    f32x4v ws[4];
+    load_vec16(wp + P::kWSDF, q, ws);
+    float part = 0.0f;
+#pragma unroll
+    for (int s = 0; s < QHS; ++s) part = fmaf(hl[s], ws[s >> 2][s & 3], part);
+    sdf = quad_sum(part) + wp[P::kBSDF];
+    load_vec16(wp + P::kBFEAT, q, fo);
+    gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, s0, op0 + NH, lane, hl, fo, s1);
+    float dh[NH > 1 ? NH - 1 : 1][QHS];
+    reverse_pass4<NH, Seq>(stage, op0 + NH + 1, wp, lane, q, sg, dh, dl, nullptr, s0, s1);
+}
+
+template <int LC, int CC, int NHC, int LF, int CF, int NHF>
+__global__ __launch_bounds__(64 * NSA_NW4_FWD, NSA_OCC4_FWD) void k_sdfnet4_fwd_pair(SdfNet4PairArgs a, GridGeom16 gc, GridGeom16 gf) {
+    using Seq = SdfOpsPair<NHC, NHF>;
+    __shared__ __attribute__((aligned(16))) float stage[2 * Seq::BUF];
+    __shared__ LevelGeom s_geom[32];
+    stage16_begin<Seq, Seq::NW, Seq::BUF>(stage, a.wp_c);
+    if (threadIdx.x < 16) s_geom[threadIdx.x] = gc.lv[threadIdx.x];
+    else if (threadIdx.x < 32) s_geom[threadIdx.x] = gf.lv[threadIdx.x - 16];
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    uint32_t tile = blockIdx.x * Seq::NW + (threadIdx.x >> 6);
+    const uint32_t n_tiles = (a.src.P + 15) / 16;
+    const bool wave_live = tile < n_tiles;
+    if (!wave_live) tile = n_tiles - 1;
+    uint32_t pid = tile * 16 + j;
+    const bool live = wave_live && pid < a.src.P;
+    if (pid >= a.src.P) pid = a.src.P - 1;
+    const uint32_t pt = point_of(a.src, pid);
+    float x[3], z;
+    uint32_t ray;
+    load_point(a.src, pt, x, ray, z);
+    __syncthreads();                                         // s_geom
+    static_assert((8 / CC) * 3 * CC == (8 / CF) * 3 * CF, "one Jacobian column serves both grids");
+    constexpr int kJac = (8 / CC) * 3 * CC;
+    __shared__ float jac_lds[Seq::NW * kJac * 64];
+    float* jstore = jac_lds + (threadIdx.x >> 6) * (kJac * 64) + lane;
+    float in[QIN], dl[QIN];
+    pe_slots4(x, q, in);                                     // slots 0..15: shared by the two networks
+    // coarse network
+    grid_slots4<LC, CC>(x, a.df_c, a.table_c, s_geom, q, in, jstore);
+    float sdf_c, g_c[3];
+    f32x4v fo_c[4];
+    net_forward4<NHC, Seq>(stage, 0, a.wp_c, a.wp_c, a.wp_f, lane, q, in, sdf_c, fo_c, dl);
+    slots_to_x_jac4<LC, CC>(a.df_c, jstore, q, in, dl, g_c);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) g_c[d] = quad_sum(g_c[d]);
+    // fine network (the Jacobian column and the grid slots are reused; the coarse ones have been consumed)
+    grid_slots4<LF, CF>(x, a.df_f, a.table_f, s_geom + 16, q, in, jstore);
+    float sdf_f, g_f[3];
+    f32x4v fo_f[4];
+    net_forward4<NHF, Seq>(stage, Seq::A::n, a.wp_f, a.wp_c, a.wp_f, lane, q, in, sdf_f, fo_f, dl);
+    slots_to_x_jac4<LF, CF>(a.df_f, jstore, q, in, dl, g_f);
+    if (wave_live) {
+        float* fdst = a.feat + hl_base4(tile, j, q);
+#pragma unroll
+        for (int s = 0; s < QHS; ++s) fdst[hl_step4(s)] = fo_f[s >> 2][s & 3] + fo_c[s >> 2][s & 3];
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) g_f[d] = quad_sum(g_f[d]);
+    if (live && q == 0) {
+        a.sdf[pt] = sdf_f + sdf_c;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) a.grad[(size_t)pt * 3 + d] = g_f[d] + g_c[d];
+    }
 }
 
 template <int L, int C, int NH, bool MAP>
@@ -460,6 +568,27 @@ int NSA_ENTRY(nsa_sdfnet4_backward)(const nsa_points_t* pts, const nsa_grid_t* g
     a.g_sdf = g_sdf; a.g_feat = g_feat_hl; a.g_grad = g_grad; a.g_x = g_x;
     a.g_table = g_table; a.emit = emit; a.emit_ld = emit_ld;
     return launch_sdfnet4(true, grid, a, (hipStream_t)stream);
+}
+
+int NSA_ENTRY(nsa_sdfnet4_forward_pair)(const nsa_points_t* pts, const nsa_grid_t* coarse, const nsa_grid_t* fine,
+                                        const float* packed_coarse, const float* packed_fine, float* sdf, float* grad,
+                                        float* feat_hl, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!(coarse->L == 4 && coarse->C == 8 && coarse->n_hidden == 1 && fine->L == 8 && fine->C == 4 && fine->n_hidden == 3))
+        return NSA_EUNSUPPORTED_NET;
+    SdfNet4PairArgs a{};
+    a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S, pts->order};
+    a.table_c = coarse->table; a.table_f = fine->table; a.wp_c = packed_coarse; a.wp_f = packed_fine;
+    a.df_c = coarse->divide_factor; a.df_f = fine->divide_factor;
+    a.sdf = sdf; a.grad = grad; a.feat = feat_hl;
+    GridGeom16 gc, gf;
+    if (int rc = make_grid_geom16(coarse->offsets_host, coarse->L, coarse->S, coarse->H, &gc, coarse->C)) return rc;
+    if (int rc = make_grid_geom16(fine->offsets_host, fine->L, fine->S, fine->H, &gf, fine->C)) return rc;
+    const uint32_t tiles = (a.src.P + 15) / 16;
+    launch_begin();
+    hipLaunchKernelGGL((k_sdfnet4_fwd_pair<4, 8, 1, 8, 4, 3>), dim3((tiles + NSA_NW4_FWD - 1) / NSA_NW4_FWD), dim3(64 * NSA_NW4_FWD), 0,
+                       (hipStream_t)stream, a, gc, gf);
+    return launch_end();
 }
 
 #ifdef NSA_X_TS

@@ -12,7 +12,7 @@ import torch
 from .._native import lib, check, PointsDesc
 from ..hashencoder.backend import _timed
 from . import pack
-from .sampler import grid_desc, packed_sdf, precision_of, sdf_grid_desc, tile_of
+from .sampler import forward_pair_ok, grid_desc, packed_sdf, precision_of, sdf_grid_desc, tile_of
 
 
 def hl_size(P):
@@ -89,13 +89,21 @@ def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd, sort_p
              depth=torch.empty(R, device=dev), nmap=torch.empty(R, 3, device=dev), entropy=torch.empty(R, device=dev),
              vox=model.voxels.contiguous(), packs=(pc, pf, pr), keep=(keep_c, keep_f, keep_r))
     st = _stream()
-    with _timed("k_sdfnet_fwd<coarse>", P * 4 * 8 * 8 * 4):
-        check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), 0, b["sdf"].data_ptr(),
-                                     b["grad"].data_ptr(), b["feat"].data_ptr(), st))
-    if stage != "coarse":
-        with _timed("k_sdfnet_fwd<fine>", P * 8 * 8 * 4 * 4):
-            check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), 1, b["sdf"].data_ptr(),
+    if stage != "coarse" and forward_pair_ok(model):          # ImplicitNetworkGrid_COMBINE in one launch (quad tiling)
+        gcp, keep_cp = sdf_grid_desc(model, "coarse", "coarse_pair")
+        pcp = packed_sdf(model, "coarse", use="coarse_pair")
+        b["keep"] += (keep_cp, pcp)
+        with _timed("k_sdfnet_fwd<pair>", P * (4 * 8 * 8 * 4 + 8 * 8 * 4 * 4)):
+            check(lib.nsa_sdfnet_forward_pair(ctypes.byref(pts), ctypes.byref(gcp), ctypes.byref(gf), pcp.data_ptr(), pf.data_ptr(),
+                                              b["sdf"].data_ptr(), b["grad"].data_ptr(), b["feat"].data_ptr(), st))
+    else:
+        with _timed("k_sdfnet_fwd<coarse>", P * 4 * 8 * 8 * 4):
+            check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), 0, b["sdf"].data_ptr(),
                                          b["grad"].data_ptr(), b["feat"].data_ptr(), st))
+        if stage != "coarse":
+            with _timed("k_sdfnet_fwd<fine>", P * 8 * 8 * 4 * 4):
+                check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), 1, b["sdf"].data_ptr(),
+                                             b["grad"].data_ptr(), b["feat"].data_ptr(), st))
     with _timed("k_colour_fwd", P * 16 * 8 * 2 * 4):
         check(lib.nsa_colour_forward(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
                                      b["feat"].data_ptr(), b["rgb"].data_ptr(),

@@ -46,7 +46,9 @@ def precision_of(model, which):
 # "sampler": 64 = the 32-point tiling with TWO point tiles per wave: one weight-fragment stream feeds both tiles and the
 # operand split of one overlaps the matrix instructions of the other; bit-identical results, 2 waves per SIMD instead of 3,
 # 208-214 -> 206 us (profiles/r02_ab_experiments.txt r3b).
-DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 64, "coarse_map": 16, "sampler_large": 16}
+# "coarse_pair": the coarse network inside nsa_sdfnet_forward_pair (both networks' forward in one launch; quad tiling only).
+DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 64, "coarse_map": 16, "sampler_large": 16, "coarse_pair": 16}
+FWD_PAIR = os.environ.get("NSA_SDF_FWD_PAIR", "1") != "0"          # 0: two forward launches (A/B runs)
 SAMPLER_LARGE_RAYS = 4096
 _FORCE = int(os.environ.get("NSA_SDF_TILE", "0"))
 _FORCE_SAMPLER = int(os.environ.get("NSA_SAMPLER_TILE", "0"))      # A/B runs of the sampler pass alone: 16 | 32 | 64
@@ -54,13 +56,19 @@ _FORCE_SAMPLER = int(os.environ.get("NSA_SAMPLER_TILE", "0"))      # A/B runs of
 
 def tile_of(model, which):
     """``which``: "coarse" / "fine" (composite-pass kernels of that network), "coarse_map" (the coarse network's MAP backward),
-    "sampler" / "sampler_large" (SDF-only pass, both networks; by batch size)."""
+    "coarse_pair" (the coarse network inside the paired forward), "sampler" / "sampler_large" (SDF-only pass, both networks; by
+    batch size)."""
     t = int(getattr(model, "sdf_tile", 0) or _FORCE or DEFAULT_TILES[which])
     if which.startswith("sampler") and _FORCE_SAMPLER and not getattr(model, "sdf_tile", 0):
         t = _FORCE_SAMPLER
     if t not in (16, 32) and not (t == 64 and which.startswith("sampler")):
         raise ValueError(f"sdf_tile must be 16 or 32 (64 = 32-point tiling with two tiles per wave, sampler only), got {t}")
     return t
+
+
+def forward_pair_ok(model):
+    """The composite pass runs both SDF networks' forward as ONE launch (nsa_sdfnet_forward_pair) when the quad tiling is in use."""
+    return FWD_PAIR and tile_of(model, "fine") == 16 and tile_of(model, "coarse_pair") == 16
 
 
 def grid_desc(net_or_enc, divide_factor, n_hidden, precision=0, tile=0):

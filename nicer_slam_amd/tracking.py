@@ -150,6 +150,8 @@ class KernelTracker:
         for which in ("coarse", "fine"):
             for u in (use, None):
                 specs.append(((which, fs.tile_of(model, u or which)), which, u))
+        if self.stage != "coarse" and fs.forward_pair_ok(model):       # the paired forward reads the coarse net's quad pack
+            specs.append((("coarse", fs.tile_of(model, "coarse_pair")), "coarse", "coarse_pair"))
         return specs
 
     def _ensure_packs(self):

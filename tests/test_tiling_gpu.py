@@ -139,3 +139,62 @@ def test_mfma_kernels_are_bit_reproducible_and_match_the_oracle_at_scale():
         with torch.no_grad():
             ref = R.sdf_vals(params, cfg, pts[sel.cuda()].cpu()).reshape(-1)
         assert_close(sdf.reshape(-1)[sel.cuda()], ref, 2e-5, 1e-4, f"sampler sdf vs oracle (tile {tile})")
+
+
+@pytest.mark.parametrize("mode,P", [("rays", 64 * 128), ("rays", 37 * 98), ("points", 1000), ("points", 5)])
+def test_paired_forward_is_the_two_quad_launches_bit_for_bit(mode, P):
+    """nsa_sdfnet_forward_pair (both networks of the COMBINE in one launch, coarse results carried in registers) against
+    nsa_sdfnet_forward(coarse, accumulate 0) + nsa_sdfnet_forward(fine, accumulate 1) in the quad tiling: sdf, grad sdf and the
+    HL feature buffer must be identical -- shipped grid sizes, ragged point counts, ray-sample and explicit-point sources, and a
+    permuted launch order."""
+    import ctypes
+    from nicer_slam_amd._native import lib, check, PointsDesc
+    from nicer_slam_amd.fused import render as fr, sampler as fs
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    torch.manual_seed(0)
+    model = SLAMNetwork(replica_model_conf(use_warp_loss=False), n_images=1,
+                        colour_grid=dict(base_resolution=16, desired_resolution=64, log2_hashmap_size=12)).cuda().train()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    with torch.no_grad():
+        for enc in (model.implicit_network.coarse.encoding, model.implicit_network.fine.encoding):
+            enc.embeddings.copy_((torch.rand(enc.embeddings.shape, device="cuda", generator=g) * 2 - 1) * 0.05)
+        for n_, p in model.named_parameters():
+            if n_.startswith("implicit_network") and n_.endswith("weight_v"):
+                p.add_(0.05 * torch.randn(p.shape, device="cuda", generator=g))
+    model.sdf_tile = 16
+    assert fs.forward_pair_ok(model)
+    gc, keep_c = fs.sdf_grid_desc(model, "coarse", "coarse_pair")
+    gf, keep_f = fs.sdf_grid_desc(model, "fine")
+    pc, pf = fs.packed_sdf(model, "coarse", use="coarse_pair"), fs.packed_sdf(model, "fine")
+    if mode == "rays":
+        S = 128 if P % 128 == 0 else 98
+        R = P // S
+        rays_d = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda", generator=g), dim=-1)
+        rays_o = ((torch.rand(R, 3, device="cuda", generator=g) - 0.5) * 0.4).contiguous()
+        z = torch.sort(torch.rand(R, S, device="cuda", generator=g) * 1.6, dim=1).values.contiguous()     # some samples leave the cube
+        srcs = [(PointsDesc(rays_o.data_ptr(), rays_d.data_ptr(), z.data_ptr(), None, P, S, None), None)]
+        order = torch.randperm(P, device="cuda", generator=g).to(torch.int32)
+        srcs.append((PointsDesc(rays_o.data_ptr(), rays_d.data_ptr(), z.data_ptr(), None, P, S, order.data_ptr()), order))
+    else:
+        x = ((torch.rand(P, 3, device="cuda", generator=g) * 2 - 1) * 1.05).contiguous()
+        srcs = [(PointsDesc(None, None, None, x.data_ptr(), P, 0, None), None)]
+    st = torch.cuda.current_stream().cuda_stream
+    for pts, _ in srcs:
+        two = [torch.full((P,), float("nan"), device="cuda"), torch.full((P, 3), float("nan"), device="cuda"),
+               torch.zeros(fr.hl_size(P), device="cuda")]
+        one = [t.clone() for t in two]
+        check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), 0, two[0].data_ptr(), two[1].data_ptr(),
+                                     two[2].data_ptr(), st))
+        check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), 1, two[0].data_ptr(), two[1].data_ptr(),
+                                     two[2].data_ptr(), st))
+        check(lib.nsa_sdfnet_forward_pair(ctypes.byref(pts), ctypes.byref(gc), ctypes.byref(gf), pc.data_ptr(), pf.data_ptr(),
+                                          one[0].data_ptr(), one[1].data_ptr(), one[2].data_ptr(), st))
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(two[0]).all()) and float(two[0].abs().max()) > 0
+        for a, b, what in zip(one, two, ("sdf", "grad sdf", "features")):
+            assert torch.equal(a, b), f"{what}: {int((a != b).sum())} of {a.numel()} differ, max {float((a - b).abs().max()):.3g}"
+    # mismatched descriptors are refused
+    g32, _k = fs.grid_desc(model.implicit_network.coarse.encoding, model.implicit_network.coarse.divide_factor, 1, 0, 32)
+    assert lib.nsa_sdfnet_forward_pair(ctypes.byref(srcs[0][0]), ctypes.byref(g32), ctypes.byref(gf), pc.data_ptr(), pf.data_ptr(),
+                                       one[0].data_ptr(), one[1].data_ptr(), one[2].data_ptr(), st) == 4

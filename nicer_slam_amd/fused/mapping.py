@@ -25,7 +25,7 @@ from .._native import lib, check, PointsDesc
 from ..hashencoder.backend import _timed
 from . import pack
 from .render import composite_forward_raw, composite_backward_raw, hl_size, morton_order, _stream
-from .sampler import grid_desc, packed_sdf, precision_of, sdf_grid_desc, tile_of
+from .sampler import forward_pair_ok, grid_desc, packed_sdf, precision_of, sdf_grid_desc, tile_of
 
 KCHUNK = 4096
 SORT_POINTS = True      # run the per-point kernels of a mapping iteration in Morton order (see render.morton_order)
@@ -233,13 +233,20 @@ class FusedSdfGradient(torch.autograd.Function):
         grad = torch.empty(N, 3, device=dev)
         feat = torch.empty(hl_size(N), device=dev)
         st = _stream()
-        with _timed("k_sdfnet_fwd<coarse,eik>", 0):
-            check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), 0, sdf.data_ptr(),
-                                         grad.data_ptr(), feat.data_ptr(), st))
-        if stage != "coarse":
-            with _timed("k_sdfnet_fwd<fine,eik>", 0):
-                check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), 1, sdf.data_ptr(),
+        if stage != "coarse" and forward_pair_ok(model):
+            gcp, keep_cp = sdf_grid_desc(model, "coarse", "coarse_pair")
+            pcp = packed_sdf(model, "coarse", use="coarse_pair")
+            with _timed("k_sdfnet_fwd<pair,eik>", 0):
+                check(lib.nsa_sdfnet_forward_pair(ctypes.byref(pts), ctypes.byref(gcp), ctypes.byref(gf), pcp.data_ptr(),
+                                                  pf.data_ptr(), sdf.data_ptr(), grad.data_ptr(), feat.data_ptr(), st))
+        else:
+            with _timed("k_sdfnet_fwd<coarse,eik>", 0):
+                check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), 0, sdf.data_ptr(),
                                              grad.data_ptr(), feat.data_ptr(), st))
+            if stage != "coarse":
+                with _timed("k_sdfnet_fwd<fine,eik>", 0):
+                    check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), 1, sdf.data_ptr(),
+                                                 grad.data_ptr(), feat.data_ptr(), st))
         ctx.save_for_backward(points)
         ctx.model, ctx.stage, ctx.packs, ctx.order = model, stage, (pc, pf), order
         return grad

@@ -99,22 +99,37 @@ __device__ __forceinline__ void keep_best(const AdamArgs& a) {
     }
 }
 
-__device__ __forceinline__ void adam_one(const AdamArgs& a, uint32_t i, float t) {
+// b^e for a non-negative integer e by squaring (<= 2 log2 e double multiplications, a few ulp of double: the bias corrections and
+// the StepLR factor round to the same fp32 as Python's pow; the library pow costs ~400 fp64 instructions on a lone wave)
+__device__ __forceinline__ double ipow(double b, double e_real) {
+    unsigned long long e = (unsigned long long)e_real;
+    double r = 1.0;
+    while (e) {
+        if (e & 1ull) r *= b;
+        b *= b;
+        e >>= 1;
+    }
+    return r;
+}
+
+// (m0, v0, p0: the moments and the parameter as they were BEFORE the step -- loaded by the caller, possibly long before)
+__device__ __forceinline__ void adam_one(const AdamArgs& a, uint32_t i, float t, float m0, float v0, float p0) {
     {
         const float g = a.g_div ? a.g[i] / a.g_div[0] : a.g[i];
-        const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
-        const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
+        const float m = a.beta1 * m0 + (1.0f - a.beta1) * g;
+        const float v = a.beta2 * v0 + (1.0f - a.beta2) * g * g;
         a.m[i] = m;
         a.v[i] = v;
-        const double bc1 = 1.0 - pow((double)a.beta1, (double)t);
-        const double bc2 = 1.0 - pow((double)a.beta2, (double)t);
+        const double bc1 = 1.0 - ipow((double)a.beta1, (double)t);
+        const double bc2 = 1.0 - ipow((double)a.beta2, (double)t);
         float lr = a.lr;
-        if (a.lr_step) lr *= (float)pow((double)a.lr_gamma, floor(((double)t - 1.0) / (double)a.lr_step));
+        if (a.lr_step) lr *= (float)ipow((double)a.lr_gamma, floor(((double)t - 1.0) / (double)a.lr_step));
         const float step_size = (float)((double)lr / bc1);
         const float denom = sqrtf(v) / (float)sqrt(bc2) + a.eps;
-        a.p[i] -= step_size * m / denom;
+        a.p[i] = p0 - step_size * m / denom;
     }
 }
+__device__ __forceinline__ void adam_one(const AdamArgs& a, uint32_t i, float t) { adam_one(a, i, t, a.m[i], a.v[i], a.p[i]); }
 
 __global__ void k_adam(AdamArgs a) {
     const uint32_t i = threadIdx.x;
@@ -302,6 +317,15 @@ __global__ __launch_bounds__(256) void k_track_finish(FinishArgs f) {
     const uint32_t ray = blockIdx.x * 4 + wv;
     float P[16];
     cam_to_pose(a.cam, P);
+    // optimizer state as it is before the step, requested now by every block: only the last block to arrive uses it, and there
+    // these loads would otherwise sit at the end of a chain of dependent round trips (ticket -> partials -> gradient -> state)
+    float t0 = 0.0f, m0 = 0.0f, v0 = 0.0f, p0 = 0.0f;
+    if (a.adam.p && threadIdx.x < 7) {
+        t0 = a.adam.step[0];
+        m0 = a.adam.m[threadIdx.x];
+        v0 = a.adam.v[threadIdx.x];
+        p0 = a.adam.p[threadIdx.x];
+    }
     float vals[FIN_Q];
 #pragma unroll
     for (int q = 0; q < FIN_Q; ++q) vals[q] = 0.0f;
@@ -345,27 +369,43 @@ __global__ __launch_bounds__(256) void k_track_finish(FinishArgs f) {
         for (int q = 0; q < FIN_Q; ++q) rp[wv][q] = vals[q];
     }
     __syncthreads();
-    if (threadIdx.x < FIN_Q) {
-        const int q = threadIdx.x;
-        const float x = ((rp[0][q] + rp[1][q]) + rp[2][q]) + rp[3][q];
-        __hip_atomic_store(f.part + (size_t)blockIdx.x * 16 + q, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wv == 0) {                          // one wave publishes the block's partial sums and takes the ticket
+        if (lane < FIN_Q) {
+            const float x = ((rp[0][lane] + rp[1][lane]) + rp[2][lane]) + rp[3][lane];
+            __hip_atomic_store(f.part + (size_t)blockIdx.x * 16 + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();                    // the partials are visible device-wide before the ticket is taken
+        if (lane == 0) last = atomicAdd(f.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
     }
-    __threadfence();                        // the partials are visible device-wide before the ticket is taken
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(f.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (!last) return;
     __threadfence();
-    // 16 threads per quantity, each adds every 16th block's partial in block order, then a 16-lane butterfly
+    // the last block adds the partials in a fixed order: thread t takes blocks t, t + 256, ... (all 13 loads of a block row are
+    // independent and in flight together), then a butterfly over the 64 lanes and the four waves in wave order
     {
-        const int q = threadIdx.x >> 4, j = threadIdx.x & 15;
-        float x = 0.0f;
-        if (q < FIN_Q)
-            for (uint32_t b = j; b < gridDim.x; b += 16)
-                x += __hip_atomic_load(f.part + (size_t)b * 16 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float x[FIN_Q];
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) x += __shfl_xor(x, off);
-        if (j == 0 && q < FIN_Q) G[q] = x;
+        for (int q = 0; q < FIN_Q; ++q) x[q] = 0.0f;
+        for (uint32_t b = threadIdx.x; b < gridDim.x; b += 256) {
+            float v[FIN_Q];
+#pragma unroll
+            for (int q = 0; q < FIN_Q; ++q)
+                v[q] = __hip_atomic_load(f.part + (size_t)b * 16 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int q = 0; q < FIN_Q; ++q) x[q] += v[q];
+        }
+#pragma unroll
+        for (int q = 0; q < FIN_Q; ++q) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) x[q] += __shfl_xor(x[q], off);
+        }
+        __syncthreads();                    // rp is free again (every wave passed the read above before the ticket barrier)
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < FIN_Q; ++q) rp[wv][q] = x[q];
+        }
+        __syncthreads();
+        if (threadIdx.x < FIN_Q) G[threadIdx.x] = ((rp[0][threadIdx.x] + rp[1][threadIdx.x]) + rp[2][threadIdx.x]) + rp[3][threadIdx.x];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -383,8 +423,8 @@ __global__ __launch_bounds__(256) void k_track_finish(FinishArgs f) {
     }
     __syncthreads();
     if (a.adam.p) {
-        const float t = a.adam.step[0] + 1.0f;
-        if (threadIdx.x < 7) adam_one(a.adam, threadIdx.x, t);
+        const float t = t0 + 1.0f;
+        if (threadIdx.x < 7) adam_one(a.adam, threadIdx.x, t, m0, v0, p0);
         __syncthreads();
         if (threadIdx.x == 0) {
             a.adam.step[0] = t;

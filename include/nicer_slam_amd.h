@@ -239,6 +239,15 @@ int nsa_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
 int nsa_draw_picks(const float *u, uint32_t E, uint32_t n_extra, uint32_t R, uint32_t S, int32_t *extra_idx,
                    int32_t *eik_idx, nsa_stream_t stream);
 
+/* Every random draw of one sampler call in one launch, from a counter-based generator (Philox4x32-10, the generator behind
+ * torch.rand) whose state the caller owns: state = 4 x uint64 on the device {seed, call number, 0, 0}; the kernel advances the
+ * call number itself, so a captured graph draws fresh numbers on every replay.  t_rand[n_rand] uniforms in [0,1) (the stratified
+ * jitter, ray_sampler.py:57-58), extra_idx / eik_idx as nsa_draw_picks (any output may be NULL).  Value i of call c is
+ * philox(key = seed, counter = (i / 4, region, c))[i % 4] >> 8, region 0 = t_rand, 1 = the E permutation keys, 2 = eik_idx.
+ * replaces torch.rand / torch.randperm / torch.randint of code/model/ray_sampler.py:57-58,148,158. */
+int nsa_draw(uint64_t *state, uint64_t n_rand, float *t_rand, uint32_t E, uint32_t n_extra, uint32_t R, uint32_t S,
+             int32_t *extra_idx, int32_t *eik_idx, nsa_stream_t stream);
+
 /* SDF (coarse + fine; fine == NULL: stage "coarse") at N explicit points, no gradients: batch inference for mesh
  * extraction grids and plots.  replaces ImplicitNetworkGrid_COMBINE.get_sdf_vals (code/model/base_networks.py:25-35)
  * as called by code/utils/plots.py:91,142. */

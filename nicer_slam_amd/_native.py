@@ -151,7 +151,9 @@ EXPORTS += ["nsa_sdf_points"]
 
 lib.nsa_draw_picks.restype = _i
 lib.nsa_draw_picks.argtypes = [_p, _u32, _u32, _u32, _u32, _p, _p, _p]
-EXPORTS += ["nsa_draw_picks"]
+lib.nsa_draw.restype = _i
+lib.nsa_draw.argtypes = [_p, ctypes.c_uint64, _p, _u32, _u32, _u32, _u32, _p, _p, _p]
+EXPORTS += ["nsa_draw_picks", "nsa_draw"]
 
 lib.nsa_track_head.restype = _i
 lib.nsa_track_head.argtypes = [_p, _p, _p, _u32, _p, _p, _p, _p, _p]

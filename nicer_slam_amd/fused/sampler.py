@@ -185,6 +185,25 @@ def sample_rays(model, rays_o, rays_d, z, sdf, far, extra_idx, eik_idx):
     return z_vals, (z_eik.unsqueeze(-1) if ek is not None else None)
 
 
+# The sampler's draws come from the engine's own Philox4x32-10 stream (nsa_draw: jitter, permutation picks and eikonal indices in
+# one launch, state advanced on the device) -- seeded from torch's generator when the model first draws, so torch.manual_seed
+# still fixes the run.  NSA_OWN_RNG=0: torch.rand + nsa_draw_picks (inside a captured graph torch's graph-safe generator adds four
+# small launches in front of every replay).
+OWN_RNG = os.environ.get("NSA_OWN_RNG", "1") != "0"
+
+
+def draw_state(model):
+    """{seed, call number, ticket, -} of nsa_draw on the model's device.  Created on first use: call it (or run one iteration)
+    BEFORE capturing a graph around the sampler."""
+    st = model.__dict__.get("_draw_state")
+    dev = model.voxels.device
+    if st is None or st.device != dev:
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))        # torch's CPU generator: follows torch.manual_seed
+        st = torch.tensor([seed, 0, 0, 0], dtype=torch.int64).to(dev)
+        model.__dict__["_draw_state"] = st
+    return st
+
+
 def get_z_vals(model, ray_dirs, cam_loc, need_eik=True, rows=None):
     """Drop-in for ImportantSampler.get_z_vals (fused engine).  ``need_eik=False`` (tracking) skips the near-surface
     eikonal sample, which only mapping consumes.  ``rows = (lo, hi)``: these rays are rows lo..hi of a larger batch (a chunk of
@@ -196,8 +215,18 @@ def get_z_vals(model, ray_dirs, cam_loc, need_eik=True, rows=None):
     n_extra = samp.N_samples_extra
     S = samp.N_samples + 2 + n_extra
     dev = rays_d.device
+    if model.training and model.draws is None and E <= 1024 and OWN_RNG:
+        # fast path: every draw of this call from ONE launch of the engine's own counter-based generator (nsa_draw)
+        t_rand = torch.empty(R, E, device=dev)
+        extra = torch.empty(n_extra, device=dev, dtype=torch.int32) if n_extra > 0 else None
+        eik_idx = torch.empty(R, device=dev, dtype=torch.int32) if need_eik else None
+        check(lib.nsa_draw(draw_state(model).data_ptr(), R * E, t_rand.data_ptr(), E, n_extra, R, S,
+                           extra.data_ptr() if extra is not None else None, eik_idx.data_ptr() if eik_idx is not None else None,
+                           torch.cuda.current_stream().cuda_stream))
+        z, sdf, far = sampler_sdf(model, rays_o, rays_d, t_rand)
+        return sample_rays(model, rays_o, rays_d, z, sdf, far, extra, eik_idx)
     if model.training and model.draws is None and E <= 1024:
-        # fast path: ONE device rand for every draw of this call + one kernel for the integer picks
+        # the same with torch's generator: ONE device rand for every draw of this call + one kernel for the integer picks
         u = torch.rand(R * E + E + R, device=dev)
         z, sdf, far = sampler_sdf(model, rays_o, rays_d, u[:R * E].view(R, E))
         extra = torch.empty(n_extra, device=dev, dtype=torch.int32) if n_extra > 0 else None

@@ -261,15 +261,16 @@ __global__ __launch_bounds__(256) void k_draw(DrawArgs a) {
     __shared__ uint32_t part[4][64];
     const uint64_t seed = a.state[0], call = a.state[1];
     if (blockIdx.x < a.rand_blocks) {
-        const uint64_t i4 = (uint64_t)blockIdx.x * 256 + threadIdx.x;          // group of four consecutive draws
-        if (i4 * 4 < a.n_rand) {
-            float u[4];
+        // (few workgroups, each looping: the closing ticket is one same-address device-scope atomic per workgroup, ~15 ns apiece)
+        for (uint64_t i4 = (uint64_t)blockIdx.x * 256 + threadIdx.x; i4 * 4 < a.n_rand; i4 += (uint64_t)a.rand_blocks * 256) {
+            float u[4];                                                         // group of four consecutive draws
             draw4(a, (uint32_t)i4, 0u, call, seed, u);
             if (i4 * 4 + 3 < a.n_rand) *reinterpret_cast<float4*>(a.t_rand + i4 * 4) = make_float4(u[0], u[1], u[2], u[3]);
             else for (uint64_t k = 0; i4 * 4 + k < a.n_rand; ++k) a.t_rand[i4 * 4 + k] = u[k];
         }
     } else {
-        // the picks: 64 keys per workgroup, every workgroup regenerates all E keys (E / 4 generator calls)
+        // the picks: 16 keys per workgroup (the E^2 comparisons spread over E/16 workgroups), every workgroup regenerates all E
+        // keys (E / 4 generator calls); thread (key k, segment s) = k + 16 s counts one sixteenth of the comparison range
         const uint32_t pb = blockIdx.x - a.rand_blocks, n_pb = gridDim.x - a.rand_blocks;
         const uint32_t lane = threadIdx.x & 63, q = threadIdx.x >> 6;
         {
@@ -279,14 +280,14 @@ __global__ __launch_bounds__(256) void k_draw(DrawArgs a) {
             for (int k = 0; k < 4; ++k) key[4 * threadIdx.x + k] = 4 * threadIdx.x + k < a.E ? u[k] : 2.0f;
         }
         __syncthreads();
-        const uint32_t t = pb * 64 + lane;
         if (a.extra_idx) {
+            const uint32_t kk = threadIdx.x & 15, sg = threadIdx.x >> 4;
+            const uint32_t t = pb * 16 + kk;
             const float mine = key[t < 1024 ? t : 1023];
             uint32_t rank = 0;
             const float4* k4 = reinterpret_cast<const float4*>(key);
-            const uint32_t n4 = (a.E + 3) / 4, per = (n4 + 3) / 4;
-            const uint32_t lo = q * per, hi = lo + per < n4 ? lo + per : n4;
-#pragma unroll 8
+            const uint32_t n4 = (a.E + 3) / 4, per = (n4 + 15) / 16;
+            const uint32_t lo = sg * per, hi = lo + per < n4 ? lo + per : n4;
             for (uint32_t j4 = lo; j4 < hi; ++j4) {
                 const float4 o = k4[j4];
                 const uint32_t j = 4 * j4;
@@ -295,10 +296,12 @@ __global__ __launch_bounds__(256) void k_draw(DrawArgs a) {
                 rank += (o.z < mine || (o.z == mine && j + 2 < t)) ? 1u : 0u;
                 rank += (o.w < mine || (o.w == mine && j + 3 < t)) ? 1u : 0u;
             }
-            part[q][lane] = rank;
+            rank += __shfl_xor(rank, 16);
+            rank += __shfl_xor(rank, 32);
+            if (lane < 16) part[q][lane] = rank;
             __syncthreads();
-            if (q == 0 && t < a.E) {
-                const uint32_t r = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+            if (threadIdx.x < 16 && t < a.E) {
+                const uint32_t r = part[0][kk] + part[1][kk] + part[2][kk] + part[3][kk];
                 if (r < a.n_extra) a.extra_idx[r] = (int32_t)t;
             }
         }
@@ -640,9 +643,10 @@ int NSA_ENTRY(nsa_draw)(uint64_t* state, uint64_t n_rand, float* t_rand, uint32_
     a.state = reinterpret_cast<unsigned long long*>(state);
     a.t_rand = t_rand; a.n_rand = n_rand; a.E = extra_idx ? E : 0; a.n_extra = extra_idx ? n_extra : 0; a.R = eik_idx ? R : 0; a.S = S;
     a.rand_blocks = (uint32_t)((n_rand + 1023) / 1024);
+    if (a.rand_blocks > 128) a.rand_blocks = 128;
     a.extra_idx = extra_idx; a.eik_idx = eik_idx;
     uint32_t pick_blocks = 0;
-    if (extra_idx) pick_blocks = (E + 63) / 64;
+    if (extra_idx) pick_blocks = (E + 15) / 16;
     else if (eik_idx) pick_blocks = 1;
     if (a.rand_blocks + pick_blocks == 0) return NSA_OK;
     launch_begin();

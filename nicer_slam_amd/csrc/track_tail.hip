@@ -112,10 +112,10 @@ __device__ __forceinline__ double ipow(double b, double e_real) {
     return r;
 }
 
-// (m0, v0, p0: the moments and the parameter as they were BEFORE the step -- loaded by the caller, possibly long before)
-__device__ __forceinline__ void adam_one(const AdamArgs& a, uint32_t i, float t, float m0, float v0, float p0) {
+// (m0, v0, p0: the moments and the parameter as they were BEFORE the step, g: the gradient -- loaded by the caller, possibly long
+// before; returns the stepped parameter)
+__device__ __forceinline__ float adam_one(const AdamArgs& a, uint32_t i, float t, float m0, float v0, float p0, float g) {
     {
-        const float g = a.g_div ? a.g[i] / a.g_div[0] : a.g[i];
         const float m = a.beta1 * m0 + (1.0f - a.beta1) * g;
         const float v = a.beta2 * v0 + (1.0f - a.beta2) * g * g;
         a.m[i] = m;
@@ -126,10 +126,14 @@ __device__ __forceinline__ void adam_one(const AdamArgs& a, uint32_t i, float t,
         if (a.lr_step) lr *= (float)ipow((double)a.lr_gamma, floor(((double)t - 1.0) / (double)a.lr_step));
         const float step_size = (float)((double)lr / bc1);
         const float denom = sqrtf(v) / (float)sqrt(bc2) + a.eps;
-        a.p[i] = p0 - step_size * m / denom;
+        const float p = p0 - step_size * m / denom;
+        a.p[i] = p;
+        return p;
     }
 }
-__device__ __forceinline__ void adam_one(const AdamArgs& a, uint32_t i, float t) { adam_one(a, i, t, a.m[i], a.v[i], a.p[i]); }
+__device__ __forceinline__ void adam_one(const AdamArgs& a, uint32_t i, float t) {
+    adam_one(a, i, t, a.m[i], a.v[i], a.p[i], a.g_div ? a.g[i] / a.g_div[0] : a.g[i]);
+}
 
 __global__ void k_adam(AdamArgs a) {
     const uint32_t i = threadIdx.x;
@@ -308,13 +312,17 @@ __global__ __launch_bounds__(256) void k_track_begin(TrackArgs a, const float* u
     a.depth_scale[r] = c[2] / (c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
 }
 
-__global__ __launch_bounds__(256) void k_track_finish(FinishArgs f) {
-    __shared__ float rp[4][FIN_Q];
+// FIN_W rays per workgroup: the ticket is one device-scope atomic on ONE address per workgroup, and those serialise at the memory
+// side (~15 ns each): 64 workgroups of 16 waves instead of 256 of 4.
+constexpr int FIN_W = 16;
+
+__global__ __launch_bounds__(64 * FIN_W) void k_track_finish(FinishArgs f) {
+    __shared__ float rp[FIN_W][FIN_Q];
     __shared__ float G[16];
     __shared__ unsigned last;
     const TrackArgs& a = f.t;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t ray = blockIdx.x * 4 + wv;
+    const uint32_t ray = blockIdx.x * FIN_W + wv;
     float P[16];
     cam_to_pose(a.cam, P);
     // optimizer state as it is before the step, requested now by every block: only the last block to arrive uses it, and there
@@ -326,6 +334,7 @@ __global__ __launch_bounds__(256) void k_track_finish(FinishArgs f) {
         v0 = a.adam.v[threadIdx.x];
         p0 = a.adam.p[threadIdx.x];
     }
+    const float best0 = (a.adam.p && a.adam.best && threadIdx.x == 0) ? a.adam.best[0] : 0.0f;
     float vals[FIN_Q];
 #pragma unroll
     for (int q = 0; q < FIN_Q; ++q) vals[q] = 0.0f;
@@ -371,7 +380,9 @@ __global__ __launch_bounds__(256) void k_track_finish(FinishArgs f) {
     __syncthreads();
     if (wv == 0) {                          // one wave publishes the block's partial sums and takes the ticket
         if (lane < FIN_Q) {
-            const float x = ((rp[0][lane] + rp[1][lane]) + rp[2][lane]) + rp[3][lane];
+            float x = 0.0f;
+#pragma unroll
+            for (int w = 0; w < FIN_W; ++w) x += rp[w][lane];
             __hip_atomic_store(f.part + (size_t)blockIdx.x * 16 + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __threadfence();                    // the partials are visible device-wide before the ticket is taken
@@ -380,13 +391,13 @@ __global__ __launch_bounds__(256) void k_track_finish(FinishArgs f) {
     __syncthreads();
     if (!last) return;
     __threadfence();
-    // the last block adds the partials in a fixed order: thread t takes blocks t, t + 256, ... (all 13 loads of a block row are
-    // independent and in flight together), then a butterfly over the 64 lanes and the four waves in wave order
+    // the last block adds the partials in a fixed order: thread t takes blocks t, t + 1024, ... (all 13 loads of a block row are
+    // independent and in flight together), then a butterfly over the 64 lanes and the waves in wave order
     {
         float x[FIN_Q];
 #pragma unroll
         for (int q = 0; q < FIN_Q; ++q) x[q] = 0.0f;
-        for (uint32_t b = threadIdx.x; b < gridDim.x; b += 256) {
+        for (uint32_t b = threadIdx.x; b < gridDim.x; b += 64 * FIN_W) {
             float v[FIN_Q];
 #pragma unroll
             for (int q = 0; q < FIN_Q; ++q)
@@ -405,30 +416,36 @@ __global__ __launch_bounds__(256) void k_track_finish(FinishArgs f) {
             for (int q = 0; q < FIN_Q; ++q) rp[wv][q] = x[q];
         }
         __syncthreads();
-        if (threadIdx.x < FIN_Q) G[threadIdx.x] = ((rp[0][threadIdx.x] + rp[1][threadIdx.x]) + rp[2][threadIdx.x]) + rp[3][threadIdx.x];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        f.ticket[0] = 0u;
-        float o[7];
-        pose_grad_to_cam(a.cam, G, o);
+        if (threadIdx.x < FIN_Q) {
+            float g = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) a.g_cam[i] = o[i];
-        a.g_cam[7] = G[12] * f.inv_n;
-        if (a.reduce_weight > 0.0f) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a.g_cam[i] *= a.reduce_weight;
-            a.g_cam[8] = a.reduce_weight;
+            for (int w = 0; w < FIN_W; ++w) g += rp[w][threadIdx.x];
+            G[threadIdx.x] = g;
         }
     }
     __syncthreads();
-    if (a.adam.p) {
+    __shared__ float msg[9], stepped[8];    // the message as it goes to global memory; the camera after the step
+    if (threadIdx.x == 0) {
+        f.ticket[0] = 0u;
+        float o[8];
+        pose_grad_to_cam(a.cam, G, o);
+        o[7] = G[12] * f.inv_n;
+        const float w = a.reduce_weight > 0.0f ? a.reduce_weight : 1.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { msg[i] = o[i] * w; a.g_cam[i] = msg[i]; }      // (x * 1.0f == x)
+        if (a.reduce_weight > 0.0f) a.g_cam[8] = a.reduce_weight;
+    }
+    __syncthreads();
+    if (a.adam.p) {                         // (single GPU, one chunk: reduce_weight == 0, the message IS the gradient and the loss)
         const float t = t0 + 1.0f;
-        if (threadIdx.x < 7) adam_one(a.adam, threadIdx.x, t, m0, v0, p0);
+        if (threadIdx.x < 7) stepped[threadIdx.x] = adam_one(a.adam, threadIdx.x, t, m0, v0, p0, msg[threadIdx.x]);
         __syncthreads();
         if (threadIdx.x == 0) {
             a.adam.step[0] = t;
-            keep_best(a.adam);
+            if (a.adam.best && msg[7] < best0) {       // keep_best with the loss, the old minimum and the new camera at hand
+                a.adam.best[0] = msg[7];
+                for (int i = 0; i < 7; ++i) a.adam.best[1 + i] = stepped[i];
+            }
         }
     }
 }
@@ -543,11 +560,11 @@ int nsa_track_finish(const float* uv, const float* K, float* cam, uint32_t n, ui
                                       best, g_cam + 7, nullptr};
     f.z_vals = z_vals; f.g_x = g_x; f.g_dir = g_dir; f.ray_loss = ray_loss; f.S = S;
     f.inv_n = 1.0f / (float)(3 * (uint64_t)n);
-    const uint32_t blocks = (n + 3) / 4;
+    const uint32_t blocks = (n + FIN_W - 1) / FIN_W;
     f.ticket = reinterpret_cast<unsigned*>(workspace);       // first 4 floats: the ticket (zero-filled by the caller once)
     f.part = workspace + 4;
     launch_begin();
-    hipLaunchKernelGGL(k_track_finish, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f);
+    hipLaunchKernelGGL(k_track_finish, dim3(blocks), dim3(64 * FIN_W), 0, (hipStream_t)stream, f);
     return launch_end();
 }
 

@@ -8,6 +8,8 @@ import ctypes
 import os
 import sys
 
+os.environ.setdefault("NSA_SDF_FWD_PAIR", "0")     # the instrumented forward is the single-network kernel (two launches)
+
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -15,6 +15,8 @@ the environment) or directly as `python bench.py --gpus N`, which re-executes it
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
+import gc
 import json
 import os
 import sys
@@ -48,6 +50,21 @@ ALGO_MAC = {
 }
 
 
+@contextlib.contextmanager
+def quiet_gc():
+    """Timed regions run with Python's cyclic collector off, after a full collection -- as `timeit` does.  A generation-2 pass over
+    this process's ~10^6 objects is a 35-60 ms host stall (measured: profiles/r03_ab_experiments.txt r3ab), i.e. 50-100
+    tracking iterations; with K = 20 timed steps one such pause multiplies the measured step time by 3-5."""
+    was = gc.isenabled()
+    gc.collect()          # (callers enter BEFORE their warm-up steps: the collection itself idles the GPU for tens of ms, and the
+    gc.disable()          #  first ~20 iterations after an idle gap run at lower clocks)
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,6 +73,10 @@ def parse():
     ap.add_argument("--prewarm-s", type=float, default=1.0,
                     help="seconds of an unrelated GEMM loop before the W warm-up steps: a step is < 1 ms, so W steps alone "
                          "end before the GPU's power management has left its idle clocks (measured: 1.1 vs 0.8 ms/step)")
+    ap.add_argument("--prewarm-steps", type=int, default=100,
+                    help="iterations of the tracker itself after the GEMM loop, followed by a reset of camera / optimizer state to "
+                         "their initial values: the first ~20 iterations after construction run ~4 %% slower (cold TLBs / Infinity "
+                         "Cache for the 1 GiB table; profiles/r03_ab_experiments.txt r3ab) -- with the driver's K = 20 that IS the sample")
     ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step (weak scaling)")
     ap.add_argument("--global-rays", type=int, default=0,
                     help="total rays per step over all GPUs (strong scaling: each rank renders global/N); e.g. 4096 = BASELINE "
@@ -219,6 +240,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    gc_off = quiet_gc()
+    gc_off.__enter__()              # collector off from here to the end of the timed region (prewarm and warm-up included)
     probe_tflops = None
     if args.prewarm_s > 0:          # bring the clocks up with work that touches none of the tracker's state or caches
         a = torch.randn(4096, 4096, device=device)
@@ -232,6 +255,15 @@ def main():
         # by up to 1.3x with identical binaries, and every kernel of the iteration scales with it
         probe_tflops = round(n_mm * 2 * 4096 ** 3 / (time.perf_counter() - t_pre) / 1e12, 1)
         del a
+    cache_prewarm = 0
+    if args.prewarm_steps > 0 and hasattr(stepper, "reset"):
+        # ... and the memory side with the iteration itself; afterwards camera, Adam moments, step counter and candidate are put
+        # back, so the W + K steps below start from the state they would have started from without this
+        cam_start = stepper.cam.detach().clone()
+        for i in range(args.prewarm_steps):
+            step(i % total)
+        stepper.reset(cam_start)
+        cache_prewarm = args.prewarm_steps
     for i in range(args.warmup):
         step(i)
     fence()
@@ -240,6 +272,7 @@ def main():
         last = step(i)
     fence()
     dt = time.perf_counter() - t0
+    gc_off.__exit__(None, None, None)
     last = float(last)
     # Per-kernel durations: graph nodes cannot be bracketed by events, so the same K batches are run once more,
     # eagerly, right after the timed region with an event pair around every launch of ours (on the launch stream).
@@ -326,7 +359,7 @@ def main():
                        "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "sampler_evals_per_ray": 640,
                        "global_rays": args.rays * world,
                        "engine": "fused" if Stepper.__name__ == "KernelTracker" else model.last_engine, "param_grads": args.param_grads,
-                       "hip_graph": bool(use_graph), "driver": Stepper.__name__, "ray_chunks": ray_chunks, "clock_prewarm_s": args.prewarm_s, "box_probe_fp32_gemm_tflops": probe_tflops,
+                       "hip_graph": bool(use_graph), "driver": Stepper.__name__, "python_gc": "off inside the timed regions (as timeit)", "ray_chunks": ray_chunks, "clock_prewarm_s": args.prewarm_s, "cache_prewarm_steps": cache_prewarm, "box_probe_fp32_gemm_tflops": probe_tflops,
                        "parallelism": f"ray-shard x{world}" if world > 1 else "single",
                        "rccl_ranks": rccl_ranks,
                        "exchange": None if world == 1 else "one 9-float all-reduce (pose gradient, loss, ray count) per step"
@@ -409,14 +442,15 @@ def mapping_leg(device, rays=8192, frames=8, iters=5, cpu=True):
         opt.step()
         return loss
 
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        last = step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
+    with quiet_gc():
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            last = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
     assert model.last_engine == "fused"
     # per-kernel durations of one more iteration (event pairs on the launch stream) and the roofline of its dominant kernel
     import nicer_slam_amd.hashencoder.backend as be
@@ -594,14 +628,15 @@ def dropin_leg(args, device, K, batches, steps=60):
         try:
             st = TrackingStepper(model, K, args.rays, cam, lr=0.005, use_graph=graph, world=1)
             n = min(steps, len(batches))
-            for i in range(min(5, n)):
-                st.step(*batches[i])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(n):
-                st.step(*batches[i])
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / n
+            with quiet_gc():
+                for i in range(min(5, n)):
+                    st.step(*batches[i])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n):
+                    st.step(*batches[i])
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / n
             out[row] = {"ms_per_step": round(dt * 1e3, 4), "rays_per_s": round(args.rays / dt, 1), "engine": model.last_engine,
                         "hip_graph": graph, "steps": n}
         except Exception as e:      # a context leg must never take the headline down

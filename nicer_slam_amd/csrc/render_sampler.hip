@@ -53,12 +53,19 @@ __device__ __forceinline__ float cube_far(const float (&o)[3], const float (&d)[
 
 // sample position i of ray `ray`: stratified z and the point (ray_sampler.py:49-59); every product rounded separately, as the
 // reference's elementwise torch ops do (see mul_rn)
-__device__ __forceinline__ void sampler_point(const SamplerArgs& a, uint64_t pid, uint32_t ray, uint32_t i, float (&x)[3], float& zi,
-                                              float& farv) {
-    float o[3], d[3];
+struct RayOfTile {
+    float o[3], d[3], farv;
+};
+__device__ __forceinline__ void ray_of_tile(const SamplerArgs& a, uint32_t ray, RayOfTile& r) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { o[k] = a.rays_o[ray * 3 + k]; d[k] = a.rays_d[ray * 3 + k]; }
-    farv = cube_far(o, d, a.bound, a.far_cap, a.near);
+    for (int k = 0; k < 3; ++k) { r.o[k] = a.rays_o[ray * 3 + k]; r.d[k] = a.rays_d[ray * 3 + k]; }
+    r.farv = cube_far(r.o, r.d, a.bound, a.far_cap, a.near);
+}
+__device__ __forceinline__ void sampler_point(const SamplerArgs& a, uint64_t pid, const RayOfTile& r, uint32_t i, float (&x)[3],
+                                              float& zi, float& farv) {
+    const float (&o)[3] = r.o;
+    const float (&d)[3] = r.d;
+    farv = r.farv;
     const float nearv = a.near;
     // z_lin(i) = near (1 - t_i) + far t_i ; stratified: lower + (upper - lower) * rand
     const uint32_t E = a.E;
@@ -104,6 +111,7 @@ __global__ __launch_bounds__(256, NSA_OCC_SAMPLER) void k_sampler_sdf(SamplerArg
     uint32_t ray[T], idx[T];
     float x[T][3], zi[T], farv[T];
     float in[T][SDF_IN_STEPS];
+    RayOfTile rt;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         pid[t] = ((uint64_t)wave * T + t) * 32 + (lane & 31);
@@ -111,7 +119,10 @@ __global__ __launch_bounds__(256, NSA_OCC_SAMPLER) void k_sampler_sdf(SamplerArg
         if (!live[t]) pid[t] = total - 1;       // keep the wave converged for the MFMAs; store is predicated
         ray[t] = (uint32_t)(pid[t] / a.E);
         idx[t] = (uint32_t)(pid[t] - (uint64_t)ray[t] * a.E);
-        sampler_point(a, pid[t], ray[t], idx[t], x[t], zi[t], farv[t]);
+        // the ray's origin, direction and far end (six divisions) are shared by the wave's tiles whenever they lie on one ray --
+        // always at the shipped E = 640 = 10 x 64
+        if (t == 0 || !__all(ray[t] == ray[t - 1])) ray_of_tile(a, ray[t], rt);
+        sampler_point(a, pid[t], rt, idx[t], x[t], zi[t], farv[t]);
         STS_MARK(4 + 3 * 0)
         pe_slots(x[t], h, in[t]);               // shared by both networks
         STS_MARK(5)

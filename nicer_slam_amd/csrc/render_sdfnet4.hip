@@ -21,6 +21,11 @@ namespace nsa {
 #ifndef NSA_NW4_BWD
 #define NSA_NW4_BWD 8
 #endif
+// the paired forward (both networks, ten staged GEMMs per tile) stages twice the weights of a single forward: 8-wave workgroups
+// measured 106.3 -> 102.9 us against 4-wave ones (profiles/r03_ab_experiments.txt r3af)
+#ifndef NSA_NW4_PAIR
+#define NSA_NW4_PAIR 8
+#endif
 constexpr int stage_floats4(int nw) { return nw >= 8 ? 9216 : 6144; }
 
 struct SdfNet4Args {
@@ -96,7 +101,7 @@ template <int NHA, int NHB>
 struct SdfOpsPair {
     using A = SdfOps4<NHA, false>;
     using B = SdfOps4<NHB, false>;
-    static constexpr int NW = NSA_NW4_FWD;
+    static constexpr int NW = NSA_NW4_PAIR;
     static constexpr int BUF = stage_floats4(NW);
     static constexpr int n = A::n + B::n;
     __host__ __device__ static constexpr int net(int i) { return i < A::n ? 0 : 1; }
@@ -306,7 +311,7 @@ __device__ __forceinline__ void net_forward4(float* stage, int op0, const float*
 }
 
 template <int LC, int CC, int NHC, int LF, int CF, int NHF>
-__global__ __launch_bounds__(64 * NSA_NW4_FWD, NSA_OCC4_FWD) void k_sdfnet4_fwd_pair(SdfNet4PairArgs a, GridGeom16 gc, GridGeom16 gf) {
+__global__ __launch_bounds__(64 * NSA_NW4_PAIR, NSA_OCC4_FWD) void k_sdfnet4_fwd_pair(SdfNet4PairArgs a, GridGeom16 gc, GridGeom16 gf) {
     using Seq = SdfOpsPair<NHC, NHF>;
     __shared__ __attribute__((aligned(16))) float stage[2 * Seq::BUF];
     __shared__ LevelGeom s_geom[32];
@@ -586,7 +591,7 @@ int NSA_ENTRY(nsa_sdfnet4_forward_pair)(const nsa_points_t* pts, const nsa_grid_
     if (int rc = make_grid_geom16(fine->offsets_host, fine->L, fine->S, fine->H, &gf, fine->C)) return rc;
     const uint32_t tiles = (a.src.P + 15) / 16;
     launch_begin();
-    hipLaunchKernelGGL((k_sdfnet4_fwd_pair<4, 8, 1, 8, 4, 3>), dim3((tiles + NSA_NW4_FWD - 1) / NSA_NW4_FWD), dim3(64 * NSA_NW4_FWD), 0,
+    hipLaunchKernelGGL((k_sdfnet4_fwd_pair<4, 8, 1, 8, 4, 3>), dim3((tiles + NSA_NW4_PAIR - 1) / NSA_NW4_PAIR), dim3(64 * NSA_NW4_PAIR), 0,
                        (hipStream_t)stream, a, gc, gf);
     return launch_end();
 }

@@ -139,3 +139,32 @@ def test_folded_tracker_follows_the_plain_sequence_and_is_reproducible():
         assert_close(runs[tag][2], runs["plain"][2], 1e-6, 1e-5, f"candidate ({tag})")
     assert torch.equal(runs["fold"][0], runs["fold2"][0]) and torch.equal(runs["fold"][1], runs["fold2"][1])
     assert torch.equal(runs["fold"][1], runs["fold_eager"][1])
+
+
+def test_two_thousand_replays_stay_finite_reproducible_and_leave_the_tickets_at_zero():
+    """Soak: the last-workgroup tickets of nsa_track_finish and nsa_draw are re-armed by the kernels themselves; 2000 graph replays of
+    two identically seeded trackers must agree bit for bit, stay finite, and leave both tickets at zero and the call counter at the
+    number of sampler calls."""
+    from nicer_slam_amd.tracking import KernelTracker
+    from nicer_slam_amd.fused import sampler as fs
+    fx, model, cam, pose, _, _ = _setup("full_tracking")
+    model.train(True)
+    model.engine = "fused"
+    model.draws = None
+    K, uv, gt = tt(fx["in_K"]).cuda(), tt(fx["in_uv"]).cuda(), tt(fx["gt_rgb"]).cuda()
+    cam0 = tt(fx["in_cam"]).reshape(-1)
+    outs = []
+    for rep in range(2):
+        model.__dict__.pop("_draw_state", None)
+        torch.manual_seed(5)
+        kt = KernelTracker(model, K, uv.shape[1], cam0, lr=0.0005, use_graph=True)
+        calls0 = int(fs.draw_state(model)[1])
+        losses = torch.stack([kt.step(uv, gt).clone() for _ in range(2000)])
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(losses).all()) and bool(torch.isfinite(kt.cam).all())
+        st = fs.draw_state(model).cpu().tolist()
+        assert st[1] == calls0 + 2000 and st[2] == 0
+        assert int(kt.fin_ws[:1].view(torch.int32)) == 0
+        assert float(kt.t) == 2000.0 + float(0)                       # Adam steps of this tracker since construction (reset by capture)
+        outs.append((losses, kt.cam.clone(), kt.candidate.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])

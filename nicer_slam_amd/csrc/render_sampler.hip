@@ -10,78 +10,9 @@
 // k_sample_rays   one workgroup per ray: SDF -> Laplace density (beta from the visit counter) -> alpha/transmittance
 //                 weights via a workgroup scan -> pdf/cdf in LDS -> inverse-CDF samples by binary search ->
 //                 merge with near/far/extras -> rank sort out of LDS.
-#include "sdf_net.hpp"
+#include "sampler_common.hpp"
 
 namespace nsa {
-
-struct SamplerArgs {
-    const float* rays_o;      // [R,3]
-    const float* rays_d;      // [R,3]
-    const float* t_lin;       // [E] = linspace(0,1,E)
-    const float* t_rand;      // [R,E] stratified jitter in [0,1) or nullptr (eval mode)
-    float* z;                 // [R,E] out
-    float* sdf;               // [R,E] out
-    float* far;               // [R] out
-    uint32_t R, E;
-    float near, bound, far_cap;
-    const float* table_c;
-    const float* table_f;
-    const float* wp_c;
-    const float* wp_f;
-    float df_c, df_f;
-};
-
-// far end of the ray inside the cube [-bound, bound]^3, clamped to far_cap (ray_sampler.py:23-35).
-__device__ __forceinline__ float cube_far(const float (&o)[3], const float (&d)[3], float bound, float far_cap, float near_clamp) {
-    float nearv = -INFINITY, farv = INFINITY;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float den = d[k] + 1e-15f;
-        const float t0 = (-bound - o[k]) / den;
-        const float t1 = (bound - o[k]) / den;
-        nearv = fmaxf(nearv, t0 < t1 ? t0 : t1);
-        farv = fminf(farv, t0 > t1 ? t0 : t1);
-    }
-    if (farv < nearv) farv = 1e9f;
-    (void)near_clamp;
-    return fminf(farv, far_cap);
-}
-
-#ifndef NSA_OCC_SAMPLER
-#define NSA_OCC_SAMPLER 2      // (asks for <= 256 registers; the kernel needs 167: three waves per SIMD.  4 = 128 registers spills 60+)
-#endif
-
-// sample position i of ray `ray`: stratified z and the point (ray_sampler.py:49-59); every product rounded separately, as the
-// reference's elementwise torch ops do (see mul_rn)
-struct RayOfTile {
-    float o[3], d[3], farv;
-};
-__device__ __forceinline__ void ray_of_tile(const SamplerArgs& a, uint32_t ray, RayOfTile& r) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { r.o[k] = a.rays_o[ray * 3 + k]; r.d[k] = a.rays_d[ray * 3 + k]; }
-    r.farv = cube_far(r.o, r.d, a.bound, a.far_cap, a.near);
-}
-__device__ __forceinline__ void sampler_point(const SamplerArgs& a, uint64_t pid, const RayOfTile& r, uint32_t i, float (&x)[3],
-                                              float& zi, float& farv) {
-    const float (&o)[3] = r.o;
-    const float (&d)[3] = r.d;
-    farv = r.farv;
-    const float nearv = a.near;
-    // z_lin(i) = near (1 - t_i) + far t_i ; stratified: lower + (upper - lower) * rand
-    const uint32_t E = a.E;
-    const float ti = a.t_lin[i];
-    zi = mul_rn(nearv, 1.0f - ti) + mul_rn(farv, ti);
-    if (a.t_rand) {
-        const float tp = a.t_lin[i + 1 < E ? i + 1 : i], tm = a.t_lin[i > 0 ? i - 1 : 0];
-        const float zp = mul_rn(nearv, 1.0f - tp) + mul_rn(farv, tp);
-        const float zm = mul_rn(nearv, 1.0f - tm) + mul_rn(farv, tm);
-        const float upper = i + 1 < E ? 0.5f * (zp + zi) : zi;
-        const float lower = i > 0 ? 0.5f * (zi + zm) : zi;
-        zi = lower + mul_rn(upper - lower, a.t_rand[pid]);
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) x[k] = o[k] + mul_rn(zi, d[k]);
-}
 
 // T = point tiles (of 32 points) per wave.  T = 1: the round-1 form, 167 registers, three waves per SIMD.  T = 2: one weight
 // fragment stream serves both tiles (sdf_only_tiles), two waves per SIMD.
@@ -565,6 +496,10 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
 #endif
 #include "bf16_entries.hpp"
 #include "quad_entries.hpp"
+extern "C" int nsa_sampler_ws_sdf(const float* rays_o, const float* rays_d, uint32_t R, uint32_t E, const float* t_lin,
+                                  const float* t_rand, float near, float bound, float far_cap, const nsa_grid_t* coarse,
+                                  const nsa_grid_t* fine, const float* packed_coarse, const float* packed_fine, float* z, float* sdf,
+                                  float* far, nsa_stream_t stream);
 
 extern "C" {
 
@@ -581,6 +516,13 @@ int NSA_ENTRY(nsa_sampler_sdf)(const float* rays_o, const float* rays_d, uint32_
         return NSA_EBADARG;
     if (!(coarse->L == 4 && coarse->C == 8 && coarse->n_hidden == 1 && fine->L == 8 && fine->C == 4 && fine->n_hidden == 3))
         return NSA_EUNSUPPORTED_NET;
+#if NSA_PIECES == 3
+    if (coarse->tile == 96 || fine->tile == 96) {         // wave-specialised form (render_sampler_ws.hip)
+        if (coarse->tile != fine->tile) return NSA_EBADARG;
+        return nsa_sampler_ws_sdf(rays_o, rays_d, R, E, t_lin, t_rand, near, bound, far_cap, coarse, fine, packed_coarse,
+                                  packed_fine, z, sdf, far, stream);
+    }
+#endif
     if (coarse->tile == 16 || fine->tile == 16) {
         if (coarse->tile != fine->tile) return NSA_EBADARG;
         return NSA_ENTRY(nsa_sampler4_sdf)(rays_o, rays_d, R, E, t_lin, t_rand, near, bound, far_cap, coarse, fine, packed_coarse,

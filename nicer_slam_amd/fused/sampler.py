@@ -51,7 +51,7 @@ DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 64, "coarse_map": 16, "sam
 FWD_PAIR = os.environ.get("NSA_SDF_FWD_PAIR", "1") != "0"          # 0: two forward launches (A/B runs)
 SAMPLER_LARGE_RAYS = 4096
 _FORCE = int(os.environ.get("NSA_SDF_TILE", "0"))
-_FORCE_SAMPLER = int(os.environ.get("NSA_SAMPLER_TILE", "0"))      # A/B runs of the sampler pass alone: 16 | 32 | 64
+_FORCE_SAMPLER = int(os.environ.get("NSA_SAMPLER_TILE", "0"))      # A/B runs of the sampler pass alone: 16 | 32 | 64 | 96
 
 
 def tile_of(model, which):
@@ -61,8 +61,11 @@ def tile_of(model, which):
     t = int(getattr(model, "sdf_tile", 0) or _FORCE or DEFAULT_TILES[which])
     if which.startswith("sampler") and _FORCE_SAMPLER and not getattr(model, "sdf_tile", 0):
         t = _FORCE_SAMPLER
-    if t not in (16, 32) and not (t == 64 and which.startswith("sampler")):
-        raise ValueError(f"sdf_tile must be 16 or 32 (64 = 32-point tiling with two tiles per wave, sampler only), got {t}")
+    if t in (64, 96) and not which.startswith("sampler"):
+        t = 32                                 # (both are forms of the 32-point tiling's sampler pass)
+    if t not in (16, 32) and not (t in (64, 96) and which.startswith("sampler")):
+        raise ValueError(f"sdf_tile must be 16 or 32 (sampler only: 64 = 32-point tiling with two tiles per wave, 96 = "
+                         f"wave-specialised 32-point form), got {t}")
     return t
 
 

@@ -259,10 +259,14 @@ def main():
     if args.prewarm_steps > 0 and hasattr(stepper, "reset"):
         # ... and the memory side with the iteration itself; afterwards camera, Adam moments, step counter and candidate are put
         # back, so the W + K steps below start from the state they would have started from without this
+        # (its own batches, drawn from a separate generator: none of the W + K batches below has been rendered before it is timed)
+        gen_pre = torch.Generator(device=device).manual_seed(1000 + rank)
+        pre_batches = [synth_batch(gen_pre, args.rays, device) for _ in range(min(args.prewarm_steps, 32))]
         cam_start = stepper.cam.detach().clone()
         for i in range(args.prewarm_steps):
-            step(i % total)
+            stepper.step(*pre_batches[i % len(pre_batches)])
         stepper.reset(cam_start)
+        del pre_batches
         cache_prewarm = args.prewarm_steps
     for i in range(args.warmup):
         step(i)
@@ -285,7 +289,20 @@ def main():
     prof, be.PROFILE = be.PROFILE, None
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     rccl_ranks = 0
+    per_rank_ms, exchange_us = None, None
     if world > 1:
+        # what the N > 1 line needs to explain itself: every rank's own time for the K steps (the reported one is their max) and
+        # the cost of the step's only exchange -- the 9-float all-reduce + nsa_adam_step_scaled -- measured alone, back to back
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank_ms = [round(float(x.item()) / args.steps * 1e3, 4) for x in every]
+        if hasattr(stepper, "_exchange"):
+            fence()
+            t_ex = time.perf_counter()
+            for _ in range(50):
+                stepper._exchange()
+            fence()
+            exchange_us = round((time.perf_counter() - t_ex) / 50 * 1e6, 1)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ones = torch.ones(1, device=device)
         dist.all_reduce(ones)                      # the number of ranks that actually took part in a collective
@@ -343,9 +360,11 @@ def main():
             roof.update({"launches": n, "avg_launch_us": round(tms / n * 1e3, 2), "share_of_step": round(tms / n / ms, 4),
                          "all_kernels_us": {k: round(v[0] / v[2] * 1e3, 1) for k, v in sorted(agg.items())}})
         cpu = None if args.no_cpu_baseline else cpu_baseline(args, model, conf)
-        mapping, dropin = None, None
+        mapping, dropin, ref_gpu = None, None, None
+        gather = colour_gather_roofline(agg, args) if agg else None
         if world == 1 and not args.no_dropin and args.engine != "composed" and args.precision == "fp32":
             dropin = dropin_leg(args, device, K, batches)
+            ref_gpu = reference_shaped_gpu_leg(args, device, K, batches, rays_total / dt)
         if world == 1 and not args.no_mapping and args.engine != "composed" and args.precision == "fp32":
             del stepper, eager
             mapping = mapping_leg(device)
@@ -359,18 +378,31 @@ def main():
                        "rays_per_gpu": args.rays, "samples_per_ray": args.samples, "sampler_evals_per_ray": 640,
                        "global_rays": args.rays * world,
                        "engine": "fused" if Stepper.__name__ == "KernelTracker" else model.last_engine, "param_grads": args.param_grads,
-                       "hip_graph": bool(use_graph), "driver": Stepper.__name__, "python_gc": "off inside the timed regions (as timeit)", "ray_chunks": ray_chunks, "clock_prewarm_s": args.prewarm_s, "cache_prewarm_steps": cache_prewarm, "box_probe_fp32_gemm_tflops": probe_tflops,
+                       "hip_graph": bool(use_graph), "driver": Stepper.__name__, "python_gc": "off inside the timed regions (as timeit)", "ray_chunks": ray_chunks, "clock_prewarm_s": args.prewarm_s, "cache_prewarm_steps": cache_prewarm, "cache_prewarm_batches": "disjoint from the warm-up and timed batches", "box_probe_fp32_gemm_tflops": probe_tflops,
                        "parallelism": f"ray-shard x{world}" if world > 1 else "single",
                        "rccl_ranks": rccl_ranks,
                        "exchange": None if world == 1 else "one 9-float all-reduce (pose gradient, loss, ray count) per step"
                                    + (", captured in the hipGraph" if collective_in_graph else ", between graph replay and Adam launch"),
+                       "per_rank_ms_per_step": per_rank_ms,
+                       "exchange_us_per_step": exchange_us if world > 1 else None,
+                       "exchange_measured": None if world == 1 else "all-reduce of the 9-float message + nsa_adam_step_scaled, 50 back-to-back "
+                                            "calls after the timed region (host-issued: includes launch latency, which a step hides "
+                                            "behind the graph replay of the next iteration only when collective_in_graph)",
                        "oversubscribed": oversub or None},
             "final_loss": round(last, 6),
-            "roofline": roof, "cpu_baseline": cpu, "dropin": dropin, "mapping_iteration": mapping,
+            "roofline": roof, "colour_gather": gather, "cpu_baseline": cpu, "reference_shaped_gpu": ref_gpu, "dropin": dropin,
+            "mapping_iteration": mapping,
         }
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def mapping_signature(rays=8192, frames=8, samples=98):
+    """What a committed atomic-request profile (profiles/rNN_mapping_pmc_per_kernel.csv) must have been taken with to be quoted
+    beside a launch time of THIS run: the batch shape and the kernels' tilings (tools/profile_mapping.sh stores it next to the CSV)."""
+    from nicer_slam_amd.fused.sampler import DEFAULT_TILES
+    return {"rays": rays, "keyframes": frames, "samples_per_ray": samples, "tiles": dict(sorted(DEFAULT_TILES.items()))}
 
 
 def mapping_leg(device, rays=8192, frames=8, iters=5, cpu=True):
@@ -481,7 +513,7 @@ def mapping_leg(device, rays=8192, frames=8, iters=5, cpu=True):
             # counters cannot be read from inside the run, so the newest committed summary is quoted and named).
             pmc_key = {"k_colour_bwd<map>": "k_colour_bwd<true>", "k_sdfnet_bwd<fine,map>": "k_sdfnet4_bwd<8, 4, 3, true>",
                        "k_sdfnet_bwd<coarse,map>": "k_sdfnet4_bwd<4, 8, 1, true>"}[name]
-            reqs, req_src = None, None
+            reqs, req_src, req_ok = None, None, None
             import csv
             import glob
             for ppath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mapping_pmc_per_kernel.csv")), reverse=True):
@@ -489,6 +521,12 @@ def mapping_leg(device, rays=8192, frames=8, iters=5, cpu=True):
                     if pmc_key in row["kernel"] and row["counter"] == "TCC_ATOMIC_sum" and float(row["mean_per_dispatch"]) > 0:
                         reqs, req_src = float(row["mean_per_dispatch"]), os.path.relpath(ppath, ROOT)
                 if reqs:
+                    # counters of another shape / tiling beside this run's launch time would be a silently wrong fraction
+                    meta = ppath.replace("_pmc_per_kernel.csv", "_pmc_meta.json")
+                    req_ok = ("unverified (profile older than the signature file)" if not os.path.exists(meta) else
+                              "matches this run" if json.load(open(meta)) == mapping_signature(rays, frames, S) else "STALE")
+                    if req_ok == "STALE":
+                        reqs = None
                     break
             if reqs and "sdfnet" in name:      # the counter's per-dispatch mean covers this kernel's two launches per iteration
                 reqs = reqs * 2 * P / (P + 22 * rays)      # (composite points and eikonal points): the composite launch's share
@@ -496,7 +534,7 @@ def mapping_leg(device, rays=8192, frames=8, iters=5, cpu=True):
             per_launch_s = tms * 1e-3 / max(launches, 1)
             ATOMIC_CEILING = 20e9
             atomic = {"table_rows_per_launch": rows // max(launches, 1), "atomic_requests_per_launch": reqs,
-                      "requests_source": req_src, "rows_per_request": round(rows / max(launches, 1) / reqs, 2) if reqs else None,
+                      "requests_source": req_src, "requests_profile": req_ok, "rows_per_request": round(rows / max(launches, 1) / reqs, 2) if reqs else None,
                       "requests_per_s": round(reqs / per_launch_s, 0) if reqs else None,
                       "ceiling_requests_per_s": ATOMIC_CEILING,
                       "frac_of_ceiling": round(reqs / per_launch_s / ATOMIC_CEILING, 3) if reqs else None,
@@ -559,7 +597,9 @@ def cpu_mapping_baseline(model, n=256, frames=8):
     med = timed[len(timed) // 2]
     return {"value": round(n / med, 1), "unit": "rays/s", "cores": max(torch.get_num_threads(), min(16, os.cpu_count() or 1)),
             "kind": "port", "sample": f"{n} rays over {frames} keyframes x (640 sampler + 98 composite) samples + {22 * n} eikonal "
-                                      f"points, fwd+bwd to every trainable parameter (no optimizer step), median of "
+                                      f"points, objective rgb L1 + 0.1 eikonal ONLY (the GPU leg beside it also runs the smooth, ssi-depth, "
+                                      f"normal, patch-warp and flow terms and the Adam step: the CPU side does LESS work per ray), "
+                                      f"fwd+bwd to every trainable parameter (no optimizer step), median of "
                                       f"{len(timed)} iterations after 1 warm-up ({round(sum(times), 1)} s of host time in all)"}
 
 
@@ -606,6 +646,82 @@ def cpu_baseline(args, model, conf):
                       f"median of {len(timed)} iterations after 2 warm-ups ({round(sum(times), 1)} s of host time in all); "
                       f"{torch.get_num_threads()} torch + {omp} OpenMP threads of {os.cpu_count()} host cores: more threads only "
                       f"slow this sample's [n x 768, 64] GEMMs down (all {os.cpu_count()} cores measured ~1 ray/s on this box type)"}
+
+
+GATHER_CEILING_REQ_S = 55e9     # tools/micro/gather_bench.hip on MI355X (profiles/r04_gather_bench.txt): random 8-16 B row loads retire at
+                                # ~55 G requests/s chip-wide, whatever the table size (128 MiB .. 768 MiB), depth or width
+
+
+def colour_gather_roofline(agg, args):
+    """Second roofline of the line: k_colour_fwd, the one HBM-resident gather (1 GiB colour table, 16 levels x 8 corner rows of 8 B
+    per point), in the unit that bounds it -- memory-side REQUESTS per second (a request = one 64-byte line touched by one
+    instruction) against the measured random-gather ceiling.  Time: this run's events.  Requests: TCC_HIT + TCC_MISS per launch from
+    the newest committed `rocprofv3 --pmc` summary of this command (counters cannot be read inside the run; the source is named)."""
+    if "k_colour_fwd" not in agg or args.rays != 1024 or args.samples != 128:
+        return None
+    import csv
+    import glob
+    tms, nbytes, n = agg["k_colour_fwd"]
+    us = tms / n * 1e3
+    hit = miss = None
+    src = None
+    for ppath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_kernel.csv")), reverse=True):
+        vals = {}
+        for row in csv.DictReader(open(ppath)):
+            if "k_colour_fwd" in row["kernel"] and "bf16" not in row["kernel"] and row["counter"] in ("TCC_HIT", "TCC_MISS", "TCC_HIT_sum", "TCC_MISS_sum"):
+                vals[row["counter"].replace("_sum", "")] = float(row["mean_per_dispatch"])
+        if "TCC_HIT" in vals and "TCC_MISS" in vals:
+            hit, miss, src = vals["TCC_HIT"], vals["TCC_MISS"], os.path.relpath(ppath, ROOT)
+            break
+    pts = args.rays * args.samples
+    algo_rows = pts * 16 * 8
+    out = {"kernel": "k_colour_fwd", "bound": "memory-side requests (random 8-byte rows)", "avg_launch_us": round(us, 2),
+           "algorithmic_rows_per_launch": algo_rows, "algorithmic_bytes_per_launch": nbytes // n,
+           "algorithmic_GBps": round(nbytes / n / (us * 1e-6) / 1e9, 1), "frac_of_hbm_peak": round(nbytes / n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+           "peak": GATHER_CEILING_REQ_S, "unit": "requests/s", "requests_source": src,
+           "ceiling_source": "tools/micro/gather_bench.hip, profiles/r04_gather_bench.txt"}
+    if hit is not None:
+        req = hit + miss
+        out.update({"l2_requests_per_launch": req, "l2_hit_rate": round(hit / req, 3), "rows_per_request": round(algo_rows / req, 2),
+                    "achieved": round(req / (us * 1e-6), 0), "frac": round(req / (us * 1e-6) / GATHER_CEILING_REQ_S, 3),
+                    "misses_per_s": round(miss / (us * 1e-6), 0),
+                    "note": "frac > 1 is possible: the ceiling is for requests that all miss the L2; this kernel's hits are cheaper"})
+    return out
+
+
+def reference_shaped_gpu_leg(args, device, K, batches, value, steps=10):
+    """Same-box GPU stand-in for north_star's 'reference single-GPU PyTorch path': the COMPOSED engine -- torch autograd around the
+    stand-alone hash-encoder operator (C ABI section 1), i.e. the reference's op structure (code/model/network.py:78-347) launched
+    eagerly, every parameter gradient computed as volsdf_train.py:417-427 does -- on the same 1024 x 128 batches.  It is a LOWER
+    bound on the reference's own time: its hash operator is already this library's (the reference's CUDA extension cannot run
+    here), and the loss / pose parametrisation use this library's kernels."""
+    from nicer_slam_amd.tracking import TrackingStepper
+    a = argparse.Namespace(**vars(args))
+    a.param_grads, a.engine = True, "composed"
+    try:
+        model, _ = make_model(a, device)
+        model.tracking_param_grads = True
+        cam = torch.tensor([1.0, 0, 0, 0, 0.1, 0.0, -0.2], device=device)
+        st = TrackingStepper(model, K, args.rays, cam, lr=0.005, use_graph=False, world=1)
+        n = min(steps, len(batches))
+        with quiet_gc():
+            for i in range(3):
+                st.step(*batches[i])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                st.step(*batches[i])
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+        out = {"ms_per_step": round(dt * 1e3, 3), "rays_per_s": round(args.rays / dt, 1), "engine": model.last_engine, "steps": n,
+               "value_over_this": round(value / (args.rays / dt), 2),
+               "what": "composed engine: torch autograd + the stand-alone HIP hash operator, eager, all parameter gradients "
+                       "(reference op structure); a lower bound on the reference's time on this GPU"}
+        del model, st
+    except Exception as e:      # a context leg must never take the headline down
+        out = {"error": f"{type(e).__name__}: {e}"[:300]}
+    torch.cuda.empty_cache()
+    return out
 
 
 def dropin_leg(args, device, K, batches, steps=60):

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256, NSA_OCC_SAMPLER) void k_sampler_sdf(SamplerArg
         pid[t] = ((uint64_t)wave * T + t) * 32 + (lane & 31);
         live[t] = pid[t] < total;
         if (!live[t]) pid[t] = total - 1;       // keep the wave converged for the MFMAs; store is predicated
-        ray[t] = (uint32_t)(pid[t] / a.E);
+        ray[t] = ray_of_point(pid[t], a.E, total);
         idx[t] = (uint32_t)(pid[t] - (uint64_t)ray[t] * a.E);
         // the ray's origin, direction and far end (six divisions) are shared by the wave's tiles whenever they lie on one ray --
         // always at the shipped E = 640 = 10 x 64

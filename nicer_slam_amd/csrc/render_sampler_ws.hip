@@ -229,7 +229,7 @@ __device__ __forceinline__ void ws_vector_wave(const SamplerArgs& a, const GridG
         uint64_t pid = (uint64_t)tile * 32 + (lane & 31);
         const bool live = pid < total;
         if (!live) pid = total - 1;
-        const uint32_t ray = (uint32_t)(pid / a.E);
+        const uint32_t ray = ray_of_point(pid, a.E, total);
         const uint32_t idx = (uint32_t)(pid - (uint64_t)ray * a.E);
         RayOfTile rt;
         ray_of_tile(a, ray, rt);

@@ -43,6 +43,12 @@ __device__ __forceinline__ float cube_far(const float (&o)[3], const float (&d)[
 #define NSA_OCC_SAMPLER 2      // (asks for <= 256 registers; the kernel needs 167: three waves per SIMD.  4 = 128 registers spills 60+)
 #endif
 
+// ray index of point `pid` (pid < R * E): a 32-bit division whenever the point count allows it (always at the shipped sizes; the
+// 64-bit one is ~100 vector instructions per tile)
+__device__ __forceinline__ uint32_t ray_of_point(uint64_t pid, uint32_t E, uint64_t total) {
+    return total <= 0xFFFFFFFFull ? (uint32_t)pid / E : (uint32_t)(pid / E);
+}
+
 // sample position i of ray `ray`: stratified z and the point (ray_sampler.py:49-59); every product rounded separately, as the
 // reference's elementwise torch ops do (see mul_rn)
 struct RayOfTile {

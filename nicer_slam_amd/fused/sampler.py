@@ -195,15 +195,28 @@ def sample_rays(model, rays_o, rays_d, z, sdf, far, extra_idx, eik_idx):
 OWN_RNG = os.environ.get("NSA_OWN_RNG", "1") != "0"
 
 
-def draw_state(model):
+def draw_state(model, stream_key=0):
     """{seed, call number, ticket, -} of nsa_draw on the model's device.  Created on first use: call it (or run one iteration)
-    BEFORE capturing a graph around the sampler."""
-    st = model.__dict__.get("_draw_state")
+    BEFORE capturing a graph around the sampler.
+
+    ``stream_key``: one state PER CONCURRENT CALLER.  The kernel advances the state itself (the last workgroup of a launch resets
+    the ticket and bumps the call number), so two nsa_draw launches that may run at the same time -- the ray chunks of
+    KernelTracker(chunks > 1) on their forked streams -- must not share one: the ticket would count both launches' arrivals, bump
+    the call number early and leave picks ranked against keys of two different calls.  Chunk c (first row ``lo``) therefore draws
+    from its own state, seeded seed ^ mix(lo): independent jitter per chunk, still a function of torch.manual_seed."""
+    states = model.__dict__.setdefault("_draw_states", {})
     dev = model.voxels.device
+    st = states.get(stream_key)
     if st is None or st.device != dev:
-        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))        # torch's CPU generator: follows torch.manual_seed
+        base = model.__dict__.get("_draw_seed")
+        if base is None:
+            base = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))    # torch's CPU generator: follows torch.manual_seed
+            model.__dict__["_draw_seed"] = base
+        seed = (base ^ ((int(stream_key) * 0x9E3779B97F4A7C15) & (2 ** 62 - 1))) if stream_key else base
         st = torch.tensor([seed, 0, 0, 0], dtype=torch.int64).to(dev)
-        model.__dict__["_draw_state"] = st
+        states[stream_key] = st
+        if stream_key == 0:
+            model.__dict__["_draw_state"] = st
     return st
 
 
@@ -223,9 +236,10 @@ def get_z_vals(model, ray_dirs, cam_loc, need_eik=True, rows=None):
         t_rand = torch.empty(R, E, device=dev)
         extra = torch.empty(n_extra, device=dev, dtype=torch.int32) if n_extra > 0 else None
         eik_idx = torch.empty(R, device=dev, dtype=torch.int32) if need_eik else None
-        check(lib.nsa_draw(draw_state(model).data_ptr(), R * E, t_rand.data_ptr(), E, n_extra, R, S,
-                           extra.data_ptr() if extra is not None else None, eik_idx.data_ptr() if eik_idx is not None else None,
-                           torch.cuda.current_stream().cuda_stream))
+        with _timed("k_draw", R * E * 4):
+            check(lib.nsa_draw(draw_state(model, rows[0] if rows is not None else 0).data_ptr(), R * E, t_rand.data_ptr(), E, n_extra,
+                               R, S, extra.data_ptr() if extra is not None else None,
+                               eik_idx.data_ptr() if eik_idx is not None else None, torch.cuda.current_stream().cuda_stream))
         z, sdf, far = sampler_sdf(model, rays_o, rays_d, t_rand)
         return sample_rays(model, rays_o, rays_d, z, sdf, far, extra, eik_idx)
     if model.training and model.draws is None and E <= 1024:

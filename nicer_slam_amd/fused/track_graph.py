@@ -1,0 +1,206 @@
+"""The tracking forward / backward of an UNMODIFIED caller as two cached hipGraphs behind one autograd.Function.
+
+The reference's tracking loop (code/training/volsdf_train.py:406-443) is eager: camera tensor -> get_camera_from_tensor ->
+model(input, ..., mode="tracking") -> loss -> loss.backward() -> optimizer.step().  Driven that way the fused engine was host-bound
+(bench.py `dropin.pose_only_eager`, round 3: 1.045 ms per iteration against 0.62 ms of device time): eleven launches of ours with
+their ctypes glue, ~25 buffer allocations, pack-cache lookups and the autograd bookkeeping of four Functions per iteration.
+
+Here SLAMNetwork.forward(mode="tracking") -- same signature, same dict, same gradients on ``input["pose"]`` -- runs
+
+    copy(pose, uv) -> REPLAY [rays -> draws -> sampler SDF pass -> per-ray sampling -> SDF pair forward -> colour forward -> composite]
+    ... caller's loss ...
+    copy(d loss / d rgb_values) -> REPLAY [composite backward -> colour backward -> SDF backward x2 -> ray sums -> pose backward]
+
+with both graphs captured on the second call of a given shape (the first runs eagerly and warms allocator, packs and lazy state)
+and keyed on everything a replay reads through a captured ADDRESS: ray count, stage / colour stage, tilings, precision, the three
+tables, the visit counter.  The packed MLP snapshots are owned by the cache and re-packed IN PLACE when a parameter version changes
+(a mapping step between two tracked frames), exactly as KernelTracker does.  Cotangent patterns other than "rgb_values only" (the
+tracking objective, loss.py:131) run the backward kernels eagerly.  Outputs are views of the graph's static buffers: a later
+forward overwrites them, and a backward through stale outputs raises instead of returning another iteration's gradient.
+
+NSA_TRACK_GRAPH=0 keeps the eager Functions (A/B runs)."""
+import os
+
+import torch
+
+from .._native import lib, check
+from ..hashencoder.backend import _timed
+
+ENABLED = os.environ.get("NSA_TRACK_GRAPH", "1") != "0"
+
+
+# ---- packed MLP snapshots owned by a long-lived consumer (a captured graph reads their addresses) ---------------------------------
+def pack_specs(model, n_rays, stage):
+    """(cache key, network, use) of every packed block a tracking iteration over ``n_rays`` rays reads (fused/sampler.py::tile_of)."""
+    from . import sampler as fs
+    use = "sampler_large" if n_rays >= fs.SAMPLER_LARGE_RAYS else "sampler"
+    specs = []
+    for which in ("coarse", "fine"):
+        for u in (use, None):
+            specs.append(((which, fs.tile_of(model, u or which)), which, u))
+    if stage != "coarse" and fs.forward_pair_ok(model):       # the paired forward reads the coarse net's quad pack
+        specs.append((("coarse", fs.tile_of(model, "coarse_pair")), "coarse", "coarse_pair"))
+    return specs
+
+
+def ensure_packs(model, owned, specs):
+    """Fresh packed blocks for every tiling in ``specs`` (+ the colour net) on the current stream, RE-PACKED IN PLACE into the
+    tensors ``owned`` already holds: a captured graph keeps reading the same addresses after a parameter update.  (A plain cache
+    miss would allocate a new snapshot and free the captured one while the graph kept replaying on stale -- possibly recycled --
+    memory.)"""
+    from . import render as fr, sampler as fs
+    cache = model.__dict__.setdefault("_fused_pack", {})
+    jobs = [(k, (lambda w=w, u=u: fs.packed_sdf(model, w, use=u)), getattr(model.implicit_network, w).mlp_parameters())
+            for k, w, u in specs]
+    jobs.append(("colour", lambda: fr.packed_colour(model), model.rendering_network.mlp_parameters()))
+    for k, pack_fn, params in jobs:
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        mine = owned.get(k)
+        if mine is not None and mine[0] == key and cache.get(k, (None, None))[1] is mine[1]:
+            continue
+        if mine is not None:
+            cache.pop(k, None)                     # force a re-pack, then move it into the tensor the graph knows
+            fresh = pack_fn()
+            mine[1].copy_(fresh)
+            cache[k] = (key, mine[1])
+            owned[k] = (key, mine[1])
+        else:
+            owned[k] = (key, pack_fn())
+            cache[k] = owned[k]
+
+
+# ---- the cached pair of graphs ---------------------------------------------------------------------------------------------------
+def _key(model, R, stage, color_stage, K):
+    from . import sampler as fs
+    imp, rn = model.implicit_network, model.rendering_network
+    return (R, stage, color_stage, getattr(model, "mlp_precision", "fp32"), getattr(model, "sdf_tile", 0),
+            tuple(sorted(fs.DEFAULT_TILES.items())), model.voxels.data_ptr(), imp.coarse.encoding.embeddings.data_ptr(),
+            imp.fine.encoding.embeddings.data_ptr(), rn.encoding.embeddings.data_ptr(), K.data_ptr(), K._version,
+            model.ray_sampler.N_samples, model.ray_sampler.N_samples_eval, model.ray_sampler.N_samples_extra)
+
+
+def usable(model, mode, fused_kind, input, ground_truth):
+    """The calls this cache serves: training-mode tracking on the fused data path with the engine's own draws, one camera."""
+    if not (ENABLED and mode == "tracking" and fused_kind == "data" and model.training and model.draws is None):
+        return False
+    from . import sampler as fs
+    pose, uv, K = input["pose"], input["uv"], input["intrinsics"]
+    return (fs.OWN_RNG and torch.is_grad_enabled() and pose.requires_grad and pose.is_cuda and pose.dim() == 3
+            and pose.shape[0] == 1 and pose.shape[1] == 4 and uv.dim() == 3 and uv.shape[0] == 1 and uv.dtype == torch.float32
+            and K.is_cuda and K.shape[-2:] == (4, 4) and "edges" not in ground_truth and not model.white_bkgd
+            and model.ray_sampler.N_samples_eval <= 1024 and not torch.cuda.is_current_stream_capturing())
+
+
+class TrackingGraph:
+    def __init__(self, model, R, stage, color_stage, K):
+        dev = model.voxels.device
+        self.model, self.R, self.stage, self.color_stage = model, R, stage, color_stage
+        self.pose_s = torch.zeros(1, 4, 4, device=dev)
+        self.uv_s = torch.zeros(1, R, 2, device=dev)
+        self.K = K.reshape(-1, 4, 4)[:1].contiguous()
+        self.g_rgbv_s = torch.zeros(R, 3, device=dev)
+        self.packs = {}
+        self.specs = pack_specs(model, R, stage)
+        self.calls = 0
+        self.serial = 0
+        self.fwd_graph = self.bwd_graph = None
+        self.out = self.g_pose = None
+
+    # the two launch sequences (no autograd inside: plain C-ABI launches on the current stream)
+    def _forward_body(self):
+        from . import render as fr, sampler as fs
+        model, R, dev = self.model, self.R, self.pose_s.device
+        st = torch.cuda.current_stream().cuda_stream
+        rays_o, rays_d, ds = (torch.empty(R, 3, device=dev), torch.empty(R, 3, device=dev), torch.empty(R, device=dev))
+        with _timed("k_rays_fwd", R * 32):
+            check(lib.nsa_rays_forward(self.uv_s.data_ptr(), self.pose_s.data_ptr(), self.K.data_ptr(), 1, R, rays_o.data_ptr(),
+                                       rays_d.data_ptr(), ds.data_ptr(), st))
+        z_vals, z_eik = fs.get_z_vals(model, rays_d, rays_o)
+        b = fr.composite_forward_raw(model, rays_o, rays_d, z_vals, self.stage, True)
+        self.out = dict(b=b, rays_o=rays_o, rays_d=rays_d, ds=ds, z_vals=z_vals, z_eik=z_eik)
+
+    def _backward_body(self, g_rgbv, g_depth=None, g_nmap=None, g_ent=None, g_w=None):
+        from . import render as fr
+        o = self.out
+        g_o, g_d = fr.composite_backward_raw(self.model, o["rays_o"], o["rays_d"], o["z_vals"], o["b"], self.stage, self.color_stage,
+                                             g_rgbv, g_depth, g_nmap, g_ent, g_w)
+        g_pose = torch.empty(1, 4, 4, device=g_o.device)
+        with _timed("k_rays_pose_bwd", self.R * 24):
+            check(lib.nsa_rays_pose_backward(self.uv_s.data_ptr(), self.pose_s.data_ptr(), self.K.data_ptr(), 1, self.R,
+                                             g_o.data_ptr(), g_d.data_ptr(), g_pose.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        return g_pose
+
+    def forward(self, pose, uv):
+        with torch.no_grad():
+            self.pose_s.copy_(pose.detach().reshape(1, 4, 4))
+            self.uv_s.copy_(uv.detach())
+            ensure_packs(self.model, self.packs, self.specs)
+            self.calls += 1
+            if self.fwd_graph is not None:
+                self.fwd_graph.replay()
+            elif self.calls == 1 or os.environ.get("NSA_TRACK_GRAPH") == "eager":
+                self._forward_body()                               # warm-up: allocator pools, lazy state, the draw state
+            else:
+                self._backward_body(self.g_rgbv_s)                  # (warm the backward's pools on the eager forward's buffers)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._forward_body()
+                self.fwd_graph = g
+                gb = torch.cuda.CUDAGraph()                         # the backward of the tracking objective reads the forward's
+                with torch.cuda.graph(gb):                          # static buffers: capture it now, on this thread
+                    self.g_pose = self._backward_body(self.g_rgbv_s)
+                self.bwd_graph = gb
+                g.replay()
+        self.serial += 1
+        return self.out
+
+    def backward(self, g_rgbv, g_depth, g_nmap, g_w, g_ent):
+        with torch.no_grad():
+            only_rgb = g_rgbv is not None and g_depth is None and g_nmap is None and g_w is None and g_ent is None
+            if only_rgb and self.bwd_graph is not None:
+                self.g_rgbv_s.copy_(g_rgbv.reshape(self.R, 3))
+                self.bwd_graph.replay()
+                return self.g_pose
+            if all(g is None for g in (g_rgbv, g_depth, g_nmap, g_w, g_ent)):
+                return None
+            return self._backward_body(g_rgbv, g_depth, g_nmap, g_ent, g_w)
+
+
+class _TrackingCore(torch.autograd.Function):
+    """pose[1,4,4] (+ uv, via the cache's static buffers) -> the composite pass's ray-level outputs; backward to the pose only."""
+
+    @staticmethod
+    def forward(ctx, pose, uv, tg):
+        o = tg.forward(pose, uv)
+        b, z = o["b"], o["z_vals"]
+        R, S = z.shape
+        ctx.tg, ctx.serial = tg, tg.serial
+        ctx.set_materialize_grads(False)
+        sdf_o, rgb_o, grad_o = b["sdf"].view(R, S), b["rgb"].view(R, S, 3), b["grad"]
+        ctx.mark_non_differentiable(sdf_o, rgb_o, grad_o, z, o["ds"], o["rays_o"], o["rays_d"], o["z_eik"])
+        return (b["rgb_values"], b["depth"].unsqueeze(-1), b["nmap"], b["weights"], b["entropy"], sdf_o, rgb_o, grad_o, z, o["ds"],
+                o["rays_o"], o["rays_d"], o["z_eik"])
+
+    @staticmethod
+    def backward(ctx, g_rgbv, g_depth, g_nmap, g_w, g_ent, *_unused):
+        tg = ctx.tg
+        if ctx.serial != tg.serial:
+            raise RuntimeError("SLAMNetwork tracking graph: backward through the outputs of an EARLIER forward -- the cached graph's "
+                               "static buffers were overwritten by a later forward(mode='tracking'); call backward before the next "
+                               "forward (the reference's loop does), or set NSA_TRACK_GRAPH=0")
+        return tg.backward(g_rgbv, g_depth, g_nmap, g_w, g_ent), None, None
+
+
+def render(model, input, stage, color_stage):
+    """-> the tuple FusedComposite returns (+ z_vals, depth scale, rays, eikonal sample), from the cached graphs."""
+    pose, uv, K = input["pose"], input["uv"], input["intrinsics"]
+    R = uv.shape[1]
+    key = _key(model, R, stage, color_stage, K)
+    cache = model.__dict__.setdefault("_track_graphs", {})
+    tg = cache.get("tg")
+    if tg is None or cache.get("key") != key:
+        cache.clear()                                  # (drops the old graphs and their pools)
+        tg = TrackingGraph(model, R, stage, color_stage, K.to(uv.device))
+        cache["tg"], cache["key"] = tg, key
+    return _TrackingCore.apply(pose, uv.contiguous(), tg)

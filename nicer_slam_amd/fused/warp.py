@@ -69,14 +69,17 @@ class _PatchWarp(torch.autograd.Function):
         ctx.save_for_backward(depth_, pose_, w2c_, uv_, K_)
         ctx.frames = (images, depths, index)
         ctx.meta = (H, W, patch, depth.shape)
-        ctx.mark_non_differentiable(mask, gt_rgb)
+        ctx.set_materialize_grads(False)
         if flat is None:
+            ctx.mark_non_differentiable(mask, gt_rgb)
             return sampled, mask, gt_rgb
-        ctx.mark_non_differentiable(flat)
+        ctx.mark_non_differentiable(mask, gt_rgb, flat)          # ONE call: a second call replaces the first one's list
         return sampled, mask, gt_rgb, flat
 
     @staticmethod
     def backward(ctx, g_sampled, *_):
+        if g_sampled is None:                                     # (set_materialize_grads(False): the samples were not used)
+            return (None,) * 11
         depth_, pose_, w2c_, uv_, K_ = ctx.saved_tensors
         images, depths, index = ctx.frames
         H, W, patch, dshape = ctx.meta
@@ -141,8 +144,16 @@ class _MaskedL1(torch.autograd.Function):
         dev = pred.device
         pred_, target_ = _c(pred), _c(target).to(dev)
         items = pred_.numel() // channels
+        # the kernel indexes target like pred and mask per item: anything else (a broadcast target, a mask with a trailing
+        # dimension) would read out of bounds where the reference's boolean indexing raises (loss.py:106-111)
+        if pred_.numel() != items * channels or pred.shape[-1] != channels:
+            raise ValueError(f"masked_l1: pred {tuple(pred.shape)} is not [..., {channels}]")
+        if target_.shape != pred_.shape:
+            raise ValueError(f"masked_l1: target {tuple(target.shape)} must have the shape of pred {tuple(pred.shape)}")
         m = None
         if mask is not None:
+            if mask.numel() != items:
+                raise ValueError(f"masked_l1: mask {tuple(mask.shape)} must select among the {items} items of pred {tuple(pred.shape)}")
             m = mask.to(dev).contiguous()
             m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
         loss = torch.empty(1, device=dev)

@@ -157,6 +157,19 @@ class SLAMNetwork(nn.Module):
         bs, num_pixels, _ = uv.shape
         fused_kind = self._fused_composite_ok(mode, ground_truth)
         fused = fused_kind is not None
+        graphed = False
+        if fused:
+            # an unmodified tracking loop (volsdf_train.py:406-443): rays .. composite and their backward as two cached hipGraphs
+            # behind one autograd.Function (fused/track_graph.py) -- same dict, same gradient on input["pose"]
+            from ..fused import track_graph
+            graphed = track_graph.usable(self, mode, fused_kind, input, ground_truth)
+        if graphed:
+            (rgb_values, depth, nmap_w, weights, ent_ray, sdf, rgb, gradients, z_vals, ds_flat, cam_flat, dirs,
+             z_samples_eik) = track_graph.render(self, input, stage, color_stage)
+            depth_scale = ds_flat.reshape(bs, num_pixels, 1)
+            self.last_engine = "fused"
+            return self._assemble(mode, bs, num_pixels, uv, pose, intrinsics, ground_truth, stage, fused, fused_kind, depth_scale,
+                                  cam_flat, dirs, z_vals, z_samples_eik, rgb_values, depth, nmap_w, weights, ent_ray, sdf, rgb, gradients)
         if fused and pose.shape[1] == 4 and uv.dtype == torch.float32:
             from ..fused import render as fused_render
             cam_flat, dirs, ds_flat = fused_render.rays(pose, uv, intrinsics.to(uv.device))
@@ -200,7 +213,14 @@ class SLAMNetwork(nn.Module):
             weights = self.volume_rendering(z_vals, sdf, points_flat)
             rgb_values = torch.sum(weights.unsqueeze(-1) * rgb, 1)
             depth = torch.sum(weights * z_vals, 1, keepdims=True) / (weights.sum(dim=1, keepdims=True) + 1e-8)
+            nmap_w, ent_ray = None, None
+        return self._assemble(mode, bs, num_pixels, uv, pose, intrinsics, ground_truth, stage, fused, fused_kind, depth_scale,
+                              cam_flat, dirs, z_vals, z_samples_eik, rgb_values, depth, nmap_w, weights, ent_ray, sdf, rgb, gradients)
 
+    def _assemble(self, mode, bs, num_pixels, uv, pose, intrinsics, ground_truth, stage, fused, fused_kind, depth_scale, cam_flat,
+                  dirs, z_vals, z_samples_eik, rgb_values, depth, nmap_w, weights, ent_ray, sdf, rgb, gradients):
+        """The forward's output dict from the renderer's results (network.py:153-165, 281-345)."""
+        N = z_vals.shape[1]
         output = {}
         # keyframe re-projection blocks: HIP kernels on the fused engine (fused/warp.py), torch ops otherwise (model/warp.py)
         warp_kernels = False

@@ -8,6 +8,7 @@ random draws use the default device generator (philox offsets advance per replay
 import torch
 
 from .dist import allreduce_pose_grad
+from .hashencoder.backend import _timed
 from .utils.general import get_camera_from_tensor
 
 
@@ -74,6 +75,7 @@ class KernelTracker:
             self.ray_loss = z(n_rays)
             self.fin_ws = z(int(lib.nsa_track_finish_workspace(n_rays)))      # ticket + block partials; zero once
         self.graph = None
+        self._began = False        # folded sequence: _begin (batch copy + cam -> pose -> rays) has run for the coming iteration
         if use_graph:
             self._capture()
 
@@ -117,15 +119,20 @@ class KernelTracker:
         lr, b1, b2, eps, lr_step, lr_gamma = self.hyper
         fused = not self.message
         if self.folded:                                # (the rays were lifted by _begin, in front of the graph)
+            if not self._began and not torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("KernelTracker: the folded sequence needs _begin() (nsa_track_begin) in front of every iteration -- "
+                                   "the rays of the updated camera are lifted there, not inside the graph; use step()")
+            self._began = False
             z_vals, _ = fs.get_z_vals(model, rays_d, rays_o, need_eik=False, rows=(lo, hi))
             b = fr.composite_forward_raw(model, rays_o, rays_d, z_vals, self.stage, True, composite=False)
             g_x, g_dir = fr.composite_backward_raw(model, rays_o, rays_d, z_vals, b, self.stage, self.color_stage,
                                                    track=dict(gt=gt, ray_loss=self.ray_loss), reduce_rays=False)
-            check(lib.nsa_track_finish(uv.data_ptr(), self.K.data_ptr(), self.cam.data_ptr(), R, z_vals.shape[1],
-                                       z_vals.data_ptr(), g_x.data_ptr(), g_dir.data_ptr(), self.ray_loss.data_ptr(),
-                                       red.data_ptr(), 1 if fused else 0, 0.0 if fused else float(R), self.m.data_ptr(),
-                                       self.v.data_ptr(), self.t.data_ptr(), lr, b1, b2, eps, lr_step, lr_gamma,
-                                       self.best.data_ptr() if fused else None, self.fin_ws.data_ptr(), st))
+            with _timed("k_track_finish", R * z_vals.shape[1] * 24):
+                check(lib.nsa_track_finish(uv.data_ptr(), self.K.data_ptr(), self.cam.data_ptr(), R, z_vals.shape[1],
+                                           z_vals.data_ptr(), g_x.data_ptr(), g_dir.data_ptr(), self.ray_loss.data_ptr(),
+                                           red.data_ptr(), 1 if fused else 0, 0.0 if fused else float(R), self.m.data_ptr(),
+                                           self.v.data_ptr(), self.t.data_ptr(), lr, b1, b2, eps, lr_step, lr_gamma,
+                                           self.best.data_ptr() if fused else None, self.fin_ws.data_ptr(), st))
             return
         check(lib.nsa_track_head(uv.data_ptr(), self.K.data_ptr(), self.cam.data_ptr(), R, pose.data_ptr(),
                                  rays_o.data_ptr(), rays_d.data_ptr(), ds.data_ptr(), st))
@@ -147,39 +154,14 @@ class KernelTracker:
     # possibly recycled -- memory.  The tracker therefore owns the snapshots its sequence reads: before every iteration it
     # compares the parameters' keys with those of its snapshots and, on a change, re-packs INTO the same tensors.
     def _pack_specs(self):
-        fs, model = self.fs, self.model
-        use = "sampler_large" if self.R // self.chunks >= fs.SAMPLER_LARGE_RAYS else "sampler"
-        specs = []
-        for which in ("coarse", "fine"):
-            for u in (use, None):
-                specs.append(((which, fs.tile_of(model, u or which)), which, u))
-        if self.stage != "coarse" and fs.forward_pair_ok(model):       # the paired forward reads the coarse net's quad pack
-            specs.append((("coarse", fs.tile_of(model, "coarse_pair")), "coarse", "coarse_pair"))
-        return specs
+        from .fused.track_graph import pack_specs
+        return pack_specs(self.model, self.R // self.chunks, self.stage)
 
     def _ensure_packs(self):
         """Fresh packed blocks for every tiling the sequence uses, on the current stream (so forked chunk streams never race a
-        cache miss), re-packed in place when the tracker already owns them."""
-        fs, fr, model = self.fs, self.fr, self.model
-        owned = self.__dict__.setdefault("_packs", {})
-        cache = model.__dict__.setdefault("_fused_pack", {})
-        jobs = [(k, (lambda w=w, u=u: fs.packed_sdf(model, w, use=u)),
-                 getattr(model.implicit_network, w).mlp_parameters()) for k, w, u in self._pack_specs()]
-        jobs.append(("colour", lambda: fr.packed_colour(model), model.rendering_network.mlp_parameters()))
-        for k, pack_fn, params in jobs:
-            key = tuple((p.data_ptr(), p._version) for p in params)
-            mine = owned.get(k)
-            if mine is not None and mine[0] == key and cache.get(k, (None, None))[1] is mine[1]:
-                continue
-            if mine is not None:
-                cache.pop(k, None)                     # force a re-pack, then move it into the tensor the graph knows
-                fresh = pack_fn()
-                mine[1].copy_(fresh)
-                cache[k] = (key, mine[1])
-                owned[k] = (key, mine[1])
-            else:
-                owned[k] = (key, pack_fn())
-                cache[k] = owned[k]
+        cache miss), re-packed in place when the tracker already owns them (fused/track_graph.py::ensure_packs)."""
+        from .fused.track_graph import ensure_packs
+        ensure_packs(self.model, self.__dict__.setdefault("_packs", {}), self._pack_specs())
 
     def _iteration(self):
         if self.graph is None or not torch.cuda.is_current_stream_capturing():
@@ -225,9 +207,11 @@ class KernelTracker:
         gt = gt.detach().to(device=dev, dtype=torch.float32).reshape(-1, 3).contiguous()
         if uv.shape[0] != self.R or gt.shape[0] != self.R:
             raise ValueError(f"KernelTracker.step: expected {self.R} rays, got uv {tuple(uv.shape)} / gt {tuple(gt.shape)}")
-        check(lib.nsa_track_begin(uv.data_ptr(), gt.data_ptr(), self.uv.data_ptr(), self.gt.data_ptr(), self.K.data_ptr(),
-                                  self.cam.data_ptr(), self.R, self.pose.data_ptr(), self.rays_o.data_ptr(),
-                                  self.rays_d.data_ptr(), self.ds.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        with _timed("k_track_begin", self.R * 64):
+            check(lib.nsa_track_begin(uv.data_ptr(), gt.data_ptr(), self.uv.data_ptr(), self.gt.data_ptr(), self.K.data_ptr(),
+                                      self.cam.data_ptr(), self.R, self.pose.data_ptr(), self.rays_o.data_ptr(),
+                                      self.rays_d.data_ptr(), self.ds.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        self._began = True
 
     def _capture(self):
         cam0 = self.cam.clone()
@@ -255,6 +239,7 @@ class KernelTracker:
             if self.graph is not None:
                 self._ensure_packs()               # the graph reads the tracker-owned snapshots: refresh them in place
                 self.graph.replay()
+                self._began = False
             else:
                 self._iteration()
             if self.world > 1 and not self.collective_in_graph:

@@ -142,3 +142,77 @@ def test_reference_loops_run_on_the_fused_engine_unmodified():
     for n, p in model.named_parameters():                            # the pretrained fine MLP is never stepped (:140-173)
         if n.startswith("implicit_network.fine.lin"):
             assert n not in moved and p.grad is None
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The tracking forward / backward of the unmodified loop as two cached hipGraphs (fused/track_graph.py)
+def _track_loop(model, feed, iters, objective="rgb", bump_at=None, graph=True):
+    """volsdf_train.py:406-443 on frame 1 with fresh draw state and seed; returns per-iteration (loss, camera gradient)."""
+    from nicer_slam_amd.fused import track_graph
+    from nicer_slam_amd.utils.general import get_camera_from_tensor, get_tensor_from_camera
+    for k in ("_draw_state", "_draw_states", "_draw_seed", "_track_graphs"):
+        model.__dict__.pop(k, None)
+    torch.manual_seed(3)
+    old = track_graph.ENABLED
+    track_graph.ENABLED = graph
+    try:
+        cam = get_tensor_from_camera(feed.frames[0]["pose"].cpu()).cuda().requires_grad_(True)
+        opt_cam = torch.optim.Adam([cam], lr=0.001)
+        feed.change_sampling_idx(256, generator=torch.Generator(device="cuda").manual_seed(9))
+        out_l, out_g = [], []
+        for it in range(iters):
+            if bump_at is not None and it == bump_at:            # a mapping step between two tracked frames moved the MLPs
+                with torch.no_grad():
+                    for n_, p in model.named_parameters():
+                        if n_.endswith("weight_v") or n_.endswith("bias"):
+                            p.mul_(1.01)
+            c2w = get_camera_from_tensor(cam)
+            indices, model_input, ground_truth = feed.batch([1])
+            model_input["pose"] = c2w.unsqueeze(0)
+            out = model(model_input, indices, ground_truth, mode="tracking", frame_idx=1)
+            assert model.last_engine == "fused"
+            l = (out["rgb_values"].reshape(-1, 3) - ground_truth["rgb"].reshape(-1, 3).cuda()).abs().mean()
+            if objective == "all":                               # cotangents on every differentiable output (eager backward body)
+                l = l + 0.1 * out["depth_values"].mean() + 0.01 * out["normal_map"].sum() + 0.05 * out["entropy"] + \
+                    0.02 * (out["weights"] ** 2).mean()
+            l.backward()
+            out_l.append(l.detach().clone())
+            out_g.append(cam.grad.detach().clone())
+            opt_cam.step()
+            opt_cam.zero_grad()
+        torch.cuda.synchronize()
+        tg = model.__dict__.get("_track_graphs", {}).get("tg")
+        return torch.stack(out_l), torch.stack(out_g), tg
+    finally:
+        track_graph.ENABLED = old
+
+
+@pytest.mark.parametrize("objective", ["rgb", "all"])
+def test_graph_cached_tracking_is_the_eager_functions_bit_for_bit(objective):
+    """Same kernels, same order, same draws (the engine's own Philox stream, reseeded): the cached-graph forward / backward must
+    return exactly what the eager autograd.Functions return -- loss and camera gradient of every iteration, incl. after an MLP
+    update between iterations (snapshots re-packed in place)."""
+    model, optimizer, loss_fn, tracking_loss, feed = _world()
+    la, ga, tg = _track_loop(model, feed, 7, objective, bump_at=4, graph=True)
+    assert tg is not None and tg.fwd_graph is not None and tg.bwd_graph is not None and tg.calls == 7
+    lb, gb, none = _track_loop(model, feed, 7, objective, bump_at=4, graph=False)
+    assert none is None
+    assert torch.equal(la, lb), (la - lb).abs().max()
+    assert torch.equal(ga, gb), (ga - gb).abs().max()
+    assert bool(torch.isfinite(ga).all()) and float(ga.abs().max()) > 0
+    assert not torch.equal(ga[3], ga[4])
+
+
+def test_graph_cached_tracking_refuses_a_backward_through_overwritten_outputs():
+    from nicer_slam_amd.utils.general import get_camera_from_tensor, get_tensor_from_camera
+    model, optimizer, loss_fn, tracking_loss, feed = _world()
+    cam = get_tensor_from_camera(feed.frames[0]["pose"].cpu()).cuda().requires_grad_(True)
+    feed.change_sampling_idx(256)
+    outs = []
+    for _ in range(2):
+        indices, model_input, ground_truth = feed.batch([1])
+        model_input["pose"] = get_camera_from_tensor(cam).unsqueeze(0)
+        outs.append(model(model_input, indices, ground_truth, mode="tracking", frame_idx=1))
+    outs[1]["rgb_values"].sum().backward()                        # the latest forward: fine
+    with pytest.raises(RuntimeError, match="EARLIER forward"):
+        outs[0]["rgb_values"].sum().backward()

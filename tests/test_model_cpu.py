@@ -139,6 +139,51 @@ def test_get_tensor_from_camera_roundtrip():
         assert_close(back, cam, 1e-5, 1e-5, "roundtrip")
 
 
+def test_get_tensor_from_camera_known_answers():
+    """Hand-derived known answers for general.py:103-126 (mathutils ``Matrix(R).to_quaternion()``: Hamilton quaternion (w, x, y, z)
+    of the ACTIVE rotation R, the same convention quad2rotation (general.py:52-76) inverts, w >= 0 representative):
+      rotation by angle a about unit axis n  <->  q = (cos a/2, n sin a/2);
+      R_z(90 deg)  = [[0,-1,0],[1,0,0],[0,0,1]]        -> (sqrt(1/2), 0, 0, sqrt(1/2))
+      120 deg about (1,1,1)/sqrt(3): cyclic permutation [[0,0,1],[1,0,0],[0,1,0]]  (x->y->z->x)  -> (1/2, 1/2, 1/2, 1/2)
+      R_x(180 deg) = diag(1,-1,-1)                     -> (0, +-1, 0, 0)        (w = 0: the sign is free, q and -q are one rotation)
+      R_y(90 deg)  = [[0,0,1],[0,1,0],[-1,0,0]]        -> (sqrt(1/2), 0, sqrt(1/2), 0)
+      178 deg about (0, 0.6, 0.8)                       -> (cos 89, 0, 0.6 sin 89, 0.8 sin 89)  (trace < 0 branch)
+    and the layout: [q, T] by default, [T, q] with Tquad=True; a 3x4 matrix is accepted like a 4x4."""
+    import math
+    from nicer_slam_amd.utils.general import get_tensor_from_camera, quad2rotation
+    r = math.sqrt(0.5)
+    a = math.radians(178.0)
+    n = (0.0, 0.6, 0.8)
+    c, s_, v = math.cos(a), math.sin(a), 1 - math.cos(a)
+    R178 = [[c + n[0] * n[0] * v, n[0] * n[1] * v - n[2] * s_, n[0] * n[2] * v + n[1] * s_],          # Rodrigues' formula
+            [n[1] * n[0] * v + n[2] * s_, c + n[1] * n[1] * v, n[1] * n[2] * v - n[0] * s_],
+            [n[2] * n[0] * v - n[1] * s_, n[2] * n[1] * v + n[0] * s_, c + n[2] * n[2] * v]]
+    cases = [([[0, -1, 0], [1, 0, 0], [0, 0, 1]], (r, 0, 0, r)),
+             ([[0, 0, 1], [1, 0, 0], [0, 1, 0]], (0.5, 0.5, 0.5, 0.5)),
+             ([[1, 0, 0], [0, -1, 0], [0, 0, -1]], (0, 1, 0, 0)),
+             ([[0, 0, 1], [0, 1, 0], [-1, 0, 0]], (r, 0, r, 0)),
+             (R178, (math.cos(a / 2), 0.0, 0.6 * math.sin(a / 2), 0.8 * math.sin(a / 2))),
+             ([[1, 0, 0], [0, 1, 0], [0, 0, 1]], (1, 0, 0, 0))]
+    T = torch.tensor([0.3, -1.25, 2.0])
+    for R, q in cases:
+        RT = torch.eye(4, dtype=torch.float64)
+        RT[:3, :3] = torch.tensor(R, dtype=torch.float64)
+        RT[:3, 3] = T.double()
+        got = get_tensor_from_camera(RT)
+        want = torch.tensor(q, dtype=torch.float32)
+        assert got.shape == (7,) and got.dtype == torch.float32
+        if abs(q[0]) < 1e-9:                       # half-turn: either sign
+            assert min(float((got[:4] - want).abs().max()), float((got[:4] + want).abs().max())) < 1e-6, (R, got)
+        else:
+            assert float(got[0]) > 0
+            assert_close(got[:4], want.numpy(), 1e-6, 1e-6, f"quaternion of {R}")
+        assert_close(got[4:], T.numpy(), 0, 0, "translation")
+        assert_close(quad2rotation(got[None, :4].double())[0], RT[:3, :3].numpy(), 1e-6, 1e-6, "quad2rotation inverts it")
+        tq = get_tensor_from_camera(RT, Tquad=True)
+        assert torch.equal(tq[:3], got[4:]) and torch.equal(tq[3:], got[:4])
+        assert torch.equal(get_tensor_from_camera(RT[:3]), got)          # 3x4
+
+
 def test_backend_rejects_cpu_tensors():
     """No CPU fallback: the native seam refuses host tensors like the reference's CHECK_CUDA (hashencoder.cu:16)."""
     from nicer_slam_amd.hashencoder.hashgrid import HashEncoder

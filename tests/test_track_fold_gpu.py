@@ -155,7 +155,8 @@ def test_two_thousand_replays_stay_finite_reproducible_and_leave_the_tickets_at_
     cam0 = tt(fx["in_cam"]).reshape(-1)
     outs = []
     for rep in range(2):
-        model.__dict__.pop("_draw_state", None)
+        for k in ("_draw_state", "_draw_states", "_draw_seed"):
+            model.__dict__.pop(k, None)
         torch.manual_seed(5)
         kt = KernelTracker(model, K, uv.shape[1], cam0, lr=0.0005, use_graph=True)
         calls0 = int(fs.draw_state(model)[1])
@@ -168,3 +169,44 @@ def test_two_thousand_replays_stay_finite_reproducible_and_leave_the_tickets_at_
         assert float(kt.t) == 2000.0 + float(0)                       # Adam steps of this tracker since construction (reset by capture)
         outs.append((losses, kt.cam.clone(), kt.candidate.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+@pytest.mark.parametrize("chunks,use_graph", [(2, True), (3, True), (3, False)])
+def test_chunked_tracker_draws_from_one_state_per_chunk(chunks, use_graph):
+    """KernelTracker(chunks > 1) with UNPINNED draws: the chunks run nsa_draw concurrently on forked streams, so each
+    owns a {seed, call, ticket} state (fused/sampler.py::draw_state, keyed by the chunk's first row).  After N iterations every
+    state must show N more calls and a ticket back at zero (a shared state ends with a non-zero ticket or a wrong count as soon as
+    two launches overlap), the chunks' seeds must differ (no chunk repeats another's jitter), and the run must be reproducible."""
+    from nicer_slam_amd.fused import sampler as fs
+    from nicer_slam_amd.tracking import KernelTracker
+    fx, model, cam, pose, _, _ = _setup("full_tracking")
+    model.train(True)
+    model.engine = "fused"
+    model.draws = None
+    K, uv, gt = tt(fx["in_K"]).cuda(), tt(fx["in_uv"]).cuda(), tt(fx["gt_rgb"]).cuda()
+    cam0 = tt(fx["in_cam"]).reshape(-1)
+    outs = []
+    for rep in range(2):
+        for k in ("_draw_state", "_draw_states", "_draw_seed"):
+            model.__dict__.pop(k, None)
+        torch.manual_seed(11)
+        kt = KernelTracker(model, K, uv.shape[1], cam0, lr=0.0005, use_graph=use_graph, chunks=chunks)
+        keys = [lo for lo, _ in kt.bounds]
+        states = model.__dict__["_draw_states"] if use_graph else None
+        if states is None:                        # eager: the states appear with the first iteration
+            kt.step(uv, gt)
+            states = model.__dict__["_draw_states"]
+        assert sorted(states) == sorted(keys), (sorted(states), keys)
+        before = {k: int(states[k][1]) for k in keys}
+        N = 300
+        losses = torch.stack([kt.step(uv, gt).clone() for _ in range(N)])
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(losses).all())
+        seeds = set()
+        for k in keys:
+            st = states[k].cpu().tolist()
+            assert st[1] == before[k] + N and st[2] == 0, (k, st, before[k])
+            seeds.add(st[0])
+        assert len(seeds) == chunks
+        outs.append((losses, kt.cam.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

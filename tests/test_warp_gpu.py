@@ -122,6 +122,8 @@ def test_kernels_vs_torch_twin_at_image_size(patches, ba):
     # (target, source, pixel) samples per patch cell; the depth gradients of those pixels are excluded, not loosened.
     tol = 2e-3 * float(gd_t.abs().max()) + 5e-3 * gd_t.abs()
     off = (gd_h - gd_t).abs() > tol
+    print(f"[warp kinks] patches {patches} ba {ba}: {int(off.sum())} of {off.numel()} depth gradients outside tol; "
+          f"max |dg| {float((gd_h - gd_t).abs().max()):.4g}, max |g_torch| {float(gd_t.abs().max()):.4g}, max |g_hip| {float(gd_h.abs().max()):.4g}")
     assert float(off.float().mean()) < 0.01, int(off.sum())
     assert float((gd_h - gd_t).abs().max()) <= 2.0 * float(gd_t.abs().max())
     if ba:

@@ -15,6 +15,7 @@ cp $(find /tmp/mk -name "*kernel_stats.csv" | head -1) $OUT/mapping_kernel_stats
 if [ "${1:-}" != "--stats-only" ]; then
 timeout 240 rocprofv3 --pmc TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum --output-format csv -d /tmp/m1 -- $BE > /tmp/m1.log 2>&1
 python $R/tools/pmc_summary.py /tmp/m1 > $OUT/mapping_pmc_per_kernel.csv
+(cd $R && python -c "import json, bench; print(json.dumps(bench.mapping_signature()))") > $OUT/mapping_pmc_meta.json
 fi
 head -25 $OUT/mapping_kernel_stats.csv | cut -c1-150
 wc -l $OUT/mapping_pmc_per_kernel.csv; tail -3 /tmp/m1.log

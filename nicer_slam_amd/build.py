@@ -25,6 +25,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # regression).  The packed forms are also slower beside MFMAs (MI355X_MICROARCH.md, per-instruction constants).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"] + os.environ.get("NSA_EXTRA_HIPCC_FLAGS", "").split()
+# NSA_EXP_SLP=1 with a NSA_BUILD_TAG: a side-by-side build WITH the SLP vectoriser, for the hazard experiments of
+# tools/slp_hazard_experiments.sh only (the untagged product library can never be built this way, see _check_flags)
+if TAG and os.environ.get("NSA_EXP_SLP") == "1":
+    FLAGS.remove("-fno-slp-vectorize")
 
 
 def _check_flags():
@@ -36,8 +40,43 @@ def _check_flags():
     if bad and not TAG:
         raise SystemExit(f"build.py: {bad} are experiment macros; set NSA_BUILD_TAG=<tag> for a side-by-side build "
                          "(the untagged library is the product)")
-    if any(f in ("-fslp-vectorize", "-fvectorize") for f in extra) or "-fno-slp-vectorize" not in FLAGS:
+    if any(f in ("-fslp-vectorize", "-fvectorize") for f in extra) or ("-fno-slp-vectorize" not in FLAGS and not TAG):
         raise SystemExit("build.py: -fno-slp-vectorize is a correctness flag on gfx950 (see the comment above FLAGS)")
+
+
+OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
+
+
+def isa_check(lib):
+    """Build-time ISA check of the PRODUCT library: no packed-fp32 arithmetic (v_pk_mul/add/fma_f32) in any gfx950 code object.
+    Those instructions are what the SLP vectoriser makes of adjacent fp32 math; with them the quad-tiling MFMA kernels return
+    run-to-run different values on MI355X (tools/slp_hazard_experiments.sh).  -fno-slp-vectorize keeps them out; this
+    check makes a toolchain or flag change that brings them back a build failure instead of a silent numerical one.
+    Returns {instruction: count} of the offenders (empty = clean); skipped (None) when llvm-objdump is not available."""
+    import re
+    import shutil
+    import tempfile
+    if not os.path.exists(OBJDUMP):
+        return None
+    tmp = tempfile.mkdtemp(prefix="nsa_isa_")
+    try:
+        copy = os.path.join(tmp, os.path.basename(lib))
+        shutil.copy(lib, copy)
+        subprocess.run([OBJDUMP, "--offloading", copy], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        found = {}
+        n_objs = 0
+        for f in sorted(os.listdir(tmp)):
+            if "amdgcn" not in f:
+                continue
+            n_objs += 1
+            dis = subprocess.run([OBJDUMP, "-d", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+            for m in re.finditer(r"\b(v_pk_(?:mul|add|fma)_f32)\b", dis):
+                found[m.group(1)] = found.get(m.group(1), 0) + 1
+        if n_objs == 0:
+            raise SystemExit(f"build.py: isa_check found no gfx950 code object in {lib}")
+        return found
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _stale(target, deps):
@@ -72,6 +111,12 @@ def build_native(force=False, verbose=False):
     objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        if not TAG:                                   # (experiment builds may contain anything)
+            bad = isa_check(LIB)
+            if bad:
+                os.remove(LIB)
+                raise SystemExit(f"build.py: packed-fp32 arithmetic in the product library {bad}: these make the MFMA kernels "
+                                 "irreproducible on gfx950 (DESIGN.md 4.1); check that -fno-slp-vectorize reached every compile")
     return LIB
 
 

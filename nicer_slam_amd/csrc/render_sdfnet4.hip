@@ -468,7 +468,9 @@ __global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd(
         f32x4v acc[4], ws[4];
         load_vec16(a.wp + P::kWSDF, q, ws);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = sbar * ws[t];
+        for (int t = 0; t < 4; ++t)        // (element by element: a vector * scalar here becomes v_pk_mul_f32, see build.py::isa_check)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] = sbar * ws[t][r];
         gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, a.wp, 3 * NH, lane, fb, acc);
 #pragma unroll
         for (int s = 0; s < QHS; ++s) ab[s] = sg[NH - 1][s] * acc[s >> 2][s & 3] + e[NH - 1][s];

@@ -70,13 +70,18 @@ def ensure_packs(model, owned, specs):
 
 
 # ---- the cached pair of graphs ---------------------------------------------------------------------------------------------------
-def _key(model, R, stage, color_stage, K):
+def _key(model, R, stage, color_stage):
+    """Everything a replay reads through a captured ADDRESS or a compiled choice.  (The intrinsics are NOT in it: the reference's
+    loop hands over a fresh tensor from its data loader every iteration -- they are copied into a static buffer like the pixels.)"""
     from . import sampler as fs
-    imp, rn = model.implicit_network, model.rendering_network
-    return (R, stage, color_stage, getattr(model, "mlp_precision", "fp32"), getattr(model, "sdf_tile", 0),
-            tuple(sorted(fs.DEFAULT_TILES.items())), model.voxels.data_ptr(), imp.coarse.encoding.embeddings.data_ptr(),
-            imp.fine.encoding.embeddings.data_ptr(), rn.encoding.embeddings.data_ptr(), K.data_ptr(), K._version,
-            model.ray_sampler.N_samples, model.ray_sampler.N_samples_eval, model.ray_sampler.N_samples_extra)
+    imp, rn, rs = model.implicit_network, model.rendering_network, model.ray_sampler
+    return (R, stage, color_stage, getattr(model, "mlp_precision", "fp32"), getattr(model, "sdf_tile", 0), _tiles_key(fs),
+            model.voxels.data_ptr(), imp.coarse.encoding.embeddings.data_ptr(), imp.fine.encoding.embeddings.data_ptr(),
+            rn.encoding.embeddings.data_ptr(), rs.N_samples, rs.N_samples_eval, rs.N_samples_extra)
+
+
+def _tiles_key(fs):
+    return tuple(sorted(fs.DEFAULT_TILES.items()))
 
 
 def usable(model, mode, fused_kind, input, ground_truth):
@@ -92,12 +97,16 @@ def usable(model, mode, fused_kind, input, ground_truth):
 
 
 class TrackingGraph:
-    def __init__(self, model, R, stage, color_stage, K):
+    def __init__(self, model, R, stage, color_stage):
         dev = model.voxels.device
         self.model, self.R, self.stage, self.color_stage = model, R, stage, color_stage
         self.pose_s = torch.zeros(1, 4, 4, device=dev)
         self.uv_s = torch.zeros(1, R, 2, device=dev)
-        self.K = K.reshape(-1, 4, 4)[:1].contiguous()
+        self.K = torch.zeros(1, 4, 4, device=dev)
+        # every MLP parameter a packed block is built from: their version counters say when to re-pack (cheap per-call check)
+        self._mlp_params = (list(model.implicit_network.coarse.mlp_parameters()) + list(model.implicit_network.fine.mlp_parameters())
+                            + list(model.rendering_network.mlp_parameters()))
+        self._mlp_stamp = None
         self.g_rgbv_s = torch.zeros(R, 3, device=dev)
         self.packs = {}
         self.specs = pack_specs(model, R, stage)
@@ -130,11 +139,15 @@ class TrackingGraph:
                                              g_o.data_ptr(), g_d.data_ptr(), g_pose.data_ptr(), torch.cuda.current_stream().cuda_stream))
         return g_pose
 
-    def forward(self, pose, uv):
+    def forward(self, pose, uv, K):
         with torch.no_grad():
             self.pose_s.copy_(pose.detach().reshape(1, 4, 4))
             self.uv_s.copy_(uv.detach())
-            ensure_packs(self.model, self.packs, self.specs)
+            self.K.copy_(K.detach().reshape(-1, 4, 4)[:1])
+            stamp = [(p.data_ptr(), p._version) for p in self._mlp_params]
+            if stamp != self._mlp_stamp:                            # first call, or a mapping step moved the MLPs: re-pack in place
+                ensure_packs(self.model, self.packs, self.specs)
+                self._mlp_stamp = stamp
             self.calls += 1
             if self.fwd_graph is not None:
                 self.fwd_graph.replay()
@@ -171,8 +184,8 @@ class _TrackingCore(torch.autograd.Function):
     """pose[1,4,4] (+ uv, via the cache's static buffers) -> the composite pass's ray-level outputs; backward to the pose only."""
 
     @staticmethod
-    def forward(ctx, pose, uv, tg):
-        o = tg.forward(pose, uv)
+    def forward(ctx, pose, uv, K, tg):
+        o = tg.forward(pose, uv, K)
         b, z = o["b"], o["z_vals"]
         R, S = z.shape
         ctx.tg, ctx.serial = tg, tg.serial
@@ -189,18 +202,18 @@ class _TrackingCore(torch.autograd.Function):
             raise RuntimeError("SLAMNetwork tracking graph: backward through the outputs of an EARLIER forward -- the cached graph's "
                                "static buffers were overwritten by a later forward(mode='tracking'); call backward before the next "
                                "forward (the reference's loop does), or set NSA_TRACK_GRAPH=0")
-        return tg.backward(g_rgbv, g_depth, g_nmap, g_w, g_ent), None, None
+        return tg.backward(g_rgbv, g_depth, g_nmap, g_w, g_ent), None, None, None
 
 
 def render(model, input, stage, color_stage):
     """-> the tuple FusedComposite returns (+ z_vals, depth scale, rays, eikonal sample), from the cached graphs."""
     pose, uv, K = input["pose"], input["uv"], input["intrinsics"]
     R = uv.shape[1]
-    key = _key(model, R, stage, color_stage, K)
+    key = _key(model, R, stage, color_stage)
     cache = model.__dict__.setdefault("_track_graphs", {})
     tg = cache.get("tg")
     if tg is None or cache.get("key") != key:
         cache.clear()                                  # (drops the old graphs and their pools)
-        tg = TrackingGraph(model, R, stage, color_stage, K.to(uv.device))
+        tg = TrackingGraph(model, R, stage, color_stage)
         cache["tg"], cache["key"] = tg, key
-    return _TrackingCore.apply(pose, uv.contiguous(), tg)
+    return _TrackingCore.apply(pose, uv, K, tg)

@@ -273,7 +273,8 @@ class SLAMNetwork(nn.Module):
         else:
             normals = gradients / (gradients.norm(2, -1, keepdim=True) + 1e-6)
             normal_map = torch.sum(weights.unsqueeze(-1) * normals.reshape(-1, N, 3), 1).reshape(bs, -1, 3)
-        output["normal_map"] = torch.einsum("bij,bni->bnj", pose[:, :3, :3], normal_map)
+        # einsum("bij,bni->bnj", R, n) (network.py:345) = n @ R per camera: the same batched GEMM without einsum's host-side planning
+        output["normal_map"] = torch.matmul(normal_map, pose[:, :3, :3])
         return output
 
     def volume_rendering(self, z_vals, sdf, points_flat, rays_o=None, rays_d=None, gradients=None, frame_idx=1,

@@ -93,3 +93,15 @@ def test_argument_validation_needs_no_gpu():
     # empty work is a no-op, not an error (reference: a zero-size launch is never issued either)
     assert lib.nsa_sdf_points(None, 0, None, None, None, None, None, None) == 0
     assert lib.nsa_sampler_sdf(None, None, 0, 640, None, None, 0.0, 1.0, 3.5, None, None, None, None, None, None, None, None) == 0
+
+
+def test_product_library_has_no_packed_fp32_arithmetic():
+    """Build-time ISA rule (nicer_slam_amd/build.py::isa_check, DESIGN 4.1): v_pk_mul/add/fma_f32 -- what the SLP vectoriser makes of
+    adjacent fp32 math -- must not appear in any gfx950 code object of the product library: with them the quad-tiling MFMA kernels
+    are run-to-run irreproducible on MI355X (profiles/r04_slp_hazard_experiments.txt)."""
+    import os
+    import pytest
+    from nicer_slam_amd import build
+    if not os.path.exists(build.OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    assert build.isa_check(build.LIB) == {}

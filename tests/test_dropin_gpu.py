@@ -193,8 +193,12 @@ def test_graph_cached_tracking_is_the_eager_functions_bit_for_bit(objective):
     return exactly what the eager autograd.Functions return -- loss and camera gradient of every iteration, incl. after an MLP
     update between iterations (snapshots re-packed in place)."""
     model, optimizer, loss_fn, tracking_loss, feed = _world()
+    start = {k: v.detach().clone() for k, v in model.state_dict().items()}
     la, ga, tg = _track_loop(model, feed, 7, objective, bump_at=4, graph=True)
     assert tg is not None and tg.fwd_graph is not None and tg.bwd_graph is not None and tg.calls == 7
+    with torch.no_grad():                                          # (the loop moved the MLPs at iteration 4: same start for both)
+        for k, v in model.state_dict().items():
+            v.copy_(start[k])
     lb, gb, none = _track_loop(model, feed, 7, objective, bump_at=4, graph=False)
     assert none is None
     assert torch.equal(la, lb), (la - lb).abs().max()

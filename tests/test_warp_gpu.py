@@ -124,8 +124,11 @@ def test_kernels_vs_torch_twin_at_image_size(patches, ba):
     off = (gd_h - gd_t).abs() > tol
     print(f"[warp kinks] patches {patches} ba {ba}: {int(off.sum())} of {off.numel()} depth gradients outside tol; "
           f"max |dg| {float((gd_h - gd_t).abs().max()):.4g}, max |g_torch| {float(gd_t.abs().max()):.4g}, max |g_hip| {float(gd_h.abs().max()):.4g}")
-    assert float(off.float().mean()) < 0.01, int(off.sum())
-    assert float((gd_h - gd_t).abs().max()) <= 2.0 * float(gd_t.abs().max())
+    # counted and bounded (measured on MI355X, round 4: 0 or 1 of the 1200 depth gradients outside `tol`, largest difference 1.0e-5
+    # where the largest gradient is 2.5e-3 .. 0.2): at most 6 kink pixels, and none of them differs by more than 2 % of the largest
+    # gradient (the round-3 bound allowed 1 % of the pixels and 200 %)
+    assert int(off.sum()) <= 6, int(off.sum())
+    assert float((gd_h - gd_t).abs().max()) <= 2e-2 * float(gd_t.abs().max())
     if ba:
         assert_close(gc_h, gc_t, 2e-3 * float(gc_t.abs().max()), 5e-3, "d loss / d camera tensors")
 

@@ -15,6 +15,7 @@
 //   36             h0: grad2 [32]    h1: pad
 //   37+2j, 38+2j   sin, cos of 2^k d_dd, pair g = 2j+h, k = g/3, dd = g%3    [6+6k+dd], [9+6k+dd]      (j < 6)
 //   49+2jl+c       colour-grid level 2jl+h, channel c                         [97 + 2(2jl+h) + c]       (jl < 8)
+#include <cstdlib>
 #include "sdf_net.hpp"
 
 namespace nsa {
@@ -89,6 +90,28 @@ struct ColEmitter {
     }
 };
 
+// features of one colour-grid level into the first-layer slots and, with a save area, features + Jacobian for the backward
+__device__ __forceinline__ void colour_level_out(const float (&v)[8][CC], const float (&w)[3], const float (&dw)[3], float scale,
+                                                 bool inside, int jl, float (&in)[COL_IN_STEPS], float* sv) {
+    float f[CC];
+    blend<3, CC>(v, w, f);
+#pragma unroll
+    for (int c = 0; c < CC; ++c) in[49 + jl * CC + c] = inside ? f[c] : 0.0f;
+    if (sv) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) sv[(jl * CC + c) * 64] = in[49 + jl * CC + c];
+#pragma unroll
+        for (int gd = 0; gd < 3; ++gd) {
+            float jr[CC];
+            jacobian_row<3, CC>(v, w, dw, scale, gd, jr);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) sv[(16 + (jl * 3 + gd) * CC + c) * 64] = inside ? jr[c] : 0.0f;
+        }
+    }
+}
+
+// XP: leading level pairs gathered with one 16-byte load per x-neighbour pair (0: every level through gather_corners)
+template <int XP = 0>
 __device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeom16& geom, uint32_t tile, uint32_t q, int lane,
                                               int h, const float (&x)[3], const float (&dir)[3], float (&in)[COL_IN_STEPS],
                                               bool from_save, bool wave_live) {
@@ -120,6 +143,13 @@ __device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeo
 #pragma unroll
     for (int d = 0; d < 3; ++d) u[d] = to_unit(x[d], a.divide_factor);
     float* sv = (a.save && wave_live) ? a.save + (size_t)tile * 64 * 64 + lane : nullptr;   // clamped waves write nothing
+    // XP leading level pairs (levels 0 .. 2 XP - 1, both half-waves) are dense with x-stride one row: the x / x+1 corner rows of a
+    // cell are 16 contiguous bytes, fetched as ONE load -- four requests per level instead of eight, for every lane, no per-lane
+    // path (the round-3 attempt paired rows only where a lane's level allowed it: divergent, slower).  The pair is exactly the two
+    // rows the reference indexes (dense index(x+1) = index(x) + 1, hashencoder.cu:56-70) unless the cell touches the level's last
+    // rows, where the reference's modulo wraps: a coordinate of exactly 1.0 -- the far sample of a ray on the cube face.  Those
+    // lanes load from a clamped address and the whole wave repeats the XP levels through the generic gather afterwards (rare).
+    bool redo = false;
 #pragma unroll
     for (int jl = 0; jl < CL / 2; ++jl) {
         const LevelGeom lg = geom.lv[2 * jl + h];
@@ -127,21 +157,34 @@ __device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeo
         float w[3], dw[3];
         const bool inside = locate<3>(u, lg.scale, cell, w, dw);
         float v[8][CC];
-        gather_corners<3, CC>(a.table, lg, cell, v);
-        float f[CC];
-        blend<3, CC>(v, w, f);
+        if (jl < XP) {
+            constexpr uint32_t B = CC * 4;
+            uint32_t o00 = __umul24(cell[1], lg.s1B) + (cell[0] * B + lg.row0B);
+            o00 = __umul24(cell[2], lg.s2B) + o00;
+            const bool fast = o00 < lg.limB;                   // all eight corner rows inside the level (limB = 0 unless LV_FASTDENSE)
+            redo = redo || !fast;
+            if (!fast) o00 = lg.row0B;
+            const uint32_t off[4] = {o00, o00 + lg.s1B, o00 + lg.s2B, o00 + lg.s2B + lg.s1B};
 #pragma unroll
-        for (int c = 0; c < CC; ++c) in[49 + jl * CC + c] = inside ? f[c] : 0.0f;
-        if (sv) {
-#pragma unroll
-            for (int c = 0; c < CC; ++c) sv[(jl * CC + c) * 64] = in[49 + jl * CC + c];
-#pragma unroll
-            for (int gd = 0; gd < 3; ++gd) {
-                float jr[CC];
-                jacobian_row<3, CC>(v, w, dw, lg.scale, gd, jr);
-#pragma unroll
-                for (int c = 0; c < CC; ++c) sv[(16 + (jl * 3 + gd) * CC + c) * 64] = inside ? jr[c] : 0.0f;
+            for (int yz = 0; yz < 4; ++yz) {
+                const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.table) + (size_t)off[yz]);
+                v[2 * yz][0] = r.x; v[2 * yz][1] = r.y; v[2 * yz + 1][0] = r.z; v[2 * yz + 1][1] = r.w;
             }
+        } else {
+            gather_corners<3, CC>(a.table, lg, cell, v);
+        }
+        colour_level_out(v, w, dw, lg.scale, inside, jl, in, sv);
+    }
+    if (XP > 0 && __any(redo)) {
+#pragma unroll
+        for (int jl = 0; jl < XP; ++jl) {
+            const LevelGeom lg = geom.lv[2 * jl + h];
+            uint32_t cell[3];
+            float w[3], dw[3];
+            const bool inside = locate<3>(u, lg.scale, cell, w, dw);
+            float v[8][CC];
+            gather_corners<3, CC>(a.table, lg, cell, v);
+            colour_level_out(v, w, dw, lg.scale, inside, jl, in, sv);
         }
     }
 }
@@ -184,6 +227,7 @@ __device__ __forceinline__ void colour_mlp(float* stage, const float* __restrict
 #ifndef NSA_OCC_COL_FWD
 #define NSA_OCC_COL_FWD 2
 #endif
+template <int XP>
 __global__ __launch_bounds__(256, NSA_OCC_COL_FWD) void k_colour_fwd(ColourArgs a, GridGeom16 geom) {
     using Seq = ColOps<false>;
     desync_simd_partners();
@@ -202,7 +246,7 @@ __global__ __launch_bounds__(256, NSA_OCC_COL_FWD) void k_colour_fwd(ColourArgs 
 #pragma unroll
     for (int d = 0; d < 3; ++d) dir[d] = a.src.rays_d[ray * 3 + d];
     float in[COL_IN_STEPS];
-    colour_inputs(a, geom, tile, q, lane, h, x, dir, in, false, wave_live);
+    colour_inputs<XP>(a, geom, tile, q, lane, h, x, dir, in, false, wave_live);
     f32x16 a1[2], a2[2];
     float rgb[3];
     colour_mlp<Seq, false>(nullptr, a.wp, lane, h, in, a1, a2, rgb);
@@ -428,7 +472,17 @@ int NSA_ENTRY(nsa_colour_forward)(const nsa_points_t* pts, const nsa_grid_t* gri
     a.wp = packed; a.grad = grad; a.feat = feat_hl; a.rgb = rgb; a.save = save;
     const uint32_t tiles = (pts->P + 31) / 32;
     launch_begin();
-    hipLaunchKernelGGL(k_colour_fwd, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
+    // x-pair gather of the leading dense levels (colour_inputs<XP>): levels 0..7 must be plain dense levels (LV_FASTDENSE: no
+    // index wrap, byte offsets < 2^31, limB set) -- true for the reference's colour grid (base 16 ... 2048, 2^24 rows: levels
+    // 0..8 are dense); any other geometry takes the all-generic kernel.
+    // Measured on MI355X (profiles/r04_ab_experiments.txt): 73.8 -> 83 us -- the 16-byte loads sit at 8-byte alignment, the kernel
+    // needs 218 instead of 124 registers (two instead of four waves per SIMD; capped at 128 it spills: 112 us).  OFF by default;
+    // NSA_COLOUR_XPAIR=1 selects it (A/B runs).
+    static const bool xpair_on = [] { const char* e = getenv("NSA_COLOUR_XPAIR"); return e && e[0] == '1'; }();
+    bool xpair = xpair_on && grid->L == 16;
+    for (int l = 0; l < 8 && xpair; ++l) xpair = (geom.lv[l].flags & LV_FASTDENSE) && geom.lv[l].limB > 0;
+    if (xpair) hipLaunchKernelGGL(k_colour_fwd<4>, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
+    else       hipLaunchKernelGGL(k_colour_fwd<0>, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
     return launch_end();
 }
 

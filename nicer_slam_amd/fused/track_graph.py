@@ -126,7 +126,13 @@ class TrackingGraph:
                                        rays_d.data_ptr(), ds.data_ptr(), st))
         z_vals, z_eik = fs.get_z_vals(model, rays_d, rays_o)
         b = fr.composite_forward_raw(model, rays_o, rays_d, z_vals, self.stage, True)
-        self.out = dict(b=b, rays_o=rays_o, rays_d=rays_d, ds=ds, z_vals=z_vals, z_eik=z_eik)
+        # the forward's output dict (network.py:147-151, 281-300, 338-345) inside the same graph: five small torch launches that
+        # would otherwise be dispatched, and recorded by autograd, on every call of the caller's loop
+        rot = self.pose_s[:, :3, :3]
+        final = dict(rgb_values=b["rgb_values"].view(1, R, 3), depth_values=(ds * b["depth"]).view(1, R, 1),
+                     normal_map=torch.matmul(b["nmap"].view(1, R, 3), rot), entropy=b["entropy"].mean(),
+                     depth_vals=z_vals * ds.view(R, 1))
+        self.out = dict(b=b, rays_o=rays_o, rays_d=rays_d, ds=ds, z_vals=z_vals, z_eik=z_eik, final=final)
 
     def _backward_body(self, g_rgbv, g_depth=None, g_nmap=None, g_ent=None, g_w=None):
         from . import render as fr
@@ -168,45 +174,56 @@ class TrackingGraph:
         self.serial += 1
         return self.out
 
-    def backward(self, g_rgbv, g_depth, g_nmap, g_w, g_ent):
+    def backward(self, g_rgbv, g_depth_values, g_normal_map, g_w, g_entropy):
+        """Cotangents of (rgb_values, depth_values, normal_map, weights, entropy) -> d / d pose."""
         with torch.no_grad():
-            only_rgb = g_rgbv is not None and g_depth is None and g_nmap is None and g_w is None and g_ent is None
+            only_rgb = g_rgbv is not None and g_depth_values is None and g_normal_map is None and g_w is None and g_entropy is None
             if only_rgb and self.bwd_graph is not None:
                 self.g_rgbv_s.copy_(g_rgbv.reshape(self.R, 3))
                 self.bwd_graph.replay()
                 return self.g_pose
-            if all(g is None for g in (g_rgbv, g_depth, g_nmap, g_w, g_ent)):
+            if all(g is None for g in (g_rgbv, g_depth_values, g_normal_map, g_w, g_entropy)):
                 return None
-            return self._backward_body(g_rgbv, g_depth, g_nmap, g_ent, g_w)
+            # any other objective: back through the output assembly with torch ops, then the backward kernels eagerly
+            R, o = self.R, self.out
+            g_depth = None if g_depth_values is None else (g_depth_values.reshape(R) * o["ds"]).contiguous()
+            g_ent = None if g_entropy is None else (g_entropy / R).expand(R).contiguous()
+            rot = self.pose_s[0, :3, :3]
+            g_nmap = None if g_normal_map is None else torch.matmul(g_normal_map.reshape(R, 3), rot.t()).contiguous()
+            g_rgb = None if g_rgbv is None else g_rgbv.reshape(R, 3).contiguous()
+            g_pose = self._backward_body(g_rgb, g_depth, g_nmap, g_ent, None if g_w is None else g_w.contiguous())
+            if g_normal_map is not None:          # normal_map = n @ R also depends on the pose directly
+                g_pose = g_pose.clone()
+                g_pose[0, :3, :3] += torch.matmul(o["b"]["nmap"].reshape(R, 3).t(), g_normal_map.reshape(R, 3))
+            return g_pose
 
 
 class _TrackingCore(torch.autograd.Function):
-    """pose[1,4,4] (+ uv, via the cache's static buffers) -> the composite pass's ray-level outputs; backward to the pose only."""
+    """pose[1,4,4] (+ uv, K via the cache's static buffers) -> the tensors of SLAMNetwork.forward's output dict; backward to the pose."""
 
     @staticmethod
     def forward(ctx, pose, uv, K, tg):
         o = tg.forward(pose, uv, K)
-        b, z = o["b"], o["z_vals"]
+        b, z, f = o["b"], o["z_vals"], o["final"]
         R, S = z.shape
         ctx.tg, ctx.serial = tg, tg.serial
         ctx.set_materialize_grads(False)
-        sdf_o, rgb_o, grad_o = b["sdf"].view(R, S), b["rgb"].view(R, S, 3), b["grad"]
-        ctx.mark_non_differentiable(sdf_o, rgb_o, grad_o, z, o["ds"], o["rays_o"], o["rays_d"], o["z_eik"])
-        return (b["rgb_values"], b["depth"].unsqueeze(-1), b["nmap"], b["weights"], b["entropy"], sdf_o, rgb_o, grad_o, z, o["ds"],
-                o["rays_o"], o["rays_d"], o["z_eik"])
+        sdf_o, rgb_o = b["sdf"].view(R, S), b["rgb"].view(R, S, 3)
+        ctx.mark_non_differentiable(sdf_o, rgb_o, z, f["depth_vals"])
+        return f["rgb_values"], f["depth_values"], f["normal_map"], b["weights"], f["entropy"], sdf_o, rgb_o, z, f["depth_vals"]
 
     @staticmethod
-    def backward(ctx, g_rgbv, g_depth, g_nmap, g_w, g_ent, *_unused):
+    def backward(ctx, g_rgbv, g_depth_values, g_normal_map, g_w, g_entropy, *_unused):
         tg = ctx.tg
         if ctx.serial != tg.serial:
             raise RuntimeError("SLAMNetwork tracking graph: backward through the outputs of an EARLIER forward -- the cached graph's "
                                "static buffers were overwritten by a later forward(mode='tracking'); call backward before the next "
                                "forward (the reference's loop does), or set NSA_TRACK_GRAPH=0")
-        return tg.backward(g_rgbv, g_depth, g_nmap, g_w, g_ent), None, None, None
+        return tg.backward(g_rgbv, g_depth_values, g_normal_map, g_w, g_entropy), None, None, None
 
 
 def render(model, input, stage, color_stage):
-    """-> the tuple FusedComposite returns (+ z_vals, depth scale, rays, eikonal sample), from the cached graphs."""
+    """-> the output dict of SLAMNetwork.forward(mode="tracking") from the cached graphs."""
     pose, uv, K = input["pose"], input["uv"], input["intrinsics"]
     R = uv.shape[1]
     key = _key(model, R, stage, color_stage)
@@ -216,4 +233,7 @@ def render(model, input, stage, color_stage):
         cache.clear()                                  # (drops the old graphs and their pools)
         tg = TrackingGraph(model, R, stage, color_stage)
         cache["tg"], cache["key"] = tg, key
-    return _TrackingCore.apply(pose, uv, K, tg)
+    rgb_values, depth_values, normal_map, weights, entropy, sdf, rgb, z_vals, depth_vals = _TrackingCore.apply(pose, uv, K, tg)
+    return {"rgb": rgb, "rgb_values": rgb_values, "depth_values": depth_values, "z_vals": z_vals, "depth_vals": depth_vals,
+            "sdf": sdf, "weights": weights, "entropy": entropy, "scene_bounding_sphere": model.scene_bounding_sphere,
+            "normal_map": normal_map}

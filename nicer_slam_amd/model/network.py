@@ -164,12 +164,8 @@ class SLAMNetwork(nn.Module):
             from ..fused import track_graph
             graphed = track_graph.usable(self, mode, fused_kind, input, ground_truth)
         if graphed:
-            (rgb_values, depth, nmap_w, weights, ent_ray, sdf, rgb, gradients, z_vals, ds_flat, cam_flat, dirs,
-             z_samples_eik) = track_graph.render(self, input, stage, color_stage)
-            depth_scale = ds_flat.reshape(bs, num_pixels, 1)
             self.last_engine = "fused"
-            return self._assemble(mode, bs, num_pixels, uv, pose, intrinsics, ground_truth, stage, fused, fused_kind, depth_scale,
-                                  cam_flat, dirs, z_vals, z_samples_eik, rgb_values, depth, nmap_w, weights, ent_ray, sdf, rgb, gradients)
+            return track_graph.render(self, input, stage, color_stage)
         if fused and pose.shape[1] == 4 and uv.dtype == torch.float32:
             from ..fused import render as fused_render
             cam_flat, dirs, ds_flat = fused_render.rays(pose, uv, intrinsics.to(uv.device))

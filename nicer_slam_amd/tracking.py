@@ -311,12 +311,13 @@ class TrackingStepper:
 
     def step(self, uv, gt):
         """uv [1,R,2] float pixels, gt [R,3] colours (device tensors).  Returns the (device) loss of this iteration."""
-        self.uv.copy_(uv)
-        self.gt.copy_(gt)
         if self.graph is not None:
+            self.uv.copy_(uv)
+            self.gt.copy_(gt)
             self.graph.replay()
             loss = self.loss
         else:
+            self.uv, self.gt = uv, gt                  # eager: no static inputs to fill (the reference's loop has none either)
             if self.cam.grad is not None:
                 self.cam.grad.zero_()
             loss = self._fwd_bwd()

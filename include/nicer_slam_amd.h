@@ -312,6 +312,16 @@ int nsa_update_voxels(const nsa_points_t *pts, float *voxels, uint32_t res, nsa_
 int nsa_adam_table_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, uint32_t step,
                         float lr, float beta1, float beta2, float eps, nsa_stream_t stream);
 
+/* Packed MLP parameter block (MFMA fragment order) from the flat effective parameters in one launch:
+ *   out[o] = word order[o] of concat( split3(flat[a_index]) as [group][piece hi/mid/lo][lane][4 words of 2 bf16], flat[v_index] )
+ * a_index: n_a = groups * 64 * 8 indices into `flat` (the 8 fp32 weights lane l supplies to one MFMA k-group; every weight is
+ * split exactly into three round-to-nearest bf16 pieces), v_index: n_v indices of per-feature values kept in fp32, order:
+ * n_out <= n_a * 3 / 2 + n_v word indices into that concatenation.  The index arrays are the host-built layout tables of the
+ * packed blocks (nicer_slam_amd/fused/pack.py; layout: csrc/mlp_common.hpp, csrc/mlp16.hpp).  New -- the reference has no
+ * packed weights; replaces the per-layer weight_norm'ed nn.Linear weights of code/model/base_networks.py:127-149 as kernel input. */
+int nsa_pack_blocks(const float *flat, const int64_t *a_index, uint64_t n_a, const int64_t *v_index, uint64_t n_v,
+                    const int64_t *order, uint64_t n_out, float *out, nsa_stream_t stream);
+
 /* MLP weight gradients from the emission rows of the *_backward_params kernels: emit is [rows][ld] fp32 (column = point,
  * ld a multiple of 4096, columns past the last point zero).
  *   out[m][n] = sum_j sum_p emit[a_rows[j] + m][p] * emit[b_rows[j] + n][p],   j < pairs (1 or 2), m < M <= 64, n < N <= 192

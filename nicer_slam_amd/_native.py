@@ -128,6 +128,9 @@ lib.nsa_emit_gemm.argtypes = [_p, ctypes.c_uint64, _u32, ctypes.POINTER(ctypes.c
 lib.nsa_emit_gemm_workspace.restype = ctypes.c_uint64
 lib.nsa_emit_gemm_workspace.argtypes = [ctypes.c_uint64, _u32, _u32, ctypes.c_int]
 EXPORTS += ["nsa_emit_gemm", "nsa_emit_gemm_workspace"]
+lib.nsa_pack_blocks.restype = _i
+lib.nsa_pack_blocks.argtypes = [_p, _p, ctypes.c_uint64, _p, ctypes.c_uint64, _p, ctypes.c_uint64, _p, _p]
+EXPORTS += ["nsa_pack_blocks"]
 
 class LossDesc(ctypes.Structure):
     """nsa_loss_t"""

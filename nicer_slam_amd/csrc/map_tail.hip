@@ -76,6 +76,8 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = p - a.step_size * (m / denom);
 }
 
+// (A variant with 2 / 4 float4 groups per thread and all their loads issued first measured the same 4.9 TB/s = 0.78 of the 6.29 TB/s
+// streaming-copy rate on a 1 GiB table, profiles/r04_ab_experiments.txt r4h: seven concurrent streams, not load depth, set the rate.)
 __global__ __launch_bounds__(256) void k_adam_table(AdamTableArgs a) {
     const uint64_t n4 = a.n / 4;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
@@ -98,9 +100,60 @@ __global__ __launch_bounds__(256) void k_adam_table(AdamTableArgs a) {
     }
 }
 
+// ---- packed MLP parameter blocks in one launch (fused/pack.py::pack_blocks) ----------------------------------------------------
+// out[o] = word perm[o] of  concat( split3(flat[ia]) viewed as [group][piece][lane][4 x (2 bf16)],  flat[iv] ):
+// the gather plan of pack.py (index of every fp32 weight an MFMA lane holds, of every per-feature value, and the block order)
+// applied with the exact 3-way bf16 split of the weights -- hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), each
+// round-to-nearest-even like torch's .to(torch.bfloat16).  One launch instead of the gather / 3 conversions / 2 subtractions /
+// stack / cat / gather that torch makes of it (a mapping iteration re-packs three networks: its MLPs move every step).
+__device__ __forceinline__ uint32_t bf16_rne(float x) {
+    const uint32_t u = __float_as_uint(x);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;          // NaN stays NaN (quiet)
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ uint32_t bf16_piece(float x, int piece) {
+    const uint32_t hi = bf16_rne(x);
+    if (piece == 0) return hi;
+    const float r = x - __uint_as_float(hi << 16);
+    const uint32_t mid = bf16_rne(r);
+    if (piece == 1) return mid;
+    return bf16_rne(r - __uint_as_float(mid << 16));
+}
+
+__global__ __launch_bounds__(256) void k_pack_blocks(const float* __restrict__ flat, const int64_t* __restrict__ ia,
+                                                     uint64_t n_a_words, const int64_t* __restrict__ iv,
+                                                     const int64_t* __restrict__ perm, uint64_t n_out, uint32_t* __restrict__ out) {
+    const uint64_t o = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_out) return;
+    const uint64_t p = (uint64_t)perm[o];
+    if (p < n_a_words) {                                   // [group][piece][lane][word w = bf16 elements 2w, 2w+1]
+        const uint64_t g = p / 768;
+        const uint32_t rem = (uint32_t)(p - g * 768);
+        const int piece = rem >> 8, lane = (rem & 255) >> 2, w = rem & 3;
+        const int64_t* src = ia + (g * 64 + lane) * 8 + 2 * w;
+        const float x0 = flat[src[0]], x1 = flat[src[1]];
+        out[o] = bf16_piece(x0, piece) | (bf16_piece(x1, piece) << 16);
+    } else {
+        out[o] = __float_as_uint(flat[iv[p - n_a_words]]);
+    }
+}
+
 }  // namespace nsa
 
 extern "C" {
+
+int nsa_pack_blocks(const float* flat, const int64_t* a_index, uint64_t n_a, const int64_t* v_index, uint64_t n_v,
+                    const int64_t* order, uint64_t n_out, float* out, nsa_stream_t stream) {
+    using namespace nsa;
+    if (n_out == 0) return NSA_OK;
+    if (!flat || !order || !out || (n_a && !a_index) || (n_v && !v_index) || (n_a % 512) != 0) return NSA_EBADARG;
+    const uint64_t n_a_words = n_a / 8 * 3 * 4;            // 8 weights of a lane -> 3 pieces x 4 words
+    if (n_out > n_a_words + n_v || n_out > 0x7FFFFFFFull * 256) return NSA_EBADARG;
+    launch_begin();
+    hipLaunchKernelGGL(k_pack_blocks, dim3((uint32_t)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat, a_index,
+                       n_a_words, v_index, order, n_out, reinterpret_cast<uint32_t*>(out));
+    return launch_end();
+}
 
 int nsa_update_voxels(const nsa_points_t* pts, float* voxels, uint32_t res, nsa_stream_t stream) {
     using namespace nsa;

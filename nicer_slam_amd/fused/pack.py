@@ -113,6 +113,14 @@ def pack_blocks(flat, blocks):
     """Gather every block from the flat parameter vector; 'A' blocks become [group][piece][lane][8 bf16] (viewed as
     float32 words), 'V' blocks stay fp32.  Layout: csrc/mlp_common.hpp.  All blocks of a kind go through one gather."""
     ia, iv, perm = _plan(blocks, flat.device)
+    if flat.is_cuda and not flat.requires_grad and flat.dtype == torch.float32 and not torch.is_grad_enabled():
+        # the whole plan in ONE launch (csrc/map_tail.hip::k_pack_blocks) -- what the fused engine always asks for (detached packs)
+        from .._native import lib, check
+        flat = flat.contiguous()
+        out = torch.empty(perm.numel(), device=flat.device, dtype=torch.float32)
+        check(lib.nsa_pack_blocks(flat.data_ptr(), ia.data_ptr(), ia.numel(), iv.data_ptr(), iv.numel(), perm.data_ptr(),
+                                  perm.numel(), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        return out
     hi, mid, lo = split_bf16x3(flat[ia])
     words = torch.stack([hi, mid, lo], 1).contiguous().view(torch.float32).reshape(-1)
     return torch.cat([words, flat[iv]])[perm]

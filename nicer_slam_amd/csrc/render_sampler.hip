@@ -496,6 +496,10 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
 #endif
 #include "bf16_entries.hpp"
 #include "quad_entries.hpp"
+extern "C" int nsa_sampler_sys_sdf(const float* rays_o, const float* rays_d, uint32_t R, uint32_t E, const float* t_lin,
+                                   const float* t_rand, float near, float bound, float far_cap, const nsa_grid_t* coarse,
+                                   const nsa_grid_t* fine, const float* packed_coarse, const float* packed_fine, float* z, float* sdf,
+                                   float* far, nsa_stream_t stream);
 extern "C" int nsa_sampler_ws_sdf(const float* rays_o, const float* rays_d, uint32_t R, uint32_t E, const float* t_lin,
                                   const float* t_rand, float near, float bound, float far_cap, const nsa_grid_t* coarse,
                                   const nsa_grid_t* fine, const float* packed_coarse, const float* packed_fine, float* z, float* sdf,
@@ -517,6 +521,11 @@ int NSA_ENTRY(nsa_sampler_sdf)(const float* rays_o, const float* rays_d, uint32_
     if (!(coarse->L == 4 && coarse->C == 8 && coarse->n_hidden == 1 && fine->L == 8 && fine->C == 4 && fine->n_hidden == 3))
         return NSA_EUNSUPPORTED_NET;
 #if NSA_PIECES == 3
+    if (coarse->tile == 97 || fine->tile == 97) {         // systolic wave-specialised form (render_sampler_sys.hip)
+        if (coarse->tile != fine->tile) return NSA_EBADARG;
+        return nsa_sampler_sys_sdf(rays_o, rays_d, R, E, t_lin, t_rand, near, bound, far_cap, coarse, fine, packed_coarse,
+                                   packed_fine, z, sdf, far, stream);
+    }
     if (coarse->tile == 96 || fine->tile == 96) {         // wave-specialised form (render_sampler_ws.hip)
         if (coarse->tile != fine->tile) return NSA_EBADARG;
         return nsa_sampler_ws_sdf(rays_o, rays_d, R, E, t_lin, t_rand, near, bound, far_cap, coarse, fine, packed_coarse,

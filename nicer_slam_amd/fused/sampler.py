@@ -61,11 +61,11 @@ def tile_of(model, which):
     t = int(getattr(model, "sdf_tile", 0) or _FORCE or DEFAULT_TILES[which])
     if which.startswith("sampler") and _FORCE_SAMPLER and not getattr(model, "sdf_tile", 0):
         t = _FORCE_SAMPLER
-    if t in (64, 96) and not which.startswith("sampler"):
+    if t in (64, 96, 97) and not which.startswith("sampler"):
         t = 32                                 # (both are forms of the 32-point tiling's sampler pass)
-    if t not in (16, 32) and not (t in (64, 96) and which.startswith("sampler")):
-        raise ValueError(f"sdf_tile must be 16 or 32 (sampler only: 64 = 32-point tiling with two tiles per wave, 96 = "
-                         f"wave-specialised 32-point form), got {t}")
+    if t not in (16, 32) and not (t in (64, 96, 97) and which.startswith("sampler")):
+        raise ValueError(f"sdf_tile must be 16 or 32 (sampler only: 64 = 32-point tiling with two tiles per wave, 96 / 97 = "
+                         f"wave-specialised 32-point forms: matrix waves on loan / systolic layer engines), got {t}")
     return t
 
 

@@ -81,16 +81,18 @@ def test_sampler_sdf_stage_both_tilings():
         t_rand = torch.rand(R, 640, device="cuda", generator=g)
         res = {}
         # 64 = 32-point tiling, two point tiles per wave; 96 = wave-specialised 32-point form (render_sampler_ws.hip)
-        for tile in (16, 32, 64, 96):
+        # 97 = systolic form (layer-engine waves, render_sampler_sys.hip)
+        for tile in (16, 32, 64, 96, 97):
             model.sdf_tile = tile
             res[tile] = fs.sampler_sdf(model, o, d, t_rand)
         for a, b, what in zip(res[16], res[32], ("z", "sdf", "far")):
             assert_close(a, b.cpu().numpy(), 1e-6 if what == "sdf" else 0, 1e-5 if what == "sdf" else 0, f"{what} (R={R})")
         for a, b, what in zip(res[64], res[32], ("z", "sdf", "far")):
             assert torch.equal(a, b), f"two tiles per wave: {what} differs from one tile per wave (R={R})"
-        for a, b, what in zip(res[96], res[32], ("z", "sdf", "far")):   # same MFMA order per accumulator: bit-identical
-            assert torch.equal(a, b), f"wave-specialised sampler: {what} differs from the one-program form (R={R}): " \
-                                      f"{int((a != b).sum())} of {a.numel()}"
+        for t in (96, 97):                                               # same MFMA order per accumulator: bit-identical
+            for a, b, what in zip(res[t], res[32], ("z", "sdf", "far")):
+                assert torch.equal(a, b), f"wave-specialised sampler (tile code {t}): {what} differs from the one-program form " \
+                                          f"(R={R}): {int((a != b).sum())} of {a.numel()}"
     pts = (torch.rand(100003, 3, device="cuda", generator=g) * 2 - 1) * 1.2
     for stage in ("fine", "coarse"):
         vals = {}
@@ -128,7 +130,7 @@ def test_mfma_kernels_are_bit_reproducible_and_match_the_oracle_at_scale():
     cfg = R.RenderConfig(coarse=R.SdfNetSpec(mk(4, 8, 32, 32, 19), 2), fine=R.SdfNetSpec(mk(8, 4, 32, 128, 19), 4),
                          colour_grid=mk(16, 2, 16, 64, 12), n_samples=94, n_samples_eval=640, n_samples_extra=32)
     params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    for tile in (16, 32, 96):
+    for tile in (16, 32, 96, 97):
         model.sdf_tile = tile
         runs = [fs.sampler_sdf(model, o, d, t_rand) for _ in range(5)]
         for r in runs[1:]:

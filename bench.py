@@ -405,7 +405,7 @@ def mapping_signature(rays=8192, frames=8, samples=98):
     return {"rays": rays, "keyframes": frames, "samples_per_ray": samples, "tiles": dict(sorted(DEFAULT_TILES.items()))}
 
 
-def mapping_leg(device, rays=8192, frames=8, iters=5, cpu=True):
+def mapping_leg(device, rays=8192, frames=8, iters=5, cpu=True, step_hook=None):
     """Context number, not `value`: one MAPPING iteration as the shipped Replica configuration runs it
     (code/confs/replica/runconf_replica_1.conf; volsdf_train.py:548-576): SLAMNetwork.forward(mode="mapping", stage "fine",
     colour stage "highfreq", use_warp_loss = true, mapping_patchsizes = [1], flow edges between neighbouring keyframes) ->
@@ -484,6 +484,8 @@ def mapping_leg(device, rays=8192, frames=8, iters=5, cpu=True):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / iters
     assert model.last_engine == "fused"
+    if step_hook is not None:          # tools/profile_mapping_host.py: the warmed-up iteration, handed out for a profiler
+        return step_hook(step)
     # per-kernel durations of one more iteration (event pairs on the launch stream) and the roofline of its dominant kernel
     import nicer_slam_amd.hashencoder.backend as be
     be.PROFILE = []

@@ -421,6 +421,22 @@ int nsa_masked_l1(const float *pred, const float *target, const uint8_t *mask, u
                   float *g_pred, float *workspace, nsa_stream_t stream);
 uint64_t nsa_masked_l1_workspace(uint64_t items);
 
+/* ---- Section 6: per-iteration input batch from frames resident in HBM ------------------------------------------------ */
+
+/* One field of the frame stores: store [capacity, pixels, channels] fp32, out [b, n, channels]. */
+typedef struct nsa_feed_field {
+    const float *store;
+    float *out;
+    uint32_t channels; /* 1..16 */
+} nsa_feed_field_t;
+
+/* out_f[i,k,:] = store_f[slots[i], sel[k], :] for every field (at most 8), uv[i,k] = (sel[k] % width, sel[k] / width) (uv may be
+ * NULL) in one launch.  slots: [b] int32 store slots of the batch's frames, sel: [n] int64 pixel indices (an index outside
+ * [0, pixels) yields NaN rows).  replaces SLAMDataset.__getitem__'s `[self.sampling_idx, :]` of every image + collate_fn
+ * (code/datasets/scene_dataset.py:214-275) for frames kept on the device (nicer_slam_amd/feed.py). */
+int nsa_feed_gather(const nsa_feed_field_t *fields, uint32_t n_fields, const int32_t *slots, uint32_t b, const int64_t *sel,
+                    uint32_t n, uint64_t pixels, uint32_t width, float *uv, nsa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,6 +134,16 @@ lib.nsa_pack_blocks.restype = _i
 lib.nsa_pack_blocks.argtypes = [_p, _p, ctypes.c_uint64, _p, ctypes.c_uint64, _p, ctypes.c_uint64, _p, _p]
 EXPORTS += ["nsa_pack_blocks"]
 
+
+class FeedField(ctypes.Structure):
+    """nsa_feed_field_t"""
+    _fields_ = [("store", _p), ("out", _p), ("channels", _u32)]
+
+
+lib.nsa_feed_gather.restype = _i
+lib.nsa_feed_gather.argtypes = [ctypes.POINTER(FeedField), _u32, _p, _u32, _p, _u32, ctypes.c_uint64, _u32, _p, _p]
+EXPORTS += ["nsa_feed_gather"]
+
 class LossDesc(ctypes.Structure):
     """nsa_loss_t"""
     _fields_ = ([("bs", _u32), ("n", _u32), ("S", _u32), ("E", _u32)]

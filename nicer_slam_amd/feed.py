@@ -4,7 +4,9 @@ The reference's dataset re-uploads the full RGB / mask / depth / normal / GT-dep
 with ``.cuda()`` on EVERY iteration and draws the pixel subset on the CPU (code/datasets/scene_dataset.py:214-257,
 change_sampling_idx :277-287): ~23 MB of PCIe traffic per frame per iteration to use 1024-8192 pixels.  Here every
 frame is uploaded once when it arrives and stays resident (680x1200: 26 MB per frame, 2000 frames = 52 GB of the
-288 GB; colour and metric depth in two contiguous stores that the patch-warp kernels index by slot); one iteration draws pixel indices with the device generator and gathers uv / GT with index_select.
+288 GB; every image kind in one contiguous store [capacity, H*W, C] that kernels index by slot); one iteration draws pixel
+indices with the device generator and gathers uv and all ground-truth fields of all frames of the batch in ONE launch
+(nsa_feed_gather, csrc/feed_gather.hip; on CPU tensors: one index_select per field).
 
 Output dictionaries have the reference's keys and shapes (collate_fn :259-275), so SLAMNetwork.forward and SLAMLoss
 consume them unchanged.  Image decoding / file layout stay with the caller (dataset tooling is out of scope).
@@ -13,6 +15,16 @@ import torch
 
 
 class FrameFeed:
+    FIELDS = (("rgb", 3), ("depth", 1), ("normal", 3), ("gt_depth", 1), ("mask", 1))     # ground-truth keys of collate_fn, channels
+
+    @property
+    def _store_rgb(self):
+        return self._stores["rgb"]
+
+    @property
+    def _store_depth(self):
+        return self._stores["gt_depth"]
+
     def __init__(self, img_res, device="cuda", scene_scale=1.0, capacity=8):
         self.H, self.W = int(img_res[0]), int(img_res[1])
         self.total_pixels = self.H * self.W
@@ -20,12 +32,11 @@ class FrameFeed:
         self.scene_scale = float(scene_scale)
         self.frames = {}
         self.sampling_idx = None
-        # full frames live in two stores ([capacity, H*W, 3] colour, [capacity, H*W, 1] metric depth already divided by
-        # scene_scale); a frame's tensors are views of its slot, so the re-projection kernels (fused/warp.py) can index the
-        # store by slot instead of receiving a per-iteration stacked copy (8 x 26 MB at 680x1200).
+        # full frames live in one store per image kind ([capacity, H*W, C]; metric depth already divided by scene_scale); a
+        # frame's tensors are views of its slot, so the batch gather (below) and the re-projection kernels (fused/warp.py) index
+        # the stores by slot instead of receiving a per-iteration stacked copy (8 x 26 MB at 680x1200).
         self.capacity = int(capacity)
-        self._store_rgb = torch.empty(self.capacity, self.total_pixels, 3, device=self.device)
-        self._store_depth = torch.empty(self.capacity, self.total_pixels, 1, device=self.device)
+        self._stores = {k: torch.empty(self.capacity, self.total_pixels, c, device=self.device) for k, c in self.FIELDS}
         self._slot = {}
         self._free = list(range(self.capacity - 1, -1, -1))
         self._index_cache = {}
@@ -41,12 +52,17 @@ class FrameFeed:
         to = lambda t, c: torch.as_tensor(t, dtype=torch.float32).reshape(n, c).to(self.device, non_blocking=True)
         depth = to(depth, 1)
         slot = self._take_slot(int(idx))
-        self._store_rgb[slot].copy_(to(rgb, 3))
-        self._store_depth[slot].copy_((to(gt_depth, 1) if gt_depth is not None else torch.ones_like(depth)) / self.scene_scale)
+        st = self._stores
+        st["rgb"][slot].copy_(to(rgb, 3))
+        st["depth"][slot].copy_(depth)
+        st["normal"][slot].copy_(to(normal, 3))
+        st["gt_depth"][slot].copy_((to(gt_depth, 1) if gt_depth is not None else torch.ones_like(depth)) / self.scene_scale)
+        if mask is not None:
+            st["mask"][slot].copy_(to(mask, 1))
+        else:
+            st["mask"][slot].fill_(1.0)
         self.frames[int(idx)] = {
-            "rgb": self._store_rgb[slot], "depth": depth, "normal": to(normal, 3),
-            "gt_depth": self._store_depth[slot],                          # already / scene_scale
-            "mask": to(mask, 1) if mask is not None else torch.ones_like(depth),
+            **{k: st[k][slot] for k, _ in self.FIELDS},                   # views of the slot; gt_depth already / scene_scale
             "intrinsics": torch.as_tensor(intrinsics, dtype=torch.float32).reshape(4, 4).to(self.device),
             "pose": torch.as_tensor(pose, dtype=torch.float32).reshape(4, 4).to(self.device).clone(),
         }
@@ -65,13 +81,13 @@ class FrameFeed:
         if not self._free:                                                # grow x2; frames re-point at the new storage
             old_cap = self.capacity
             self.capacity *= 2
-            for name in ("_store_rgb", "_store_depth"):
-                old = getattr(self, name)
+            for name, old in list(self._stores.items()):
                 new = torch.empty(self.capacity, *old.shape[1:], device=self.device)
                 new[:old_cap].copy_(old)
-                setattr(self, name, new)
+                self._stores[name] = new
             for i, sl in self._slot.items():
-                self.frames[i]["rgb"], self.frames[i]["gt_depth"] = self._store_rgb[sl], self._store_depth[sl]
+                for name, _ in self.FIELDS:
+                    self.frames[i][name] = self._stores[name][sl]
             self._free = list(range(self.capacity - 1, old_cap - 1, -1))
             self._index_cache.clear()
         self._slot[idx] = self._free.pop()
@@ -88,6 +104,38 @@ class FrameFeed:
                 self._index_cache.clear()
             self._index_cache[key] = hit
         return hit
+
+    def _indices_of(self, frame_ids):
+        """The batch's frame ids as a long tensor ON THE FEED'S DEVICE, cached per keyframe list like the slots: a per-iteration
+        `.cuda()` of a fresh host tensor (what the reference's loop does with collate_fn's indices) is a pageable upload, i.e. a full
+        device synchronisation at the head of every iteration -- it kept the host from running ahead and left the GPU idle for 1 ms of
+        every 14.5-ms mapping iteration (profiles/r04_mapping_host.txt)."""
+        key = ("ids",) + tuple(int(i) for i in frame_ids)
+        hit = self._index_cache.get(key)
+        if hit is None:
+            hit = torch.tensor(key[1:], dtype=torch.long, device=self.device)
+            if len(self._index_cache) > 64:
+                self._index_cache.clear()
+            self._index_cache[key] = hit
+        return hit
+
+    def _gather(self, frame_ids, sel):
+        """uv [b,n,2] and the ground-truth fields [b,n,C] of the batch's frames at the pixel indices ``sel`` [n]."""
+        slots = self._slots_of(frame_ids)
+        b, n = len(slots), int(sel.shape[0])
+        if self.device.type == "cuda":
+            import ctypes
+            from ._native import lib, check, FeedField
+            sel = sel.contiguous()
+            uv = torch.empty(b, n, 2, device=self.device)
+            gt = {k: torch.empty(b, n, c, device=self.device) for k, c in self.FIELDS}
+            fields = (FeedField * len(self.FIELDS))(*[FeedField(self._stores[k].data_ptr(), gt[k].data_ptr(), c) for k, c in self.FIELDS])
+            check(lib.nsa_feed_gather(fields, len(self.FIELDS), slots.data_ptr(), b, sel.data_ptr(), n, self.total_pixels, self.W,
+                                      uv.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream))
+            return uv, gt
+        flat = (slots.long().unsqueeze(1) * self.total_pixels + sel.unsqueeze(0)).reshape(-1)
+        gt = {k: self._stores[k].view(-1, c).index_select(0, flat).view(b, n, c) for k, c in self.FIELDS}
+        return self.uv.index_select(0, sel).unsqueeze(0).expand(b, -1, -1).contiguous(), gt
 
     # ------------------------------------------------------------------ sampling
     def change_sampling_idx(self, sampling_size, generator=None, total_pixels=None):
@@ -107,14 +155,14 @@ class FrameFeed:
         "store": fused/warp.py::FrameStore views of the resident stores + the batch's slot indices (no copy)."""
         fr = [self.frames[int(i)] for i in frame_ids]
         sel = self.sampling_idx
-        pick = (lambda t: t) if sel is None else (lambda t: t.index_select(0, sel))
-        stack = lambda key, f=pick: torch.stack([f(x[key]) for x in fr])
         b = len(fr)
-        model_input = {"uv": pick(self.uv).unsqueeze(0).expand(b, -1, -1).contiguous(),
-                       "intrinsics": torch.stack([x["intrinsics"] for x in fr]),
+        if sel is None:                                                   # whole images (visualisation)
+            uv = self.uv.unsqueeze(0).expand(b, -1, -1).contiguous()
+            gt = {k: torch.stack([x[k] for x in fr]) for k, _ in self.FIELDS}
+        else:
+            uv, gt = self._gather(frame_ids, sel)
+        model_input = {"uv": uv, "intrinsics": torch.stack([x["intrinsics"] for x in fr]),
                        "pose": torch.stack([x["pose"] for x in fr])}
-        gt = {"rgb": stack("rgb"), "mask": stack("mask"), "depth": stack("depth"), "normal": stack("normal"),
-              "gt_depth": stack("gt_depth")}
         if sel is not None:
             model_input["sampling_idx"] = sel.unsqueeze(0).expand(b, -1)
             if full == "store":
@@ -124,4 +172,4 @@ class FrameFeed:
             else:
                 gt["full_rgb"] = torch.stack([x["rgb"] for x in fr])
                 gt["full_depth"] = torch.stack([x["gt_depth"] for x in fr])
-        return torch.as_tensor([int(i) for i in frame_ids], dtype=torch.long), model_input, gt
+        return self._indices_of(frame_ids), model_input, gt

@@ -12,6 +12,13 @@ from .._native import lib, check, WarpDesc
 from ..hashencoder.backend import _timed
 
 
+def _inv(pose):
+    """torch.inverse of the [b,4,4] poses (code/model/network.py:156-157, 190-191) without torch.linalg.inv's error check: that check
+    reads the LU status back (`info.any().item()`), a device synchronisation in the middle of every mapping forward.  Same factorisation,
+    same values and gradient; a singular pose yields inf / nan instead of raising."""
+    return torch.linalg.inv_ex(pose).inverse
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -183,7 +190,7 @@ def patch_warp(model, uv, pose, intrinsics, rendered_depth, ground_truth, batch_
     depths, _ = _frames(ground_truth["full_depth"]) if "full_depth" in ground_truth else (None, None)
     images = images.to(uv.device, torch.float32).contiguous()
     depths = None if depths is None else depths.to(uv.device, torch.float32).contiguous()
-    w2c = torch.linalg.inv(pose)                                     # network.py:190-191
+    w2c = _inv(pose)                                                 # network.py:190-191
     K = intrinsics.to(uv.device)
     out = {}
     for ps in model.patchsizes:
@@ -196,5 +203,5 @@ def patch_warp(model, uv, pose, intrinsics, rendered_depth, ground_truth, batch_
 
 def flow(model, uv, pose, intrinsics, rendered_depth, edges):
     idii, idjj = edges[0], edges[1]
-    w2c = torch.linalg.inv(pose)                                     # network.py:156-157 (inverse of every pose, gathered in-kernel)
+    w2c = _inv(pose)                                                 # network.py:156-157 (inverse of every pose, gathered in-kernel)
     return _Flow.apply(rendered_depth, pose, w2c, uv, intrinsics.to(uv.device), idii, idjj, model.H, model.W)

@@ -76,3 +76,32 @@ def check_feed_against_reference(device):
 
 def test_frame_feed_vs_reference_dataset_batches():
     check_feed_against_reference("cpu")
+
+
+def test_frame_feed_store_growth_drop_and_slot_reuse():
+    """Frames stay addressable while the stores grow past their capacity, a dropped frame's slot is reused, and a batch returns the
+    right rows of the right frames (the CPU path of FrameFeed._gather: one flat index_select per field)."""
+    from nicer_slam_amd.feed import FrameFeed
+    H, W = 17, 23
+    g = torch.Generator().manual_seed(0)
+    feed = FrameFeed((H, W), device="cpu", capacity=2)
+    src = {}
+    for idx in (5, 9, 2, 11, 7):
+        src[idx] = dict(rgb=torch.rand(H * W, 3, generator=g), depth=torch.rand(H * W, 1, generator=g),
+                        normal=torch.rand(H * W, 3, generator=g), gt_depth=torch.rand(H * W, 1, generator=g),
+                        mask=(torch.rand(H * W, 1, generator=g) > 0.3).float(), intrinsics=torch.eye(4), pose=torch.eye(4))
+        feed.add_frame(idx, **src[idx])
+    assert feed.capacity == 8
+    feed.drop_frame(9)
+    src[4] = dict(src[5], rgb=torch.rand(H * W, 3, generator=g))
+    feed.add_frame(4, **src[4])
+    assert len(set(feed._slot.values())) == 5
+    sel = feed.change_sampling_idx(301, generator=torch.Generator().manual_seed(3))
+    ids = [7, 4, 5, 11, 2]
+    indices, inp, gt = feed.batch(ids)
+    assert indices.tolist() == ids and indices.dtype == torch.long
+    assert feed.batch(ids)[0] is indices                                 # cached: no per-iteration upload
+    for i, fid in enumerate(ids):
+        for k in ("rgb", "depth", "normal", "gt_depth", "mask"):
+            assert torch.equal(gt[k][i], src[fid][k][sel]), (fid, k)
+            assert torch.equal(feed.frames[fid][k], src[fid][k])

@@ -23,7 +23,9 @@ static __device__ unsigned long long* g_ts_s = nullptr;
 #define STS_MARK(slot) { const unsigned long long t_ = ts_now(); ts_add(slot, t_ - ts_prev); ts_prev = t_; }
 #define STS_END { ts_add(15, ts_now() - ts_start); if (g_ts_s && (threadIdx.x & 63) == 0) { \
     unsigned long long* o_ = g_ts_s + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16; \
-    for (int i = 0; i < 16; ++i) o_[i] = nsa_ts_lds[threadIdx.x >> 6][i]; } }
+    for (int i = 0; i < 16; ++i) o_[i] = nsa_ts_lds[threadIdx.x >> 6][i]; \
+    o_[0] = ts_start; o_[1] = ts_now(); /* absolute: slot timeline (tools/slot_timeline.py) */ \
+    o_[2] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) | ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32); } }
 #else
 #define STS_BEGIN
 #define STS_MARK(slot)

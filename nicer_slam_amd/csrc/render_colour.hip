@@ -256,10 +256,24 @@ __global__ __launch_bounds__(256, NSA_OCC_COL_FWD) void k_colour_fwd(ColourArgs 
     }
 }
 
+#ifdef NSA_X_TS      // profiling build only (tools/ts_profile.py --colour)
+static __device__ unsigned long long* g_ts_c = nullptr;
+#define CTS_BEGIN const unsigned long long ts_start = ts_now(); unsigned long long ts_prev = ts_start; \
+    if ((threadIdx.x & 63) == 0) for (int i = 0; i < 16; ++i) nsa_ts_lds[threadIdx.x >> 6][i] = 0;
+#define CTS_MARK(slot) { const unsigned long long t_ = ts_now(); ts_add(slot, t_ - ts_prev); ts_prev = t_; }
+#define CTS_END { ts_add(15, ts_now() - ts_start); if (g_ts_c && (threadIdx.x & 63) == 0) { \
+    unsigned long long* o_ = g_ts_c + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16; \
+    for (int i = 0; i < 16; ++i) o_[i] = nsa_ts_lds[threadIdx.x >> 6][i]; } }
+#else
+#define CTS_BEGIN
+#define CTS_MARK(slot)
+#define CTS_END
+#endif
 template <bool MAP>
 __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 geom) {
     using Seq = ColOps<true>;
     __shared__ __attribute__((aligned(16))) float stage[2 * kColStage];
+    CTS_BEGIN
     stage_issue_op(a.wp, Seq::op(0), stage);
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
@@ -278,9 +292,11 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
     for (int d = 0; d < 3; ++d) dir[d] = a.src.rays_d[ray * 3 + d];
     float in[COL_IN_STEPS];
     colour_inputs(a, geom, tile, q, lane, h, x, dir, in, true, wave_live);
+    CTS_MARK(4)
     f32x16 a1[2], a2[2];
     float rgb[3];
     colour_mlp<Seq, true>(stage, a.wp, lane, h, in, a1, a2, rgb);
+    CTS_MARK(5)
     const bool emit = MAP && a.emit != nullptr && wave_live;
     const ColEmitter em{emit ? a.emit + (size_t)tile * 32 + (lane & 31) : nullptr, a.emit_ld, live};
     if (emit) {
@@ -322,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
 #pragma unroll
         for (int q = 0; q < HS; ++q) em.hid(CE_AB2, q, h, ab[q]);
     }
+    CTS_MARK(6)
     {
         f32x16 acc[2];
 #pragma unroll
@@ -338,6 +355,7 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
 #pragma unroll
         for (int q = 0; q < HS; ++q) em.hid(CE_AB1, q, h, ab[q]);
     }
+    CTS_MARK(7)
     float ib[80];
     {
         f32x16 a5[5];
@@ -352,6 +370,7 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
 #pragma unroll
             for (int r = 0; r < 16; ++r) ib[16 * t + r] = a5[t][r];
     }
+    CTS_MARK(8)
     // feature cotangent -> HL
     float* fdst = a.g_feat + (size_t)tile * 32 * 64 + lane;
     if (wave_live) {
@@ -371,6 +390,7 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
         gd[g0 % 3] += h ? 0.0f : t;
         gd[g1 % 3] += h ? t : 0.0f;
     }
+    CTS_MARK(9)
     if (a.grid_grad) {   // x += J^T fbar / (2 df) with the Jacobian saved by the forward pass
         const float* sv = a.save + (size_t)tile * 64 * 64 + lane;
         const float chain = 1.0f / (2.0f * a.divide_factor);
@@ -382,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
                 for (int c = 0; c < CC; ++c)
                     gx[d] = fmaf(sv[(16 + (jl * 3 + d) * CC + c) * 64] * chain, ib[49 + jl * CC + c], gx[d]);
     }
+    CTS_MARK(10)
     if (MAP && a.grid_grad && a.g_table) {   // colour-table gradient: w_corner * fbar, run-merged (kernel_grid_backward)
         float u[3];
 #pragma unroll
@@ -432,9 +453,17 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
             a.g_grad[(size_t)q * 3 + d] += gg[d];
         }
     }
+    CTS_MARK(11)
+    CTS_END
 }
 
 }  // namespace nsa
+
+#if defined(NSA_X_TS) && NSA_PIECES == 3
+extern "C" int nsa_debug_set_ts_colour(unsigned long long* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(nsa::g_ts_c), &p, sizeof(p)) == hipSuccess ? 0 : 3;
+}
+#endif
 
 // Entry-point naming: this file is compiled twice -- as is (fp32-faithful GEMMs) and through *_bf16.hip with
 // NSA_PIECES = 1, `nsa` renamed and every entry point suffixed _bf16; the fp32 entry points forward to those when

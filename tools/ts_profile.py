@@ -56,6 +56,24 @@ def main():
     for k, name in SLOTS_BWD.items():
         v = t[:, k].mean().item()
         print(f"  slot {k:2d}  {v:9.0f}  {100 * v / tot:5.1f} %   {name}")
+    # the colour backward (32-point tiles, 4-wave workgroups, staged weights)
+    if hasattr(lib, "nsa_debug_set_ts_colour"):
+        n_c = 131072 // 32
+        bufc = torch.zeros((n_c + 64) * 16, dtype=torch.int64, device=dev)
+        lib.nsa_debug_set_ts_colour.argtypes = [ctypes.c_void_p]
+        assert lib.nsa_debug_set_ts_colour(bufc.data_ptr()) == 0
+        tr.step(*batches[5])
+        torch.cuda.synchronize()
+        lib.nsa_debug_set_ts_colour(None)
+        t = bufc.view(-1, 16)[:n_c].double()
+        tot = t[:, 15].mean().item()
+        print(f"k_colour_bwd: waves {n_c}  mean wave lifetime {tot:.0f} cycles (min {t[:, 15].min().item():.0f}, max {t[:, 15].max().item():.0f})")
+        for k, name in {0: "   of which stage_wait: vmcnt(0)", 1: "   of which stage_wait: barrier", 4: "point, dir, saved features -> inputs",
+                        5: "MLP recompute (3 staged GEMMs)", 6: "d/d pre-sigmoid, d/d h2 (VALU)", 7: "W1^T GEMM", 8: "W0^T GEMM (2 parts)",
+                        9: "feature-cotangent store, PE / direction terms", 10: "Jacobian loads (save area) + d/dx", 11: "half sums + stores",
+                        15: "whole kernel"}.items():
+            v = t[:, k].mean().item()
+            print(f"  slot {k:2d}  {v:9.0f}  {100 * v / tot:5.1f} %   {name}")
     # the sampler (two 32-point tiles per wave)
     n_s = 1024 * 640 // 64
     buf2 = torch.zeros((n_s + 64) * 16, dtype=torch.int64, device=dev)

@@ -145,7 +145,8 @@ int nsa_sdfnet_backward_pair(const nsa_points_t *pts, const nsa_grid_t *coarse, 
 int nsa_rays_forward(const float *uv, const float *pose, const float *K, uint32_t b, uint32_t n, float *rays_o,
                      float *rays_d, float *depth_scale, nsa_stream_t stream);
 
-/* Backward of the above to the camera-to-world matrices: g_pose[b,4,4] (overwritten; bottom row zero). */
+/* Backward of the above to the camera-to-world matrices: g_pose[b,4,4] (overwritten; bottom row zero).  Deterministic: one
+ * workgroup per image, fixed-order sums, no atomics. */
 int nsa_rays_pose_backward(const float *uv, const float *pose, const float *K, uint32_t b, uint32_t n,
                            const float *g_rays_o, const float *g_rays_d, float *g_pose, nsa_stream_t stream);
 

@@ -1,7 +1,7 @@
 // render_rays.hip -- pixel -> ray lifting and its backward to the camera-to-world matrix.
 // Reference: rend_util.get_camera_params + lift (code/utils/rend_util.py:68-93,107-129) and the identity-pose second
 // call that yields depth_scale (code/model/network.py:99-102).  One thread per ray; the backward reduces
-// d/d(pose[:3,:3]) = sum_rays vbar c^T and d/d(pose[:3,3]) = sum_rays obar with wave reductions + 12 atomics per wave.
+// d/d(pose[:3,:3]) = sum_rays vbar c^T and d/d(pose[:3,3]) = sum_rays obar per image in a fixed order (no atomics).
 #include "grid_common.hpp"
 
 namespace nsa {
@@ -16,7 +16,7 @@ struct RaysArgs {
     float* depth_scale;  // [b*n]     z component of the identity-pose ray
     const float* g_o;    // [b*n,3]
     const float* g_d;    // [b*n,3]
-    float* g_pose;       // [b,4,4] pre-zeroed
+    float* g_pose;       // [b,4,4] overwritten
 };
 
 __device__ __forceinline__ void lift_pixel(const float* __restrict__ K, float u, float v, float (&c)[3]) {
@@ -46,46 +46,56 @@ __global__ __launch_bounds__(256) void k_rays_fwd(RaysArgs a) {
     a.depth_scale[r] = c[2] / (c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
 }
 
-__global__ __launch_bounds__(256) void k_rays_pose_bwd(RaysArgs a) {
-    const uint32_t r0 = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t total = a.b * a.n;
-    const bool live = r0 < total;
-    const uint32_t r = live ? r0 : total - 1;
-    const uint32_t bi = r / a.n;
+// One workgroup per image, every sum in a fixed order (thread t adds rays t, t + 1024, ...; butterfly over the lanes; waves in wave
+// order): the camera gradient of the eager autograd path is reproducible to the bit, like the kernel tracker's (track_tail.hip).
+// (Until round 4: one thread per ray and 12 atomics per wave -- run-to-run differences in the last bits of the pose gradient, which
+// an optimizer step turns into last-bit differences of every later iteration.)
+constexpr int POSE_BWD_W = 16;
+__global__ __launch_bounds__(64 * POSE_BWD_W) void k_rays_pose_bwd(RaysArgs a) {
+    __shared__ float part[POSE_BWD_W][12];
+    const uint32_t bi = blockIdx.x;
     const float* P = a.pose + bi * 16;
-    float c[3];
-    lift_pixel(a.K + bi * 16, a.uv[2 * r], a.uv[2 * r + 1], c);
-    float v[3], gd[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float w = P[4 * k] * c[0] + P[4 * k + 1] * c[1] + P[4 * k + 2] * c[2] + P[4 * k + 3];
-        v[k] = w - P[4 * k + 3];
-        gd[k] = live ? a.g_d[3 * r + k] : 0.0f;
-    }
-    const float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-    const float vg = v[0] * gd[0] + v[1] * gd[1] + v[2] * gd[2];
+    const float* Kb = a.K + bi * 16;
     float acc[12];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float vb = gd[k] / s - 2.0f * v[k] * vg / (s * s);     // d = v / (v.v)
+    for (int q = 0; q < 12; ++q) acc[q] = 0.0f;
+    for (uint32_t i = threadIdx.x; i < a.n; i += 64 * POSE_BWD_W) {
+        const uint32_t r = bi * a.n + i;
+        float c[3];
+        lift_pixel(Kb, a.uv[2 * r], a.uv[2 * r + 1], c);
+        float v[3], gd[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[4 * k + j] = vb * c[j];
-        acc[4 * k + 3] = live ? a.g_o[3 * r + k] : 0.0f;             // cam_loc = pose[:3,3]; (w - cam_loc) cancels
-    }
-    // all rays of a wave belong to one image when n % 64 == 0; otherwise fall back to per-lane atomics
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t first = __shfl(bi, 0), last = __shfl(bi, 63);
-    if (first == last) {
-#pragma unroll
-        for (int q = 0; q < 12; ++q) {
-            float x = acc[q];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-            if (lane == 0) atomicAdd(a.g_pose + bi * 16 + q, x);
+        for (int k = 0; k < 3; ++k) {
+            const float w = P[4 * k] * c[0] + P[4 * k + 1] * c[1] + P[4 * k + 2] * c[2] + P[4 * k + 3];
+            v[k] = w - P[4 * k + 3];
+            gd[k] = a.g_d[3 * r + k];
         }
-    } else if (live) {
+        const float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+        const float vg = v[0] * gd[0] + v[1] * gd[1] + v[2] * gd[2];
 #pragma unroll
-        for (int q = 0; q < 12; ++q) atomicAdd(a.g_pose + bi * 16 + q, acc[q]);
+        for (int k = 0; k < 3; ++k) {
+            const float vb = gd[k] / s - 2.0f * v[k] * vg / (s * s);     // d = v / (v.v)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[4 * k + j] += vb * c[j];
+            acc[4 * k + 3] += a.g_o[3 * r + k];                          // cam_loc = pose[:3,3]; (w - cam_loc) cancels
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        float x = acc[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        if (lane == 0) part[wv][q] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float g = 0.0f;
+        if (threadIdx.x < 12) {
+#pragma unroll
+            for (int w = 0; w < POSE_BWD_W; ++w) g += part[w][threadIdx.x];
+        }
+        a.g_pose[bi * 16 + threadIdx.x] = g;                              // bottom row: zero
     }
 }
 
@@ -109,11 +119,11 @@ int nsa_rays_pose_backward(const float* uv, const float* pose, const float* K, u
     using namespace nsa;
     if (!g_pose) return NSA_EBADARG;
     launch_begin();
-    if (hipMemsetAsync(g_pose, 0, sizeof(float) * 16 * b, (hipStream_t)stream) != hipSuccess) return NSA_ELAUNCH;
-    if (b * n == 0) return NSA_OK;
+    if (b == 0) return NSA_OK;
+    if (n == 0) return hipMemsetAsync(g_pose, 0, sizeof(float) * 16 * b, (hipStream_t)stream) == hipSuccess ? NSA_OK : NSA_ELAUNCH;
     if (!uv || !pose || !K || !g_rays_o || !g_rays_d) return NSA_EBADARG;
     RaysArgs a{uv, pose, K, b, n, nullptr, nullptr, nullptr, g_rays_o, g_rays_d, g_pose};
-    hipLaunchKernelGGL(k_rays_pose_bwd, dim3((b * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_rays_pose_bwd, dim3(b), dim3(64 * POSE_BWD_W), 0, (hipStream_t)stream, a);
     return launch_end();
 }
 

@@ -130,15 +130,6 @@ int nsa_sdfnet_backward(const nsa_points_t *pts, const nsa_grid_t *grid, const f
                         const float *g_feat_hl, const float *g_grad, int accumulate, float *g_x,
                         nsa_stream_t stream);
 
-/* Both networks' data-path backward in ONE launch: what nsa_sdfnet_backward(coarse, accumulate) followed by
- * nsa_sdfnet_backward(fine, accumulate 1) leave in g_x, bit for bit, for the quad tiling (both descriptors tile == 16 with
- * their quad packs, the same precision).  Both networks receive the same cotangents (the COMBINE adds their outputs,
- * code/model/base_networks.py:33-47); point, positional encoding, level geometry and g_x are handled once. */
-int nsa_sdfnet_backward_pair(const nsa_points_t *pts, const nsa_grid_t *coarse, const nsa_grid_t *fine,
-                             const float *packed_coarse, const float *packed_fine, const float *g_sdf,
-                             const float *g_feat_hl, const float *g_grad, int accumulate, float *g_x,
-                             nsa_stream_t stream);
-
 /* Pixels -> rays for b images x n pixels: rays_o[b*n,3] = pose[:3,3], rays_d = (p - o)/|p - o|^2 (NOT unit length),
  * depth_scale[b*n] = z of the identity-pose direction.  replaces rend_util.get_camera_params + lift
  * (code/utils/rend_util.py:68-93,107-129), both calls of code/model/network.py:98-102. */

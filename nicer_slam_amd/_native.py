@@ -71,8 +71,6 @@ lib.nsa_sdfnet_forward.restype = _i
 lib.nsa_sdfnet_forward.argtypes = [_pp, _gp, _p, _i, _p, _p, _p, _p]
 lib.nsa_sdfnet_forward_pair.restype = _i
 lib.nsa_sdfnet_forward_pair.argtypes = [_pp, _gp, _gp, _p, _p, _p, _p, _p, _p]
-lib.nsa_sdfnet_backward_pair.restype = _i
-lib.nsa_sdfnet_backward_pair.argtypes = [_pp, _gp, _gp, _p, _p, _p, _p, _p, _i, _p, _p]
 lib.nsa_sdfnet_backward.restype = _i
 lib.nsa_sdfnet_backward.argtypes = [_pp, _gp, _p, _p, _p, _p, _i, _p, _p]
 lib.nsa_colour_forward.restype = _i
@@ -99,7 +97,7 @@ lib.nsa_sdfnet_emit_rows_tile.restype = _i
 lib.nsa_sdfnet_emit_rows_tile.argtypes = [_u32, _u32]
 EXPORTS += ["nsa_sdfnet_backward_params", "nsa_colour_backward_params", "nsa_sdfnet_emit_rows", "nsa_colour_emit_rows",
             "nsa_sdfnet_emit_rows_nh", "nsa_sdfnet_emit_rows_tile"]
-EXPORTS += ["nsa_sdfnet_forward", "nsa_sdfnet_forward_pair", "nsa_sdfnet_backward", "nsa_sdfnet_backward_pair", "nsa_colour_forward", "nsa_colour_backward",
+EXPORTS += ["nsa_sdfnet_forward", "nsa_sdfnet_forward_pair", "nsa_sdfnet_backward", "nsa_colour_forward", "nsa_colour_backward",
             "nsa_composite_forward", "nsa_composite_backward", "nsa_rays_backward"]
 
 lib.nsa_rays_forward.restype = _i

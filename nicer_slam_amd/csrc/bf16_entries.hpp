@@ -5,7 +5,6 @@ extern "C" {
 int nsa_sdfnet_forward_bf16(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, int accumulate, float* sdf, float* grad, float* feat_hl, nsa_stream_t stream);
 int nsa_sdfnet_forward_pair_bf16(const nsa_points_t* pts, const nsa_grid_t* coarse, const nsa_grid_t* fine, const float* packed_coarse, const float* packed_fine, float* sdf, float* grad, float* feat_hl, nsa_stream_t stream);
 int nsa_sdfnet_backward_bf16(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* g_sdf, const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x, nsa_stream_t stream);
-int nsa_sdfnet_backward_pair_bf16(const nsa_points_t* pts, const nsa_grid_t* coarse, const nsa_grid_t* fine, const float* packed_coarse, const float* packed_fine, const float* g_sdf, const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x, nsa_stream_t stream);
 int nsa_sdfnet_backward_params_bf16(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* g_sdf, const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x, float* g_table, float* emit, uint32_t emit_ld, nsa_stream_t stream);
 int nsa_colour_forward_bf16(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad, const float* feat_hl, float* rgb, float* save, nsa_stream_t stream);
 int nsa_colour_backward_bf16(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad, const float* feat_hl, const float* save, const float* g_rgb, int grid_grad, float* g_feat_hl, float* g_grad, float* g_x, float* g_dir, nsa_stream_t stream);

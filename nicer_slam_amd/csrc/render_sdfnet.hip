@@ -494,21 +494,6 @@ int NSA_ENTRY(nsa_sdfnet_backward)(const nsa_points_t* pts, const nsa_grid_t* gr
     return launch_sdfnet(true, grid, a, (hipStream_t)stream);
 }
 
-int NSA_ENTRY(nsa_sdfnet_backward_pair)(const nsa_points_t* pts, const nsa_grid_t* coarse, const nsa_grid_t* fine,
-                             const float* packed_coarse, const float* packed_fine, const float* g_sdf, const float* g_feat_hl,
-                             const float* g_grad, int accumulate, float* g_x, nsa_stream_t stream) {
-#if NSA_PIECES == 3
-    if (coarse && fine && coarse->precision == 1 && fine->precision == 1)
-        return nsa_sdfnet_backward_pair_bf16(pts, coarse, fine, packed_coarse, packed_fine, g_sdf, g_feat_hl, g_grad, accumulate, g_x, stream);
-#endif
-    using namespace nsa;
-    if (!pts || !coarse || !fine || !packed_coarse || !packed_fine || !g_x) return NSA_EBADARG;
-    if (pts->P == 0) return NSA_OK;
-    if (!pts->points && (!pts->rays_o || !pts->rays_d || !pts->z_vals || pts->S == 0)) return NSA_EBADARG;
-    if (coarse->tile != 16 || fine->tile != 16 || coarse->precision != fine->precision) return NSA_EBADARG;   // quad packs, one precision
-    return NSA_ENTRY(nsa_sdfnet4_backward_pair)(pts, coarse, fine, packed_coarse, packed_fine, g_sdf, g_feat_hl, g_grad, accumulate, g_x, stream);
-}
-
 int NSA_ENTRY(nsa_sdfnet_backward_params)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* g_sdf,
                                const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x, float* g_table,
                                float* emit, uint32_t emit_ld, nsa_stream_t stream) {

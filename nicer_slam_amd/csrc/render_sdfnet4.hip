@@ -366,130 +366,11 @@ __global__ __launch_bounds__(64 * NSA_NW4_PAIR, NSA_OCC4_FWD) void k_sdfnet4_fwd
     }
 }
 
-// One network's backward for this lane's point (recompute, reverse pass, tangent sweep, reverse sweep: GEMMs op0 .. op0 + 4 NH of Seq).
-// In: the first-layer slots `in`, the grid Jacobian behind `jstore`, the cotangents of this network's outputs (`g_grad`, `g_sdf`, `g_feat`
-// may be null = zero).  Out: hb0 = cotangent of the first-layer slots, dl = dh_0 of the reverse pass, nbar = the grad-sdf cotangent it
-// loaded, xb2 = the tangent's direct term in x.  `s0` / `s1`: the packed blocks a two-network sequence stages from (null: `wp`).
-template <int L, int C, int NH, class Seq>
-__device__ __forceinline__ void net_backward4(float* stage, int op0, const float* __restrict__ wp, const float* __restrict__ s0,
-                                              const float* __restrict__ s1, int lane, int q, float divide_factor, float* jstore,
-                                              const float (&in)[QIN], uint32_t pt, const float* __restrict__ g_sdf,
-                                              const float* __restrict__ g_grad, const float* __restrict__ fsrc, const Emitter4* em,
-                                              float (&hb0)[QIN], float (&dl)[QIN], float (&nbar)[3], float (&xb2)[3]
-#ifdef NSA_X_TS
-                                              , unsigned long long& ts_prev
-#endif
-                                              ) {
-    using P = SdfPack4<NH>;
-    using E = SE4<NH>;
-    if (!s0) s0 = wp;
-    float sg[NH][QHS], hl[QHS];
-    hidden_forward4<NH, Seq>(stage, op0, wp, lane, q, in, sg, hl, em, s0, s1);
-    TS_MARK(6)
-    float dh[NH > 1 ? NH - 1 : 1][QHS];
-    reverse_pass4<NH, Seq>(stage, op0 + NH, wp, lane, q, sg, dh, dl, em, s0, s1);
-    TS_MARK(7)
-    if (em) {
-#pragma unroll
-        for (int s = 0; s < QIN; ++s) em->slot(E::H0, s, q, in[s]);
-    }
-
-#pragma unroll
-    for (int d = 0; d < 3; ++d) nbar[d] = g_grad ? g_grad[(size_t)pt * 3 + d] : 0.0f;
-    const float sbar = g_sdf ? g_sdf[pt] : 0.0f;
-
-    // ---- tangent sweep: e_k = sp''(a_k) dh_k ta_k (kept in e[k-1]) ----
-    float e[NH][QHS];
-    {
-        float tin[QIN];
-        tangent_from_jac4<L, C>(divide_factor, jstore, q, in, nbar, dl, tin, xb2);
-        if (em) {
-#pragma unroll
-            for (int s = 0; s < QIN; ++s) em->slot(E::TIN, s, q, tin[s]);
-        }
-        f32x4v acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        gemm16_staged<Seq, Seq::NW, Seq::BUF, QIN_G, 4>(stage, s0, op0 + 2 * NH, lane, tin, acc, s1);
-        f32x4v ws[4];
-        load_vec16(wp + P::kWSDF, q, ws);
-        float th[QHS];
-#pragma unroll
-        for (int k = 1; k <= NH; ++k) {
-#pragma unroll
-            for (int s = 0; s < QHS; ++s) {
-                const float s1v = sg[k - 1][s];
-                const float s2 = 100.0f * s1v * (1.0f - s1v);        // 0 in the linear region (s1 == 1)
-                const float dhk = (k == NH) ? ws[s >> 2][s & 3] : dh[k - 1][s];
-                const float ta = acc[s >> 2][s & 3];
-                e[k - 1][s] = s2 * dhk * ta;
-                th[s] = s1v * ta;
-                if (em) em->hid(E::TH(k), s, q, th[s]);
-            }
-            if (k < NH) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-                gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, s0, op0 + 2 * NH + k, lane, th, acc, s1);
-            }
-        }
-    }
-    TS_MARK(8)
-    // ---- reverse sweep ----
-    float ab[QHS];
-    {
-        float fb[QHS];
-#pragma unroll
-        for (int s = 0; s < QHS; ++s) fb[s] = fsrc ? fsrc[hl_step4(s)] : 0.0f;
-        if (em) {
-#pragma unroll
-            for (int s = 0; s < QHS; ++s) em->hid(E::FB, s, q, fb[s]);
-        }
-        f32x4v acc[4], ws[4];
-        load_vec16(wp + P::kWSDF, q, ws);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)        // (element by element: a vector * scalar here becomes v_pk_mul_f32, see build.py::isa_check)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[t][r] = sbar * ws[t][r];
-        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, s0, op0 + 3 * NH, lane, fb, acc, s1);
-#pragma unroll
-        for (int s = 0; s < QHS; ++s) ab[s] = sg[NH - 1][s] * acc[s >> 2][s & 3] + e[NH - 1][s];
-    }
-#pragma unroll
-    for (int k = NH - 1; k >= 1; --k) {
-        if (em) {
-#pragma unroll
-            for (int s = 0; s < QHS; ++s) em->hid(E::AB(k + 1), s, q, ab[s]);
-        }
-        f32x4v acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, s0, op0 + 3 * NH + 1 + (NH - 1 - k), lane, ab, acc, s1);
-#pragma unroll
-        for (int s = 0; s < QHS; ++s) ab[s] = sg[k - 1][s] * acc[s >> 2][s & 3] + e[k - 1][s];
-    }
-    if (em) {
-#pragma unroll
-        for (int s = 0; s < QHS; ++s) em->hid(E::AB(1), s, q, ab[s]);
-    }
-    TS_MARK(9)
-    {
-        f32x4v a6[6];
-#pragma unroll
-        for (int t = 0; t < 6; ++t) a6[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 6>(stage, s0, op0 + 4 * NH, lane, ab, a6, s1);
-#pragma unroll
-        for (int s = 0; s < QIN; ++s) hb0[s] = a6[s >> 2][s & 3];
-    }
-}
-#ifdef NSA_X_TS
-#define TS_ARG , ts_prev
-#else
-#define TS_ARG
-#endif
-
 template <int L, int C, int NH, bool MAP>
 __global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd(SdfNet4Args a, GridGeom16 geom) {
+    using P = SdfPack4<NH>;
     using Seq = SdfOps4<NH, true>;
+    using E = SE4<NH>;
     TS_BEGIN
     __shared__ __attribute__((aligned(16))) float stage[2 * Seq::BUF];
     __shared__ LevelGeom s_geom[16];
@@ -519,10 +400,108 @@ __global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd(
     grid_slots4<L, C>(x, a.divide_factor, a.table, s_geom, q, in, jstore);
     const bool emit = MAP && a.emit != nullptr && wave_live;   // (a clamped wave must not touch the last tile's rows)
     const Emitter4 em{emit ? a.emit + (size_t)tile * 16 + j : nullptr, a.emit_ld, live};
+    float sg[NH][QHS], hl[QHS];
     TS_MARK(5)
-    float hb0[QIN], dl[QIN], nbar[3], xb2[3];
-    net_backward4<L, C, NH, Seq>(stage, 0, a.wp, nullptr, nullptr, lane, q, a.divide_factor, jstore, in, pt, a.g_sdf, a.g_grad,
-                                 a.g_feat ? a.g_feat + hl_base4(tile, j, q) : nullptr, emit ? &em : nullptr, hb0, dl, nbar, xb2 TS_ARG);
+    hidden_forward4<NH, Seq>(stage, 0, a.wp, lane, q, in, sg, hl, emit ? &em : nullptr);
+    TS_MARK(6)
+    float dh[NH > 1 ? NH - 1 : 1][QHS], dl[QIN];
+    reverse_pass4<NH, Seq>(stage, NH, a.wp, lane, q, sg, dh, dl, emit ? &em : nullptr);
+    TS_MARK(7)
+    if (emit) {
+#pragma unroll
+        for (int s = 0; s < QIN; ++s) em.slot(E::H0, s, q, in[s]);
+    }
+
+    float nbar[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) nbar[d] = a.g_grad ? a.g_grad[(size_t)pt * 3 + d] : 0.0f;
+    const float sbar = a.g_sdf ? a.g_sdf[pt] : 0.0f;
+
+    // ---- tangent sweep: e_k = sp''(a_k) dh_k ta_k (kept in e[k-1]) ----
+    float e[NH][QHS];
+    float xb2[3];
+    {
+        float tin[QIN];
+        tangent_from_jac4<L, C>(a.divide_factor, jstore, q, in, nbar, dl, tin, xb2);
+        if (emit) {
+#pragma unroll
+            for (int s = 0; s < QIN; ++s) em.slot(E::TIN, s, q, tin[s]);
+        }
+        f32x4v acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        gemm16_staged<Seq, Seq::NW, Seq::BUF, QIN_G, 4>(stage, a.wp, 2 * NH, lane, tin, acc);
+        f32x4v ws[4];
+        load_vec16(a.wp + P::kWSDF, q, ws);
+        float th[QHS];
+#pragma unroll
+        for (int k = 1; k <= NH; ++k) {
+#pragma unroll
+            for (int s = 0; s < QHS; ++s) {
+                const float s1 = sg[k - 1][s];
+                const float s2 = 100.0f * s1 * (1.0f - s1);          // 0 in the linear region (s1 == 1)
+                const float dhk = (k == NH) ? ws[s >> 2][s & 3] : dh[k - 1][s];
+                const float ta = acc[s >> 2][s & 3];
+                e[k - 1][s] = s2 * dhk * ta;
+                th[s] = s1 * ta;
+                if (emit) em.hid(E::TH(k), s, q, th[s]);
+            }
+            if (k < NH) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+                gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, a.wp, 2 * NH + k, lane, th, acc);
+            }
+        }
+    }
+    TS_MARK(8)
+    // ---- reverse sweep ----
+    float ab[QHS];
+    {
+        float fb[QHS];
+        const float* fsrc = a.g_feat ? a.g_feat + hl_base4(tile, j, q) : nullptr;
+#pragma unroll
+        for (int s = 0; s < QHS; ++s) fb[s] = fsrc ? fsrc[hl_step4(s)] : 0.0f;
+        if (emit) {
+#pragma unroll
+            for (int s = 0; s < QHS; ++s) em.hid(E::FB, s, q, fb[s]);
+        }
+        f32x4v acc[4], ws[4];
+        load_vec16(a.wp + P::kWSDF, q, ws);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)        // (element by element: a vector * scalar here becomes v_pk_mul_f32, see build.py::isa_check)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] = sbar * ws[t][r];
+        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, a.wp, 3 * NH, lane, fb, acc);
+#pragma unroll
+        for (int s = 0; s < QHS; ++s) ab[s] = sg[NH - 1][s] * acc[s >> 2][s & 3] + e[NH - 1][s];
+    }
+#pragma unroll
+    for (int k = NH - 1; k >= 1; --k) {
+        if (emit) {
+#pragma unroll
+            for (int s = 0; s < QHS; ++s) em.hid(E::AB(k + 1), s, q, ab[s]);
+        }
+        f32x4v acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, a.wp, 3 * NH + 1 + (NH - 1 - k), lane, ab, acc);
+#pragma unroll
+        for (int s = 0; s < QHS; ++s) ab[s] = sg[k - 1][s] * acc[s >> 2][s & 3] + e[k - 1][s];
+    }
+    if (emit) {
+#pragma unroll
+        for (int s = 0; s < QHS; ++s) em.hid(E::AB(1), s, q, ab[s]);
+    }
+    TS_MARK(9)
+    float hb0[QIN];
+    {
+        f32x4v a6[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) a6[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 6>(stage, a.wp, 4 * NH, lane, ab, a6);
+#pragma unroll
+        for (int s = 0; s < QIN; ++s) hb0[s] = a6[s >> 2][s & 3];
+    }
     float gx[3];
     slots_to_x_jac4<L, C>(a.divide_factor, jstore, q, in, hb0, gx);
     // scatter scratch: the stage buffer the last GEMM part does NOT read; every wave passed the barrier of that part and
@@ -539,105 +518,6 @@ __global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd(
             float v = gx[d];
             if (a.accumulate) v += a.g_x[(size_t)pt * 3 + d];
             a.g_x[(size_t)pt * 3 + d] = v;
-        }
-    }
-    TS_MARK(10)
-    TS_END
-}
-
-// ---- the backward of BOTH networks in one pass (tracking: no parameter gradients) -----------------------------------------------
-// What k_sdfnet4_bwd<coarse> followed by k_sdfnet4_bwd<fine> (both accumulating into g_x) compute, with the point, the positional
-// encoding, the level geometry and g_x handled once and one staging chain over the 4 + 13 GEMMs: bit-identical to the two quad launches
-// (g_x <- gx_fine + (gx_coarse + g_x), the order of the two accumulating launches), one kernel tail instead of two.
-template <int NHA, int NHB>
-struct SdfOpsPairBwd {
-    using A = SdfOps4<NHA, true>;
-    using B = SdfOps4<NHB, true>;
-    static constexpr int NW = NSA_NW4_BWD;
-    static constexpr int BUF = stage_floats4(NW);
-    static constexpr int n = A::n + B::n;
-    __host__ __device__ static constexpr int net(int i) { return i < A::n ? 0 : 1; }
-    __host__ __device__ static constexpr int off(int i) { return i < A::n ? A::off(i) : B::off(i - A::n); }
-    __host__ __device__ static constexpr int mt(int i) { return i < A::n ? A::mt(i) : B::mt(i - A::n); }
-    __host__ __device__ static constexpr int kg(int i) { return i < A::n ? A::kg(i) : B::kg(i - A::n); }
-};
-
-struct SdfNet4PairBwdArgs {
-    PointSrc src;
-    const float* table_c; const float* table_f;
-    const float* wp_c; const float* wp_f;
-    float df_c, df_f;
-    int accumulate;
-    const float* g_sdf; const float* g_feat; const float* g_grad;
-    float* g_x;
-};
-
-template <int LC, int CC, int NHC, int LF, int CF, int NHF>
-__global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd_pair(SdfNet4PairBwdArgs a, GridGeom16 gc, GridGeom16 gf) {
-    using Seq = SdfOpsPairBwd<NHC, NHF>;
-    TS_BEGIN
-    __shared__ __attribute__((aligned(16))) float stage[2 * Seq::BUF];
-    __shared__ LevelGeom s_geom[32];
-    stage16_begin<Seq, Seq::NW, Seq::BUF>(stage, a.wp_c);
-    if (threadIdx.x < 16) s_geom[threadIdx.x] = gc.lv[threadIdx.x];
-    else if (threadIdx.x < 32) s_geom[threadIdx.x] = gf.lv[threadIdx.x - 16];
-    const int lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    uint32_t tile = blockIdx.x * Seq::NW + (threadIdx.x >> 6);
-    const uint32_t n_tiles = (a.src.P + 15) / 16;
-    const bool wave_live = tile < n_tiles;
-    if (!wave_live) tile = n_tiles - 1;
-    uint32_t pid = tile * 16 + j;
-    const bool live = wave_live && pid < a.src.P;
-    if (pid >= a.src.P) pid = a.src.P - 1;
-    const uint32_t pt = point_of(a.src, pid);
-    float x[3], z;
-    uint32_t ray;
-    load_point(a.src, pt, x, ray, z);
-    __syncthreads();                                         // s_geom
-    TS_MARK(4)
-    static_assert((8 / CC) * 3 * CC == (8 / CF) * 3 * CF, "one Jacobian column serves both grids");
-    constexpr int kJac = (8 / CC) * 3 * CC;
-    __shared__ float jac_lds[Seq::NW * kJac * 64];
-    float* jstore = jac_lds + (threadIdx.x >> 6) * (kJac * 64) + lane;
-    const float* fsrc = a.g_feat ? a.g_feat + hl_base4(tile, j, q) : nullptr;
-    float in[QIN];
-    pe_slots4(x, q, in);                                     // slots 0..15: shared by the two networks
-    // the coarse network's d/dx waits in LDS while the fine network (256 registers, none to spare) runs: written and read by the same lane
-    __shared__ float gxc_lds[3 * 16 * Seq::NW];
-    float* gxc_mine = gxc_lds + (threadIdx.x >> 6) * 48 + j;
-    {   // coarse network
-        float gxc[3];
-        grid_slots4<LC, CC>(x, a.df_c, a.table_c, s_geom, q, in, jstore);
-        TS_MARK(5)
-        float hb0[QIN], dl[QIN], nbar[3], xb2[3];
-        net_backward4<LC, CC, NHC, Seq>(stage, 0, a.wp_c, a.wp_c, a.wp_f, lane, q, a.df_c, jstore, in, pt, a.g_sdf, a.g_grad, fsrc, nullptr,
-                                        hb0, dl, nbar, xb2 TS_ARG);
-        slots_to_x_jac4<LC, CC>(a.df_c, jstore, q, in, hb0, gxc);
-#pragma unroll
-        for (int d = 0; d < 3; ++d) gxc[d] = quad_sum(gxc[d] + xb2[d]);
-        if (q == 0) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) gxc_mine[16 * d] = gxc[d];
-        }
-    }
-    float gxf[3];
-    {   // fine network (the Jacobian column and the grid slots are reused; the coarse ones have been consumed)
-        grid_slots4<LF, CF>(x, a.df_f, a.table_f, s_geom + 16, q, in, jstore);
-        TS_MARK(5)
-        float hb0[QIN], dl[QIN], nbar[3], xb2[3];
-        net_backward4<LF, CF, NHF, Seq>(stage, Seq::A::n, a.wp_f, a.wp_c, a.wp_f, lane, q, a.df_f, jstore, in, pt, a.g_sdf, a.g_grad, fsrc,
-                                        nullptr, hb0, dl, nbar, xb2 TS_ARG);
-        slots_to_x_jac4<LF, CF>(a.df_f, jstore, q, in, hb0, gxf);
-#pragma unroll
-        for (int d = 0; d < 3; ++d) gxf[d] = quad_sum(gxf[d] + xb2[d]);
-    }
-    if (live && q == 0) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            float v = gxc_mine[16 * d];
-            if (a.accumulate) v += a.g_x[(size_t)pt * 3 + d];
-            a.g_x[(size_t)pt * 3 + d] = gxf[d] + v;
         }
     }
     TS_MARK(10)
@@ -714,27 +594,6 @@ int NSA_ENTRY(nsa_sdfnet4_forward_pair)(const nsa_points_t* pts, const nsa_grid_
     const uint32_t tiles = (a.src.P + 15) / 16;
     launch_begin();
     hipLaunchKernelGGL((k_sdfnet4_fwd_pair<4, 8, 1, 8, 4, 3>), dim3((tiles + NSA_NW4_PAIR - 1) / NSA_NW4_PAIR), dim3(64 * NSA_NW4_PAIR), 0,
-                       (hipStream_t)stream, a, gc, gf);
-    return launch_end();
-}
-
-int NSA_ENTRY(nsa_sdfnet4_backward_pair)(const nsa_points_t* pts, const nsa_grid_t* coarse, const nsa_grid_t* fine,
-                                         const float* packed_coarse, const float* packed_fine, const float* g_sdf,
-                                         const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x, nsa_stream_t stream) {
-    using namespace nsa;
-    if (!(coarse->L == 4 && coarse->C == 8 && coarse->n_hidden == 1 && fine->L == 8 && fine->C == 4 && fine->n_hidden == 3))
-        return NSA_EUNSUPPORTED_NET;
-    SdfNet4PairBwdArgs a{};
-    a.src = PointSrc{pts->rays_o, pts->rays_d, pts->z_vals, pts->points, pts->P, pts->S, pts->order};
-    a.table_c = coarse->table; a.table_f = fine->table; a.wp_c = packed_coarse; a.wp_f = packed_fine;
-    a.df_c = coarse->divide_factor; a.df_f = fine->divide_factor; a.accumulate = accumulate;
-    a.g_sdf = g_sdf; a.g_feat = g_feat_hl; a.g_grad = g_grad; a.g_x = g_x;
-    GridGeom16 gc, gf;
-    if (int rc = make_grid_geom16(coarse->offsets_host, coarse->L, coarse->S, coarse->H, &gc, coarse->C)) return rc;
-    if (int rc = make_grid_geom16(fine->offsets_host, fine->L, fine->S, fine->H, &gf, fine->C)) return rc;
-    const uint32_t tiles = (a.src.P + 15) / 16;
-    launch_begin();
-    hipLaunchKernelGGL((k_sdfnet4_bwd_pair<4, 8, 1, 8, 4, 3>), dim3((tiles + NSA_NW4_BWD - 1) / NSA_NW4_BWD), dim3(64 * NSA_NW4_BWD), 0,
                        (hipStream_t)stream, a, gc, gf);
     return launch_end();
 }

@@ -12,7 +12,7 @@ import torch
 from .._native import lib, check, PointsDesc
 from ..hashencoder.backend import _timed
 from . import pack
-from .sampler import backward_pair_ok, forward_pair_ok, grid_desc, packed_sdf, precision_of, sdf_grid_desc, tile_of
+from .sampler import forward_pair_ok, grid_desc, packed_sdf, precision_of, sdf_grid_desc, tile_of
 
 
 def hl_size(P):
@@ -178,14 +178,7 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
             check(lib.nsa_colour_backward(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
                                           b["feat"].data_ptr(), b["save"].data_ptr(), g_rgb.data_ptr(), grid_grad,
                                           g_feat.data_ptr(), g_grad.data_ptr(), g_x.data_ptr(), g_dir.data_ptr(), st))
-    paired = (stage != "coarse" and not any(want.get(k) for k in ("flat_c", "tab_c", "flat_f", "tab_f")) and backward_pair_ok(model))
-    if paired:                                   # both networks' data-path backward in one launch (quad tiling)
-        gcp, keep_cp = sdf_grid_desc(model, "coarse", "coarse_pair")
-        pcp = packed_sdf(model, "coarse", use="coarse_pair")
-        with _timed("k_sdfnet_bwd<pair>", P * 3 * (4 * 8 * 8 * 4 + 8 * 8 * 4 * 4)):
-            check(lib.nsa_sdfnet_backward_pair(ctypes.byref(pts), ctypes.byref(gcp), ctypes.byref(gf), pcp.data_ptr(), pf.data_ptr(),
-                                               g_sdf.data_ptr(), g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))
-    elif want.get("flat_c") or want.get("tab_c"):
+    if want.get("flat_c") or want.get("tab_c"):
         from . import mapping
         enc = imp.coarse.encoding
         # the MAP backward has its own tiling (the forward's results reach it in tiling-independent layouts only)
@@ -207,7 +200,7 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
         with _timed("k_sdfnet_bwd<coarse>", P * 3 * 4 * 8 * 8 * 4):
             check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), g_sdf.data_ptr(),
                                           g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))
-    if stage != "coarse" and not paired:
+    if stage != "coarse":
         if want.get("tab_f") or want.get("flat_f"):
             from . import mapping
             enc = imp.fine.encoding

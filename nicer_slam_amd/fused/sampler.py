@@ -49,10 +49,6 @@ def precision_of(model, which):
 # "coarse_pair": the coarse network inside nsa_sdfnet_forward_pair (both networks' forward in one launch; quad tiling only).
 DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 64, "coarse_map": 16, "sampler_large": 16, "coarse_pair": 16}
 FWD_PAIR = os.environ.get("NSA_SDF_FWD_PAIR", "1") != "0"          # 0: two forward launches (A/B runs)
-# 1: both data-path backwards in one launch (nsa_sdfnet_backward_pair).  Built and bit-identical to two quad launches, but NOT faster
-# than the shipped 32-point coarse + quad fine pair (170.3 -> 173.1 us, 171.9 -> 174.7 us, profiles/r04_ab_experiments.txt r4k: the
-# backward shares little between the networks and the quad coarse backward is the slower coarse form) -- off by default.
-BWD_PAIR = os.environ.get("NSA_SDF_BWD_PAIR", "0") == "1"
 SAMPLER_LARGE_RAYS = 4096
 _FORCE = int(os.environ.get("NSA_SDF_TILE", "0"))
 _FORCE_SAMPLER = int(os.environ.get("NSA_SAMPLER_TILE", "0"))      # A/B runs of the sampler pass alone: 16 | 32 | 64 | 96
@@ -76,11 +72,6 @@ def tile_of(model, which):
 def forward_pair_ok(model):
     """The composite pass runs both SDF networks' forward as ONE launch (nsa_sdfnet_forward_pair) when the quad tiling is in use."""
     return FWD_PAIR and tile_of(model, "fine") == 16 and tile_of(model, "coarse_pair") == 16
-
-
-def backward_pair_ok(model):
-    """Tracking (no parameter gradients) runs both SDF networks' backward as ONE launch (nsa_sdfnet_backward_pair), quad tiling."""
-    return BWD_PAIR and tile_of(model, "fine") == 16 and tile_of(model, "coarse_pair") == 16
 
 
 def grid_desc(net_or_enc, divide_factor, n_hidden, precision=0, tile=0):

@@ -204,72 +204,3 @@ def test_paired_forward_is_the_two_quad_launches_bit_for_bit(mode, P):
     g32, _k = fs.grid_desc(model.implicit_network.coarse.encoding, model.implicit_network.coarse.divide_factor, 1, 0, 32)
     assert lib.nsa_sdfnet_forward_pair(ctypes.byref(srcs[0][0]), ctypes.byref(g32), ctypes.byref(gf), pc.data_ptr(), pf.data_ptr(),
                                        one[0].data_ptr(), one[1].data_ptr(), one[2].data_ptr(), st) == 4
-
-
-@pytest.mark.parametrize("mode,P", [("rays", 64 * 128), ("rays", 37 * 98), ("points", 1000), ("points", 5)])
-def test_paired_backward_is_the_two_quad_launches_bit_for_bit(mode, P):
-    """nsa_sdfnet_backward_pair (both networks' data-path backward in one launch) against nsa_sdfnet_backward(coarse, accumulate 1)
-    + nsa_sdfnet_backward(fine, accumulate 1) in the quad tiling: d/dx must be identical -- with and without a prior g_x, all three
-    cotangents / only some of them, ragged point counts, ray-sample and explicit-point sources, a permuted launch order -- and
-    within fp32 rounding of the shipped combination (32-point coarse + quad fine)."""
-    import ctypes
-    from nicer_slam_amd._native import lib, check, PointsDesc
-    from nicer_slam_amd.fused import render as fr, sampler as fs
-    from nicer_slam_amd.model.network import SLAMNetwork
-    from nicer_slam_amd.utils.conf import replica_model_conf
-    torch.manual_seed(0)
-    model = SLAMNetwork(replica_model_conf(use_warp_loss=False), n_images=1,
-                        colour_grid=dict(base_resolution=16, desired_resolution=64, log2_hashmap_size=12)).cuda().train()
-    g = torch.Generator(device="cuda").manual_seed(11)
-    with torch.no_grad():
-        for enc in (model.implicit_network.coarse.encoding, model.implicit_network.fine.encoding):
-            enc.embeddings.copy_((torch.rand(enc.embeddings.shape, device="cuda", generator=g) * 2 - 1) * 0.05)
-        for n_, p in model.named_parameters():
-            if n_.startswith("implicit_network") and n_.endswith("weight_v"):
-                p.add_(0.05 * torch.randn(p.shape, device="cuda", generator=g))
-    gc, keep_c = fs.sdf_grid_desc(model, "coarse", "coarse_pair")
-    gf, keep_f = fs.sdf_grid_desc(model, "fine")
-    assert gc.tile == 16 and gf.tile == 16
-    pc, pf = fs.packed_sdf(model, "coarse", use="coarse_pair"), fs.packed_sdf(model, "fine")
-    g32, keep_32 = fs.sdf_grid_desc(model, "coarse")
-    p32 = fs.packed_sdf(model, "coarse")
-    assert g32.tile == 32
-    if mode == "rays":
-        S = 128 if P % 128 == 0 else 98
-        R = P // S
-        rays_d = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda", generator=g), dim=-1)
-        rays_o = ((torch.rand(R, 3, device="cuda", generator=g) - 0.5) * 0.4).contiguous()
-        z = torch.sort(torch.rand(R, S, device="cuda", generator=g) * 1.6, dim=1).values.contiguous()
-        srcs = [PointsDesc(rays_o.data_ptr(), rays_d.data_ptr(), z.data_ptr(), None, P, S, None)]
-        order = torch.randperm(P, device="cuda", generator=g).to(torch.int32)
-        srcs.append(PointsDesc(rays_o.data_ptr(), rays_d.data_ptr(), z.data_ptr(), None, P, S, order.data_ptr()))
-    else:
-        x = ((torch.rand(P, 3, device="cuda", generator=g) * 2 - 1) * 1.05).contiguous()
-        srcs = [PointsDesc(None, None, None, x.data_ptr(), P, 0, None)]
-    g_sdf = torch.randn(P, device="cuda", generator=g)
-    g_feat = torch.randn(fr.hl_size(P), device="cuda", generator=g)
-    g_grad = torch.randn(P, 3, device="cuda", generator=g)
-    prior = torch.randn(P, 3, device="cuda", generator=g)
-    st = torch.cuda.current_stream().cuda_stream
-    ptr = lambda t: None if t is None else t.data_ptr()
-    for pts in srcs:
-        for cot in ((g_sdf, g_feat, g_grad), (g_sdf, None, None), (None, g_feat, g_grad)):
-            for acc in (1, 0):
-                two, one, mix = prior.clone(), prior.clone(), prior.clone()
-                check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), ptr(cot[0]), ptr(cot[1]), ptr(cot[2]),
-                                              acc, two.data_ptr(), st))
-                check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), ptr(cot[0]), ptr(cot[1]), ptr(cot[2]),
-                                              1, two.data_ptr(), st))
-                check(lib.nsa_sdfnet_backward_pair(ctypes.byref(pts), ctypes.byref(gc), ctypes.byref(gf), pc.data_ptr(), pf.data_ptr(),
-                                                   ptr(cot[0]), ptr(cot[1]), ptr(cot[2]), acc, one.data_ptr(), st))
-                check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(g32), p32.data_ptr(), ptr(cot[0]), ptr(cot[1]), ptr(cot[2]),
-                                              acc, mix.data_ptr(), st))
-                check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), ptr(cot[0]), ptr(cot[1]), ptr(cot[2]),
-                                              1, mix.data_ptr(), st))
-                torch.cuda.synchronize()
-                assert bool(torch.isfinite(two).all()) and float((two - prior).abs().max()) > 0
-                assert torch.equal(one, two), f"d/dx (accumulate {acc}): {int((one != two).sum())} of {one.numel()} differ, max {float((one - two).abs().max()):.3g}"
-                assert_close(one, mix.cpu().numpy(), 2e-5 * float(mix.abs().max()), 1e-4, "paired backward vs 32-point coarse + quad fine")
-    # mismatched descriptors are refused
-    assert lib.nsa_sdfnet_backward_pair(ctypes.byref(srcs[0]), ctypes.byref(g32), ctypes.byref(gf), pc.data_ptr(), pf.data_ptr(),
-                                        g_sdf.data_ptr(), g_feat.data_ptr(), g_grad.data_ptr(), 1, one.data_ptr(), st) == 4

@@ -32,8 +32,9 @@ if TAG and os.environ.get("NSA_EXP_SLP") == "1":
 
 
 def _check_flags():
-    """The product library (no NSA_BUILD_TAG) must be the product: timing-ablation / experiment macros (NSA_ABL_*, NSA_EXP_*,
-    NSA_X_*) compute wrong numbers or change kernels and are only accepted for a tagged side-by-side build; and the correctness
+    """The product library (no NSA_BUILD_TAG) must be the product: experiment macros (NSA_X_*: the profiling instrumentation of
+    tools/ts_profile*.py, tools/slot_timeline.py; NSA_EXP_* / NSA_ABL_*: none left in the sources since round 4) change kernels
+    and are only accepted for a tagged side-by-side build; and the correctness
     flag -fno-slp-vectorize (above) cannot be dropped or overridden in any build."""
     extra = os.environ.get("NSA_EXTRA_HIPCC_FLAGS", "").split()
     bad = [f for f in extra if any(f.startswith("-D" + p) for p in ("NSA_ABL_", "NSA_EXP_", "NSA_X_"))]

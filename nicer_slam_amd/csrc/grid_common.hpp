@@ -330,11 +330,7 @@ __device__ __forceinline__ void gather_corners_generic(const float* __restrict__
         if (GENERIC) {
             if ((g.flags & LV_GENERIC) != 0) idx = (hashed ? x : a) % g.rows;
         }
-#ifdef NSA_ABL_NOGATHER     // timing experiment only: index arithmetic kept, no memory access
-        _Pragma("unroll") for (int c = 0; c < C; ++c) v[corner][c] = __uint_as_float((idx + c) | 0x3F000000u);
-#else
         load_row<C>(table + (size_t)(g.row0 + idx) * C, v[corner]);
-#endif
     }
 }
 
@@ -389,9 +385,6 @@ __device__ __forceinline__ void corner_offsets(const LevelGeom& g, const uint32_
 template <int D, int C, bool GENERIC = false, bool FAST = false>
 __device__ __forceinline__ void gather_corners(const float* __restrict__ table, const LevelGeom& g,
                                                const uint32_t (&cell)[D], float (&v)[1 << D][C]) {
-#ifdef NSA_ABL_NOGATHER
-    gather_corners_generic<D, C, GENERIC>(table, g, cell, v);
-#else
     if constexpr (D != 3 || GENERIC || !FAST) {
         gather_corners_generic<D, C, GENERIC>(table, g, cell, v);
     } else {
@@ -401,7 +394,6 @@ __device__ __forceinline__ void gather_corners(const float* __restrict__ table, 
         for (int corner = 0; corner < 8; ++corner)
             load_row<C>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + (size_t)off[corner]), v[corner]);
     }
-#endif
 }
 
 // Smoothstep-weighted multilinear blend, corner order/product order as kernel_grid (:203-229).

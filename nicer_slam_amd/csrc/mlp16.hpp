@@ -43,10 +43,6 @@ template <int TC>
 __device__ __forceinline__ void mma16_tiles(const u32x4 (&a)[TC][3], const bf16x8_t bh, const bf16x8_t bm, const bf16x8_t bl,
                                             f32x4v* acc) {
     if constexpr (kPieces == 3) {
-#ifdef NSA_ABL_NOMFMA
-        _Pragma("unroll") for (int t = 0; t < TC; ++t) acc[t][0] += __uint_as_float((a[t][0][0] ^ a[t][1][1] ^ a[t][2][2]) & 0x3F800000u);
-        return;
-#endif
 #define NSA_MM16(AP, BV)                                                                               \
         _Pragma("unroll") for (int t = 0; t < TC; ++t)                                                 \
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a[t][AP]), BV, acc[t], 0, 0, 0);

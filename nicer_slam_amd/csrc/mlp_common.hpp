@@ -67,15 +67,10 @@ __device__ __forceinline__ void split8(const float (&x)[8], BFrag& f) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         u0[e] = __float_as_uint(x[e]);
-#ifdef NSA_ABL_NOSPLIT      // timing experiment only (tools/ab_kernels.py): no residual arithmetic, wrong numbers
-        u1[e] = u0[e];
-        u2[e] = u0[e];
-#else
         const float r1 = x[e] - __uint_as_float(u0[e] & 0xFFFF0000u);
         u1[e] = __float_as_uint(r1);
         const float r2 = r1 - __uint_as_float(u1[e] & 0xFFFF0000u);
         u2[e] = __float_as_uint(r2);
-#endif
     }
 #define NSA_PK(u, d) __builtin_amdgcn_perm(u[2 * d + 1], u[2 * d], 0x07060302u)
     f.p[0] = make_uint4(NSA_PK(u0, 0), NSA_PK(u0, 1), NSA_PK(u0, 2), NSA_PK(u0, 3));
@@ -124,14 +119,6 @@ __device__ __forceinline__ void mma_group(const AV (&a)[MT][3], const float (&x)
     if constexpr (kPieces == 3) {
         BFrag bf;
         split8(x, bf);
-#ifdef NSA_ABL_NOMFMA       // timing experiment only: keep the split alive, drop the matrix instructions and the A fragments
-        {
-            unsigned t = bf.p[0].x ^ bf.p[0].y ^ bf.p[0].z ^ bf.p[0].w ^ bf.p[1].x ^ bf.p[1].y ^ bf.p[1].z ^ bf.p[1].w ^
-                         bf.p[2].x ^ bf.p[2].y ^ bf.p[2].z ^ bf.p[2].w;
-            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt][0] += __uint_as_float(t & 0x3F800000u);
-            return;
-        }
-#endif
         const bf16x8_t bh = as_bf16x8(bf.p[0]), bm = as_bf16x8(bf.p[1]), bl = as_bf16x8(bf.p[2]);
         // smallest terms first; the MT accumulators alternate so no MFMA waits on its predecessor
 #define NSA_MM(AP, BV)                                                                                   \
@@ -175,11 +162,7 @@ __device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane,
 #pragma unroll
             for (int pc = 0; pc < kPieces; ++pc) {
                 a[mt][pc] = f.g[mt][pc];
-#ifdef NSA_EXP_WCACHE   // timing experiment only: every fragment load hits the same 3 KB (L1-resident)
-                if (g + 1 < KS8) f.g[mt][pc] = w4[pc * 64];
-#else
                 if (g + 1 < KS8) f.g[mt][pc] = w4[((mt * KS8 + g + 1) * 3 + pc) * 64];
-#endif
             }
         float x[8];
 #pragma unroll
@@ -190,7 +173,7 @@ __device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane,
 }
 
 // ---- block-cooperative weight staging -------------------------------------------------------------------------
-// Measured (profiles/, experiment NSA_EXP_WCACHE): with every wave streaming its own copy of the packed weights from
+// Measured (profiles/r01_*, an ablation build of round 1 in which every fragment load hit the same 3 KB): with every wave streaming its own copy of the packed weights from
 // L2, the fine SDF backward spends 59 % of its wave cycles in s_waitcnt and 127 of its 280 us disappear when the
 // fragment loads hit L1 -- at one wave per SIMD there is nothing to hide the L2 latency behind, and the four waves of a
 // block fetch the same bytes four times.  The staged GEMM fetches each layer's packed block ONCE per workgroup with
@@ -428,9 +411,6 @@ __device__ __forceinline__ float relu_f(float a) { return fmaxf(a, 0.0f); }
 // value only (sampler): the overflow-free form max(a,0) + ln(1 + e^{-|beta a|})/beta -- no compare/select, and equal to
 // torch's thresholded softplus to the last ulp (for beta a > 20 the log term is < 2e-9 relative and rounds away).
 __device__ __forceinline__ float softplus100(float a) {
-#ifdef NSA_ABL_NOSOFTPLUS   // timing experiment only
-    return fmaxf(a, 0.0f);
-#endif
     const float t = SP_K * a;
     return fmaf(SP_OUT, __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(t))), relu_f(a));
 }
@@ -440,10 +420,6 @@ __device__ __forceinline__ float softplus100_d1(float a) {
     return t > SP_LIN ? 1.0f : e * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 __device__ __forceinline__ void softplus100_all(float a, float& y, float& d1, float& d2) {
-#ifdef NSA_ABL_NOSOFTPLUS   // timing experiment only
-    y = fmaxf(a, 0.0f); d1 = a > 0.0f ? 1.0f : 0.5f; d2 = 0.0f;
-    return;
-#endif
     const float t = SP_K * a;
     const float e = __builtin_amdgcn_exp2f(t);
     const bool lin = t > SP_LIN;
@@ -455,10 +431,6 @@ __device__ __forceinline__ void softplus100_all(float a, float& y, float& d1, fl
 
 // sin and cos of a (|a| <~ 1e3) sharing one Cody-Waite reduction to [-pi/4, pi/4]; ~1 ulp-class polynomials.
 __device__ __forceinline__ void sincos_f(float a, float& s, float& c) {
-#ifdef NSA_ABL_NOPE         // timing experiment only
-    s = a; c = 1.0f - a;
-    return;
-#endif
     const float n = rintf(a * 0.63661977236758134f);          // a / (pi/2)
     float r = fmaf(n, -1.5707963705062866f, a);                 // pi/2 = c1 + c2 + c3 (float32 parts)
     r = fmaf(n, 4.371138828673793e-08f, r);

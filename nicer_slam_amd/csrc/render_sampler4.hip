@@ -5,7 +5,7 @@
 // Weight residency: these passes only run the forward chain W0 (coarse) and W0, W1, W2 (fine) -- 120 KiB of packed blocks.
 // One persistent workgroup per CU copies them into LDS ONCE (asynchronous global->LDS copies), then its waves loop over
 // 16-point tiles with no barrier and no weight traffic at all: the per-wave L2 streaming of the 32-point kernel was 12 % of its
-// time (ablation NSA_EXP_WCACHE), and staging with a barrier per GEMM cost it a wave per SIMD.
+// time (round-1 ablation build), and staging with a barrier per GEMM cost it a wave per SIMD.
 // Reference: UniformSampler.get_z_vals (code/model/ray_sampler.py:37-61), ImplicitNetworkGrid_COMBINE.get_sdf_vals
 // (code/model/base_networks.py:25-35).
 #include "sdf_net4.hpp"

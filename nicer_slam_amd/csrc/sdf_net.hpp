@@ -71,13 +71,6 @@ __device__ __forceinline__ void grid_slots(const float (&x)[3], float divide_fac
     float u[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) u[d] = to_unit(x[d], divide_factor);   // hashgrid.py:203 (size = 1)
-#ifdef NSA_ABL_NOGRID       // timing experiment only: no grid encoder at all
-    if (!jstore) {
-#pragma unroll
-        for (int s = 20; s < SDF_IN_STEPS; ++s) in[s] = u[s % 3];
-        return;
-    }
-#endif
 #pragma unroll
     for (int jl = 0; jl < L / 2; ++jl) {
         const LevelGeom g = geom.lv[2 * jl + h];

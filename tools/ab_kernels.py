@@ -4,7 +4,8 @@ with NSA_BUILD_TAG / NSA_EXTRA_HIPCC_FLAGS, see nicer_slam_amd/build.py).  Print
 duration (events on the launch stream, eager replay of the bench batches) and the graph-replayed ms/iteration.
 
     NSA_LIB_TAG=nosplit python tools/ab_kernels.py [--steps 40]
-Development tool; ablation builds (NSA_ABL_*) compute wrong numbers on purpose."""
+Development tool.  (The wrong-numbers ablation macros NSA_ABL_* of rounds 1-3 were removed from the kernel headers in round 4; their
+results are in profiles/r0[1-3]_ab_experiments.txt, the code in the history up to commit 2d72c93.)"""
 import argparse
 import json
 import os

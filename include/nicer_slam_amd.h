@@ -284,6 +284,12 @@ int nsa_track_tail(const float *uv, const float *K, float *cam, uint32_t n, cons
  *                         `best` compares g_cam[7]. */
 int nsa_track_begin(const float *uv_in, const float *gt_in, float *uv, float *gt, const float *K, const float *cam, uint32_t n,
                     float *pose, float *rays_o, float *rays_d, float *depth_scale, nsa_stream_t stream);
+/* nsa_track_begin and the iteration's sampler draws (nsa_draw with n_rand uniforms into t_rand, the n_extra picks of E into
+ * extra_idx, no eikonal picks; R = n) in ONE launch: the draw's workgroups ride beside the ray lifting instead of being a graph
+ * node of their own.  Same draws, bit for bit, as nsa_draw on the same state. */
+int nsa_track_begin_draw(const float *uv_in, const float *gt_in, float *uv, float *gt, const float *K, const float *cam, uint32_t n,
+                         float *pose, float *rays_o, float *rays_d, float *depth_scale, uint64_t *state, uint64_t n_rand,
+                         float *t_rand, uint32_t E, uint32_t n_extra, uint32_t S, int32_t *extra_idx, nsa_stream_t stream);
 int nsa_composite_track(const float *rays_o, const float *rays_d, const float *z_vals, const float *sdf, const float *rgb,
                         const float *voxels, uint32_t voxel_res, uint32_t R, uint32_t S, const float *gt, uint32_t n_total,
                         float *rgb_values, float *ray_loss, float *g_sdf, float *g_rgb, float *g_grad, nsa_stream_t stream);

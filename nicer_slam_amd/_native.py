@@ -183,7 +183,9 @@ lib.nsa_track_finish.argtypes = [_p, _p, _p, _u32, _u32, _p, _p, _p, _p, _p, _i,
                                  _f32, _p, _p, _p]
 lib.nsa_track_finish_workspace.restype = ctypes.c_uint64
 lib.nsa_track_finish_workspace.argtypes = [_u32]
-EXPORTS += ["nsa_track_begin", "nsa_composite_track", "nsa_track_finish", "nsa_track_finish_workspace"]
+lib.nsa_track_begin_draw.restype = _i
+lib.nsa_track_begin_draw.argtypes = [_p, _p, _p, _p, _p, _p, _u32, _p, _p, _p, _p, _p, ctypes.c_uint64, _p, _u32, _u32, _u32, _p, _p]
+EXPORTS += ["nsa_track_begin", "nsa_track_begin_draw", "nsa_composite_track", "nsa_track_finish", "nsa_track_finish_workspace"]
 
 lib.nsa_morton_keys.restype = _i
 lib.nsa_morton_keys.argtypes = [_pp, _p, _p]

@@ -8,6 +8,7 @@
 //   k_adam               torch.optim.Adam update of the (tiny) camera vector, optional StepLR schedule
 //                        (code/training/volsdf_train.py:396-399,425-427)
 #include "grid_common.hpp"
+#include "draw_common.hpp"
 
 namespace nsa {
 
@@ -282,9 +283,10 @@ struct FinishArgs {
 
 constexpr int FIN_Q = 13;   // 12 pose-gradient entries (rows 0..2 of the 4x4) + the L1 sum
 
-__global__ __launch_bounds__(256) void k_track_begin(TrackArgs a, const float* uv_in, const float* gt_in, float* uv, float* gt) {
+__device__ __forceinline__ void track_begin_block(const TrackArgs& a, const float* uv_in, const float* gt_in, float* uv, float* gt,
+                                                  const uint32_t bid) {
     // (uv_in / gt_in may BE uv / gt: every thread reads its own elements before it writes them)
-    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t r = bid * 256 + threadIdx.x;
     float P[16];
     cam_to_pose(a.cam, P);
     if (r == 0) {
@@ -310,6 +312,18 @@ __global__ __launch_bounds__(256) void k_track_begin(TrackArgs a, const float* u
 #pragma unroll
     for (int k = 0; k < 3; ++k) a.rays_d[3 * r + k] = v[k] / s;
     a.depth_scale[r] = c[2] / (c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+}
+
+__global__ __launch_bounds__(256) void k_track_begin(TrackArgs a, const float* uv_in, const float* gt_in, float* uv, float* gt) {
+    track_begin_block(a, uv_in, gt_in, uv, gt, blockIdx.x);
+}
+
+// The same launch also makes the iteration's random draws (draw_common.hpp: what nsa_draw launches as a graph node of its own):
+// workgroups [0, begin_blocks) lift the rays, the others are the draw's rand / pick workgroups.  The two halves share nothing.
+__global__ __launch_bounds__(256) void k_track_begin_draw(TrackArgs a, const float* uv_in, const float* gt_in, float* uv, float* gt,
+                                                          DrawArgs d, uint32_t begin_blocks) {
+    if (blockIdx.x < begin_blocks) track_begin_block(a, uv_in, gt_in, uv, gt, blockIdx.x);
+    else draw_block(d, blockIdx.x - begin_blocks, gridDim.x - begin_blocks);
 }
 
 // FIN_W rays per workgroup: the ticket is one device-scope atomic on ONE address per workgroup, and those serialise at the memory
@@ -541,6 +555,25 @@ int nsa_track_begin(const float* uv_in, const float* gt_in, float* uv, float* gt
     a.rays_o = rays_o; a.rays_d = rays_d; a.depth_scale = depth_scale;
     launch_begin();
     hipLaunchKernelGGL(k_track_begin, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, uv_in, gt_in, uv, gt);
+    return launch_end();
+}
+
+int nsa_track_begin_draw(const float* uv_in, const float* gt_in, float* uv, float* gt, const float* K, const float* cam, uint32_t n,
+                         float* pose, float* rays_o, float* rays_d, float* depth_scale, uint64_t* state, uint64_t n_rand, float* t_rand,
+                         uint32_t E, uint32_t n_extra, uint32_t S, int32_t* extra_idx, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!uv_in || !gt_in || !uv || !gt || !K || !cam || !pose || !rays_o || !rays_d || !depth_scale || n == 0) return NSA_EBADARG;
+    if (!draw_args_ok(state, n_rand, t_rand, E, n_extra, n, S, extra_idx, nullptr)) return NSA_EBADARG;
+    TrackArgs a{};
+    a.K = K; a.cam = const_cast<float*>(cam); a.pose = pose; a.n = n;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.depth_scale = depth_scale;
+    DrawArgs d{};
+    const uint32_t draw_blocks = draw_launch_shape(d, reinterpret_cast<unsigned long long*>(state), n_rand, t_rand, E, n_extra, n, S,
+                                                   extra_idx, nullptr);
+    const uint32_t begin_blocks = (n + 255) / 256;
+    launch_begin();
+    hipLaunchKernelGGL(k_track_begin_draw, dim3(begin_blocks + draw_blocks), dim3(256), 0, (hipStream_t)stream, a, uv_in, gt_in, uv, gt,
+                       d, begin_blocks);
     return launch_end();
 }
 

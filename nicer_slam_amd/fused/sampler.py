@@ -220,10 +220,17 @@ def draw_state(model, stream_key=0):
     return st
 
 
-def get_z_vals(model, ray_dirs, cam_loc, need_eik=True, rows=None):
+def own_draws(model):
+    """True when get_z_vals would make its draws with nsa_draw (training, no pinned draws, E <= 1024, the engine's own generator)."""
+    return bool(model.training and model.draws is None and model.ray_sampler.N_samples_eval <= 1024 and OWN_RNG)
+
+
+def get_z_vals(model, ray_dirs, cam_loc, need_eik=True, rows=None, drawn=None):
     """Drop-in for ImportantSampler.get_z_vals (fused engine).  ``need_eik=False`` (tracking) skips the near-surface
     eikonal sample, which only mapping consumes.  ``rows = (lo, hi)``: these rays are rows lo..hi of a larger batch (a chunk of
-    KernelTracker) -- pinned per-ray draws (``model.draws``, tests) are sliced accordingly."""
+    KernelTracker) -- pinned per-ray draws (``model.draws``, tests) are sliced accordingly.  ``drawn = (t_rand [R,E], extra_idx
+    [n_extra] int32)``: this call's draws have been made already (nsa_track_begin_draw: the tracker's head launch) -- only when
+    own_draws(model) and not need_eik."""
     samp = model.ray_sampler
     rays_d = ray_dirs.detach().contiguous()
     rays_o = cam_loc.detach().contiguous()
@@ -231,6 +238,14 @@ def get_z_vals(model, ray_dirs, cam_loc, need_eik=True, rows=None):
     n_extra = samp.N_samples_extra
     S = samp.N_samples + 2 + n_extra
     dev = rays_d.device
+    if drawn is not None:
+        if need_eik or not own_draws(model):
+            raise RuntimeError("get_z_vals(drawn=...): only for the engine's own draws without eikonal picks")
+        t_rand, extra = drawn
+        if t_rand.shape != (R, E) or (n_extra > 0 and (extra is None or extra.numel() != n_extra)):
+            raise ValueError("get_z_vals(drawn=...): draw buffers of the wrong shape")
+        z, sdf, far = sampler_sdf(model, rays_o, rays_d, t_rand)
+        return sample_rays(model, rays_o, rays_d, z, sdf, far, extra if n_extra > 0 else None, None)
     if model.training and model.draws is None and E <= 1024 and OWN_RNG:
         # fast path: every draw of this call from ONE launch of the engine's own counter-based generator (nsa_draw)
         t_rand = torch.empty(R, E, device=dev)

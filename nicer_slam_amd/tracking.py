@@ -74,6 +74,16 @@ class KernelTracker:
             from ._native import lib
             self.ray_loss = z(n_rays)
             self.fin_ws = z(int(lib.nsa_track_finish_workspace(n_rays)))      # ticket + block partials; zero once
+        # folded sequence: the sampler's draws of an iteration are made by the head launch as well (nsa_track_begin_draw) instead of
+        # a graph node of their own -- same generator state, same numbers.  NSA_TRACK_DRAW_IN_BEGIN=0: nsa_draw inside the graph (A/B).
+        self.drawn = None
+        if self.folded and os.environ.get("NSA_TRACK_DRAW_IN_BEGIN", "1") != "0":
+            samp = model.ray_sampler
+            E, n_extra = samp.N_samples_eval, samp.N_samples_extra
+            if E <= 1024:
+                self.drawn = (torch.empty(n_rays, E, device=dev),
+                              torch.empty(max(n_extra, 1), device=dev, dtype=torch.int32)[:n_extra] if n_extra > 0 else None)
+        self._drawn_now = False    # whether the coming iteration's draws were made by _begin
         self.graph = None
         self._began = False        # folded sequence: _begin (batch copy + cam -> pose -> rays) has run for the coming iteration
         if use_graph:
@@ -123,7 +133,8 @@ class KernelTracker:
                 raise RuntimeError("KernelTracker: the folded sequence needs _begin() (nsa_track_begin) in front of every iteration -- "
                                    "the rays of the updated camera are lifted there, not inside the graph; use step()")
             self._began = False
-            z_vals, _ = fs.get_z_vals(model, rays_d, rays_o, need_eik=False, rows=(lo, hi))
+            z_vals, _ = fs.get_z_vals(model, rays_d, rays_o, need_eik=False, rows=(lo, hi),
+                                      drawn=self.drawn if self._drawn_now else None)
             b = fr.composite_forward_raw(model, rays_o, rays_d, z_vals, self.stage, True, composite=False)
             g_x, g_dir = fr.composite_backward_raw(model, rays_o, rays_d, z_vals, b, self.stage, self.color_stage,
                                                    track=dict(gt=gt, ray_loss=self.ray_loss), reduce_rays=False)
@@ -207,10 +218,25 @@ class KernelTracker:
         gt = gt.detach().to(device=dev, dtype=torch.float32).reshape(-1, 3).contiguous()
         if uv.shape[0] != self.R or gt.shape[0] != self.R:
             raise ValueError(f"KernelTracker.step: expected {self.R} rays, got uv {tuple(uv.shape)} / gt {tuple(gt.shape)}")
+        # a captured graph replays the choice made at capture; an eager tracker follows the model's state (pinned draws, eval mode)
+        draw = (self.drawn is not None and self.fs.own_draws(self.model)) if self.graph is None else self._drawn_now
+        st = torch.cuda.current_stream().cuda_stream
         with _timed("k_track_begin", self.R * 64):
-            check(lib.nsa_track_begin(uv.data_ptr(), gt.data_ptr(), self.uv.data_ptr(), self.gt.data_ptr(), self.K.data_ptr(),
-                                      self.cam.data_ptr(), self.R, self.pose.data_ptr(), self.rays_o.data_ptr(),
-                                      self.rays_d.data_ptr(), self.ds.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            if draw:
+                samp = self.model.ray_sampler
+                t_rand, extra = self.drawn
+                check(lib.nsa_track_begin_draw(uv.data_ptr(), gt.data_ptr(), self.uv.data_ptr(), self.gt.data_ptr(), self.K.data_ptr(),
+                                               self.cam.data_ptr(), self.R, self.pose.data_ptr(), self.rays_o.data_ptr(),
+                                               self.rays_d.data_ptr(), self.ds.data_ptr(), self.fs.draw_state(self.model, 0).data_ptr(),
+                                               t_rand.numel(), t_rand.data_ptr(), samp.N_samples_eval, samp.N_samples_extra,
+                                               samp.N_samples + 2 + samp.N_samples_extra,
+                                               None if extra is None else extra.data_ptr(), st))
+            else:
+                check(lib.nsa_track_begin(uv.data_ptr(), gt.data_ptr(), self.uv.data_ptr(), self.gt.data_ptr(), self.K.data_ptr(),
+                                          self.cam.data_ptr(), self.R, self.pose.data_ptr(), self.rays_o.data_ptr(),
+                                          self.rays_d.data_ptr(), self.ds.data_ptr(), st))
+        if self.graph is None:
+            self._drawn_now = draw
         self._began = True
 
     def _capture(self):

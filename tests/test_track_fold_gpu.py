@@ -210,3 +210,51 @@ def test_chunked_tracker_draws_from_one_state_per_chunk(chunks, use_graph):
         assert len(seeds) == chunks
         outs.append((losses, kt.cam.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_head_launch_draws_change_no_bit(use_graph):
+    """The sampler's draws made by the tracker's head launch (nsa_track_begin_draw) instead of an nsa_draw node of their own, at the
+    shipped sample counts (640 sampler evaluations, 128 samples per ray): the same generator state, the same numbers -- losses, camera,
+    Adam moments, candidate and message of 8 iterations must be IDENTICAL, and the generator's call counter advances once per step."""
+    from nicer_slam_amd.fused import sampler as fs
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.tracking import KernelTracker
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    torch.manual_seed(0)
+    model = SLAMNetwork(replica_model_conf(94, 640, 32, use_warp_loss=False), n_images=1,
+                        colour_grid=dict(base_resolution=16, desired_resolution=256, log2_hashmap_size=14)).cuda().train()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    with torch.no_grad():
+        for enc in (model.implicit_network.coarse.encoding, model.implicit_network.fine.encoding, model.rendering_network.encoding):
+            enc.embeddings.copy_((torch.rand(enc.embeddings.shape, device="cuda", generator=g) * 2 - 1) * 0.05)
+    R = 256
+    K = torch.eye(4, device="cuda")
+    K[0, 0] = K[1, 1] = 600.0
+    K[0, 2], K[1, 2] = 599.5, 339.5
+    batches = [(torch.stack([torch.rand(R, device="cuda", generator=g) * 1199, torch.rand(R, device="cuda", generator=g) * 679], -1)[None],
+                torch.rand(R, 3, device="cuda", generator=g)) for _ in range(8)]
+    cam0 = torch.tensor([1.0, 0.02, -0.01, 0.03, 0.1, 0.0, -0.2], device="cuda")
+    runs = {}
+    for tag, env in (("node", {"NSA_TRACK_DRAW_IN_BEGIN": "0"}), ("head", {})):
+        for k in ("_draw_state", "_draw_states", "_draw_seed"):
+            model.__dict__.pop(k, None)
+        torch.manual_seed(7)
+        os.environ.update(env)
+        try:
+            kt = KernelTracker(model, K[None], R, cam0, lr=0.002, use_graph=use_graph)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert (kt.drawn is not None) == (tag == "head")
+        calls0 = int(fs.draw_state(model)[1])
+        ls = torch.stack([kt.step(*b).clone() for b in batches])
+        torch.cuda.synchronize()
+        st = fs.draw_state(model).cpu().tolist()
+        assert st[1] == calls0 + len(batches) and st[2] == 0
+        runs[tag] = (ls, kt.cam.clone(), kt.m.clone(), kt.v.clone(), kt.best.clone(), kt.red.clone())
+    assert bool(torch.isfinite(runs["node"][0]).all()) and not torch.equal(runs["node"][1], cam0)
+    for a, b, what in zip(runs["head"], runs["node"], ("losses", "camera", "exp_avg", "exp_avg_sq", "candidate", "message")):
+        assert torch.equal(a, b), f"{what} differ by {float((a - b).abs().max()):.3g}"

@@ -154,6 +154,16 @@ int nsa_colour_backward(const nsa_points_t *pts, const nsa_grid_t *grid, const f
                         const float *feat_hl, const float *save, const float *g_rgb, int grid_grad,
                         float *g_feat_hl, float *g_grad, float *g_x, float *g_dir, nsa_stream_t stream);
 
+/* nsa_colour_backward followed by nsa_sdfnet_backward(coarse, accumulate 1) -- the coarse network in the 32-point tiling, the
+ * tiles of the colour kernels -- as two phases of ONE launch: every wave runs the colour backward of its 32 points and then the
+ * coarse SDF backward of the same points (g_sdf: d/d sdf from the composite; the feature and normal cotangents and the d/dx to
+ * accumulate onto are what its first phase has just written).  The same statements as the two kernels: identical results.
+ * For a tracking batch, where both kernels run only two rounds of waves, the input burst of a round is paid once. */
+int nsa_colour_coarse_backward(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, const float *grad,
+                               const float *feat_hl, const float *save, const float *g_rgb, int grid_grad, float *g_feat_hl,
+                               float *g_grad, float *g_x, float *g_dir, const nsa_grid_t *coarse, const float *packed_coarse,
+                               const float *g_sdf, nsa_stream_t stream);
+
 /* Mapping-mode backward (parameter gradients): the same kernels as nsa_sdfnet_backward / nsa_colour_backward with two
  * more outputs.  replaces, for a mapping iteration, what torch.autograd does through ImplicitNetworkGrid /
  * RenderingNetwork / _hash_encode.backward / _hash_encode_second_backward (code/model/base_networks.py:195-221,

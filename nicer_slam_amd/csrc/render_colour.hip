@@ -274,187 +274,45 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
     using Seq = ColOps<true>;
     __shared__ __attribute__((aligned(16))) float stage[2 * kColStage];
     CTS_BEGIN
-    stage_issue_op(a.wp, Seq::op(0), stage);
-    const int lane = threadIdx.x & 63;
-    const int h = lane >> 5;
-    uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t n_tiles = (a.src.P + 31) / 32;
-    const bool wave_live = tile < n_tiles;
-    if (!wave_live) tile = n_tiles - 1;
-    uint32_t pid = tile * 32 + (lane & 31);
-    const bool live = wave_live && pid < a.src.P;
-    if (pid >= a.src.P) pid = a.src.P - 1;
-    const uint32_t q = point_of(a.src, pid);                // point handled by this lane pair
-    float x[3], z, dir[3];
-    uint32_t ray;
-    load_point(a.src, q, x, ray, z);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) dir[d] = a.src.rays_d[ray * 3 + d];
-    float in[COL_IN_STEPS];
-    colour_inputs(a, geom, tile, q, lane, h, x, dir, in, true, wave_live);
-    CTS_MARK(4)
-    f32x16 a1[2], a2[2];
-    float rgb[3];
-    colour_mlp<Seq, true>(stage, a.wp, lane, h, in, a1, a2, rgb);
-    CTS_MARK(5)
-    const bool emit = MAP && a.emit != nullptr && wave_live;
-    const ColEmitter em{emit ? a.emit + (size_t)tile * 32 + (lane & 31) : nullptr, a.emit_ld, live};
-    if (emit) {
-#pragma unroll
-        for (int s = 0; s < COL_IN_STEPS; ++s) em.slot(CE_IN, s, h, in[s]);
-#pragma unroll
-        for (int q = 0; q < HS; ++q) {
-            em.hid(CE_H1, q, h, relu_f(a1[q >> 4][q & 15]));
-            em.hid(CE_H2, q, h, relu_f(a2[q >> 4][q & 15]));
-        }
-    }
-    // d/d(pre-sigmoid), d/d h2 = sum_j ob_j W2[j,:], relu masks (torch: grad * (a > 0))
-    float ab[HS];
-    {
-        float ob[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) ob[j] = a.g_rgb[(size_t)q * 3 + j] * rgb[j] * (1.0f - rgb[j]);
-        if (emit && h == 0) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) em.base[(size_t)(CE_OB + j) * em.ld] = live ? ob[j] : 0.0f;
-        }
-#pragma unroll
-        for (int q = 0; q < HS; ++q) ab[q] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            f32x16 wv[2];
-            load_vec<2>(a.wp + ColPack::kW2V + 64 * j, h, wv);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ab[16 * t + r] = fmaf(ob[j], wv[t][r], ab[16 * t + r]);
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ab[16 * t + r] = a2[t][r] > 0.0f ? ab[16 * t + r] : 0.0f;
-    }
-    if (emit) {
-#pragma unroll
-        for (int q = 0; q < HS; ++q) em.hid(CE_AB2, q, h, ab[q]);
-    }
-    CTS_MARK(6)
-    {
-        f32x16 acc[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        gemm_staged_part<Seq, kColStage, HS, 2, 0, 4>(stage, a.wp, 3, lane, ab, acc);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ab[16 * t + r] = a1[t][r] > 0.0f ? acc[t][r] : 0.0f;
-    }
-    if (emit) {
-#pragma unroll
-        for (int q = 0; q < HS; ++q) em.hid(CE_AB1, q, h, ab[q]);
-    }
-    CTS_MARK(7)
-    float ib[80];
-    {
-        f32x16 a5[5];
-#pragma unroll
-        for (int t = 0; t < 5; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a5[t][r] = 0.0f;
-        gemm_staged_part<Seq, kColStage, HS, 5, 0, 2>(stage, a.wp, 4, lane, ab, a5);
-        gemm_staged_part<Seq, kColStage, HS, 5, 2, 2>(stage, a.wp, 5, lane, ab, a5);
-#pragma unroll
-        for (int t = 0; t < 5; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ib[16 * t + r] = a5[t][r];
-    }
-    CTS_MARK(8)
-    // feature cotangent -> HL
-    float* fdst = a.g_feat + (size_t)tile * 32 * 64 + lane;
-    if (wave_live) {
-#pragma unroll
-        for (int q = 0; q < HS; ++q) fdst[q * 64] = ib[q];
-    }
-    // scalar slots
-    float gx[3], gd[3], gg[3];
-    gx[0] = h ? 0.0f : ib[32];   gx[1] = h ? ib[32] : 0.0f;   gx[2] = h ? 0.0f : ib[33];
-    gd[0] = h ? ib[33] : 0.0f;   gd[1] = h ? 0.0f : ib[34];   gd[2] = h ? ib[34] : 0.0f;
-    gg[0] = h ? 0.0f : ib[35];   gg[1] = h ? ib[35] : 0.0f;   gg[2] = h ? 0.0f : ib[36];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int g0 = 2 * j, g1 = 2 * j + 1;
-        const float sc = h ? (float)(1 << (g1 / 3)) : (float)(1 << (g0 / 3));
-        const float t = sc * (in[38 + 2 * j] * ib[37 + 2 * j] - in[37 + 2 * j] * ib[38 + 2 * j]);
-        gd[g0 % 3] += h ? 0.0f : t;
-        gd[g1 % 3] += h ? t : 0.0f;
-    }
-    CTS_MARK(9)
-    if (a.grid_grad) {   // x += J^T fbar / (2 df) with the Jacobian saved by the forward pass
-        const float* sv = a.save + (size_t)tile * 64 * 64 + lane;
-        const float chain = 1.0f / (2.0f * a.divide_factor);
-#pragma unroll
-        for (int jl = 0; jl < CL / 2; ++jl)
-#pragma unroll
-            for (int d = 0; d < 3; ++d)
-#pragma unroll
-                for (int c = 0; c < CC; ++c)
-                    gx[d] = fmaf(sv[(16 + (jl * 3 + d) * CC + c) * 64] * chain, ib[49 + jl * CC + c], gx[d]);
-    }
-    CTS_MARK(10)
-    if (MAP && a.grid_grad && a.g_table) {   // colour-table gradient: w_corner * fbar, run-merged (kernel_grid_backward)
-        float u[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) u[d] = to_unit(x[d], a.divide_factor);
-#pragma unroll
-        for (int jl = 0; jl < CL / 2; ++jl) {
-            const LevelGeom lg = geom.lv[2 * jl + h];
-            uint32_t cell[3];
-            float w[3], dw[3];
-            const bool active = locate<3>(u, lg.scale, cell, w, dw) && live;
-            // scratch: stage buffer 0 -- the last GEMM part (op 5, odd) reads buffer 1, and every wave is past op 4
-            float* tile = stage + (threadIdx.x >> 6) * 64 * (2 * CC + 1);
-            uint32_t row[8];
-            float wt8[8];
-#pragma unroll
-            for (int corner = 0; corner < 8; ++corner) {
-                float wt = 1.0f;
-                uint32_t q[3];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const int bit = (corner >> d) & 1;
-                    wt *= bit ? w[d] : 1.0f - w[d];
-                    q[d] = cell[d] + bit;
-                }
-                row[corner] = lg.row0 + level_row<3>(lg, q);
-                wt8[corner] = wt;
-            }
-            // x-neighbour corners leave as one 16-byte span wherever they are adjacent rows (dense levels; even cells of hashed ones)
-#pragma unroll
-            for (int yz = 0; yz < 4; ++yz) {
-                float v0[CC], v1[CC];
-#pragma unroll
-                for (int c = 0; c < CC; ++c) {
-                    v0[c] = wt8[2 * yz] * ib[49 + jl * CC + c];
-                    v1[c] = wt8[2 * yz + 1] * ib[49 + jl * CC + c];
-                }
-                scatter_x_pair<CC>(a.g_table, row[2 * yz], row[2 * yz + 1], active, v0, v1, lane, tile);
-            }
-        }
-    }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { gx[d] = xhalf_sum(gx[d]); gd[d] = xhalf_sum(gd[d]); gg[d] = xhalf_sum(gg[d]); }
-    if (live && h == 0) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            a.g_x[(size_t)q * 3 + d] = gx[d];
-            a.g_dir[(size_t)q * 3 + d] = gd[d];
-            a.g_grad[(size_t)q * 3 + d] += gg[d];
-        }
-    }
+#include "colour_bwd_body.inc"
     CTS_MARK(11)
     CTS_END
+}
+
+}  // namespace nsa
+
+// ---- colour backward + coarse SDF backward as two phases of ONE 32-point launch (tracking: no parameter gradients) ------------------
+// The two kernels tile the same points the same way (workgroup = 4 waves x 32 points), the coarse backward consumes what the colour
+// backward has just written (feature and normal cotangents, d/dx to accumulate onto) and both run only two rounds of waves at the
+// tracking batch: as one launch the input burst of a round is paid once, the coarse phase re-reads its cotangents from L2 and one
+// launch disappears.  The bodies are the two kernels' own statements (colour_bwd_body.inc, sdfnet_bwd_body.inc): identical results.
+#define NSA_SDFNET_AS_HEADER
+#include "render_sdfnet.hip"
+#undef NSA_SDFNET_AS_HEADER
+
+namespace nsa {
+
+__global__ __launch_bounds__(256, 2) void k_colour_coarse_bwd(ColourArgs ca, GridGeom16 cgeom, SdfNetArgs sa, GridGeom16 sgeom) {
+    __shared__ __attribute__((aligned(16))) float stage[2 * kStageFloats];
+    static_assert(kStageFloats >= kColStage, "the colour phase stages its parts in the SDF kernel's buffers");
+    {   // phase 1: k_colour_bwd<false>
+        constexpr bool MAP = false;
+        using Seq = ColOps<true>;
+        const ColourArgs& a = ca;
+        const GridGeom16& geom = cgeom;
+#include "colour_bwd_body.inc"
+    }
+    __syncthreads();     // every wave is done with the colour phase's last staged part before the buffers are refilled; the feature /
+                         // normal cotangents and d/dx this workgroup wrote are complete (vmcnt(0) + barrier)
+    {   // phase 2: k_sdfnet_bwd<4, 8, 1, false> on the same tiles
+        constexpr int L = 4, C = 8, NH = 1;
+        constexpr bool MAP = false;
+        using P = SdfPack<NH>;
+        using Seq = SdfOps<NH, true>;
+        const SdfNetArgs& a = sa;
+        const GridGeom16& geom = sgeom;
+#include "sdfnet_bwd_body.inc"
+    }
 }
 
 }  // namespace nsa
@@ -532,6 +390,38 @@ int NSA_ENTRY(nsa_colour_backward)(const nsa_points_t* pts, const nsa_grid_t* gr
     const uint32_t tiles = (pts->P + 31) / 32;
     launch_begin();
     hipLaunchKernelGGL(k_colour_bwd<false>, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
+    return launch_end();
+}
+
+int NSA_ENTRY(nsa_colour_coarse_backward)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad,
+                               const float* feat_hl, const float* save, const float* g_rgb, int grid_grad, float* g_feat_hl,
+                               float* g_grad, float* g_x, float* g_dir, const nsa_grid_t* coarse, const float* packed_coarse,
+                               const float* g_sdf, nsa_stream_t stream) {
+#if NSA_PIECES == 3
+    if (grid && coarse && grid->precision == 1 && coarse->precision == 1)
+        return nsa_colour_coarse_backward_bf16(pts, grid, packed, grad, feat_hl, save, g_rgb, grid_grad, g_feat_hl, g_grad, g_x, g_dir, coarse,
+                                               packed_coarse, g_sdf, stream);
+#endif
+    using namespace nsa;
+    if (!packed || !grad || !feat_hl || !save || !g_rgb || !g_feat_hl || !g_grad || !g_x || !g_dir || !coarse || !packed_coarse)
+        return NSA_EBADARG;
+    if (grid->precision != coarse->precision) return NSA_EBADARG;
+    // the coarse network in the 32-point tiling (the tiles of the colour kernels), 4 levels x 8 channels, one hidden layer
+    if (coarse->tile == 16 || !(coarse->L == 4 && coarse->C == 8 && coarse->n_hidden == 1)) return NSA_EUNSUPPORTED_NET;
+    ColourArgs a{};
+    GridGeom16 geom, sgeom;
+    if (int rc = colour_common(pts, grid, &a, &geom)) return rc;
+    if (pts->P == 0) return NSA_OK;
+    if (int rc = make_grid_geom16(coarse->offsets_host, coarse->L, coarse->S, coarse->H, &sgeom, coarse->C)) return rc;
+    a.wp = packed; a.grad = grad; a.feat = feat_hl; a.save = const_cast<float*>(save); a.g_rgb = g_rgb;
+    a.g_feat = g_feat_hl; a.g_grad = g_grad; a.g_x = g_x; a.g_dir = g_dir; a.grid_grad = grid_grad;
+    SdfNetArgs sa{};
+    sa.src = a.src;
+    sa.table = coarse->table; sa.wp = packed_coarse; sa.divide_factor = coarse->divide_factor; sa.accumulate = 1;
+    sa.g_sdf = g_sdf; sa.g_feat = g_feat_hl; sa.g_grad = g_grad; sa.g_x = g_x;
+    const uint32_t tiles = (pts->P + 31) / 32;
+    launch_begin();
+    hipLaunchKernelGGL(k_colour_coarse_bwd, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom, sa, sgeom);
     return launch_end();
 }
 

@@ -252,164 +252,10 @@ __global__ __launch_bounds__(256, (NH == 1 ? (MAP ? 1 : NSA_OCC_BWD_COARSE) : NS
     using P = SdfPack<NH>;
     using Seq = SdfOps<NH, true>;
     __shared__ __attribute__((aligned(16))) float stage[2 * kStageFloats];
-    stage_begin<Seq>(stage, a.wp);
-    const int lane = threadIdx.x & 63;
-    const int h = lane >> 5;
-    uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t n_tiles = (a.src.P + 31) / 32;
-    const bool wave_live = tile < n_tiles;
-    if (!wave_live) tile = n_tiles - 1;
-    uint32_t pid = tile * 32 + (lane & 31);
-    const bool live = wave_live && pid < a.src.P;
-    if (pid >= a.src.P) pid = a.src.P - 1;
-    const uint32_t q = point_of(a.src, pid);                // point handled by this lane pair
-    float x[3], z;
-    uint32_t ray;
-    load_point(a.src, q, x, ray, z);
-    // Kernels that run one workgroup per CU (the fine network; the MAP variants) have LDS to spare: keep the grid
-    // Jacobian of this lane's levels there and skip the second and third corner gather of the backward.
-    constexpr bool kJacLds = (NH > 1) || MAP;
-    __shared__ float jac_lds[kJacLds ? 4 * (L / 2) * 3 * C * 64 : 1];
-    float* jstore = kJacLds ? jac_lds + (threadIdx.x >> 6) * ((L / 2) * 3 * C * 64) + lane : nullptr;
-    float in[SDF_IN_STEPS];
-    sdf_net_inputs<L, C>(x, a.divide_factor, a.table, geom, h, in, jstore);
-    using E = SE<NH>;
-    const bool emit = MAP && a.emit != nullptr && wave_live;   // (a clamped wave must not touch the last tile's rows)
-    const Emitter em{emit ? a.emit + (size_t)tile * 32 + (lane & 31) : nullptr, a.emit_ld, live};
-    float sg[NH][HS], hl[HS];
-    hidden_forward<NH, Seq>(stage, 0, a.wp, lane, h, in, sg, hl, emit ? &em : nullptr);
-    float dh[NH > 1 ? NH - 1 : 1][HS], dl[48];
-    reverse_pass<NH, Seq>(stage, NH, a.wp, lane, h, sg, dh, dl, emit ? &em : nullptr);
-    if (emit) {
-#pragma unroll
-        for (int s = 0; s < SDF_IN_STEPS; ++s) em.slot(E::H0, s, h, in[s]);
-    }
-
-    float nbar[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) nbar[d] = a.g_grad ? a.g_grad[(size_t)q * 3 + d] : 0.0f;
-    const float sbar = a.g_sdf ? a.g_sdf[q] : 0.0f;
-
-    // ---- tangent sweep: e_k = sp''(a_k) dh_k ta_k (kept in e[k-1]) ----
-    float e[NH][HS];
-    float xb2[3];
-    {
-        float tin[SDF_IN_STEPS];
-        if (kJacLds) tangent_from_jac<L, C>(a.divide_factor, jstore, h, in, nbar, dl, tin, xb2);
-        else         x_to_slots_tangent<L, C>(x, a.divide_factor, a.table, geom, h, in, nbar, dl, tin, xb2);
-        if (emit) {
-#pragma unroll
-            for (int s = 0; s < SDF_IN_STEPS; ++s) em.slot(E::TIN, s, h, tin[s]);
-        }
-        f32x16 acc[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        gemm_staged<Seq, SDF_IN_STEPS, 2>(stage, a.wp, 2 * NH, lane, tin, acc);
-        f32x16 ws[2];
-        load_vec<2>(a.wp + P::kWSDF, h, ws);
-        float th[HS];
-#pragma unroll
-        for (int k = 1; k <= NH; ++k) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int q = 16 * t + r;
-                    const float s1 = sg[k - 1][q];
-                    const float s2 = 100.0f * s1 * (1.0f - s1);          // 0 in the linear region (s1 == 1)
-                    const float dhk = (k == NH) ? ws[t][r] : dh[k - 1][q];
-                    e[k - 1][q] = s2 * dhk * acc[t][r];
-                    th[q] = s1 * acc[t][r];
-                    if (emit) em.hid(E::TH(k), q, h, th[q]);
-                }
-            if (k < NH) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-                gemm_staged<Seq, HS, 2>(stage, a.wp, 2 * NH + k, lane, th, acc);
-            }
-        }
-    }
-    // ---- reverse sweep ----
-    float ab[HS];
-    {
-        float fb[HS];
-        const float* fsrc = a.g_feat ? a.g_feat + (size_t)tile * 32 * 64 + lane : nullptr;
-#pragma unroll
-        for (int q = 0; q < HS; ++q) fb[q] = fsrc ? fsrc[q * 64] : 0.0f;
-        if (emit) {
-#pragma unroll
-            for (int q = 0; q < HS; ++q) em.hid(E::FB, q, h, fb[q]);
-        }
-        f32x16 acc[2], ws[2];
-        load_vec<2>(a.wp + P::kWSDF, h, ws);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = sbar * ws[t][r];
-        gemm_staged<Seq, HS, 2>(stage, a.wp, 3 * NH, lane, fb, acc);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ab[16 * t + r] = sg[NH - 1][16 * t + r] * acc[t][r] + e[NH - 1][16 * t + r];
-    }
-#pragma unroll
-    for (int k = NH - 1; k >= 1; --k) {
-        if (emit) {
-#pragma unroll
-            for (int q = 0; q < HS; ++q) em.hid(E::AB(k + 1), q, h, ab[q]);
-        }
-        f32x16 acc[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        gemm_staged<Seq, HS, 2>(stage, a.wp, 3 * NH + 1 + (NH - 1 - k), lane, ab, acc);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ab[16 * t + r] = sg[k - 1][16 * t + r] * acc[t][r] + e[k - 1][16 * t + r];
-    }
-    if (emit) {
-#pragma unroll
-        for (int q = 0; q < HS; ++q) em.hid(E::AB(1), q, h, ab[q]);
-    }
-    float hb0[48];
-    {
-        f32x16 a3[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a3[t][r] = 0.0f;
-        gemm_staged<Seq, HS, 3>(stage, a.wp, 4 * NH, lane, ab, a3);
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hb0[16 * t + r] = a3[t][r];
-    }
-    float gx[3];
-    if (kJacLds) slots_to_x_jac<L, C>(a.divide_factor, jstore, h, in, hb0, gx);
-    else         slots_to_x<L, C>(x, a.divide_factor, a.table, geom, h, in, hb0, gx);
-    // scatter scratch: the stage buffer the last GEMM (op 4 NH, even) does NOT read; every wave passed the barrier of
-    // that GEMM, so nobody reads it any more
-    if (MAP && a.g_table)
-        table_grad_scatter<L, C>(x, a.divide_factor, geom, h, lane, live, hb0, dl, nbar, a.g_table,
-                                 stage + kStageFloats + (threadIdx.x >> 6) * 64 * (2 * C + 1));
-#pragma unroll
-    for (int d = 0; d < 3; ++d) gx[d] = xhalf_sum(gx[d] + xb2[d]);
-    if (live && h == 0) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            float v = gx[d];
-            if (a.accumulate) v += a.g_x[(size_t)q * 3 + d];
-            a.g_x[(size_t)q * 3 + d] = v;
-        }
-    }
+#include "sdfnet_bwd_body.inc"
 }
 
+#ifndef NSA_SDFNET_AS_HEADER   // (render_colour.hip includes this file for the kernel pieces only: k_colour_coarse_bwd)
 static int launch_sdfnet(bool bwd, const nsa_grid_t* grid, const SdfNetArgs& a, hipStream_t st) {
     const bool map = a.g_table != nullptr || a.emit != nullptr;
     GridGeom16 geom;
@@ -430,9 +276,11 @@ static int launch_sdfnet(bool bwd, const nsa_grid_t* grid, const SdfNetArgs& a, 
     }
     return launch_end();
 }
+#endif  // NSA_SDFNET_AS_HEADER
 
 }  // namespace nsa
 
+#ifndef NSA_SDFNET_AS_HEADER
 // Entry-point naming: this file is compiled twice -- as is (fp32-faithful GEMMs) and through *_bf16.hip with
 // NSA_PIECES = 1, `nsa` renamed and every entry point suffixed _bf16; the fp32 entry points forward to those when
 // nsa_grid_t.precision == 1.
@@ -524,3 +372,4 @@ int NSA_ENTRY(nsa_sdfnet_emit_rows_tile)(uint32_t n_hidden, uint32_t tile) {
 }
 
 }  // extern "C"
+#endif  // NSA_SDFNET_AS_HEADER

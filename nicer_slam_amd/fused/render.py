@@ -12,7 +12,7 @@ import torch
 from .._native import lib, check, PointsDesc
 from ..hashencoder.backend import _timed
 from . import pack
-from .sampler import forward_pair_ok, grid_desc, packed_sdf, precision_of, sdf_grid_desc, tile_of
+from .sampler import COLOUR_COARSE_BWD, forward_pair_ok, grid_desc, packed_sdf, precision_of, sdf_grid_desc, tile_of
 
 
 def hl_size(P):
@@ -160,6 +160,10 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
     grid_grad = 1 if color_stage != "base" else 0
     pg = {}
     want = params or {}
+    # data-path backward (no parameter gradients) with the coarse network in the 32-point tiling: its backward rides in the colour
+    # backward's launch (nsa_colour_coarse_backward)
+    merged = (COLOUR_COARSE_BWD and not any(want.get(k) for k in ("flat_r", "tab_r", "flat_c", "tab_c")) and gc.tile != 16
+              and gc.precision == gr.precision)
     if want.get("flat_r") or want.get("tab_r"):
         from . import mapping
         emit = mapping.new_emit(mapping.CE["ROWS"], P, dev) if want.get("flat_r") else None
@@ -173,6 +177,12 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
             pg["flat_r"] = mapping.colour_flat_grad(emit)
             del emit
         pg["tab_r"] = gt
+    elif merged:        # colour backward + coarse SDF backward: two phases of one launch (same 32-point tiles)
+        with _timed("k_colour_coarse_bwd", P * (512 + 3 * 4 * 8 * 8 * 4)):
+            check(lib.nsa_colour_coarse_backward(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
+                                                 b["feat"].data_ptr(), b["save"].data_ptr(), g_rgb.data_ptr(), grid_grad,
+                                                 g_feat.data_ptr(), g_grad.data_ptr(), g_x.data_ptr(), g_dir.data_ptr(),
+                                                 ctypes.byref(gc), pc.data_ptr(), g_sdf.data_ptr(), st))
     else:
         with _timed("k_colour_bwd", P * 512):
             check(lib.nsa_colour_backward(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
@@ -196,7 +206,7 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
             pg["flat_c"] = mapping.sdf_flat_grad(emit, g_sdf_w, P, enc.num_levels, enc.level_dim, tile=tile_m)
             del emit
         pg["tab_c"] = gt
-    else:
+    elif not merged:
         with _timed("k_sdfnet_bwd<coarse>", P * 3 * 4 * 8 * 8 * 4):
             check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), g_sdf.data_ptr(),
                                           g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), st))

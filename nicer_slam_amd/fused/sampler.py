@@ -49,6 +49,9 @@ def precision_of(model, which):
 # "coarse_pair": the coarse network inside nsa_sdfnet_forward_pair (both networks' forward in one launch; quad tiling only).
 DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 64, "coarse_map": 16, "sampler_large": 16, "coarse_pair": 16}
 FWD_PAIR = os.environ.get("NSA_SDF_FWD_PAIR", "1") != "0"          # 0: two forward launches (A/B runs)
+# 1: the colour backward and the coarse SDF backward of a data-path backward as ONE launch (nsa_colour_coarse_backward; 32-point tiling of
+# the coarse network).  0: two launches (A/B runs).
+COLOUR_COARSE_BWD = os.environ.get("NSA_COLOUR_COARSE_BWD", "1") != "0"
 SAMPLER_LARGE_RAYS = 4096
 _FORCE = int(os.environ.get("NSA_SDF_TILE", "0"))
 _FORCE_SAMPLER = int(os.environ.get("NSA_SAMPLER_TILE", "0"))      # A/B runs of the sampler pass alone: 16 | 32 | 64 | 96

@@ -204,3 +204,51 @@ def test_paired_forward_is_the_two_quad_launches_bit_for_bit(mode, P):
     g32, _k = fs.grid_desc(model.implicit_network.coarse.encoding, model.implicit_network.coarse.divide_factor, 1, 0, 32)
     assert lib.nsa_sdfnet_forward_pair(ctypes.byref(srcs[0][0]), ctypes.byref(g32), ctypes.byref(gf), pc.data_ptr(), pf.data_ptr(),
                                        one[0].data_ptr(), one[1].data_ptr(), one[2].data_ptr(), st) == 4
+
+
+@pytest.mark.parametrize("R,S,stage,color_stage", [(64, 128, "fine", "highfreq"), (37, 98, "fine", "base"), (5, 64, "coarse", "highfreq")])
+def test_colour_plus_coarse_backward_in_one_launch_changes_no_bit(R, S, stage, color_stage):
+    """nsa_colour_coarse_backward (the colour backward and the coarse SDF backward of the same 32-point tiles as two phases of one launch)
+    against nsa_colour_backward + nsa_sdfnet_backward(coarse, accumulate 1): the same statements, so every output of the data-path
+    backward -- d/dx, d/d(view dir), the feature and normal cotangents and the ray sums -- must be identical; ragged point counts,
+    both stages, colour grid gradient on and off."""
+    from nicer_slam_amd.fused import render as fr
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    torch.manual_seed(0)
+    model = SLAMNetwork(replica_model_conf(use_warp_loss=False), n_images=1,
+                        colour_grid=dict(base_resolution=16, desired_resolution=128, log2_hashmap_size=13)).cuda().train()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    with torch.no_grad():
+        for enc in (model.implicit_network.coarse.encoding, model.implicit_network.fine.encoding, model.rendering_network.encoding):
+            enc.embeddings.copy_((torch.rand(enc.embeddings.shape, device="cuda", generator=g) * 2 - 1) * 0.05)
+        for n_, p in model.named_parameters():
+            if n_.endswith("weight_v"):
+                p.add_(0.05 * torch.randn(p.shape, device="cuda", generator=g))
+    rays_d = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda", generator=g), dim=-1)
+    rays_o = ((torch.rand(R, 3, device="cuda", generator=g) - 0.5) * 0.4).contiguous()
+    z = torch.sort(torch.rand(R, S, device="cuda", generator=g) * 1.4 + 0.05, dim=1).values.contiguous()
+    g_rgbv = torch.randn(R, 3, device="cuda", generator=g)
+    g_depth = torch.randn(R, device="cuda", generator=g)
+    outs = {}
+    assert fr.COLOUR_COARSE_BWD
+    for merged in (False, True):
+        fr.COLOUR_COARSE_BWD = merged
+        try:
+            b = fr.composite_forward_raw(model, rays_o, rays_d, z, stage, True)
+            b["_keep"] = {}
+            g_o, g_d = fr.composite_backward_raw(model, rays_o, rays_d, z, b, stage, color_stage, g_rgbv=g_rgbv, g_depth=g_depth)
+        finally:
+            fr.COLOUR_COARSE_BWD = True
+        torch.cuda.synchronize()
+        k = b["_keep"]
+        outs[merged] = dict(g_o=g_o, g_d=g_d, g_x=k["g_x"], g_dir=k["g_dir"], g_feat=k["g_feat"], g_grad=k["g_grad"])
+    assert bool(torch.isfinite(outs[False]["g_x"]).all()) and float(outs[False]["g_x"].abs().max()) > 0
+    live = fr.hl_index(R * S, "cuda")                  # [P,64] positions of the live points' features in the HL buffer: the columns of the
+    for name in outs[False]:                           # last tile's dead lanes derive from never-written forward features (garbage in, ignored)
+        a, b_ = outs[True][name], outs[False][name]
+        if name == "g_feat":
+            a, b_ = a[live], b_[live]
+        assert torch.equal(a, b_), f"{name}: {int((a != b_).sum())} of {a.numel()} differ, max {float((a - b_).abs().max()):.3g}"

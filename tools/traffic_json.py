@@ -5,7 +5,7 @@ import csv
 import json
 import sys
 
-LABEL = [("k_sdfnet4_fwd_pair", "k_sdfnet_fwd<pair>"), ("k_composite_track", "k_composite_track"), ("k_sdfnet4_bwd<8, 4, 3", "k_sdfnet_bwd<fine>"), ("k_sdfnet4_bwd<4, 8, 1", "k_sdfnet_bwd<coarse>"),
+LABEL = [("k_sdfnet4_fwd_pair", "k_sdfnet_fwd<pair>"), ("k_colour_coarse_bwd", "k_colour_coarse_bwd"), ("k_composite_track", "k_composite_track"), ("k_sdfnet4_bwd<8, 4, 3", "k_sdfnet_bwd<fine>"), ("k_sdfnet4_bwd<4, 8, 1", "k_sdfnet_bwd<coarse>"),
          ("k_sdfnet4_fwd<8, 4, 3", "k_sdfnet_fwd<fine>"), ("k_sdfnet4_fwd<4, 8, 1", "k_sdfnet_fwd<coarse>"),
          ("k_sampler4_sdf", "k_sampler_sdf"), ("k_sdfnet_bwd<8, 4, 3", "k_sdfnet_bwd<fine>"), ("k_sdfnet_bwd<4, 8, 1", "k_sdfnet_bwd<coarse>"),
          ("k_sdfnet_fwd<8, 4, 3", "k_sdfnet_fwd<fine>"), ("k_sdfnet_fwd<4, 8, 1", "k_sdfnet_fwd<coarse>"),

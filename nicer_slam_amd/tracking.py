@@ -14,10 +14,10 @@ from .utils.general import get_camera_from_tensor
 
 class KernelTracker:
     """The same iteration with NO autograd in the loop: a fixed sequence of our kernels launched through the C ABI, optionally one
-    hipGraph.  One ray chunk (the default): nsa_track_begin (batch copy, cam->pose, rays; in front of the graph) | nsa_draw,
-    nsa_sampler_sdf, nsa_sample_rays, nsa_sdfnet_forward_pair, nsa_colour_forward, nsa_composite_track (composite + L1 +
-    composite-bwd), nsa_colour_coarse_backward (colour + coarse SDF backward), nsa_sdfnet_backward (fine), nsa_track_finish (ray sums, pose-bwd, cam-bwd, Adam,
-    candidate) -- eleven launches; with ray chunks the plain entry points (head, composite, L1, composite-bwd, ray reduction, tail),
+    hipGraph.  One ray chunk (the default): nsa_track_begin_draw (batch copy, cam->pose, rays and the sampler's draws; in front of
+    the graph) | nsa_sampler_sdf, nsa_sample_rays, nsa_sdfnet_forward_pair, nsa_colour_forward, nsa_composite_track (composite +
+    L1 + composite-bwd), nsa_colour_coarse_backward (colour + coarse SDF backward), nsa_sdfnet_backward (fine), nsa_track_finish
+    (ray sums, pose-bwd, cam-bwd, Adam, candidate) -- nine launches; with ray chunks the plain entry points (head, composite, L1, composite-bwd, ray reduction, tail),
     and with N > 1 ranks [all-reduce] + nsa_adam_step_scaled after the message.
     Only tracking (pose gradient) is covered; it needs a configuration in the fused engine's compiled set.
 

@@ -274,7 +274,9 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
     using Seq = ColOps<true>;
     __shared__ __attribute__((aligned(16))) float stage[2 * kColStage];
     CTS_BEGIN
+#define NSA_BODY_NW 4
 #include "colour_bwd_body.inc"
+#undef NSA_BODY_NW
     CTS_MARK(11)
     CTS_END
 }
@@ -292,7 +294,11 @@ __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 
 
 namespace nsa {
 
-__global__ __launch_bounds__(256, 2) void k_colour_coarse_bwd(ColourArgs ca, GridGeom16 cgeom, SdfNetArgs sa, GridGeom16 sgeom) {
+// (4-wave workgroups, two per CU, as the two kernels run on their own: with one 8-wave workgroup per CU -- twice the waves behind every
+//  staging barrier -- the launch measured 99.1 -> 106.7 us, profiles/r04_ab_experiments.txt r4t)
+#define NSA_CC_NW 4
+#define NSA_BODY_NW NSA_CC_NW
+__global__ __launch_bounds__(64 * NSA_CC_NW, 2) void k_colour_coarse_bwd(ColourArgs ca, GridGeom16 cgeom, SdfNetArgs sa, GridGeom16 sgeom) {
     __shared__ __attribute__((aligned(16))) float stage[2 * kStageFloats];
     static_assert(kStageFloats >= kColStage, "the colour phase stages its parts in the SDF kernel's buffers");
     {   // phase 1: k_colour_bwd<false>
@@ -314,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void k_colour_coarse_bwd(ColourArgs ca, Gri
 #include "sdfnet_bwd_body.inc"
     }
 }
+#undef NSA_BODY_NW
 
 }  // namespace nsa
 
@@ -421,7 +428,7 @@ int NSA_ENTRY(nsa_colour_coarse_backward)(const nsa_points_t* pts, const nsa_gri
     sa.g_sdf = g_sdf; sa.g_feat = g_feat_hl; sa.g_grad = g_grad; sa.g_x = g_x;
     const uint32_t tiles = (pts->P + 31) / 32;
     launch_begin();
-    hipLaunchKernelGGL(k_colour_coarse_bwd, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom, sa, sgeom);
+    hipLaunchKernelGGL(k_colour_coarse_bwd, dim3((tiles + NSA_CC_NW - 1) / NSA_CC_NW), dim3(64 * NSA_CC_NW), 0, (hipStream_t)stream, a, geom, sa, sgeom);
     return launch_end();
 }
 

@@ -252,7 +252,9 @@ __global__ __launch_bounds__(256, (NH == 1 ? (MAP ? 1 : NSA_OCC_BWD_COARSE) : NS
     using P = SdfPack<NH>;
     using Seq = SdfOps<NH, true>;
     __shared__ __attribute__((aligned(16))) float stage[2 * kStageFloats];
+#define NSA_BODY_NW 4
 #include "sdfnet_bwd_body.inc"
+#undef NSA_BODY_NW
 }
 
 #ifndef NSA_SDFNET_AS_HEADER   // (render_colour.hip includes this file for the kernel pieces only: k_colour_coarse_bwd)

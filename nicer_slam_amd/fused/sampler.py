@@ -40,14 +40,15 @@ def precision_of(model, which):
 # render_sampler.hip).  Both compute the same numbers (tests/test_tiling_gpu.py); the defaults are what measured fastest on
 # MI355X (profiles/r02_*): the fine network (three hidden layers: 256 .. 500 registers per lane at 32 points) runs the quad
 # tiling, the coarse network and the sampler's SDF-only pass the 32-point one -- except the coarse network's MAP backward
-# (parameter gradients: one wave per SIMD at 32 points, two in quad form: 969 -> 748 us per launch at 8192 rays) and the sampler
-# on mapping-sized batches (the persistent quad sampler with LDS-resident weights: 1739 -> 1645 us at 8192 rays, equal at 1024).
+# (parameter gradients: one wave per SIMD at 32 points, two in quad form: 969 -> 748 us per launch at 8192 rays).
 # NSA_SDF_TILE=16|32 or ``model.sdf_tile`` force one tiling everywhere.
 # "sampler": 64 = the 32-point tiling with TWO point tiles per wave: one weight-fragment stream feeds both tiles and the
 # operand split of one overlaps the matrix instructions of the other; bit-identical results, 2 waves per SIMD instead of 3,
 # 208-214 -> 206 us (profiles/r02_ab_experiments.txt r3b).
 # "coarse_pair": the coarse network inside nsa_sdfnet_forward_pair (both networks' forward in one launch; quad tiling only).
-DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 64, "coarse_map": 16, "sampler_large": 16, "coarse_pair": 16}
+# "sampler_large" (>= 4096 rays, the mapping batch): the persistent quad sampler (16) was the faster form there in round 2 (1739 -> 1645 us
+# at 8192 rays); since round 3's work on the two-tile 32-point kernel that one is: 1517 vs 1677 us (profiles/r04_ab_experiments.txt r4u).
+DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 64, "coarse_map": 16, "sampler_large": 64, "coarse_pair": 16}
 FWD_PAIR = os.environ.get("NSA_SDF_FWD_PAIR", "1") != "0"          # 0: two forward launches (A/B runs)
 # 1: the colour backward and the coarse SDF backward of a data-path backward as ONE launch (nsa_colour_coarse_backward; 32-point tiling of
 # the coarse network).  0: two launches (A/B runs).

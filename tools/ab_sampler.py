@@ -1,5 +1,5 @@
 """A/B timing of the sampler's SDF pass (nsa_sampler_sdf) at the bench shape for several tile codes, on ONE box:
-   python tools/ab_sampler.py [tiles ...]      (default 64 96)
+   python tools/ab_sampler.py [--rays=R] [tiles ...]      (default 1024 rays, tiles 64 96)
 HIP events around back-to-back launches (the kernel runs 100+ us: launch overhead is hidden), GEMM clock pre-warm, three rounds,
 the variants interleaved so that clock drift hits them alike.  Also checks that every variant returns the same bits as tile 32."""
 import sys
@@ -14,7 +14,9 @@ from nicer_slam_amd.fused import sampler as fs
 
 
 def main():
-    tiles = [int(t) for t in sys.argv[1:]] or [64, 96]
+    args = [a for a in sys.argv[1:] if not a.startswith("--rays=")]
+    rays = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--rays=")]
+    tiles = [int(t) for t in args] or [64, 96]
     torch.manual_seed(0)
     model = SLAMNetwork(replica_model_conf(94, 640, 32, use_warp_loss=False), n_images=1).cuda().train()
     g = torch.Generator(device="cuda").manual_seed(3)
@@ -24,7 +26,7 @@ def main():
         for n_, p in model.named_parameters():
             if n_.startswith("implicit_network") and n_.endswith("weight_v"):
                 p.add_(0.05 * torch.randn(p.shape, device="cuda", generator=g))
-    R = 1024
+    R = rays[0] if rays else 1024           # (--rays=8192: the mapping batch; `model.sdf_tile` overrides the by-size choice)
     d = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda", generator=g), dim=-1) * 0.7
     o = (torch.rand(R, 3, device="cuda", generator=g) - 0.5) * 0.4
     t_rand = torch.rand(R, 640, device="cuda", generator=g)
@@ -41,7 +43,7 @@ def main():
     while time.time() - t0 < 1.0:
         a @ a
     torch.cuda.synchronize()
-    N = 200
+    N = 200 if R <= 1024 else 40
     for rnd in range(3):
         line = []
         for t in tiles:

@@ -147,6 +147,16 @@ int nsa_rays_pose_backward(const float *uv, const float *pose, const float *K, u
 int nsa_colour_forward(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, const float *grad,
                        const float *feat_hl, float *rgb, float *save, nsa_stream_t stream);
 
+/* nsa_colour_forward followed by nsa_composite_track as two phases of ONE launch, for ray samples in ray order with 128 samples per
+ * ray (P a multiple of 128, no launch order): a workgroup of the colour forward holds exactly one ray, and when its colours are stored
+ * its first wave forms the ray's rendered colour, the L1 cotangent and the composite backward (arguments as for nsa_composite_track;
+ * R = P / 128).  The same statements as the two kernels: identical results; the per-ray kernel's launch disappears into the tail of
+ * the colour forward. */
+int nsa_colour_forward_track(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, const float *grad,
+                             const float *feat_hl, float *rgb, float *save, const float *sdf, const float *voxels,
+                             uint32_t voxel_res, const float *gt, uint32_t n_total, float *rgb_values, float *ray_loss,
+                             float *g_sdf, float *g_rgb, float *g_grad, nsa_stream_t stream);
+
 /* Data-path backward of the colour network: d/d(rgb)[P,3] -> d/d(feat) (HL, overwritten), d/d(grad sdf)[P,3]
  * (ADDED into g_grad), d/dx [P,3] and d/d(view dir) [P,3] (overwritten).  grid_grad = 0 reproduces
  * color_stage == "base" (grid feature detached, base_networks.py:337-339). */

@@ -85,6 +85,9 @@ lib.nsa_rays_backward.restype = _i
 lib.nsa_rays_backward.argtypes = [_p, _p, _p, _u32, _u32, _p, _p, _p]
 lib.nsa_sdfnet_backward_params.restype = _i
 lib.nsa_sdfnet_backward_params.argtypes = [_pp, _gp, _p, _p, _p, _p, _i, _p, _p, _p, _u32, _p]
+lib.nsa_colour_forward_track.restype = _i
+lib.nsa_colour_forward_track.argtypes = [_pp, _gp, _p, _p, _p, _p, _p, _p, _p, _u32, _p, _u32, _p, _p, _p, _p, _p, _p]
+EXPORTS += ["nsa_colour_forward_track"]
 lib.nsa_colour_coarse_backward.restype = _i
 lib.nsa_colour_coarse_backward.argtypes = [_pp, _gp, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _gp, _p, _p, _p]
 EXPORTS += ["nsa_colour_coarse_backward"]

@@ -7,6 +7,7 @@ int nsa_sdfnet_forward_pair_bf16(const nsa_points_t* pts, const nsa_grid_t* coar
 int nsa_sdfnet_backward_bf16(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* g_sdf, const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x, nsa_stream_t stream);
 int nsa_sdfnet_backward_params_bf16(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* g_sdf, const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x, float* g_table, float* emit, uint32_t emit_ld, nsa_stream_t stream);
 int nsa_colour_forward_bf16(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad, const float* feat_hl, float* rgb, float* save, nsa_stream_t stream);
+int nsa_colour_forward_track_bf16(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad, const float* feat_hl, float* rgb, float* save, const float* sdf, const float* voxels, uint32_t voxel_res, const float* gt, uint32_t n_total, float* rgb_values, float* ray_loss, float* g_sdf, float* g_rgb, float* g_grad, nsa_stream_t stream);
 int nsa_colour_backward_bf16(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad, const float* feat_hl, const float* save, const float* g_rgb, int grid_grad, float* g_feat_hl, float* g_grad, float* g_x, float* g_dir, nsa_stream_t stream);
 int nsa_colour_coarse_backward_bf16(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad, const float* feat_hl, const float* save, const float* g_rgb, int grid_grad, float* g_feat_hl, float* g_grad, float* g_x, float* g_dir, const nsa_grid_t* coarse, const float* packed_coarse, const float* g_sdf, nsa_stream_t stream);
 int nsa_colour_backward_params_bf16(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad, const float* feat_hl, const float* save, const float* g_rgb, int grid_grad, float* g_feat_hl, float* g_grad, float* g_x, float* g_dir, float* g_table, float* emit, uint32_t emit_ld, nsa_stream_t stream);

@@ -230,30 +230,7 @@ __device__ __forceinline__ void colour_mlp(float* stage, const float* __restrict
 template <int XP>
 __global__ __launch_bounds__(256, NSA_OCC_COL_FWD) void k_colour_fwd(ColourArgs a, GridGeom16 geom) {
     using Seq = ColOps<false>;
-    desync_simd_partners();
-    const int lane = threadIdx.x & 63;
-    const int h = lane >> 5;
-    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile * 32 >= a.src.P) return;
-    const bool wave_live = true;
-    uint32_t pid = tile * 32 + (lane & 31);
-    const bool live = pid < a.src.P;
-    if (!live) pid = a.src.P - 1;
-    const uint32_t q = point_of(a.src, pid);
-    float x[3], z, dir[3];
-    uint32_t ray;
-    load_point(a.src, q, x, ray, z);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) dir[d] = a.src.rays_d[ray * 3 + d];
-    float in[COL_IN_STEPS];
-    colour_inputs<XP>(a, geom, tile, q, lane, h, x, dir, in, false, wave_live);
-    f32x16 a1[2], a2[2];
-    float rgb[3];
-    colour_mlp<Seq, false>(nullptr, a.wp, lane, h, in, a1, a2, rgb);
-    if (live && h == 0) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) a.rgb[(size_t)q * 3 + j] = rgb[j];
-    }
+#include "colour_fwd_body.inc"
 }
 
 #ifdef NSA_X_TS      // profiling build only (tools/ts_profile.py --colour)
@@ -324,6 +301,37 @@ __global__ __launch_bounds__(64 * NSA_CC_NW, 2) void k_colour_coarse_bwd(ColourA
 
 }  // namespace nsa
 
+// ---- colour forward + the ray's composite / L1 / composite backward as two phases of ONE launch (tracker, 128 samples per ray) -------
+// A workgroup of the colour forward is 4 waves x 32 points = the 128 samples of ONE ray (ray order, P a multiple of 128): when its colours
+// are complete, its first wave runs k_composite_track for that ray -- the launch-bound per-ray kernel (7.5 us on an idle GPU) disappears
+// into the tail of the one-round colour forward.  The two kernels' own statements (colour_fwd_body.inc, composite_track_body.inc).
+#define NSA_COMPOSITE_AS_HEADER
+#include "render_composite.hip"
+#undef NSA_COMPOSITE_AS_HEADER
+
+namespace nsa {
+
+__global__ __launch_bounds__(256, NSA_OCC_COL_FWD) void k_colour_fwd_track(ColourArgs ca, GridGeom16 cgeom, CompositeArgs ta,
+                                                                            const float* __restrict__ gt, float* __restrict__ ray_loss,
+                                                                            float inv_n) {
+    {   // phase 1: k_colour_fwd<0> (every wave is live: the entry point requires P % 128 == 0)
+        constexpr int XP = 0;
+        using Seq = ColOps<false>;
+        const ColourArgs& a = ca;
+        const GridGeom16& geom = cgeom;
+#include "colour_fwd_body.inc"
+    }
+    __syncthreads();     // the ray's 128 colours are stored (vmcnt(0) + barrier)
+    if ((threadIdx.x >> 6) == 0) {   // phase 2: k_composite_track for ray blockIdx.x
+        const CompositeArgs& a = ta;
+        const int lane = threadIdx.x & 63;
+        const uint32_t ray = blockIdx.x;
+#include "composite_track_body.inc"
+    }
+}
+
+}  // namespace nsa
+
 #if defined(NSA_X_TS) && NSA_PIECES == 3
 extern "C" int nsa_debug_set_ts_colour(unsigned long long* p) {
     return hipMemcpyToSymbol(HIP_SYMBOL(nsa::g_ts_c), &p, sizeof(p)) == hipSuccess ? 0 : 3;
@@ -377,6 +385,35 @@ int NSA_ENTRY(nsa_colour_forward)(const nsa_points_t* pts, const nsa_grid_t* gri
     for (int l = 0; l < 8 && xpair; ++l) xpair = (geom.lv[l].flags & LV_FASTDENSE) && geom.lv[l].limB > 0;
     if (xpair) hipLaunchKernelGGL(k_colour_fwd<4>, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
     else       hipLaunchKernelGGL(k_colour_fwd<0>, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
+    return launch_end();
+}
+
+int NSA_ENTRY(nsa_colour_forward_track)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad,
+                             const float* feat_hl, float* rgb, float* save, const float* sdf, const float* voxels, uint32_t voxel_res,
+                             const float* gt, uint32_t n_total, float* rgb_values, float* ray_loss, float* g_sdf, float* g_rgb,
+                             float* g_grad, nsa_stream_t stream) {
+#if NSA_PIECES == 3
+    if (grid && grid->precision == 1)
+        return nsa_colour_forward_track_bf16(pts, grid, packed, grad, feat_hl, rgb, save, sdf, voxels, voxel_res, gt, n_total, rgb_values,
+                                             ray_loss, g_sdf, g_rgb, g_grad, stream);
+#endif
+    using namespace nsa;
+    if (!packed || !grad || !feat_hl || !rgb || !sdf || !voxels || !gt || !rgb_values || !ray_loss || !g_sdf || !g_rgb || !g_grad)
+        return NSA_EBADARG;
+    ColourArgs a{};
+    GridGeom16 geom;
+    if (int rc = colour_common(pts, grid, &a, &geom)) return rc;
+    if (pts->P == 0) return NSA_OK;
+    // one workgroup = one ray: ray samples in ray order, 128 per ray
+    if (pts->points || pts->order || pts->S != 128 || pts->P % 128 != 0 || n_total < pts->P / 128) return NSA_EBADARG;
+    a.wp = packed; a.grad = grad; a.feat = feat_hl; a.rgb = rgb; a.save = save;
+    CompositeArgs t{};
+    t.rays_o = pts->rays_o; t.rays_d = pts->rays_d; t.z_vals = pts->z_vals; t.sdf = sdf; t.rgb = rgb; t.voxels = voxels;
+    t.voxel_res = voxel_res; t.R = pts->P / 128; t.S = 128;
+    t.rgb_values = rgb_values; t.g_sdf = g_sdf; t.g_rgb = g_rgb; t.g_grad = g_grad;
+    launch_begin();
+    hipLaunchKernelGGL(k_colour_fwd_track, dim3(pts->P / 128), dim3(256), 0, (hipStream_t)stream, a, geom, t, gt, ray_loss,
+                       1.0f / (float)(3 * (uint64_t)n_total));
     return launch_end();
 }
 

@@ -121,6 +121,7 @@ __device__ __forceinline__ int ray_forward(const CompositeArgs& a, uint32_t ray,
     return n;
 }
 
+#ifndef NSA_COMPOSITE_AS_HEADER   // (the kernels are defined once, in this translation unit)
 __global__ __launch_bounds__(256) void k_composite_fwd(CompositeArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t ray = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -255,78 +256,7 @@ __global__ __launch_bounds__(256) void k_composite_track(CompositeArgs a, const 
     const int lane = threadIdx.x & 63;
     const uint32_t ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= a.R) return;
-    const uint32_t S = a.S, per = (S + 63) / 64;
-    float tgt[3], c3[MAX_PER][3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) tgt[c] = gt[ray * 3 + c];
-#pragma unroll
-    for (int k = 0; k < MAX_PER; ++k) {          // requested ahead of the forward's dependent loads (z -> voxel counter)
-        const uint32_t i = lane * per + k;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) c3[k][c] = ((uint32_t)k < per && i < S) ? a.rgb[((size_t)ray * S + i) * 3 + c] : 0.0f;
-    }
-    Sample sm[MAX_PER];
-    const int n = ray_forward(a, ray, lane, per, sm);
-    float acc[3] = {0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < MAX_PER; ++k)
-        if (k < n) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c] = fmaf(sm[k].w, c3[k][c], acc[c]);
-        }
-    float grv[3], l = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        acc[c] = wave_sum(acc[c]);
-        const float d = acc[c] - tgt[c];
-        l += fabsf(d);
-        grv[c] = d > 0.0f ? inv_n : (d < 0.0f ? -inv_n : 0.0f);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) a.rgb_values[ray * 3 + c] = acc[c];
-        ray_loss[ray] = l;
-    }
-    float wbar[MAX_PER], ww = 0.0f;
-#pragma unroll
-    for (int k = 0; k < MAX_PER; ++k) {
-        wbar[k] = 0.0f;
-        if (k < n) {
-            const size_t i = (size_t)ray * S + lane * per + k;
-            const float w = sm[k].w;
-            const float wb = grv[0] * c3[k][0] + grv[1] * c3[k][1] + grv[2] * c3[k][2];
-            wbar[k] = wb;
-            ww += wb * w;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                a.g_rgb[i * 3 + c] = w * grv[c];
-                a.g_grad[i * 3 + c] = 0.0f;              // no normal-map cotangent in the tracking objective
-            }
-        }
-    }
-    float later = ww;                                  // suffix scan: see k_composite_bwd
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float n2 = __shfl_down(later, off);
-        if (lane + off < 64) later += n2;
-    }
-    float suffix = __shfl_down(later, 1);
-    if (lane == 63) suffix = 0.0f;
-#pragma unroll
-    for (int k = MAX_PER - 1; k >= 0; --k) {
-        if (k < n) {
-            const size_t i = (size_t)ray * S + lane * per + k;
-            const Sample& s = sm[k];
-            const float Tn = s.T * expf(-s.en);
-            const float eb = wbar[k] * Tn - suffix;
-            suffix += wbar[k] * s.w;
-            const float sb = eb * s.dist;
-            const float sg = s.sdf > 0.0f ? 1.0f : (s.sdf < 0.0f ? -1.0f : 0.0f);
-            const float em1 = expm1f(-fabsf(s.sdf) / s.beta) + 1.0f;
-            const float dsig = -0.5f * sg * sg * em1 / (s.beta * s.beta);
-            a.g_sdf[i] = sb * dsig;
-        }
-    }
+#include "composite_track_body.inc"
 }
 
 // g_o[r] = sum_i g_x[r,i] ; g_d[r] = sum_i z_i g_x[r,i] + sum_i g_dir[r,i]        (x = o + z d, view dir = d)
@@ -355,8 +285,11 @@ __global__ __launch_bounds__(256) void k_rays_bwd(const float* __restrict__ z_va
     }
 }
 
+#endif  // NSA_COMPOSITE_AS_HEADER
+
 }  // namespace nsa
 
+#ifndef NSA_COMPOSITE_AS_HEADER   // (render_colour.hip includes this file for the kernel pieces only: k_colour_fwd_track)
 extern "C" {
 
 int nsa_composite_forward(const float* rays_o, const float* rays_d, const float* z_vals, const float* sdf, const float* rgb,
@@ -425,3 +358,4 @@ int nsa_rays_backward(const float* z_vals, const float* g_x, const float* g_dir,
 }
 
 }  // extern "C"
+#endif  // NSA_COMPOSITE_AS_HEADER

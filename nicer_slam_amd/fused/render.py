@@ -12,7 +12,7 @@ import torch
 from .._native import lib, check, PointsDesc
 from ..hashencoder.backend import _timed
 from . import pack
-from .sampler import COLOUR_COARSE_BWD, forward_pair_ok, grid_desc, packed_sdf, precision_of, sdf_grid_desc, tile_of
+from .sampler import COLOUR_COARSE_BWD, COLOUR_FWD_TRACK, forward_pair_ok, grid_desc, packed_sdf, precision_of, sdf_grid_desc, tile_of
 
 
 def hl_size(P):
@@ -68,9 +68,12 @@ def morton_order(pts_desc, P, device):
     return torch.sort(keys).indices.to(torch.int32)
 
 
-def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd, sort_points=False, composite=True):
+def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd, sort_points=False, composite=True, track=None):
     """Launch the forward kernels of the composite pass.  Returns a dict of device buffers.
     ``composite=False`` stops after the per-point kernels (the tracker's nsa_composite_track forms the ray sums itself).
+    ``track`` = dict(gt [R,3], ray_loss [R]) with ``composite=False``: when a ray is one workgroup of the colour forward (128 samples
+    per ray) that launch also runs the tracking objective's composite + L1 + composite backward (nsa_colour_forward_track); the
+    cotangents wait in b["track_out"] for composite_backward_raw(track=...), which then skips nsa_composite_track.
     ``sort_points``: run the per-point kernels in Morton order (mapping: the table-gradient scatter merges far more
     rows and the colour-table gathers share cache lines; the sort costs more than it saves for a 1024-ray tracking step)."""
     R, S = z_vals.shape
@@ -104,6 +107,16 @@ def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd, sort_p
             with _timed("k_sdfnet_fwd<fine>", P * 8 * 8 * 4 * 4):
                 check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), 1, b["sdf"].data_ptr(),
                                              b["grad"].data_ptr(), b["feat"].data_ptr(), st))
+    if track is not None and not composite and COLOUR_FWD_TRACK and S == 128 and order is None:
+        t_out = dict(g_sdf=torch.empty(P, device=dev), g_rgb=torch.empty(P, 3, device=dev), g_grad=torch.empty(P, 3, device=dev))
+        with _timed("k_colour_fwd", P * 16 * 8 * 2 * 4):
+            check(lib.nsa_colour_forward_track(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
+                                               b["feat"].data_ptr(), b["rgb"].data_ptr(), b["save"].data_ptr() if need_bwd else None,
+                                               b["sdf"].data_ptr(), b["vox"].data_ptr(), model.voxel_res, track["gt"].data_ptr(), R,
+                                               b["rgb_values"].data_ptr(), track["ray_loss"].data_ptr(), t_out["g_sdf"].data_ptr(),
+                                               t_out["g_rgb"].data_ptr(), t_out["g_grad"].data_ptr(), st))
+        b["track_out"] = t_out
+        return b
     with _timed("k_colour_fwd", P * 16 * 8 * 2 * 4):
         check(lib.nsa_colour_forward(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
                                      b["feat"].data_ptr(), b["rgb"].data_ptr(),
@@ -139,10 +152,13 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
     st = _stream()
     ptr = lambda t: None if t is None else t.data_ptr()
     gs = [None if g is None else g.contiguous() for g in (g_rgbv, g_depth, g_nmap, g_ent, g_w)]
-    g_sdf = torch.empty(P, device=dev)
-    g_rgb = torch.empty(P, 3, device=dev)
-    g_grad = torch.empty(P, 3, device=dev)
-    if track is not None:
+    done = b.get("track_out") if track is not None else None       # the colour forward's launch already ran the tracking objective
+    g_sdf = done["g_sdf"] if done else torch.empty(P, device=dev)
+    g_rgb = done["g_rgb"] if done else torch.empty(P, 3, device=dev)
+    g_grad = done["g_grad"] if done else torch.empty(P, 3, device=dev)
+    if done:
+        pass
+    elif track is not None:
         with _timed("k_composite_track", P * 60):
             check(lib.nsa_composite_track(rays_o.data_ptr(), rays_d.data_ptr(), z_vals.data_ptr(), b["sdf"].data_ptr(),
                                           b["rgb"].data_ptr(), b["vox"].data_ptr(), model.voxel_res, R, S, track["gt"].data_ptr(),

@@ -53,6 +53,9 @@ FWD_PAIR = os.environ.get("NSA_SDF_FWD_PAIR", "1") != "0"          # 0: two forw
 # 1: the colour backward and the coarse SDF backward of a data-path backward as ONE launch (nsa_colour_coarse_backward; 32-point tiling of
 # the coarse network).  0: two launches (A/B runs).
 COLOUR_COARSE_BWD = os.environ.get("NSA_COLOUR_COARSE_BWD", "1") != "0"
+# 1: the tracker's colour forward also runs the ray's composite + L1 + composite backward (nsa_colour_forward_track) when a ray is exactly
+# one workgroup of the colour forward (128 samples per ray).  0: nsa_colour_forward + nsa_composite_track (A/B runs).
+COLOUR_FWD_TRACK = os.environ.get("NSA_COLOUR_FWD_TRACK", "1") != "0"
 SAMPLER_LARGE_RAYS = 4096
 _FORCE = int(os.environ.get("NSA_SDF_TILE", "0"))
 _FORCE_SAMPLER = int(os.environ.get("NSA_SAMPLER_TILE", "0"))      # A/B runs of the sampler pass alone: 16 | 32 | 64 | 96

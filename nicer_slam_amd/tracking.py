@@ -15,9 +15,9 @@ from .utils.general import get_camera_from_tensor
 class KernelTracker:
     """The same iteration with NO autograd in the loop: a fixed sequence of our kernels launched through the C ABI, optionally one
     hipGraph.  One ray chunk (the default): nsa_track_begin_draw (batch copy, cam->pose, rays and the sampler's draws; in front of
-    the graph) | nsa_sampler_sdf, nsa_sample_rays, nsa_sdfnet_forward_pair, nsa_colour_forward, nsa_composite_track (composite +
+    the graph) | nsa_sampler_sdf, nsa_sample_rays, nsa_sdfnet_forward_pair, nsa_colour_forward_track (colour forward, then the ray's composite +
     L1 + composite-bwd), nsa_colour_coarse_backward (colour + coarse SDF backward), nsa_sdfnet_backward (fine), nsa_track_finish
-    (ray sums, pose-bwd, cam-bwd, Adam, candidate) -- nine launches; with ray chunks the plain entry points (head, composite, L1, composite-bwd, ray reduction, tail),
+    (ray sums, pose-bwd, cam-bwd, Adam, candidate) -- eight launches; with ray chunks the plain entry points (head, composite, L1, composite-bwd, ray reduction, tail),
     and with N > 1 ranks [all-reduce] + nsa_adam_step_scaled after the message.
     Only tracking (pose gradient) is covered; it needs a configuration in the fused engine's compiled set.
 
@@ -135,9 +135,10 @@ class KernelTracker:
             self._began = False
             z_vals, _ = fs.get_z_vals(model, rays_d, rays_o, need_eik=False, rows=(lo, hi),
                                       drawn=self.drawn if self._drawn_now else None)
-            b = fr.composite_forward_raw(model, rays_o, rays_d, z_vals, self.stage, True, composite=False)
+            trk = dict(gt=gt, ray_loss=self.ray_loss)
+            b = fr.composite_forward_raw(model, rays_o, rays_d, z_vals, self.stage, True, composite=False, track=trk)
             g_x, g_dir = fr.composite_backward_raw(model, rays_o, rays_d, z_vals, b, self.stage, self.color_stage,
-                                                   track=dict(gt=gt, ray_loss=self.ray_loss), reduce_rays=False)
+                                                   track=trk, reduce_rays=False)
             with _timed("k_track_finish", R * z_vals.shape[1] * 24):
                 check(lib.nsa_track_finish(uv.data_ptr(), self.K.data_ptr(), self.cam.data_ptr(), R, z_vals.shape[1],
                                            z_vals.data_ptr(), g_x.data_ptr(), g_dir.data_ptr(), self.ray_loss.data_ptr(),

@@ -258,3 +258,47 @@ def test_head_launch_draws_change_no_bit(use_graph):
     assert bool(torch.isfinite(runs["node"][0]).all()) and not torch.equal(runs["node"][1], cam0)
     for a, b, what in zip(runs["head"], runs["node"], ("losses", "camera", "exp_avg", "exp_avg_sq", "candidate", "message")):
         assert torch.equal(a, b), f"{what} differ by {float((a - b).abs().max()):.3g}"
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_colour_forward_with_the_ray_objective_in_its_launch_changes_no_bit(use_graph):
+    """nsa_colour_forward_track (at 128 samples per ray a workgroup of the colour forward is one ray: its first wave runs the composite +
+    L1 + composite backward of that ray when the colours are stored) against nsa_colour_forward + nsa_composite_track: losses, camera,
+    Adam moments, candidate and message of 8 tracker iterations must be IDENTICAL."""
+    from nicer_slam_amd.fused import render as fr
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.tracking import KernelTracker
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    torch.manual_seed(0)
+    model = SLAMNetwork(replica_model_conf(94, 640, 32, use_warp_loss=False), n_images=1,
+                        colour_grid=dict(base_resolution=16, desired_resolution=256, log2_hashmap_size=14)).cuda().train()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    with torch.no_grad():
+        for enc in (model.implicit_network.coarse.encoding, model.implicit_network.fine.encoding, model.rendering_network.encoding):
+            enc.embeddings.copy_((torch.rand(enc.embeddings.shape, device="cuda", generator=g) * 2 - 1) * 0.05)
+    R = 256
+    K = torch.eye(4, device="cuda")
+    K[0, 0] = K[1, 1] = 600.0
+    K[0, 2], K[1, 2] = 599.5, 339.5
+    batches = [(torch.stack([torch.rand(R, device="cuda", generator=g) * 1199, torch.rand(R, device="cuda", generator=g) * 679], -1)[None],
+                torch.rand(R, 3, device="cuda", generator=g)) for _ in range(8)]
+    cam0 = torch.tensor([1.0, 0.02, -0.01, 0.03, 0.1, 0.0, -0.2], device="cuda")
+    runs = {}
+    assert fr.COLOUR_FWD_TRACK
+    for merged in (False, True):
+        for k in ("_draw_state", "_draw_states", "_draw_seed"):
+            model.__dict__.pop(k, None)
+        torch.manual_seed(7)
+        fr.COLOUR_FWD_TRACK = merged
+        try:
+            kt = KernelTracker(model, K[None], R, cam0, lr=0.002, use_graph=use_graph)
+            ls = torch.stack([kt.step(*b).clone() for b in batches])
+            torch.cuda.synchronize()
+        finally:
+            fr.COLOUR_FWD_TRACK = True
+        runs[merged] = (ls, kt.cam.clone(), kt.m.clone(), kt.v.clone(), kt.best.clone(), kt.red.clone())
+    assert bool(torch.isfinite(runs[False][0]).all()) and not torch.equal(runs[False][1], cam0)
+    for a, b, what in zip(runs[True], runs[False], ("losses", "camera", "exp_avg", "exp_avg_sq", "candidate", "message")):
+        assert torch.equal(a, b), f"{what} differ by {float((a - b).abs().max()):.3g}"

@@ -136,6 +136,12 @@ int nsa_sdfnet_backward(const nsa_points_t *pts, const nsa_grid_t *grid, const f
 int nsa_rays_forward(const float *uv, const float *pose, const float *K, uint32_t b, uint32_t n, float *rays_o,
                      float *rays_d, float *depth_scale, nsa_stream_t stream);
 
+/* nsa_rays_forward and the sampler's draws of the pass (nsa_draw: n_rand uniforms into t_rand, the n_extra picks of E into
+ * extra_idx, no eikonal picks) in ONE launch -- the draw's workgroups ride beside the ray lifting.  Same rays, same draws. */
+int nsa_rays_forward_draw(const float *uv, const float *pose, const float *K, uint32_t b, uint32_t n, float *rays_o,
+                          float *rays_d, float *depth_scale, uint64_t *state, uint64_t n_rand, float *t_rand, uint32_t E,
+                          uint32_t n_extra, uint32_t S, int32_t *extra_idx, nsa_stream_t stream);
+
 /* Backward of the above to the camera-to-world matrices: g_pose[b,4,4] (overwritten; bottom row zero).  Deterministic: one
  * workgroup per image, fixed-order sums, no atomics. */
 int nsa_rays_pose_backward(const float *uv, const float *pose, const float *K, uint32_t b, uint32_t n,
@@ -146,6 +152,14 @@ int nsa_rays_pose_backward(const float *uv, const float *pose, const float *K, u
  * ceil(P/32)*4096 floats) receives what the backward needs from the 1 GiB colour table (features + Jacobian). */
 int nsa_colour_forward(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, const float *grad,
                        const float *feat_hl, float *rgb, float *save, nsa_stream_t stream);
+
+/* nsa_colour_forward followed by nsa_composite_forward as two phases of ONE launch, under the conditions of
+ * nsa_colour_forward_track below (ray samples in ray order, 128 per ray: a workgroup of the colour forward is one ray): weights,
+ * rgb_values, depth, nmap, entropy as nsa_composite_forward leaves them.  Identical results. */
+int nsa_colour_forward_composite(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, const float *grad,
+                                 const float *feat_hl, float *rgb, float *save, const float *sdf, const float *voxels,
+                                 uint32_t voxel_res, float *weights, float *rgb_values, float *depth, float *nmap,
+                                 float *entropy, nsa_stream_t stream);
 
 /* nsa_colour_forward followed by nsa_composite_track as two phases of ONE launch, for ray samples in ray order with 128 samples per
  * ray (P a multiple of 128, no launch order): a workgroup of the colour forward holds exactly one ray, and when its colours are stored

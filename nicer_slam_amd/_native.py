@@ -85,6 +85,9 @@ lib.nsa_rays_backward.restype = _i
 lib.nsa_rays_backward.argtypes = [_p, _p, _p, _u32, _u32, _p, _p, _p]
 lib.nsa_sdfnet_backward_params.restype = _i
 lib.nsa_sdfnet_backward_params.argtypes = [_pp, _gp, _p, _p, _p, _p, _i, _p, _p, _p, _u32, _p]
+lib.nsa_colour_forward_composite.restype = _i
+lib.nsa_colour_forward_composite.argtypes = [_pp, _gp, _p, _p, _p, _p, _p, _p, _p, _u32, _p, _p, _p, _p, _p, _p]
+EXPORTS += ["nsa_colour_forward_composite"]
 lib.nsa_colour_forward_track.restype = _i
 lib.nsa_colour_forward_track.argtypes = [_pp, _gp, _p, _p, _p, _p, _p, _p, _p, _u32, _p, _u32, _p, _p, _p, _p, _p, _p]
 EXPORTS += ["nsa_colour_forward_track"]
@@ -110,7 +113,9 @@ lib.nsa_rays_forward.restype = _i
 lib.nsa_rays_forward.argtypes = [_p, _p, _p, _u32, _u32, _p, _p, _p, _p]
 lib.nsa_rays_pose_backward.restype = _i
 lib.nsa_rays_pose_backward.argtypes = [_p, _p, _p, _u32, _u32, _p, _p, _p, _p]
-EXPORTS += ["nsa_rays_forward", "nsa_rays_pose_backward"]
+lib.nsa_rays_forward_draw.restype = _i
+lib.nsa_rays_forward_draw.argtypes = [_p, _p, _p, _u32, _u32, _p, _p, _p, _p, ctypes.c_uint64, _p, _u32, _u32, _u32, _p, _p]
+EXPORTS += ["nsa_rays_forward", "nsa_rays_forward_draw", "nsa_rays_pose_backward"]
 
 lib.nsa_cam_to_pose.restype = _i
 lib.nsa_cam_to_pose.argtypes = [_p, _u32, _p, _p]

@@ -330,6 +330,24 @@ __global__ __launch_bounds__(256, NSA_OCC_COL_FWD) void k_colour_fwd_track(Colou
     }
 }
 
+// the same with the generic composite forward (all five ray outputs + the weights) as the second phase: the autograd path
+__global__ __launch_bounds__(256, NSA_OCC_COL_FWD) void k_colour_fwd_composite(ColourArgs ca, GridGeom16 cgeom, CompositeArgs ta) {
+    {   // phase 1: k_colour_fwd<0> (every wave is live: the entry point requires P % 128 == 0)
+        constexpr int XP = 0;
+        using Seq = ColOps<false>;
+        const ColourArgs& a = ca;
+        const GridGeom16& geom = cgeom;
+#include "colour_fwd_body.inc"
+    }
+    __syncthreads();
+    if ((threadIdx.x >> 6) == 0) {   // phase 2: k_composite_fwd for ray blockIdx.x
+        const CompositeArgs& a = ta;
+        const int lane = threadIdx.x & 63;
+        const uint32_t ray = blockIdx.x;
+#include "composite_fwd_body.inc"
+    }
+}
+
 }  // namespace nsa
 
 #if defined(NSA_X_TS) && NSA_PIECES == 3
@@ -385,6 +403,33 @@ int NSA_ENTRY(nsa_colour_forward)(const nsa_points_t* pts, const nsa_grid_t* gri
     for (int l = 0; l < 8 && xpair; ++l) xpair = (geom.lv[l].flags & LV_FASTDENSE) && geom.lv[l].limB > 0;
     if (xpair) hipLaunchKernelGGL(k_colour_fwd<4>, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
     else       hipLaunchKernelGGL(k_colour_fwd<0>, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
+    return launch_end();
+}
+
+int NSA_ENTRY(nsa_colour_forward_composite)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad,
+                                 const float* feat_hl, float* rgb, float* save, const float* sdf, const float* voxels,
+                                 uint32_t voxel_res, float* weights, float* rgb_values, float* depth, float* nmap, float* entropy,
+                                 nsa_stream_t stream) {
+#if NSA_PIECES == 3
+    if (grid && grid->precision == 1)
+        return nsa_colour_forward_composite_bf16(pts, grid, packed, grad, feat_hl, rgb, save, sdf, voxels, voxel_res, weights, rgb_values,
+                                                 depth, nmap, entropy, stream);
+#endif
+    using namespace nsa;
+    if (!packed || !grad || !feat_hl || !rgb || !sdf || !voxels || !weights || !rgb_values || !depth || !nmap || !entropy)
+        return NSA_EBADARG;
+    ColourArgs a{};
+    GridGeom16 geom;
+    if (int rc = colour_common(pts, grid, &a, &geom)) return rc;
+    if (pts->P == 0) return NSA_OK;
+    if (pts->points || pts->order || pts->S != 128 || pts->P % 128 != 0) return NSA_EBADARG;      // one workgroup = one ray
+    a.wp = packed; a.grad = grad; a.feat = feat_hl; a.rgb = rgb; a.save = save;
+    CompositeArgs t{};
+    t.rays_o = pts->rays_o; t.rays_d = pts->rays_d; t.z_vals = pts->z_vals; t.sdf = sdf; t.rgb = rgb; t.grad = grad; t.voxels = voxels;
+    t.voxel_res = voxel_res; t.R = pts->P / 128; t.S = 128;
+    t.weights = weights; t.rgb_values = rgb_values; t.depth = depth; t.nmap = nmap; t.entropy = entropy;
+    launch_begin();
+    hipLaunchKernelGGL(k_colour_fwd_composite, dim3(pts->P / 128), dim3(256), 0, (hipStream_t)stream, a, geom, t);
     return launch_end();
 }
 

@@ -126,41 +126,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(CompositeArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= a.R) return;
-    const uint32_t S = a.S, per = (S + 63) / 64;
-    Sample sm[MAX_PER];
-    const int n = ray_forward(a, ray, lane, per, sm);
-    float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // rgb(3), sum w z, sum w, normal(3), entropy
-#pragma unroll
-    for (int k = 0; k < MAX_PER; ++k) {
-        if (k < n) {
-            const size_t i = (size_t)ray * S + lane * per + k;
-            const Sample& s = sm[k];
-            a.weights[i] = s.w;
-            float g[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                acc[c] = fmaf(s.w, a.rgb[i * 3 + c], acc[c]);
-                g[c] = a.grad[i * 3 + c];
-            }
-            const float inv = 1.0f / (sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]) + 1e-6f);   // network.py:339
-#pragma unroll
-            for (int c = 0; c < 3; ++c) acc[5 + c] = fmaf(s.w, g[c] * inv, acc[5 + c]);
-            acc[3] = fmaf(s.w, s.z, acc[3]);
-            acc[4] += s.w;
-            acc[8] -= s.w * logf(s.w + 1e-4f);                                                    // :298
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 9; ++q) acc[q] = wave_sum(acc[q]);
-    if (lane == 0) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            a.rgb_values[ray * 3 + c] = acc[c];
-            a.nmap[ray * 3 + c] = acc[5 + c];
-        }
-        a.depth[ray] = acc[3] / (acc[4] + 1e-8f);                                                 // :148
-        a.entropy[ray] = acc[8];
-    }
+#include "composite_fwd_body.inc"
 }
 
 __global__ __launch_bounds__(256) void k_composite_bwd(CompositeArgs a) {

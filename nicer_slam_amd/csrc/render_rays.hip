@@ -3,6 +3,7 @@
 // call that yields depth_scale (code/model/network.py:99-102).  One thread per ray; the backward reduces
 // d/d(pose[:3,:3]) = sum_rays vbar c^T and d/d(pose[:3,3]) = sum_rays obar per image in a fixed order (no atomics).
 #include "grid_common.hpp"
+#include "draw_common.hpp"
 
 namespace nsa {
 
@@ -26,8 +27,8 @@ __device__ __forceinline__ void lift_pixel(const float* __restrict__ K, float u,
     c[2] = 1.0f;
 }
 
-__global__ __launch_bounds__(256) void k_rays_fwd(RaysArgs a) {
-    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void rays_fwd_block(const RaysArgs& a, const uint32_t bid) {
+    const uint32_t r = bid * 256 + threadIdx.x;
     if (r >= a.b * a.n) return;
     const uint32_t bi = r / a.n;
     const float* P = a.pose + bi * 16;
@@ -44,6 +45,15 @@ __global__ __launch_bounds__(256) void k_rays_fwd(RaysArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) a.rays_d[3 * r + k] = v[k] / s;
     a.depth_scale[r] = c[2] / (c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+}
+
+__global__ __launch_bounds__(256) void k_rays_fwd(RaysArgs a) { rays_fwd_block(a, blockIdx.x); }
+
+// the same launch also makes the sampler's random draws of the pass (draw_common.hpp): workgroups [0, ray_blocks) lift the rays, the
+// others are nsa_draw's rand / pick workgroups -- one graph node less in front of the sampler
+__global__ __launch_bounds__(256) void k_rays_fwd_draw(RaysArgs a, DrawArgs d, uint32_t ray_blocks) {
+    if (blockIdx.x < ray_blocks) rays_fwd_block(a, blockIdx.x);
+    else draw_block(d, blockIdx.x - ray_blocks, gridDim.x - ray_blocks);
 }
 
 // One workgroup per image, every sum in a fixed order (thread t adds rays t, t + 1024, ...; butterfly over the lanes; waves in wave
@@ -111,6 +121,23 @@ int nsa_rays_forward(const float* uv, const float* pose, const float* K, uint32_
     RaysArgs a{uv, pose, K, b, n, rays_o, rays_d, depth_scale, nullptr, nullptr, nullptr};
     launch_begin();
     hipLaunchKernelGGL(k_rays_fwd, dim3((b * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_end();
+}
+
+int nsa_rays_forward_draw(const float* uv, const float* pose, const float* K, uint32_t b, uint32_t n, float* rays_o, float* rays_d,
+                          float* depth_scale, uint64_t* state, uint64_t n_rand, float* t_rand, uint32_t E, uint32_t n_extra, uint32_t S,
+                          int32_t* extra_idx, nsa_stream_t stream) {
+    using namespace nsa;
+    if (b * n == 0) return NSA_EBADARG;
+    if (!uv || !pose || !K || !rays_o || !rays_d || !depth_scale) return NSA_EBADARG;
+    if (!draw_args_ok(state, n_rand, t_rand, E, n_extra, b * n, S, extra_idx, nullptr)) return NSA_EBADARG;
+    RaysArgs a{uv, pose, K, b, n, rays_o, rays_d, depth_scale, nullptr, nullptr, nullptr};
+    DrawArgs d{};
+    const uint32_t draw_blocks = draw_launch_shape(d, reinterpret_cast<unsigned long long*>(state), n_rand, t_rand, E, n_extra, b * n, S,
+                                                   extra_idx, nullptr);
+    const uint32_t ray_blocks = (b * n + 255) / 256;
+    launch_begin();
+    hipLaunchKernelGGL(k_rays_fwd_draw, dim3(ray_blocks + draw_blocks), dim3(256), 0, (hipStream_t)stream, a, d, ray_blocks);
     return launch_end();
 }
 

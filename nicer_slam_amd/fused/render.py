@@ -117,6 +117,14 @@ def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd, sort_p
                                                t_out["g_rgb"].data_ptr(), t_out["g_grad"].data_ptr(), st))
         b["track_out"] = t_out
         return b
+    if composite and COLOUR_FWD_TRACK and S == 128 and order is None:      # the composite forward rides in the colour forward's launch
+        with _timed("k_colour_fwd", P * 16 * 8 * 2 * 4):
+            check(lib.nsa_colour_forward_composite(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
+                                                   b["feat"].data_ptr(), b["rgb"].data_ptr(), b["save"].data_ptr() if need_bwd else None,
+                                                   b["sdf"].data_ptr(), b["vox"].data_ptr(), model.voxel_res, b["weights"].data_ptr(),
+                                                   b["rgb_values"].data_ptr(), b["depth"].data_ptr(), b["nmap"].data_ptr(),
+                                                   b["entropy"].data_ptr(), st))
+        return b
     with _timed("k_colour_fwd", P * 16 * 8 * 2 * 4):
         check(lib.nsa_colour_forward(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
                                      b["feat"].data_ptr(), b["rgb"].data_ptr(),

@@ -121,10 +121,23 @@ class TrackingGraph:
         model, R, dev = self.model, self.R, self.pose_s.device
         st = torch.cuda.current_stream().cuda_stream
         rays_o, rays_d, ds = (torch.empty(R, 3, device=dev), torch.empty(R, 3, device=dev), torch.empty(R, device=dev))
-        with _timed("k_rays_fwd", R * 32):
-            check(lib.nsa_rays_forward(self.uv_s.data_ptr(), self.pose_s.data_ptr(), self.K.data_ptr(), 1, R, rays_o.data_ptr(),
-                                       rays_d.data_ptr(), ds.data_ptr(), st))
-        z_vals, z_eik = fs.get_z_vals(model, rays_d, rays_o)
+        samp = model.ray_sampler
+        E, n_extra = samp.N_samples_eval, samp.N_samples_extra
+        if fs.own_draws(model) and os.environ.get("NSA_TRACK_DRAW_IN_BEGIN", "1") != "0":
+            # the sampler's draws ride in the ray-lifting launch (one graph node less); tracking consumes no eikonal sample
+            t_rand = torch.empty(R, E, device=dev)
+            extra = torch.empty(n_extra, device=dev, dtype=torch.int32) if n_extra > 0 else None
+            with _timed("k_rays_fwd", R * 32):
+                check(lib.nsa_rays_forward_draw(self.uv_s.data_ptr(), self.pose_s.data_ptr(), self.K.data_ptr(), 1, R, rays_o.data_ptr(),
+                                                rays_d.data_ptr(), ds.data_ptr(), fs.draw_state(model, 0).data_ptr(), R * E,
+                                                t_rand.data_ptr(), E, n_extra, samp.N_samples + 2 + n_extra,
+                                                None if extra is None else extra.data_ptr(), st))
+            z_vals, z_eik = fs.get_z_vals(model, rays_d, rays_o, need_eik=False, drawn=(t_rand, extra))
+        else:
+            with _timed("k_rays_fwd", R * 32):
+                check(lib.nsa_rays_forward(self.uv_s.data_ptr(), self.pose_s.data_ptr(), self.K.data_ptr(), 1, R, rays_o.data_ptr(),
+                                           rays_d.data_ptr(), ds.data_ptr(), st))
+            z_vals, z_eik = fs.get_z_vals(model, rays_d, rays_o)
         b = fr.composite_forward_raw(model, rays_o, rays_d, z_vals, self.stage, True)
         # the forward's output dict (network.py:147-151, 281-300, 338-345) inside the same graph: five small torch launches that
         # would otherwise be dispatched, and recorded by autograd, on every call of the caller's loop

@@ -252,3 +252,42 @@ def test_colour_plus_coarse_backward_in_one_launch_changes_no_bit(R, S, stage, c
         if name == "g_feat":
             a, b_ = a[live], b_[live]
         assert torch.equal(a, b_), f"{name}: {int((a != b_).sum())} of {a.numel()} differ, max {float((a - b_).abs().max()):.3g}"
+
+
+def test_colour_forward_with_the_composite_in_its_launch_changes_no_bit():
+    """nsa_colour_forward_composite (128 samples per ray: the colour forward's workgroup is one ray and its first wave runs the
+    composite forward when the colours are stored) against nsa_colour_forward + nsa_composite_forward: weights, rendered colour, depth,
+    normal map, entropy and the per-sample colours must be identical."""
+    from nicer_slam_amd.fused import render as fr
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    torch.manual_seed(0)
+    model = SLAMNetwork(replica_model_conf(use_warp_loss=False), n_images=1,
+                        colour_grid=dict(base_resolution=16, desired_resolution=128, log2_hashmap_size=13)).cuda().train()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    with torch.no_grad():
+        for enc in (model.implicit_network.coarse.encoding, model.implicit_network.fine.encoding, model.rendering_network.encoding):
+            enc.embeddings.copy_((torch.rand(enc.embeddings.shape, device="cuda", generator=g) * 2 - 1) * 0.05)
+        for n_, p in model.named_parameters():
+            if n_.endswith("weight_v"):
+                p.add_(0.05 * torch.randn(p.shape, device="cuda", generator=g))
+    R, S = 77, 128
+    rays_d = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda", generator=g), dim=-1)
+    rays_o = ((torch.rand(R, 3, device="cuda", generator=g) - 0.5) * 0.4).contiguous()
+    z = torch.sort(torch.rand(R, S, device="cuda", generator=g) * 1.4 + 0.05, dim=1).values.contiguous()
+    outs = {}
+    assert fr.COLOUR_FWD_TRACK
+    for merged in (False, True):
+        fr.COLOUR_FWD_TRACK = merged
+        try:
+            b = fr.composite_forward_raw(model, rays_o, rays_d, z, "fine", True)
+        finally:
+            fr.COLOUR_FWD_TRACK = True
+        torch.cuda.synchronize()
+        outs[merged] = {k: b[k].clone() for k in ("weights", "rgb_values", "depth", "nmap", "entropy", "rgb", "sdf")}
+    assert bool(torch.isfinite(outs[False]["rgb_values"]).all()) and float(outs[False]["weights"].abs().max()) > 0
+    for k in outs[False]:
+        a, b_ = outs[True][k], outs[False][k]
+        assert torch.equal(a, b_), f"{k}: {int((a != b_).sum())} of {a.numel()} differ, max {float((a - b_).abs().max()):.3g}"

@@ -469,6 +469,15 @@ typedef struct nsa_feed_field {
 int nsa_feed_gather(const nsa_feed_field_t *fields, uint32_t n_fields, const int32_t *slots, uint32_t b, const int64_t *sel,
                     uint32_t n, uint64_t pixels, uint32_t width, float *uv, nsa_stream_t stream);
 
+/* Up to 8 float segments (dst[i][0..n) = src[i][0..n), device pointers) copied in ONE launch: the per-call inputs of a cached graph
+ * (pose, pixel batch, intrinsics -- the `.cuda()` / copy of each model input in the reference's loop, volsdf_train.py:411-416). */
+typedef struct nsa_copy_seg {
+    float *dst;
+    const float *src;
+    uint32_t n; /* floats */
+} nsa_copy_seg_t;
+int nsa_copy_segments(const nsa_copy_seg_t *segs, uint32_t n_segs, nsa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

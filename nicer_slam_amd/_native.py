@@ -149,6 +149,14 @@ class FeedField(ctypes.Structure):
     _fields_ = [("store", _p), ("out", _p), ("channels", _u32)]
 
 
+class CopySeg(ctypes.Structure):
+    """nsa_copy_seg_t"""
+    _fields_ = [("dst", _p), ("src", _p), ("n", _u32)]
+
+
+lib.nsa_copy_segments.restype = _i
+lib.nsa_copy_segments.argtypes = [ctypes.POINTER(CopySeg), _u32, _p]
+EXPORTS += ["nsa_copy_segments"]
 lib.nsa_feed_gather.restype = _i
 lib.nsa_feed_gather.argtypes = [ctypes.POINTER(FeedField), _u32, _p, _u32, _p, _u32, ctypes.c_uint64, _u32, _p, _p]
 EXPORTS += ["nsa_feed_gather"]

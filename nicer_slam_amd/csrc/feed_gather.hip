@@ -44,7 +44,38 @@ __global__ __launch_bounds__(256) void k_feed_gather(FeedArgs a) {
     }
 }
 
+// up to 8 small float segments copied in ONE launch (the per-call inputs of a cached graph: pose, pixel batch, intrinsics): blockIdx.y =
+// segment; a torch copy_ per tensor costs a launch and ~8 us of host time each
+constexpr int kMaxCopySegs = 8;
+struct CopyArgs {
+    float* dst[kMaxCopySegs];
+    const float* src[kMaxCopySegs];
+    uint32_t n[kMaxCopySegs];
+};
+__global__ __launch_bounds__(256) void k_copy_segments(CopyArgs a) {
+    const uint32_t s = blockIdx.y;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < a.n[s]; i += gridDim.x * 256) a.dst[s][i] = a.src[s][i];
+}
+
 }  // namespace nsa
+
+extern "C" int nsa_copy_segments(const nsa_copy_seg_t* segs, uint32_t n_segs, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!segs || n_segs == 0 || n_segs > kMaxCopySegs) return NSA_EBADARG;
+    CopyArgs a{};
+    uint32_t longest = 0;
+    for (uint32_t i = 0; i < n_segs; ++i) {
+        if (segs[i].n && (!segs[i].dst || !segs[i].src)) return NSA_EBADARG;
+        a.dst[i] = segs[i].dst; a.src[i] = segs[i].src; a.n[i] = segs[i].n;
+        if (segs[i].n > longest) longest = segs[i].n;
+    }
+    if (longest == 0) return NSA_OK;
+    uint32_t bx = (longest + 255) / 256;
+    if (bx > 64) bx = 64;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_copy_segments, dim3(bx, n_segs), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? NSA_OK : NSA_ELAUNCH;
+}
 
 extern "C" int nsa_feed_gather(const nsa_feed_field_t* fields, uint32_t n_fields, const int32_t* slots, uint32_t b, const int64_t* sel,
                                uint32_t n, uint64_t pixels, uint32_t width, float* uv, nsa_stream_t stream) {

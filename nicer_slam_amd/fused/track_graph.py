@@ -108,6 +108,9 @@ class TrackingGraph:
                             + list(model.rendering_network.mlp_parameters()))
         self._mlp_stamp = None
         self.g_rgbv_s = torch.zeros(R, 3, device=dev)
+        from .._native import CopySeg
+        self._segs = (CopySeg * 3)(CopySeg(self.pose_s.data_ptr(), None, 16), CopySeg(self.uv_s.data_ptr(), None, 2 * R),
+                                   CopySeg(self.K.data_ptr(), None, 16))
         self.packs = {}
         self.specs = pack_specs(model, R, stage)
         self.calls = 0
@@ -158,11 +161,23 @@ class TrackingGraph:
                                              g_o.data_ptr(), g_d.data_ptr(), g_pose.data_ptr(), torch.cuda.current_stream().cuda_stream))
         return g_pose
 
-    def forward(self, pose, uv, K):
-        with torch.no_grad():
+    def _copy_inputs(self, pose, uv, K):
+        """pose, uv, K of this call into the graph's static buffers: ONE launch (nsa_copy_segments) when they are plain float32 device
+        tensors, torch copies otherwise (strided / other dtype)."""
+        R = self.R
+        ok = lambda t, n: t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() >= n
+        if ok(pose, 16) and ok(uv, 2 * R) and ok(K, 16) and uv.numel() == 2 * R:
+            segs = self._segs
+            segs[0].src, segs[1].src, segs[2].src = pose.data_ptr(), uv.data_ptr(), K.data_ptr()
+            check(lib.nsa_copy_segments(segs, 3, torch.cuda.current_stream().cuda_stream))
+        else:
             self.pose_s.copy_(pose.detach().reshape(1, 4, 4))
             self.uv_s.copy_(uv.detach())
             self.K.copy_(K.detach().reshape(-1, 4, 4)[:1])
+
+    def forward(self, pose, uv, K):
+        with torch.no_grad():
+            self._copy_inputs(pose, uv, K)
             stamp = [(p.data_ptr(), p._version) for p in self._mlp_params]
             if stamp != self._mlp_stamp:                            # first call, or a mapping step moved the MLPs: re-pack in place
                 ensure_packs(self.model, self.packs, self.specs)

@@ -80,6 +80,16 @@ def isa_check(lib):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+# Experiment kernels that no default path selects: the two wave-specialised samplers of round 4 (tile codes 96 / 97,
+# bit-identical to k_sampler_sdf and at parity or slower).  They are NOT part of the product library; a tagged side-by-side build
+# made with NSA_X_WS=1 compiles them in (tools/pmc_ws_sampler.sh, tools/ts_profile_ws.py, tests/test_tiling_gpu.py when that
+# library is loaded through NSA_LIB_TAG).
+EXPERIMENT_SOURCES = ("render_sampler_ws.hip", "render_sampler_sys.hip")
+WITH_WS = bool(TAG) and os.environ.get("NSA_X_WS") == "1"
+if WITH_WS:
+    FLAGS.append("-DNSA_X_WS_SAMPLERS")
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -91,14 +101,15 @@ def build_native(force=False, verbose=False):
     _check_flags()
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    all_srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    srcs = [s for s in all_srcs if WITH_WS or os.path.basename(s) not in EXPERIMENT_SOURCES]
     hdrs = (sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + sorted(glob.glob(os.path.join(CSRC, "*.inc")))
             + [os.path.join(HERE, "..", "include", "nicer_slam_amd.h")])
     jobs = []
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
         # (every .hip counts as a dependency of every object: the *_bf16.hip units #include other .hip files)
-        if force or _stale(o, srcs + hdrs):
+        if force or _stale(o, all_srcs + hdrs):
             jobs.append((s, o))
 
     def cc(job):

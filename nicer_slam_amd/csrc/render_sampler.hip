@@ -395,6 +395,9 @@ __global__ __launch_bounds__(256) void k_sample_rays(RaySampleArgs a) {
 #endif
 #include "bf16_entries.hpp"
 #include "quad_entries.hpp"
+// The wave-specialised samplers (tile codes 96 / 97; render_sampler_ws.hip, render_sampler_sys.hip) are experiment kernels: compiled
+// only into a tagged side-by-side build (build.py, NSA_X_WS=1 -> NSA_X_WS_SAMPLERS); the product library refuses the two codes.
+#ifdef NSA_X_WS_SAMPLERS
 extern "C" int nsa_sampler_sys_sdf(const float* rays_o, const float* rays_d, uint32_t R, uint32_t E, const float* t_lin,
                                    const float* t_rand, float near, float bound, float far_cap, const nsa_grid_t* coarse,
                                    const nsa_grid_t* fine, const float* packed_coarse, const float* packed_fine, float* z, float* sdf,
@@ -403,6 +406,7 @@ extern "C" int nsa_sampler_ws_sdf(const float* rays_o, const float* rays_d, uint
                                   const float* t_rand, float near, float bound, float far_cap, const nsa_grid_t* coarse,
                                   const nsa_grid_t* fine, const float* packed_coarse, const float* packed_fine, float* z, float* sdf,
                                   float* far, nsa_stream_t stream);
+#endif
 
 extern "C" {
 
@@ -419,7 +423,7 @@ int NSA_ENTRY(nsa_sampler_sdf)(const float* rays_o, const float* rays_d, uint32_
         return NSA_EBADARG;
     if (!(coarse->L == 4 && coarse->C == 8 && coarse->n_hidden == 1 && fine->L == 8 && fine->C == 4 && fine->n_hidden == 3))
         return NSA_EUNSUPPORTED_NET;
-#if NSA_PIECES == 3
+#if NSA_PIECES == 3 && defined(NSA_X_WS_SAMPLERS)
     if (coarse->tile == 97 || fine->tile == 97) {         // systolic wave-specialised form (render_sampler_sys.hip)
         if (coarse->tile != fine->tile) return NSA_EBADARG;
         return nsa_sampler_sys_sdf(rays_o, rays_d, R, E, t_lin, t_rand, near, bound, far_cap, coarse, fine, packed_coarse,
@@ -430,6 +434,8 @@ int NSA_ENTRY(nsa_sampler_sdf)(const float* rays_o, const float* rays_d, uint32_
         return nsa_sampler_ws_sdf(rays_o, rays_d, R, E, t_lin, t_rand, near, bound, far_cap, coarse, fine, packed_coarse,
                                   packed_fine, z, sdf, far, stream);
     }
+#else
+    if (coarse->tile == 96 || coarse->tile == 97 || fine->tile == 96 || fine->tile == 97) return NSA_EUNSUPPORTED_NET;
 #endif
     if (coarse->tile == 16 || fine->tile == 16) {
         if (coarse->tile != fine->tile) return NSA_EBADARG;

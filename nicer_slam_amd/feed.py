@@ -126,12 +126,19 @@ class FrameFeed:
         if self.device.type == "cuda":
             import ctypes
             from ._native import lib, check, FeedField
+            # the kernel reads `sel` as int64 DEVICE memory: a CPU randperm (what the reference assigns to sampling_idx,
+            # scene_dataset.py:296-300) or an int32 index is converted here instead of faulting on the device
+            if sel.device != self.device or sel.dtype != torch.int64:
+                sel = sel.to(device=self.device, dtype=torch.int64)
             sel = sel.contiguous()
+            if slots.device != self.device:
+                slots = slots.to(self.device)
             uv = torch.empty(b, n, 2, device=self.device)
             gt = {k: torch.empty(b, n, c, device=self.device) for k, c in self.FIELDS}
             fields = (FeedField * len(self.FIELDS))(*[FeedField(self._stores[k].data_ptr(), gt[k].data_ptr(), c) for k, c in self.FIELDS])
-            check(lib.nsa_feed_gather(fields, len(self.FIELDS), slots.data_ptr(), b, sel.data_ptr(), n, self.total_pixels, self.W,
-                                      uv.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream))
+            with torch.cuda.device(self.device):       # (a feed on a non-current GPU launches on ITS device's current stream)
+                check(lib.nsa_feed_gather(fields, len(self.FIELDS), slots.data_ptr(), b, sel.data_ptr(), n, self.total_pixels, self.W,
+                                          uv.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream))
             return uv, gt
         flat = (slots.long().unsqueeze(1) * self.total_pixels + sel.unsqueeze(0)).reshape(-1)
         gt = {k: self._stores[k].view(-1, c).index_select(0, flat).view(b, n, c) for k, c in self.FIELDS}

@@ -15,8 +15,15 @@ with both graphs captured on the second call of a given shape (the first runs ea
 and keyed on everything a replay reads through a captured ADDRESS: ray count, stage / colour stage, tilings, precision, the three
 tables, the visit counter.  The packed MLP snapshots are owned by the cache and re-packed IN PLACE when a parameter version changes
 (a mapping step between two tracked frames), exactly as KernelTracker does.  Cotangent patterns other than "rgb_values only" (the
-tracking objective, loss.py:131) run the backward kernels eagerly.  Outputs are views of the graph's static buffers: a later
-forward overwrites them, and a backward through stale outputs raises instead of returning another iteration's gradient.
+tracking objective, loss.py:131) run the backward kernels eagerly.
+
+Aliasing contract (round 5).  The per-ray results a caller's loop keeps across iterations -- rgb_values, depth_values, normal_map,
+entropy: what the reference's loop logs, compares and renders from (volsdf_train.py:417-446) -- are returned as FRESH tensors, as
+the eager path returns them (one nsa_copy_segments launch out of the static buffers into one new allocation per call).  The five
+large per-sample tensors (weights, sdf, rgb, z_vals, depth_vals: [R,S]-sized, 3.7 MB per call) stay views of the graph's static
+buffers, valid until the next forward(mode="tracking") on the same model; NSA_TRACK_CLONE=all clones those too, NSA_TRACK_CLONE=none
+restores round 4's all-views behaviour.  A backward through the outputs of an earlier forward raises instead of returning another
+iteration's gradient.
 
 NSA_TRACK_GRAPH=0 keeps the eager Functions (A/B runs)."""
 import os
@@ -27,6 +34,7 @@ from .._native import lib, check
 from ..hashencoder.backend import _timed
 
 ENABLED = os.environ.get("NSA_TRACK_GRAPH", "1") != "0"
+CLONE = os.environ.get("NSA_TRACK_CLONE", "small")      # small | all | none (see the aliasing contract above)
 
 
 # ---- packed MLP snapshots owned by a long-lived consumer (a captured graph reads their addresses) ---------------------------------
@@ -75,9 +83,12 @@ def _key(model, R, stage, color_stage):
     loop hands over a fresh tensor from its data loader every iteration -- they are copied into a static buffer like the pixels.)"""
     from . import sampler as fs
     imp, rn, rs = model.implicit_network, model.rendering_network, model.ray_sampler
+    # ... and every launch SCALAR a capture bakes in: the sampler's range and the scene / counter geometry
     return (R, stage, color_stage, getattr(model, "mlp_precision", "fp32"), getattr(model, "sdf_tile", 0), _tiles_key(fs),
             model.voxels.data_ptr(), imp.coarse.encoding.embeddings.data_ptr(), imp.fine.encoding.embeddings.data_ptr(),
-            rn.encoding.embeddings.data_ptr(), rs.N_samples, rs.N_samples_eval, rs.N_samples_extra)
+            rn.encoding.embeddings.data_ptr(), rs.N_samples, rs.N_samples_eval, rs.N_samples_extra,
+            float(getattr(rs, "near", 0.0)), float(getattr(rs, "far", 0.0)), float(getattr(rs, "scene_bounding_sphere", 0.0)),
+            float(model.scene_bounding_sphere), int(model.voxel_res), bool(model.white_bkgd))
 
 
 def _tiles_key(fs):
@@ -117,6 +128,7 @@ class TrackingGraph:
         self.serial = 0
         self.fwd_graph = self.bwd_graph = None
         self.out = self.g_pose = None
+        self._out_segs = None
 
     # the two launch sequences (no autograd inside: plain C-ABI launches on the current stream)
     def _forward_body(self):
@@ -179,7 +191,10 @@ class TrackingGraph:
         with torch.no_grad():
             self._copy_inputs(pose, uv, K)
             stamp = [(p.data_ptr(), p._version) for p in self._mlp_params]
-            if stamp != self._mlp_stamp:                            # first call, or a mapping step moved the MLPs: re-pack in place
+            cache = self.model.__dict__.get("_fused_pack", {})
+            # first call, a mapping step moved the MLPs, or another consumer replaced a cache entry this graph reads through a
+            # captured address (the entry must still BE the tensor this graph owns): re-pack in place
+            if stamp != self._mlp_stamp or any(cache.get(k, (None, None))[1] is not v[1] for k, v in self.packs.items()):
                 ensure_packs(self.model, self.packs, self.specs)
                 self._mlp_stamp = stamp
             self.calls += 1
@@ -201,6 +216,25 @@ class TrackingGraph:
                 g.replay()
         self.serial += 1
         return self.out
+
+    def fresh_small_outputs(self):
+        """rgb_values [1,R,3], depth_values [1,R,1], normal_map [1,R,3], entropy [] of the last forward as views of ONE new
+        allocation (7R + 1 floats), filled by one launch: the caller may keep them across iterations like the eager path's."""
+        from .._native import CopySeg
+        R, f = self.R, self.out["final"]
+        srcs = (f["rgb_values"], f["depth_values"], f["normal_map"], f["entropy"])
+        if not all(t.is_contiguous() and t.dtype == torch.float32 for t in srcs):
+            return tuple(t.clone() for t in srcs)
+        ptrs = tuple(t.data_ptr() for t in srcs)
+        if self._out_segs is None or self._out_segs[0] != ptrs:      # (the eager warm-up call and the capture use other buffers)
+            self._out_segs = (ptrs, (CopySeg * 4)(CopySeg(None, ptrs[0], 3 * R), CopySeg(None, ptrs[1], R),
+                                                  CopySeg(None, ptrs[2], 3 * R), CopySeg(None, ptrs[3], 1)))
+        segs = self._out_segs[1]
+        buf = torch.empty(7 * R + 1, device=self.pose_s.device)
+        base = buf.data_ptr()
+        segs[0].dst, segs[1].dst, segs[2].dst, segs[3].dst = base, base + 12 * R, base + 16 * R, base + 28 * R
+        check(lib.nsa_copy_segments(segs, 4, torch.cuda.current_stream().cuda_stream))
+        return (buf[:3 * R].view(1, R, 3), buf[3 * R:4 * R].view(1, R, 1), buf[4 * R:7 * R].view(1, R, 3), buf[7 * R:].view(()))
 
     def backward(self, g_rgbv, g_depth_values, g_normal_map, g_w, g_entropy):
         """Cotangents of (rgb_values, depth_values, normal_map, weights, entropy) -> d / d pose."""
@@ -236,9 +270,15 @@ class _TrackingCore(torch.autograd.Function):
         R, S = z.shape
         ctx.tg, ctx.serial = tg, tg.serial
         ctx.set_materialize_grads(False)
-        sdf_o, rgb_o = b["sdf"].view(R, S), b["rgb"].view(R, S, 3)
-        ctx.mark_non_differentiable(sdf_o, rgb_o, z, f["depth_vals"])
-        return f["rgb_values"], f["depth_values"], f["normal_map"], b["weights"], f["entropy"], sdf_o, rgb_o, z, f["depth_vals"]
+        sdf_o, rgb_o, w_o, dv_o = b["sdf"].view(R, S), b["rgb"].view(R, S, 3), b["weights"], f["depth_vals"]
+        if CLONE == "none":
+            rgbv, depthv, nmap, ent = f["rgb_values"], f["depth_values"], f["normal_map"], f["entropy"]
+        else:
+            rgbv, depthv, nmap, ent = tg.fresh_small_outputs()
+            if CLONE == "all":
+                sdf_o, rgb_o, w_o, z, dv_o = sdf_o.clone(), rgb_o.clone(), w_o.clone(), z.clone(), dv_o.clone()
+        ctx.mark_non_differentiable(sdf_o, rgb_o, z, dv_o)
+        return rgbv, depthv, nmap, w_o, ent, sdf_o, rgb_o, z, dv_o
 
     @staticmethod
     def backward(ctx, g_rgbv, g_depth_values, g_normal_map, g_w, g_entropy, *_unused):

@@ -65,13 +65,16 @@ class _timed:
         self.name, self.nbytes = name, nbytes
 
     def __enter__(self):
-        if PROFILE is not None:
+        # (timing events cannot be recorded on a capturing stream: a PROFILE list left on while a consumer captures its
+        # hipGraph -- fused/track_graph.py, tracking.py -- must not poison the capture)
+        self.on = PROFILE is not None and not torch.cuda.is_current_stream_capturing()
+        if self.on:
             self.t0 = torch.cuda.Event(enable_timing=True)
             self.t1 = torch.cuda.Event(enable_timing=True)
             self.t0.record()
 
     def __exit__(self, *exc):
-        if PROFILE is not None:
+        if self.on and PROFILE is not None:
             self.t1.record()
             PROFILE.append((self.name, self.nbytes, self.t0, self.t1))
 

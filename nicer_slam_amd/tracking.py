@@ -47,6 +47,7 @@ class KernelTracker:
         self.cam = cam_init.detach().clone().to(dev).float().contiguous()
         self.uv = torch.zeros(1, n_rays, 2, device=dev)
         self.gt = torch.zeros(n_rays, 3, device=dev)
+        self._uv_shape, self._gt_shape = (1, n_rays, 2), (n_rays, 3)
         z = lambda *s: torch.zeros(*s, device=dev)
         self.pose, self.g_pose, self.red = z(1, 4, 4), z(1, 4, 4), z(9)     # red = [g_cam(7), loss, n_rays]
         self.m, self.v, self.t = z(7), z(7), z(1)
@@ -285,6 +286,7 @@ class TrackingStepper:
         self.cam = cam_init.detach().clone().to(dev).requires_grad_(True)
         self.uv = torch.zeros(1, n_rays, 2, device=dev)
         self.gt = torch.zeros(n_rays, 3, device=dev)
+        self._uv_shape, self._gt_shape = (1, n_rays, 2), (n_rays, 3)
         self.ind = torch.zeros(1, dtype=torch.long, device=dev)
         self.graph_all = use_graph and world == 1     # Adam inside the graph only when no all-reduce sits in between
         self.opt = torch.optim.Adam([self.cam], lr=lr, capturable=self.graph_all)
@@ -344,7 +346,14 @@ class TrackingStepper:
             self.graph.replay()
             loss = self.loss
         else:
-            self.uv, self.gt = uv, gt                  # eager: no static inputs to fill (the reference's loop has none either)
+            # eager: no static inputs to fill (the reference's loop has none either) -- but only a float32 device tensor of the
+            # expected shape is used as is; anything else (host tensor, other dtype, [R,2] pixels) is normalised by a copy
+            dev = self.cam.device
+            def _as(t, shape):
+                if t.is_cuda and t.device == dev and t.dtype == torch.float32 and tuple(t.shape) == shape and t.is_contiguous():
+                    return t
+                return t.detach().to(device=dev, dtype=torch.float32).reshape(shape).contiguous()
+            self.uv, self.gt = _as(uv, tuple(self._uv_shape)), _as(gt, tuple(self._gt_shape))
             if self.cam.grad is not None:
                 self.cam.grad.zero_()
             loss = self._fwd_bwd()

@@ -136,11 +136,67 @@ def positional_encoding(x, n_freq):
     return torch.cat(parts, -1)
 
 
-def wn_linear(params, prefix, x):
-    """nn.utils.weight_norm(nn.Linear) forward (base_networks.py:148-149,325-326): W = g*v/|v|_row."""
+# ---- optional bf16-OPERAND GEMM emulation (BASELINE configs[2] "bf16 MLP", configs[4] "bf16 + fp32 SDF head") ----------------
+# The reference has no such mode (fp32 only; hashgrid.py:15's autocast is never enabled): this restates what the product's
+# `mlp_precision = "bf16" | "bf16_colour"` kernels compute (nicer_slam_amd/csrc/mlp_common.hpp, NSA_PIECES == 1), so that those
+# modes have a checker that is independent of the HIP code:
+#   * every matrix-core GEMM takes BOTH operands rounded to bfloat16, round-to-nearest-even (weights: the first piece of the
+#     packed split, fused/pack.py::split_bf16x3; activations / cotangents / tangents: v_cvt_pk_bf16_f32), products exact,
+#     accumulation in fp32 starting from the fp32 bias;
+#   * this holds for the forward GEMMs, for the reverse pass that builds grad sdf (cotangent operand rounded) and for the GEMMs of
+#     the backward kernels (second-order sweeps included): _LinQ's backward is itself a _LinQ on the rounded cotangent;
+#   * what the kernels compute on the vector ALU stays fp32: the sdf row of an SDF network's last layer (sdf_net4.hpp /
+#     render_sdfnet4.hip: a VALU dot with the fp32 row), the colour network's 64 -> 3 output layer (render_colour.hip::colour_mlp),
+#     encoders, activations, compositing.
+def _rne_bf16(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundSTE(torch.autograd.Function):
+    """x -> bf16(x) (round to nearest even), derivative 1: the rounding of a GEMM operand is not part of the differentiated graph."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _rne_bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _LinQ(torch.autograd.Function):
+    """y = xr @ wr^T on ALREADY ROUNDED operands; every derivative GEMM rounds the vector it multiplies, recursively."""
+
+    @staticmethod
+    def forward(ctx, xr, wr):
+        ctx.save_for_backward(xr, wr)
+        return xr @ wr.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        xr, wr = ctx.saved_tensors
+        gr = _RoundSTE.apply(g)
+        gx = _LinQ.apply(gr, wr.t().contiguous()) if ctx.needs_input_grad[0] else None
+        gw = _LinQ.apply(gr.t().contiguous(), xr.t().contiguous()) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+def q_linear(x, w, b):
+    return _LinQ.apply(_RoundSTE.apply(x), _RoundSTE.apply(w)) + b
+
+
+def wn_linear(params, prefix, x, quant=False, exact_rows=0):
+    """nn.utils.weight_norm(nn.Linear) forward (base_networks.py:148-149,325-326): W = g*v/|v|_row.
+    quant: the bf16-operand emulation above; the first ``exact_rows`` output rows stay plain fp32 (vector-ALU rows)."""
     g, v, b = params[prefix + ".weight_g"], params[prefix + ".weight_v"], params[prefix + ".bias"]
     w = v * (g / v.norm(2, dim=1, keepdim=True))
-    return F.linear(x, w, b)
+    if not quant:
+        return F.linear(x, w, b)
+    if exact_rows >= w.shape[0]:
+        return F.linear(x, w, b)
+    if exact_rows == 0:
+        return q_linear(x, w, b)
+    return torch.cat((F.linear(x, w[:exact_rows], b[:exact_rows]), q_linear(x, w[exact_rows:], b[exact_rows:])), dim=-1)
 
 
 @dataclass
@@ -167,23 +223,25 @@ class RenderConfig:
     n_samples_extra: int = 32
     voxel_res: int = 64
     white_bkgd: bool = False
+    mlp_precision: str = "fp32"     # "fp32" (the reference) | "bf16" (every MLP) | "bf16_colour" (colour MLP only): see _LinQ
 
 
-def sdf_net_forward(params, prefix, spec: SdfNetSpec, x):
-    """ImplicitNetworkGrid.forward (base_networks.py:155-186): hash(x/df) ++ PE -> softplus MLP."""
+def sdf_net_forward(params, prefix, spec: SdfNetSpec, x, quant=False):
+    """ImplicitNetworkGrid.forward (base_networks.py:155-186): hash(x/df) ++ PE -> softplus MLP.
+    quant: bf16-operand GEMMs (the sdf row of the last layer stays fp32, see _LinQ)."""
     feat = grid_features(x / spec.divide_factor, params[prefix + ".encoding.embeddings"], spec.grid)
     h = torch.cat((positional_encoding(x, spec.multires), feat), dim=-1)
     for l in range(spec.n_linear):
-        h = wn_linear(params, f"{prefix}.lin{l}", h)
+        h = wn_linear(params, f"{prefix}.lin{l}", h, quant, exact_rows=1 if l == spec.n_linear - 1 else 0)
         if l < spec.n_linear - 1:
             h = F.softplus(h, beta=100)
     return h
 
 
-def _net_outputs(params, prefix, spec, x):
+def _net_outputs(params, prefix, spec, x, quant=False):
     """ImplicitNetworkGrid.get_outputs (base_networks.py:208-221)."""
     x.requires_grad_(True)
-    out = sdf_net_forward(params, prefix, spec, x)
+    out = sdf_net_forward(params, prefix, spec, x, quant)
     sdf, feat = out[:, :1], out[:, 1:]
     (g,) = torch.autograd.grad(sdf, x, torch.ones_like(sdf), create_graph=True, retain_graph=True)
     return sdf, feat, g
@@ -191,28 +249,32 @@ def _net_outputs(params, prefix, spec, x):
 
 def sdf_outputs(params, cfg: RenderConfig, x, stage="fine"):
     """ImplicitNetworkGrid_COMBINE.get_outputs (base_networks.py:34-40)."""
-    c = _net_outputs(params, "implicit_network.coarse", cfg.coarse, x)
+    q = cfg.mlp_precision == "bf16"
+    c = _net_outputs(params, "implicit_network.coarse", cfg.coarse, x, q)
     if stage == "coarse":
         return c
-    f = _net_outputs(params, "implicit_network.fine", cfg.fine, x)
+    f = _net_outputs(params, "implicit_network.fine", cfg.fine, x, q)
     return c[0] + f[0], c[1] + f[1], c[2] + f[2]
 
 
 def sdf_vals(params, cfg: RenderConfig, x, stage="fine"):
     """ImplicitNetworkGrid_COMBINE.get_sdf_vals (base_networks.py:27-32); the reference's extra
     coarse feature evaluation (:31) has no effect on the value and is not repeated."""
-    s = sdf_net_forward(params, "implicit_network.coarse", cfg.coarse, x)[:, :1]
+    q = cfg.mlp_precision == "bf16"
+    s = sdf_net_forward(params, "implicit_network.coarse", cfg.coarse, x, q)[:, :1]
     if stage == "coarse":
         return s
-    return s + sdf_net_forward(params, "implicit_network.fine", cfg.fine, x)[:, :1]
+    return s + sdf_net_forward(params, "implicit_network.fine", cfg.fine, x, q)[:, :1]
 
 
 def sdf_gradient(params, cfg: RenderConfig, x, stage="fine"):
     """ImplicitNetworkGrid_COMBINE.gradient (base_networks.py:42-47,195-206)."""
     x.requires_grad_(True)
 
+    q = cfg.mlp_precision == "bf16"
+
     def one(prefix, spec):
-        y = sdf_net_forward(params, prefix, spec, x)[:, :1]
+        y = sdf_net_forward(params, prefix, spec, x, q)[:, :1]
         return torch.autograd.grad(y, x, torch.ones_like(y), create_graph=True, retain_graph=True)[0]
 
     g = one("implicit_network.coarse", cfg.coarse)
@@ -228,8 +290,9 @@ def colour_net(params, cfg: RenderConfig, points, normals, view_dirs, feats, col
     if color_stage == "base":
         gf = gf.detach()
     h = torch.cat([points, positional_encoding(view_dirs, cfg.multires_view), normals, feats, gf], dim=-1)
+    q = cfg.mlp_precision in ("bf16", "bf16_colour")
     for l in range(cfg.colour_n_linear):
-        h = wn_linear(params, f"rendering_network.lin{l}", h)
+        h = wn_linear(params, f"rendering_network.lin{l}", h, q and l < cfg.colour_n_linear - 1)   # (64 -> 3: vector ALU, fp32)
         if l < cfg.colour_n_linear - 1:
             h = torch.relu(h)
     return torch.sigmoid(h)

@@ -1,0 +1,163 @@
+"""The optional bf16-operand MLP modes (BASELINE configs[2] "bf16 MLP", configs[4] "bf16 + fp32 SDF head") against an INDEPENDENT
+checker: oracle/render_ref.py with ``RenderConfig.mlp_precision`` = "bf16" / "bf16_colour" -- a CPU restatement of the dataflow
+(both operands of every matrix-core GEMM rounded to bfloat16 RNE, exact products, fp32 accumulation; cotangent / tangent operands of
+the derivative GEMMs rounded the same way; vector-ALU rows in fp32), at those configs' per-GPU shapes (512 rays x 128 samples,
+1024 rays x 192 samples).  tests/test_precision_gpu.py compares the bf16 kernels with the fp32 kernels (HIP vs HIP, the size of
+the bf16 effect); here the bf16 kernels are held to what bf16 operands SHOULD give.
+
+Tolerances come from the emulation, not from a flat 2e-2:
+  * D = |oracle(bf16) - oracle(fp32)| is the size of the reduced-precision effect on a tensor;
+  * a value the two sides compute identically up to fp32 rounding agrees to the fp32 bound (2e-5 abs / 1e-4 rel) -- required of
+    >= `min_tight` of the elements;
+  * the rest are ROUNDING FLIPS: an operand that sits within fp32 noise of a bf16 rounding boundary is rounded the other way on one
+    side (one bf16 ulp = 2^-8 of that operand), which moves the point's outputs by a fraction of D.  Every element must stay
+    within `flip` x the largest emulated deviation max(D) of its tensor;
+  * the oracle must EXPLAIN the deviation: ||hip - oracle(bf16)|| <= (1 - explained) ||hip - oracle(fp32)|| per tensor."""
+import pytest
+import torch
+
+from helpers import assert_close
+from test_oracle_golden import check_samples
+
+pytestmark = pytest.mark.gpu
+
+
+class _DS:
+    img_res = (680, 1200)
+
+
+def _setup(Rn, S):
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    E, NX = 640, 32
+    torch.manual_seed(0)
+    model = SLAMNetwork(replica_model_conf(S - 2 - NX, E, NX, use_warp_loss=False), dataset=_DS(), n_images=1).cuda().train()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    with torch.no_grad():
+        for enc, s in ((model.implicit_network.coarse.encoding, 0.02), (model.implicit_network.fine.encoding, 0.02),
+                       (model.rendering_network.encoding, 0.3)):
+            enc.embeddings.copy_((torch.rand(enc.embeddings.shape, device="cuda", generator=g) * 2 - 1) * s)
+        # the geometric initialisation zeroes the first-layer columns of the encodings: perturb the directions so that every
+        # GEMM operand is a generic fp32 number
+        for n_, p in model.named_parameters():
+            if n_.endswith("weight_v"):
+                p.add_(0.03 * torch.randn(p.shape, device="cuda", generator=g))
+    for p in model.parameters():
+        p.requires_grad_(False)
+    model.engine = "fused"
+    idx = torch.randint(680 * 1200, (1, Rn), device="cuda", generator=g)
+    uv = torch.stack([(idx % 1200).float(), (idx // 1200).float()], -1)
+    K = torch.eye(4, device="cuda")
+    K[0, 0] = K[1, 1] = 600.0
+    K[0, 2], K[1, 2] = 599.5, 339.5
+    gt = torch.rand(Rn, 3, device="cuda", generator=g)
+    draws = {"t_rand": torch.rand(Rn, E, device="cuda", generator=g),
+             "extra_idx": torch.randperm(E, device="cuda", generator=g)[:NX],
+             "eik_idx": torch.randint(S, (Rn,), device="cuda", generator=g)}
+    return model, uv, K, gt, draws
+
+
+def _hip(model, uv, K, gt, draws, precision):
+    from nicer_slam_amd.utils.general import get_camera_from_tensor
+    model.mlp_precision = precision
+    model.draws = dict(draws)
+    cam = torch.tensor([1.0, 0.01, -0.02, 0.015, 0.1, 0.0, -0.2], device="cuda", requires_grad=True)
+    out = model({"intrinsics": K[None], "uv": uv, "pose": get_camera_from_tensor(cam).unsqueeze(0)},
+                torch.zeros(1, dtype=torch.long, device="cuda"), {}, mode="tracking", frame_idx=1)
+    assert model.last_engine == "fused"
+    (out["rgb_values"].reshape(-1, 3) - gt).abs().mean().backward()
+    return {k: v.detach().cpu() for k, v in out.items() if torch.is_tensor(v)}, cam.grad.detach().cpu()
+
+
+def _oracle(model, uv, K, gt, draws, precision, S):
+    from oracle import render_ref as R
+    E, NX = 640, 32
+    mk = R.make_grid_spec
+    cfg = R.RenderConfig(coarse=R.SdfNetSpec(mk(4, 8, 32, 32, 19), 2), fine=R.SdfNetSpec(mk(8, 4, 32, 128, 19), 4),
+                         colour_grid=mk(16, 2, 16, 2048, 24), n_samples=S - 2 - NX, n_samples_eval=E, n_samples_extra=NX,
+                         mlp_precision=precision)
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cam = torch.tensor([1.0, 0.01, -0.02, 0.015, 0.1, 0.0, -0.2], requires_grad=True)
+    out = R.render(params, cfg, uv.cpu(), R.camera_from_tensor(cam).unsqueeze(0), K[None].cpu(), model.voxels.cpu(),
+                   {k: v.cpu() for k, v in draws.items()}, mode="tracking", training=True)
+    (out["rgb_values"].reshape(-1, 3) - gt.cpu()).abs().mean().backward()
+    return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}, cam.grad.detach()
+
+
+def _hold(name, hip, emu, fp32, min_tight, flip, explained, report):
+    """the three criteria of the module docstring for one tensor"""
+    hip, emu, fp32 = hip.reshape(-1).double(), emu.reshape(-1).double(), fp32.reshape(-1).double()
+    D = (emu - fp32).abs()
+    resid = (hip - emu).abs()
+    tight = float((resid <= 2e-5 + 1e-4 * emu.abs()).double().mean())
+    worst = float(resid.max() / max(float(D.max()), 1e-30))
+    expl = 1.0 - float((hip - emu).norm() / max(float((hip - fp32).norm()), 1e-30))
+    report.append(f"{name}: bf16 effect max {float(D.max()):.3e} median {float(D.median()):.3e} | residual max {float(resid.max()):.3e} "
+                  f"median {float(resid.median()):.3e} | tight {tight:.4f} | max residual / max effect {worst:.3f} | explained {expl:.4f}")
+    assert tight >= min_tight, report[-1]
+    assert worst <= flip, report[-1]
+    assert expl >= explained, report[-1]
+
+
+@pytest.mark.parametrize("Rn,S,precision", [(512, 128, "bf16"), (1024, 192, "bf16_colour"), (512, 128, "bf16_colour")])
+def test_bf16_modes_vs_bf16_emulating_oracle(Rn, S, precision, capsys):
+    model, uv, K, gt, draws = _setup(Rn, S)
+    # one sample set for every run: the fp32 kernels' own, far sample pulled off the cube face (tests/test_configs_gpu.py (2))
+    ref_hip, g_hip32 = _hip(model, uv, K, gt, draws, "fp32")
+    z_fix = ref_hip["z_vals"].cuda().clone()
+    z_fix[:, -1] = torch.maximum(z_fix[:, -1] * (1 - 2e-4), z_fix[:, -2])
+    fixed = dict(draws, z_vals_override=z_fix)
+    hip, g_hip = _hip(model, uv, K, gt, fixed, precision)
+    emu, g_emu = _oracle(model, uv, K, gt, fixed, precision, S)
+    f32, g_f32 = _oracle(model, uv, K, gt, fixed, "fp32", S)
+    report = []
+    if precision == "bf16_colour":                    # the SDF head stays fp32: held to the fp32 bound
+        for k in ("sdf", "weights", "depth_values", "normal_map"):
+            assert_close(hip[k], f32[k], 2e-5, 1e-4, k + " (fp32 SDF head)")
+        tensors = ("rgb", "rgb_values")
+    else:
+        tensors = ("sdf", "rgb", "weights", "rgb_values", "depth_values", "normal_map")
+    for k in tensors:
+        # per-point tensors: a few per cent of the points carry a rounding flip somewhere in their ~600 GEMM operands; per-ray
+        # tensors sum 128-192 points, so most rays contain one -- weighted by the compositing weights
+        per_ray = k in ("rgb_values", "depth_values", "normal_map")
+        _hold(k, hip[k], emu[k], f32[k], min_tight=0.50 if per_ray else 0.90, flip=0.5, explained=0.90, report=report)
+    # pose gradient: 7 numbers, sums over all rays; the emulation rounds the cotangent / tangent operands like the kernels do
+    scale = float(g_emu.abs().max())
+    g_res, g_eff = float((g_hip - g_emu).abs().max()) / scale, float((g_emu - g_f32).abs().max()) / scale
+    report.append(f"pose gradient: bf16 effect {g_eff:.3e} of the largest component | hip vs emulation {g_res:.3e} | "
+                  f"hip(bf16) vs hip(fp32) {float((g_hip - g_hip32).abs().max()) / scale:.3e}")
+    with capsys.disabled():
+        print(f"\n[{precision} {Rn}x{S}]\n  " + "\n  ".join(report))
+    assert g_res <= max(0.25 * g_eff, 2e-3), report[-1]
+
+
+def test_bf16_sampler_vs_bf16_emulating_oracle(capsys):
+    """The free-running bf16 sampler (configs[2]): its SDF pass against the emulation at every one of the 512 x 640 sampler points,
+    and its sample set in the CDF space of the emulation's own sampler (tests/test_oracle_golden.py::check_samples)."""
+    from nicer_slam_amd.fused import sampler as fs
+    from oracle import render_ref as R
+    Rn, S = 512, 128
+    model, uv, K, gt, draws = _setup(Rn, S)
+    hip, _ = _hip(model, uv, K, gt, draws, "bf16")
+    emu, _ = _oracle(model, uv, K, gt, draws, "bf16", S)
+    check_samples(hip["z_vals"], emu["z_vals"], emu["sampler_bins"], emu["sampler_cdf"], u_tol=2e-4, min_tight=0.90)
+    # the SDF pass itself, point by point
+    model.mlp_precision = "bf16"
+    pose = R.camera_from_tensor(torch.tensor([1.0, 0.01, -0.02, 0.015, 0.1, 0.0, -0.2])).unsqueeze(0)
+    d, o = R.camera_rays(uv.cpu(), pose, K[None].cpu())
+    d, o = d.reshape(-1, 3), o.expand(Rn, 3).contiguous()
+    z, sdf, _far = fs.sampler_sdf(model, o.cuda(), d.cuda(), draws["t_rand"])
+    pts = (o.unsqueeze(1) + z.cpu().unsqueeze(2) * d.unsqueeze(1)).reshape(-1, 3)
+    mk = R.make_grid_spec
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    res = {}
+    for prec in ("bf16", "fp32"):
+        cfg = R.RenderConfig(coarse=R.SdfNetSpec(mk(4, 8, 32, 32, 19), 2), fine=R.SdfNetSpec(mk(8, 4, 32, 128, 19), 4),
+                             colour_grid=mk(16, 2, 16, 2048, 24), mlp_precision=prec)
+        with torch.no_grad():
+            res[prec] = R.sdf_vals(params, cfg, pts).reshape(-1)
+    report = []
+    _hold("sampler sdf (327 680 points)", sdf.cpu(), res["bf16"], res["fp32"], min_tight=0.90, flip=0.5, explained=0.90, report=report)
+    with capsys.disabled():
+        print("\n  " + report[0])

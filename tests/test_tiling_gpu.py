@@ -58,6 +58,30 @@ def test_quad_and_32_point_tilings_agree(name):
     assert n >= 10
 
 
+def _ws_tiles():
+    """Tile codes 96 / 97 (the wave-specialised experiment samplers) exist only in a tagged side-by-side build made
+    with NSA_X_WS=1 and loaded through NSA_LIB_TAG; the product library refuses them (test_product_library_refuses_ws_codes)."""
+    from nicer_slam_amd._native import lib
+    return (96, 97) if hasattr(lib, "nsa_sampler_ws_sdf") else ()
+
+
+def test_product_library_refuses_ws_codes():
+    from nicer_slam_amd._native import lib
+    if hasattr(lib, "nsa_sampler_ws_sdf"):
+        pytest.skip("experiment build with the wave-specialised samplers loaded")
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    from nicer_slam_amd.fused import sampler as fs
+    model = SLAMNetwork(replica_model_conf(94, 640, 32, use_warp_loss=False), n_images=1,
+                        colour_grid=dict(base_resolution=16, desired_resolution=64, log2_hashmap_size=12)).cuda().train()
+    o = torch.zeros(4, 3, device="cuda")
+    d = torch.nn.functional.normalize(torch.ones(4, 3, device="cuda"), dim=-1)
+    for tile in (96, 97):
+        model.sdf_tile = tile
+        with pytest.raises(RuntimeError):
+            fs.sampler_sdf(model, o, d, torch.rand(4, 640, device="cuda"))
+
+
 def test_sampler_sdf_stage_both_tilings():
     """Coarse sampler stage (z, sdf at R*E points) and batch SDF inference, quad vs 32-point tiling, shipped grid sizes, ragged
     point counts (the quad kernels are persistent: every tile must be visited exactly once)."""
@@ -82,14 +106,14 @@ def test_sampler_sdf_stage_both_tilings():
         res = {}
         # 64 = 32-point tiling, two point tiles per wave; 96 = wave-specialised 32-point form (render_sampler_ws.hip)
         # 97 = systolic form (layer-engine waves, render_sampler_sys.hip)
-        for tile in (16, 32, 64, 96, 97):
+        for tile in (16, 32, 64) + _ws_tiles():
             model.sdf_tile = tile
             res[tile] = fs.sampler_sdf(model, o, d, t_rand)
         for a, b, what in zip(res[16], res[32], ("z", "sdf", "far")):
             assert_close(a, b.cpu().numpy(), 1e-6 if what == "sdf" else 0, 1e-5 if what == "sdf" else 0, f"{what} (R={R})")
         for a, b, what in zip(res[64], res[32], ("z", "sdf", "far")):
             assert torch.equal(a, b), f"two tiles per wave: {what} differs from one tile per wave (R={R})"
-        for t in (96, 97):                                               # same MFMA order per accumulator: bit-identical
+        for t in _ws_tiles():                                            # same MFMA order per accumulator: bit-identical
             for a, b, what in zip(res[t], res[32], ("z", "sdf", "far")):
                 assert torch.equal(a, b), f"wave-specialised sampler (tile code {t}): {what} differs from the one-program form " \
                                           f"(R={R}): {int((a != b).sum())} of {a.numel()}"
@@ -130,7 +154,7 @@ def test_mfma_kernels_are_bit_reproducible_and_match_the_oracle_at_scale():
     cfg = R.RenderConfig(coarse=R.SdfNetSpec(mk(4, 8, 32, 32, 19), 2), fine=R.SdfNetSpec(mk(8, 4, 32, 128, 19), 4),
                          colour_grid=mk(16, 2, 16, 64, 12), n_samples=94, n_samples_eval=640, n_samples_extra=32)
     params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    for tile in (16, 32, 96, 97):
+    for tile in (16, 32) + _ws_tiles():
         model.sdf_tile = tile
         runs = [fs.sampler_sdf(model, o, d, t_rand) for _ in range(5)]
         for r in runs[1:]:

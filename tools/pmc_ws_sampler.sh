@@ -1,6 +1,8 @@
 #!/bin/bash
 # Run ON THE GPU BOX: matrix-pipe co-execution counters of the three sampler forms (shipped two-tile program, matrix waves on loan = 96,
 # systolic layer engines = 97) -> gpurun_out/prof/pmc_ws_sampler.csv   (SQ_VALU_MFMA_COEXEC_CYCLES / ..._BUSY_CYCLES)
+# needs the experiment build:  NSA_BUILD_TAG=ws NSA_X_WS=1 python -m nicer_slam_amd.build   and   export NSA_LIB_TAG=ws  (the product
+# library does not contain tile codes 96 / 97 since round 5)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof

@@ -1,5 +1,5 @@
 """Where do the cycles of the wave-specialised sampler go?  Profiling build:
-   NSA_BUILD_TAG=ts NSA_EXTRA_HIPCC_FLAGS=-DNSA_X_TS python -m nicer_slam_amd.build ;  NSA_LIB_TAG=ts python tools/ts_profile_ws.py
+   NSA_BUILD_TAG=ts NSA_X_WS=1 NSA_EXTRA_HIPCC_FLAGS=-DNSA_X_TS python -m nicer_slam_amd.build ;  NSA_LIB_TAG=ts python tools/ts_profile_ws.py
 Mean cycles per 32-point tile of a V wave's phases and per GEMM of an M wave's (s_memtime, ~10 % overhead)."""
 import ctypes
 import sys

@@ -98,6 +98,7 @@ def parse():
                     help="MLP GEMM operands: fp32 = the reference's precision (default, the BASELINE metric); bf16 / "
                          "bf16_colour = the optional reduced-precision modes of BASELINE configs[2]/[4] (NOT the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-precision-modes", action="store_true", help="skip the bf16 / bf16_colour context rows (N = 1 only)")
     ap.add_argument("--no-mapping", action="store_true", help="skip the (untimed-for-value) mapping-iteration leg")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--only-mapping", type=int, default=0, metavar="ITERS",
@@ -358,10 +359,26 @@ def main():
                                      "note": "6 bf16 MFMAs per fp32 product block; the fp32-equivalent frac above prices the "
                                              "kernel against the fp32 peak, this against the matrix pipe it actually uses"}
             roof.update({"launches": n, "avg_launch_us": round(tms / n * 1e3, 2), "share_of_step": round(tms / n / ms, 4),
-                         "all_kernels_us": {k: round(v[0] / v[2] * 1e3, 1) for k, v in sorted(agg.items())}})
+                         "all_kernels_us": {k: round(v[0] / v[2] * 1e3, 1) for k, v in sorted(agg.items())},
+                         "all_kernels_us_note": "event pairs around every launch of an EAGER replay of the timed batches (graph nodes "
+                                                "cannot be bracketed): eager launches run 1-2 % above their in-graph time, so the sum "
+                                                "may exceed ms_per_step"})
+            if args.precision == "fp32" and args.engine != "composed":
+                # whole iteration against the fp32 matrix line, two counts: the work the kernels EXECUTE (backward kernels
+                # recompute their forward: ALGO_MAC includes it) and SURVEY 8d's algorithmic count (127 488 MAC per composite
+                # point, data gradients only, + the sampler's sdf-only evaluation 17 408 MAC per sampler point)
+                P_c, P_s = args.rays * args.samples, args.rays * 640
+                executed = 2.0 * sum(ALGO_MAC[k] * (P_s if k == "k_sampler_sdf" else P_c) for k in agg if k in ALGO_MAC)
+                survey = 2.0 * (127488 * P_c + 17408 * P_s)
+                roof["whole_step"] = {"executed_gflop": round(executed / 1e9, 2), "survey_8d_gflop": round(survey / 1e9, 2),
+                                      "frac_executed": round(executed / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                      "frac_survey_8d": round(survey / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                      "note": "of the fp32 matrix line (157.3 TFLOP/s), per GPU"}
         cpu = None if args.no_cpu_baseline else cpu_baseline(args, model, conf)
-        mapping, dropin, ref_gpu = None, None, None
+        mapping, dropin, ref_gpu, prec_modes = None, None, None, None
         gather = colour_gather_roofline(agg, args) if agg else None
+        if world == 1 and not args.no_precision_modes and args.engine != "composed" and args.precision == "fp32":
+            prec_modes = precision_modes_leg(args, device, K)
         if world == 1 and not args.no_dropin and args.engine != "composed" and args.precision == "fp32":
             dropin = dropin_leg(args, device, K, batches)
             ref_gpu = reference_shaped_gpu_leg(args, device, K, batches, rays_total / dt)
@@ -391,7 +408,7 @@ def main():
                        "oversubscribed": oversub or None},
             "final_loss": round(last, 6),
             "roofline": roof, "colour_gather": gather, "cpu_baseline": cpu, "reference_shaped_gpu": ref_gpu, "dropin": dropin,
-            "mapping_iteration": mapping,
+            "mapping_iteration": mapping, "precision_modes": prec_modes,
         }
         print(json.dumps(line))
     if world > 1:
@@ -684,10 +701,85 @@ def colour_gather_roofline(agg, args):
            "ceiling_source": "tools/micro/gather_bench.hip, profiles/r04_gather_bench.txt"}
     if hit is not None:
         req = hit + miss
+        # The ceiling (tools/micro/gather_bench.hip) is for requests that ALL miss the L2; about half of this kernel's requests hit.
+        # What the ceiling bounds is therefore the MISS rate: achieved = L2 misses per second (round 4 priced all requests against
+        # it and printed a fraction of 1.23, which bounds nothing)
         out.update({"l2_requests_per_launch": req, "l2_hit_rate": round(hit / req, 3), "rows_per_request": round(algo_rows / req, 2),
-                    "achieved": round(req / (us * 1e-6), 0), "frac": round(req / (us * 1e-6) / GATHER_CEILING_REQ_S, 3),
-                    "misses_per_s": round(miss / (us * 1e-6), 0),
-                    "note": "frac > 1 is possible: the ceiling is for requests that all miss the L2; this kernel's hits are cheaper"})
+                    "l2_requests_per_s": round(req / (us * 1e-6), 0),
+                    "achieved": round(miss / (us * 1e-6), 0), "frac": round(miss / (us * 1e-6) / GATHER_CEILING_REQ_S, 3),
+                    "note": "achieved = L2 MISSES per second against the all-miss random-gather ceiling (hits are served by the L2 "
+                            "and are not what the ceiling measures)"})
+    return out
+
+
+def precision_modes_leg(args, device, K, steps=100):
+    """The optional bf16-operand modes that BASELINE configs[2] / [4] name, at those configs' PER-GPU shapes (4096 x 128 over 8 GPUs =
+    512 rays per GPU; 8192 x 192 over 8 GPUs = 1024 rays per GPU) and at the headline shape: ms per tracking iteration
+    (KernelTracker, hipGraph) and the dominant kernel priced against the dense bf16 matrix line (2.5 PFLOP/s).  Context rows: the
+    reference has no reduced-precision mode (fp32 only) and `value` stays the fp32 iteration.  Parity of these modes:
+    tests/test_precision_oracle_gpu.py (bf16-emulating oracle)."""
+    from nicer_slam_amd.hashencoder import backend as be
+    from nicer_slam_amd.tracking import KernelTracker
+    out = {"what": "optional reduced-precision MLP modes (BASELINE configs[2] / [4] per-GPU shapes); never the headline",
+           "peak_tflops": MFMA_BF16_PEAK_TFLOPS}
+    rows = (("bf16", 1024, 128, "headline shape, bf16 MLP operands"), ("bf16", 512, 128, "configs[2] per GPU (4096 x 128 / 8)"),
+            ("bf16_colour", 1024, 192, "configs[4] per GPU (8192 x 192 / 8)"), ("fp32", 512, 128, "fp32 at the configs[2] per-GPU shape"),
+            ("fp32", 1024, 192, "fp32 at the configs[4] per-GPU shape"))
+    models = {}
+    for prec, rays, samples, what in rows:
+        key = f"{prec}_{rays}x{samples}"
+        try:
+            if samples not in models:
+                a = argparse.Namespace(**vars(args))
+                a.samples, a.precision, a.param_grads, a.engine = samples, "fp32", False, "auto"
+                models[samples] = make_model(a, device)[0]
+            model = models[samples]
+            model.mlp_precision = prec
+            model.__dict__.pop("_fused_pack", None)
+            gen = torch.Generator(device=device).manual_seed(77)
+            batches = [synth_batch(gen, rays, device) for _ in range(32)]
+            cam = torch.tensor([1.0, 0, 0, 0, 0.1, 0.0, -0.2], device=device)
+            tr = KernelTracker(model, K, rays, cam, lr=0.005, use_graph=True)
+            with quiet_gc():
+                for i in range(30):
+                    tr.step(*batches[i % 32])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    tr.step(*batches[i % 32])
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / steps * 1e3
+            eager = KernelTracker(model, K, rays, cam, lr=0.005, use_graph=False)
+            for i in range(3):
+                eager.step(*batches[i])
+            be.PROFILE = []
+            for i in range(10):
+                eager.step(*batches[i])
+            torch.cuda.synchronize()
+            prof, be.PROFILE = be.PROFILE, None
+            agg = {}
+            for name, nbytes, e0, e1 in prof:
+                v = agg.setdefault(name, [0.0, 0])
+                v[0] += e0.elapsed_time(e1)
+                v[1] += 1
+            us = {k: v[0] / v[1] * 1e3 for k, v in agg.items()}
+            row = {"what": what, "ms_per_step": round(ms, 4), "rays_per_s": round(rays / (ms * 1e-3), 1),
+                   "kernels_us": {k: round(v, 1) for k, v in sorted(us.items())}}
+            mlp = {k: v for k, v in us.items() if k in ALGO_MAC}
+            if mlp:
+                name = max(mlp, key=mlp.get)
+                pts = rays * (640 if name == "k_sampler_sdf" else samples)
+                bf16_kernel = prec == "bf16" or (prec == "bf16_colour" and "colour" in name)
+                peak = MFMA_BF16_PEAK_TFLOPS if bf16_kernel else MFMA_F32_PEAK_TFLOPS
+                ach = 2.0 * ALGO_MAC[name] * pts / (mlp[name] * 1e-6) / 1e12
+                row["dominant"] = {"kernel": name, "avg_launch_us": round(mlp[name], 1), "achieved_tflops": round(ach, 1),
+                                   "peak_tflops": peak, "frac": round(ach / peak, 4)}
+            out[key] = row
+            del tr, eager
+        except Exception as e:      # a context leg must never take the headline down
+            out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    models.clear()
+    torch.cuda.empty_cache()
     return out
 
 
@@ -733,18 +825,22 @@ def dropin_leg(args, device, K, batches, steps=60):
       faithful   every model parameter requires grad, exactly as volsdf_train.py builds the model (the reference computes and
                  discards all parameter gradients in tracking, :547 zeroes them before any use);
       pose_only  model.tracking_param_grads = False -- one attribute -- skips that discarded work; hipGraph-captured;
-      pose_only_eager  the same launched eagerly, i.e. the reference's unmodified loop shape (it captures nothing).
+      pose_only_eager  the same launched eagerly, i.e. the reference's unmodified loop shape (it captures nothing);
+      pose_only_eager_hip_adam  that loop with ONE line changed: torch.optim.Adam -> nicer_slam_amd.optim.Adam (same semantics and
+                 state_dict; one launch instead of torch's ~12 on the seven camera floats).
     Context numbers; `value` stays the KernelTracker iteration."""
     from nicer_slam_amd.tracking import TrackingStepper
     out = {"driver": "SLAMNetwork.forward + torch autograd + torch.optim.Adam (TrackingStepper)"}
-    for row, flag, graph in (("pose_only", False, True), ("pose_only_eager", False, False), ("faithful", True, False)):
+    from nicer_slam_amd.optim import Adam as HipAdam
+    for row, flag, graph, opt in (("pose_only", False, True, None), ("pose_only_eager", False, False, None),
+                                  ("pose_only_eager_hip_adam", False, False, HipAdam), ("faithful", True, False, None)):
         a = argparse.Namespace(**vars(args))
         a.param_grads = True                        # make_model leaves requires_grad as constructed
         model, _ = make_model(a, device)
         model.tracking_param_grads = flag
         cam = torch.tensor([1.0, 0, 0, 0, 0.1, 0.0, -0.2], device=device)
         try:
-            st = TrackingStepper(model, K, args.rays, cam, lr=0.005, use_graph=graph, world=1)
+            st = TrackingStepper(model, K, args.rays, cam, lr=0.005, use_graph=graph, world=1, **({"opt_cls": opt} if opt else {}))
             n = min(steps, len(batches))
             with quiet_gc():
                 for i in range(min(5, n)):
@@ -756,7 +852,7 @@ def dropin_leg(args, device, K, batches, steps=60):
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / n
             out[row] = {"ms_per_step": round(dt * 1e3, 4), "rays_per_s": round(args.rays / dt, 1), "engine": model.last_engine,
-                        "hip_graph": graph, "steps": n}
+                        "hip_graph": graph, "steps": n, "optimizer": "nicer_slam_amd.optim.Adam (one launch)" if opt else "torch.optim.Adam"}
         except Exception as e:      # a context leg must never take the headline down
             out[row] = {"error": f"{type(e).__name__}: {e}"[:300]}
         del model

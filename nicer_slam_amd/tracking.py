@@ -279,7 +279,8 @@ class TrackingStepper:
     """The iteration driven through torch autograd exactly as volsdf_train.py:406-446 does: get_camera_from_tensor ->
     SLAMNetwork.forward(mode="tracking") -> L1 -> loss.backward() -> torch.optim.Adam (+ StepLR) -> arg-min-loss candidate."""
 
-    def __init__(self, model, intrinsics, n_rays, cam_init, lr=0.005, use_graph=True, world=1, lr_step=0, lr_gamma=1.0):
+    def __init__(self, model, intrinsics, n_rays, cam_init, lr=0.005, use_graph=True, world=1, lr_step=0, lr_gamma=1.0,
+                 opt_cls=None):
         dev = model.voxels.device
         self.model, self.world, self.n_rays = model, world, n_rays
         self.K = intrinsics
@@ -289,7 +290,9 @@ class TrackingStepper:
         self._uv_shape, self._gt_shape = (1, n_rays, 2), (n_rays, 3)
         self.ind = torch.zeros(1, dtype=torch.long, device=dev)
         self.graph_all = use_graph and world == 1     # Adam inside the graph only when no all-reduce sits in between
-        self.opt = torch.optim.Adam([self.cam], lr=lr, capturable=self.graph_all)
+        # opt_cls: a drop-in replacement for torch.optim.Adam with the same constructor (nicer_slam_amd.optim.Adam: one launch)
+        self.opt = (torch.optim.Adam([self.cam], lr=lr, capturable=self.graph_all) if opt_cls is None
+                    else opt_cls([self.cam], lr=lr))
         if lr_step and self.graph_all:
             raise ValueError("TrackingStepper: StepLR is stepped on the host -- use use_graph=False (or KernelTracker, whose "
                              "Adam kernel applies the schedule on the device)")

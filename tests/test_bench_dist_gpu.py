@@ -22,6 +22,15 @@ def test_bench_under_torchrun_single_rank():
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"] is not None
     for key in ("metric", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config"):
         assert key in line
+    # round 5: the context legs of the default line all ran (no leg swallowed an exception) and no roofline fraction exceeds 1
+    pm = line["precision_modes"]
+    for key in ("bf16_1024x128", "bf16_512x128", "bf16_colour_1024x192"):
+        assert "error" not in pm[key] and pm[key]["ms_per_step"] > 0, pm[key]
+    for row in ("pose_only", "pose_only_eager", "pose_only_eager_hip_adam", "faithful"):
+        assert "error" not in line["dropin"][row], line["dropin"][row]
+    assert 0 < line["roofline"]["frac"] <= 1 and 0 < line["roofline"]["whole_step"]["frac_survey_8d"] <= line["roofline"]["whole_step"]["frac_executed"] <= 1
+    if line["colour_gather"] and "frac" in line["colour_gather"]:
+        assert 0 < line["colour_gather"]["frac"] <= 1
 
 
 def test_bench_self_launch_two_ranks_oversubscribed():

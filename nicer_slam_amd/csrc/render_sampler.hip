@@ -32,31 +32,46 @@ static __device__ unsigned long long* g_ts_s = nullptr;
 #define STS_MARK(slot)
 #define STS_END
 #endif
+// waves per SIMD the register allocation aims at: two tiles per wave need the whole file (2); one tile per wave fits 3 with the
+// operand split's fragments and 4 (128 registers) in the bf16-operand build, whose weight fragments are a third of the size
+#ifdef NSA_OCC_SAMPLER_T1
+constexpr int kOccSamplerT1 = NSA_OCC_SAMPLER_T1;
+#else
+constexpr int kOccSamplerT1 = kPieces == 1 ? 4 : 3;
+#endif
 template <int LC, int CC, int NHC, int LF, int CF, int NHF, int T>
-__global__ __launch_bounds__(256, NSA_OCC_SAMPLER) void k_sampler_sdf(SamplerArgs a, GridGeom16 gc, GridGeom16 gf) {
+__global__ __launch_bounds__(256, T == 1 ? kOccSamplerT1 : NSA_OCC_SAMPLER) void k_sampler_sdf(SamplerArgs a, GridGeom16 gc, GridGeom16 gf) {
     STS_BEGIN
     desync_simd_partners();
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t total = (uint64_t)a.R * a.E;
-    uint64_t pid[T];
+    // z and far are final as soon as the point exists: they are stored at once, so that only the point index stays live across the
+    // two networks (round 5: the two-tile form had 4 spilled registers -- zi / farv / ray / idx of both tiles were carried to the end)
+    uint32_t pid[T];          // pid < 2^32: the entry point refuses larger launches for this kernel (64-bit indexing is ~100 VALU per tile)
     bool live[T];
-    uint32_t ray[T], idx[T];
-    float x[T][3], zi[T], farv[T];
+    float x[T][3];
     float in[T][SDF_IN_STEPS];
     RayOfTile rt;
+    uint32_t prev_ray = 0xFFFFFFFFu;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        pid[t] = ((uint64_t)wave * T + t) * 32 + (lane & 31);
-        live[t] = pid[t] < total;
-        if (!live[t]) pid[t] = total - 1;       // keep the wave converged for the MFMAs; store is predicated
-        ray[t] = ray_of_point(pid[t], a.E, total);
-        idx[t] = (uint32_t)(pid[t] - (uint64_t)ray[t] * a.E);
+        const uint64_t p64 = ((uint64_t)wave * T + t) * 32 + (lane & 31);
+        live[t] = p64 < total;
+        pid[t] = live[t] ? (uint32_t)p64 : (uint32_t)(total - 1);       // keep the wave converged for the MFMAs; stores are predicated
+        const uint32_t ray = pid[t] / a.E;
+        const uint32_t idx = pid[t] - ray * a.E;
         // the ray's origin, direction and far end (six divisions) are shared by the wave's tiles whenever they lie on one ray --
         // always at the shipped E = 640 = 10 x 64
-        if (t == 0 || !__all(ray[t] == ray[t - 1])) ray_of_tile(a, ray[t], rt);
-        sampler_point(a, pid[t], rt, idx[t], x[t], zi[t], farv[t]);
+        if (t == 0 || !__all(ray == prev_ray)) ray_of_tile(a, ray, rt);
+        prev_ray = ray;
+        float zi, farv;
+        sampler_point(a, pid[t], rt, idx, x[t], zi, farv);
+        if (live[t] && h == 0) {
+            a.z[pid[t]] = zi;
+            if (idx == 0) a.far[ray] = farv;
+        }
         STS_MARK(4 + 3 * 0)
         pe_slots(x[t], h, in[t]);               // shared by both networks
         STS_MARK(5)
@@ -72,13 +87,8 @@ __global__ __launch_bounds__(256, NSA_OCC_SAMPLER) void k_sampler_sdf(SamplerArg
     sdf_only_tiles<NHF, T>(a.wp_f, lane, h, in, sdf_f);
     STS_MARK(9)
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        if (live[t] && h == 0) {
-            a.z[pid[t]] = zi[t];
-            a.sdf[pid[t]] = sdf[t] + sdf_f[t];
-            if (idx[t] == 0) a.far[ray[t]] = farv[t];
-        }
-    }
+    for (int t = 0; t < T; ++t)
+        if (live[t] && h == 0) a.sdf[pid[t]] = sdf[t] + sdf_f[t];
     STS_MARK(10)
     STS_END
 }
@@ -448,6 +458,7 @@ int NSA_ENTRY(nsa_sampler_sdf)(const float* rays_o, const float* rays_d, uint32_
     SamplerArgs a{rays_o, rays_d, t_lin, t_rand, z, sdf, far, R, E, near, bound, far_cap,
                   coarse->table, fine->table, packed_coarse, packed_fine, coarse->divide_factor, fine->divide_factor};
     const uint64_t total = (uint64_t)R * E;
+    if (total > 0xFFFFFFFFull) return NSA_EBADARG;        // 32-bit point indices in k_sampler_sdf (callers chunk far below this)
     const bool two = coarse->tile == 64;                  // 64: 32-point tiling, two tiles per wave
     if (two != (fine->tile == 64)) return NSA_EBADARG;
     const uint32_t waves = (uint32_t)((total + (two ? 63 : 31)) / (two ? 64 : 32));

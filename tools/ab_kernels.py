@@ -24,12 +24,13 @@ def main():
     ap.add_argument("--rays", type=int, default=1024)
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--no-graph-leg", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16_colour"])
     args = ap.parse_args()
     import bench
     from nicer_slam_amd.hashencoder import backend as be
     from nicer_slam_amd.tracking import KernelTracker
     dev = torch.device("cuda", 0)
-    bargs = argparse.Namespace(samples=args.samples, engine="auto", precision="fp32", param_grads=False)
+    bargs = argparse.Namespace(samples=args.samples, engine="auto", precision=args.precision, param_grads=False)
     model, conf = bench.make_model(bargs, dev)
     K = torch.eye(4, device=dev)
     K[0, 0] = K[1, 1] = 600.0
@@ -43,7 +44,8 @@ def main():
         for _ in range(8):
             a @ a
         torch.cuda.synchronize()
-    out = {"tag": os.environ.get("NSA_LIB_TAG", "")}
+    out = {"tag": os.environ.get("NSA_LIB_TAG", ""), "precision": args.precision, "rays": args.rays, "samples": args.samples,
+           "env": {k: v for k, v in os.environ.items() if k.startswith("NSA_") and k != "NSA_LIB_TAG"}}
     if not args.no_graph_leg:
         tr = KernelTracker(model, K[None], args.rays, cam, use_graph=True)
         for i in range(10):

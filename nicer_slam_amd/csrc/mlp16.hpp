@@ -81,7 +81,11 @@ __device__ __forceinline__ void gemm16_lds(const float* lds_block, int lane, con
 #pragma unroll
             for (int t = 0; t < TC; ++t)
 #pragma unroll
-                for (int pc = 0; pc < kPieces; ++pc) a[t][pc] = w4[(((c * TC + t) * KG + g) * 3 + pc) * 64];
+                for (int pc = 0; pc < kPieces; ++pc) a[t][pc] = w4[(((c * TC + t) * KG + g) * kLdsPieces + pc) * 64];
+#ifdef NSA_X_LDS_FENCE       // SLP-hazard bisect: every fragment read has RETURNED before the first MFMA of the chunk issues
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             mma16_tiles<TC>(a, bh, bm, bl, &acc[c * TC]);
         }
     }
@@ -126,9 +130,10 @@ __device__ __forceinline__ void gemm16_glb(const float* __restrict__ wp, int lan
 template <int NW>
 __device__ __forceinline__ void stage_issue_n(const float* __restrict__ g, int nfloats, float* lds_dst) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunks = nfloats / 256;
+    const int chunks = nfloats / 256 / 3 * kLdsPieces;      // (mlp_common.hpp::kLdsPieces: the bf16-operand build keeps one piece)
+    constexpr int kSrcStep = kLdsPieces == 3 ? 1 : 3;
     for (int ch = wave; ch < chunks; ch += NW)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + ch * 256 + lane * 4),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + ch * kSrcStep * 256 + lane * 4),
                                          (__attribute__((address_space(3))) void*)(lds_dst + ch * 256), 16, 0, 0);
 }
 
@@ -185,12 +190,13 @@ template <int NW>
 __device__ __forceinline__ void stage_issue_part(const float* __restrict__ wp, const StagePart o, float* lds_dst,
                                                  const float* __restrict__ wp1 = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per_tile = o.ng * 3;                 // 1 KiB chunks per tile in this part
+    const int per_tile = o.ng * kLdsPieces;        // 1 KiB chunks per tile in this part
     const int chunks = o.mt * per_tile;
+    constexpr int kSrcStep = kLdsPieces == 3 ? 1 : 3;
     const float* base = o.net ? wp1 : wp;
     for (int ch = wave; ch < chunks; ch += NW) {
         const int mt = ch / per_tile, rem = ch - mt * per_tile;
-        const float* src = base + o.off + ((mt * o.kg + o.g0) * 3 + rem) * 256 + lane * 4;
+        const float* src = base + o.off + ((mt * o.kg + o.g0) * 3 + rem * kSrcStep) * 256 + lane * 4;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(lds_dst + ch * 256), 16, 0, 0);
     }
@@ -228,7 +234,7 @@ __device__ __forceinline__ void gemm16_lds_part(const float* lds_block, int lane
 #pragma unroll
             for (int t = 0; t < TC; ++t)
 #pragma unroll
-                for (int pc = 0; pc < kPieces; ++pc) a[t][pc] = w4[(((c * TC + t) * NG + gl) * 3 + pc) * 64];
+                for (int pc = 0; pc < kPieces; ++pc) a[t][pc] = w4[(((c * TC + t) * NG + gl) * kLdsPieces + pc) * 64];
             mma16_tiles<TC>(a, bh, bm, bl, &acc[c * TC]);
         }
     }

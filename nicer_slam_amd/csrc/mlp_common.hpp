@@ -87,6 +87,15 @@ __device__ __forceinline__ void split8(const float (&x)[8], BFrag& f) {
 #define NSA_PIECES 3
 #endif
 constexpr int kPieces = NSA_PIECES;
+// Pieces per fragment that a block-cooperative weight stage keeps in LDS.  The packed blocks in global memory always hold all three
+// (one pack serves both precisions); the bf16-operand build multiplies with the first piece only, so its stages copy every THIRD 1-KiB
+// fragment and lay the copy out as [tile][group][lane] -- a third of the global->LDS traffic behind every staged GEMM, which in that
+// build is six times shorter and would otherwise wait for its copy (round 5).  NSA_STAGE_ALL_PIECES: the round-4 behaviour (A/B runs).
+#ifdef NSA_STAGE_ALL_PIECES
+constexpr int kLdsPieces = 3;
+#else
+constexpr int kLdsPieces = NSA_PIECES;
+#endif
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -186,12 +195,13 @@ constexpr int kStageFloats = 9216;      // largest packed block: A[3 tiles][32 s
 
 __device__ __forceinline__ void stage_issue(const float* __restrict__ g, int nfloats, float* lds_dst) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunks = nfloats / 256;
+    const int chunks = nfloats / 256 / 3 * kLdsPieces;      // 1-KiB fragments copied (a packed A block is a multiple of 3 fragments)
+    constexpr int kSrcStep = kLdsPieces == 3 ? 1 : 3;       // one piece kept: every third fragment of the block
 #pragma unroll
     for (int c = 0; c < (chunks + 3) / 4; ++c) {
         const int ch = 4 * c + wave;
         if (ch < chunks)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + ch * 256 + lane * 4),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + ch * kSrcStep * 256 + lane * 4),
                                              (__attribute__((address_space(3))) void*)(lds_dst + ch * 256), 16, 0, 0);
     }
 }
@@ -227,7 +237,7 @@ __device__ __forceinline__ void gemm_lds(const float* lds_block, int lane, const
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int pc = 0; pc < kPieces; ++pc) nxt[mt][pc] = w4[((mt * KS8 + 0) * 3 + pc) * 64];
+        for (int pc = 0; pc < kPieces; ++pc) nxt[mt][pc] = w4[((mt * KS8 + 0) * kLdsPieces + pc) * 64];
 #pragma unroll
     for (int g = 0; g < KS8; ++g) {
         u32x4 a[MT][3];
@@ -236,7 +246,7 @@ __device__ __forceinline__ void gemm_lds(const float* lds_block, int lane, const
 #pragma unroll
             for (int pc = 0; pc < kPieces; ++pc) {
                 a[mt][pc] = nxt[mt][pc];
-                if (g + 1 < KS8) nxt[mt][pc] = w4[((mt * KS8 + g + 1) * 3 + pc) * 64];
+                if (g + 1 < KS8) nxt[mt][pc] = w4[((mt * KS8 + g + 1) * kLdsPieces + pc) * 64];
             }
         float x[8];
 #pragma unroll
@@ -274,14 +284,15 @@ struct StageOp {
 
 __device__ __forceinline__ void stage_issue_op(const float* __restrict__ wp, const StageOp o, float* lds_dst) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per_tile = o.ng * 3;                 // 1 KiB chunks per tile in this part
+    const int per_tile = o.ng * kLdsPieces;        // 1 KiB chunks per tile in this part
     const int chunks = o.mt * per_tile;
+    constexpr int kSrcStep = kLdsPieces == 3 ? 1 : 3;
 #pragma unroll
     for (int c = 0; c < (chunks + 3) / 4; ++c) {
         const int ch = 4 * c + wave;
         if (ch < chunks) {
             const int mt = ch / per_tile, rem = ch - mt * per_tile;
-            const float* src = wp + o.off + ((mt * o.ks8 + o.g0) * 3 + rem) * 256 + lane * 4;
+            const float* src = wp + o.off + ((mt * o.ks8 + o.g0) * 3 + rem * kSrcStep) * 256 + lane * 4;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(lds_dst + ch * 256), 16, 0, 0);
         }
@@ -295,7 +306,7 @@ __device__ __forceinline__ void gemm_lds_part(const float* lds_block, int lane, 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int pc = 0; pc < kPieces; ++pc) nxt[mt][pc] = w4[((mt * NG + 0) * 3 + pc) * 64];
+        for (int pc = 0; pc < kPieces; ++pc) nxt[mt][pc] = w4[((mt * NG + 0) * kLdsPieces + pc) * 64];
 #pragma unroll
     for (int gl = 0; gl < NG; ++gl) {
         const int g = G0 + gl;
@@ -305,7 +316,7 @@ __device__ __forceinline__ void gemm_lds_part(const float* lds_block, int lane, 
 #pragma unroll
             for (int pc = 0; pc < kPieces; ++pc) {
                 a[mt][pc] = nxt[mt][pc];
-                if (gl + 1 < NG) nxt[mt][pc] = w4[((mt * NG + gl + 1) * 3 + pc) * 64];
+                if (gl + 1 < NG) nxt[mt][pc] = w4[((mt * NG + gl + 1) * kLdsPieces + pc) * 64];
             }
         float x[8];
 #pragma unroll

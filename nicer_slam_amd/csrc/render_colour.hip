@@ -224,11 +224,14 @@ __device__ __forceinline__ void colour_mlp(float* stage, const float* __restrict
     }
 }
 
+// The colour forward lives on memory-level parallelism (1 GiB table, HBM gather): four waves per SIMD.  The fp32 build's generic form
+// needs 123 registers either way; the bf16-operand build allocated 133 under a two-wave target and lost a wave per SIMD (round 5).
+// The x-pair form (XP > 0, off by default) needs 218 registers and keeps the two-wave target.
 #ifndef NSA_OCC_COL_FWD
-#define NSA_OCC_COL_FWD 2
+#define NSA_OCC_COL_FWD (NSA_PIECES == 1 ? 4 : 2)      // (the fp32 build lands at 123-126 registers = four waves under either target)
 #endif
 template <int XP>
-__global__ __launch_bounds__(256, NSA_OCC_COL_FWD) void k_colour_fwd(ColourArgs a, GridGeom16 geom) {
+__global__ __launch_bounds__(256, XP > 0 ? 2 : NSA_OCC_COL_FWD) void k_colour_fwd(ColourArgs a, GridGeom16 geom) {
     using Seq = ColOps<false>;
 #include "colour_fwd_body.inc"
 }

@@ -29,11 +29,18 @@ template <int NH>
 struct ResidentGemm {
     const float* lds;
     int lane;
+    const float* wp;           // the network's packed block in global memory (experiment builds only, see below)
     template <int KG, int MT>
     __device__ __forceinline__ void run(int pack_off, const float (&b)[8 * KG], f32x4v (&acc)[MT]) {
         using P = SdfPack4<NH>;
+#ifdef NSA_X_GLB_WEIGHTS
+        // SLP-hazard bisect (tools/slp_bisect.sh, profiles/r05_slp_bisect.txt): the same fragments streamed from global memory --
+        // no LDS read sits between the MFMAs.  Experiment builds only (build.py refuses NSA_X_* for the product).
+        gemm16_glb<KG, MT>(wp + pack_off, lane, b, acc);
+#else
         const int off = pack_off == P::kW0 ? 0 : a16_floats(4, QIN_G) + (pack_off - P::wh(1)) / (P::kHH + 64) * P::kHH;
         gemm16_lds<KG, MT>(lds + off, lane, b, acc);
+#endif
     }
 };
 
@@ -94,8 +101,8 @@ __global__ __launch_bounds__(64 * NWS4, NWS4 / 4) void k_sampler4_sdf(Sampler4Ar
     const int j = lane & 15, q = lane >> 4;
     const uint64_t total = (uint64_t)a.R * a.E;
     const uint32_t n_tiles = (uint32_t)((total + 15) / 16);
-    ResidentGemm<NHC> gemm_c{lds_w + kLdsCoarseW0, lane};
-    ResidentGemm<NHF> gemm_f{lds_w + kLdsFineW0, lane};
+    ResidentGemm<NHC> gemm_c{lds_w + kLdsCoarseW0, lane, a.wp_c};
+    ResidentGemm<NHF> gemm_f{lds_w + kLdsFineW0, lane, a.wp_f};
     const uint32_t E = a.E;
     for (uint32_t tile = blockIdx.x * NWS4 + (threadIdx.x >> 6); tile < n_tiles; tile += gridDim.x * NWS4) {
         uint64_t pid = (uint64_t)tile * 16 + j;
@@ -161,8 +168,8 @@ __global__ __launch_bounds__(64 * NWS4, NWS4 / 4) void k_sdf4_points(SdfPoints4A
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
     const uint64_t n_tiles = (a.N + 15) / 16;
-    ResidentGemm<NHC> gemm_c{lds_w + kLdsCoarseW0, lane};
-    ResidentGemm<NHF> gemm_f{lds_w + kLdsFineW0, lane};
+    ResidentGemm<NHC> gemm_c{lds_w + kLdsCoarseW0, lane, a.wp_c};
+    ResidentGemm<NHF> gemm_f{lds_w + kLdsFineW0, lane, a.wp_f};
     for (uint64_t tile = (uint64_t)blockIdx.x * NWS4 + (threadIdx.x >> 6); tile < n_tiles; tile += (uint64_t)gridDim.x * NWS4) {
         uint64_t pid = tile * 16 + j;
         const bool live = pid < a.N;

@@ -46,6 +46,22 @@ __device__ __forceinline__ void geom_to_lds(const GridGeom16& geom, LevelGeom* s
     if (threadIdx.x < 16) s_geom[threadIdx.x] = geom.lv[threadIdx.x];
 }
 
+// a quarter-lane's level record out of LDS.  NSA_X_GEOM_VOLATILE (SLP-hazard bisect, experiment builds only): field by field through
+// volatile reads, so that no two fields can be merged into one ds_read2_b32.
+__device__ __forceinline__ LevelGeom load_geom(const LevelGeom* p) {
+#ifdef NSA_X_GEOM_VOLATILE
+    const volatile uint32_t* w = reinterpret_cast<const volatile uint32_t*>(p);
+    uint32_t r[sizeof(LevelGeom) / 4];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(LevelGeom) / 4); ++i) r[i] = w[i];
+    LevelGeom g;
+    __builtin_memcpy(&g, r, sizeof(LevelGeom));
+    return g;
+#else
+    return *p;
+#endif
+}
+
 __device__ __forceinline__ float pow2f(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }
 
 // coordinate and frequency of positional-encoding pair n (slots 2n, 2n+1) of quarter q; sc == 0: the pair does not exist
@@ -97,7 +113,7 @@ __device__ __forceinline__ void grid_slots4(const float (&x)[3], float divide_fa
     for (int d = 0; d < 3; ++d) u[d] = to_unit(x[d], divide_factor);   // hashgrid.py:203 (size = 1)
 #pragma unroll
     for (int jl = 0; jl < 8 / C; ++jl) {
-        const LevelGeom g = s_geom[q + 4 * jl];
+        const LevelGeom g = load_geom(&s_geom[q + 4 * jl]);
         uint32_t cell[3];
         float w[3], dw[3];
         const bool inside = locate<3>(u, g.scale, cell, w, dw);
@@ -170,7 +186,7 @@ __device__ __forceinline__ void slots_to_x4(const float (&x)[3], float divide_fa
     const float chain = 1.0f / (2.0f * divide_factor);
 #pragma unroll
     for (int jl = 0; jl < 8 / C; ++jl) {
-        const LevelGeom lg = s_geom[q + 4 * jl];
+        const LevelGeom lg = load_geom(&s_geom[q + 4 * jl]);
         uint32_t cell[3];
         float w[3], dw[3];
         const bool inside = locate<3>(u, lg.scale, cell, w, dw);
@@ -235,7 +251,7 @@ __device__ __forceinline__ void x_to_slots_tangent4(const float (&x)[3], float d
     const float chain = 1.0f / (2.0f * divide_factor);
 #pragma unroll
     for (int jl = 0; jl < 8 / C; ++jl) {
-        const LevelGeom lg = s_geom[q + 4 * jl];
+        const LevelGeom lg = load_geom(&s_geom[q + 4 * jl]);
         uint32_t cell[3];
         float w[3], dw[3];
         const bool inside = locate<3>(u, lg.scale, cell, w, dw);
@@ -320,7 +336,7 @@ __device__ __forceinline__ void table_grad_scatter4(const float (&x)[3], float d
     const float chain = 1.0f / (2.0f * divide_factor);
 #pragma unroll
     for (int jl = 0; jl < 8 / C; ++jl) {
-        const LevelGeom lg = s_geom[q + 4 * jl];
+        const LevelGeom lg = load_geom(&s_geom[q + 4 * jl]);
         uint32_t cell[3];
         float w[3], dw[3];
         const bool active = locate<3>(u, lg.scale, cell, w, dw) && live;

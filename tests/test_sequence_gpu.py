@@ -54,17 +54,22 @@ def test_synthetic_sequence_fused_vs_composed_vs_oracle(capsys):
     still = ss.ate_rmse(gt.numpy(), gt[:1].repeat(n, 1, 1).numpy())    # a tracker that never moves
     # (B) shared pixels and sampler draws: arithmetic only; the CPU oracle joins on the first frames with a small batch
     nB, itB, pxB = 3, 30, 64
-    estB = {e: ss.track_sequence(e, teacher, imgs, K, gt, H, W, itB, pxB, shared_seed=7, n_frames=nB) for e in ("fused", "composed")}
+    tr = {e: [] for e in ("fused", "composed", "oracle")}
+    estB = {e: ss.track_sequence(e, teacher, imgs, K, gt, H, W, itB, pxB, shared_seed=7, n_frames=nB, trace=tr[e]) for e in ("fused", "composed")}
     cpu = teacher.to("cpu")
-    estB["oracle"] = ss.track_sequence("oracle", cpu, imgs.cpu(), K.cpu(), gt, H, W, itB, pxB, shared_seed=7, n_frames=nB)
-    d_fc = ss.pose_diff(estB["fused"], estB["composed"])
-    d_fo = ss.pose_diff(estB["fused"], estB["oracle"])
+    estB["oracle"] = ss.track_sequence("oracle", cpu, imgs.cpu(), K.cpu(), gt, H, W, itB, pxB, shared_seed=7, n_frames=nB, trace=tr["oracle"])
+    d_fc = dict(ss.pose_diff(estB["fused"], estB["composed"]), **ss.trace_diff(tr["fused"], tr["composed"]))
+    d_fo = dict(ss.pose_diff(estB["fused"], estB["oracle"]), **ss.trace_diff(tr["fused"], tr["oracle"]))
     step = float(np.linalg.norm(np.diff(gt[:, :3, 3].numpy(), axis=0), axis=1).mean())
     with capsys.disabled():
         print(f"\n  ATE RMSE (scene units; frame-to-frame motion {step:.4f}): fused {ate['fused']:.5f}  composed {ate['composed']:.5f}  "
               f"no tracking {still:.5f}\n  shared draws: fused vs composed {d_fc}\n                fused vs oracle   {d_fo}")
     assert ate["fused"] < 0.5 * still and ate["composed"] < 0.5 * still          # both engines actually track
     assert ate["fused"] <= 1.05 * ate["composed"] + 0.15 * step                   # matched ATE (short run: + a noise floor)
-    # identical inputs: the engines' trajectories differ by fp32 arithmetic amplified through 30 Adam iterations per frame
-    assert d_fc["max_trans_diff_scene_units"] < 0.1 * step and d_fc["max_rot_diff_deg"] < 0.05
-    assert d_fo["max_trans_diff_scene_units"] < 0.1 * step and d_fo["max_rot_diff_deg"] < 0.05
+    # identical inputs.  Iteration 0 of frame 1 is one forward + backward of each engine on the same batch: fp32 parity bounds.
+    # After that Adam (lr 0.005 = 1.4 frame steps per unit of m / sqrt(v)) compounds the gradient differences, and the frame's
+    # pose is the arg-min-loss ITERATE -- discontinuous in the losses: final poses agree at the level of the tracker's own scatter.
+    for d in (d_fc, d_fo):
+        assert d["iter0_loss_rel_diff"] < 1e-4 and d["iter0_grad_diff_of_largest_component"] < 5e-3, d
+        assert d["max_cam_diff_first_5_iters"] < 0.1 * step, d
+        assert d["max_trans_diff_scene_units"] < 0.6 * step and d["max_rot_diff_deg"] < 0.15, d

@@ -155,11 +155,12 @@ def make_draws(gen, R, E, n_extra, S, n_pix_total):
 
 
 def track_sequence(engine, model, frames, K, gt_poses, H, W, iters=100, pixels=1024, lr=0.005, shared_seed=None, n_frames=None,
-                   init_poses=None, log=None):
+                   init_poses=None, log=None, trace=None):
     """The reference's per-frame tracking protocol (volsdf_train.py:373-446) on `engine` in {"fused", "composed", "oracle"}.
     frames [n, H*W, 3] (on the model's device; CPU for the oracle).  shared_seed: every iteration's pixels and sampler draws come
     from a CPU generator seeded by (shared_seed, frame, iteration) -- identical for every engine; None: the engine's own RNG.
     init_poses: use these estimates for frames 0 .. len-1 (experiment B continues the oracle from the fused run's start).
+    trace: a list that receives (frame, iteration, loss, camera 7-vector BEFORE the step, camera gradient) of every iteration.
     -> est c2w [n,4,4] (CPU float32)."""
     from nicer_slam_amd.utils.general import get_camera_from_tensor, get_tensor_from_camera
     n = n_frames or frames.shape[0]
@@ -218,10 +219,12 @@ def track_sequence(engine, model, frames, K, gt_poses, H, W, iters=100, pixels=1
                 assert model.last_engine == engine, model.last_engine
             loss = (out["rgb_values"].reshape(-1, 3) - gt).abs().mean()          # SLAMLoss tracking objective (loss.py:57-65,131)
             loss.backward()
+            if trace is not None:
+                trace.append((f, it, float(loss.detach()), cam.detach().cpu().clone(), cam.grad.detach().cpu().clone()))
             opt.step()
             sched.step()
             opt.zero_grad()
-            lv = float(loss)
+            lv = float(loss.detach())
             if lv < best:                                                      # :436-438 (the camera AFTER the step, as there)
                 best, cand = lv, cam.detach().clone()
         est.append(get_camera_from_tensor(cand).detach().cpu().float() if not oracle else R.camera_from_tensor(cand).detach().float())
@@ -245,6 +248,20 @@ def pose_diff(a, b):
     n = min(len(a), len(b))
     return {"max_trans_diff_scene_units": float(np.linalg.norm(a[:n, :3, 3] - b[:n, :3, 3], axis=1).max()),
             "max_rot_diff_deg": float(rot_err_deg(a[:n, :3, :3], b[:n, :3, :3]).max())}
+
+
+def trace_diff(a, b, first=5):
+    """per-iteration agreement of two traces over frame 1 (same start, same draws): iteration 0 compares one forward + backward of
+    the two engines; the camera drift over the first iterations shows how fast Adam amplifies fp32-level gradient differences"""
+    a = [t for t in a if t[0] == 1][:first]
+    b = [t for t in b if t[0] == 1][:first]
+    n = min(len(a), len(b))
+    if n == 0:
+        return {}
+    g0 = float((a[0][4] - b[0][4]).abs().max() / b[0][4].abs().max())
+    return {"iter0_loss_rel_diff": abs(a[0][2] - b[0][2]) / abs(b[0][2]), "iter0_grad_diff_of_largest_component": g0,
+            "max_cam_diff_first_%d_iters" % n: max(float((a[i][3] - b[i][3]).abs().max()) for i in range(n)),
+            "max_loss_rel_diff_first_%d_iters" % n: max(abs(a[i][2] - b[i][2]) / abs(b[i][2]) for i in range(n))}
 
 
 def run(frames=50, iters=100, pixels=1024, H=340, W=600, oracle_frames=3, oracle_pixels=128, oracle_iters=100, colour_grid=None,
@@ -279,20 +296,26 @@ def run(frames=50, iters=100, pixels=1024, H=340, W=600, oracle_frames=3, oracle
         out["free_running_pose_difference"] = pose_diff(res["fused"], res["composed"])
     # (B) shared draws, reduced pixel count so that the CPU oracle can take part
     nB = max(2, oracle_frames + 1)
-    estB = {}
+    estB, trB = {}, {}
     for eng in ("fused", "composed"):
-        estB[eng] = track_sequence(eng, teacher, imgs, K, gt, H, W, oracle_iters, oracle_pixels, shared_seed=7, n_frames=nB)
+        trB[eng] = []
+        estB[eng] = track_sequence(eng, teacher, imgs, K, gt, H, W, oracle_iters, oracle_pixels, shared_seed=7, n_frames=nB, trace=trB[eng])
         out["shared_draws_" + eng] = summarise(gt, estB[eng])
-    out["shared_draws_fused_vs_composed"] = pose_diff(estB["fused"], estB["composed"])
+    out["shared_draws_fused_vs_composed"] = dict(pose_diff(estB["fused"], estB["composed"]), **trace_diff(trB["fused"], trB["composed"]))
     if oracle_frames > 0:
         t0 = time.perf_counter()
         teacher_cpu = teacher.to("cpu")
+        trB["oracle"] = []
         estB["oracle"] = track_sequence("oracle", teacher_cpu, imgs.cpu(), K.cpu(), gt, H, W, oracle_iters, oracle_pixels, shared_seed=7,
-                                        n_frames=nB)
+                                        n_frames=nB, trace=trB["oracle"])
         out["shared_draws_oracle"] = dict(summarise(gt, estB["oracle"]), wall_s=round(time.perf_counter() - t0, 1))
-        out["shared_draws_fused_vs_oracle"] = pose_diff(estB["fused"], estB["oracle"])
-        out["shared_draws_composed_vs_oracle"] = pose_diff(estB["composed"], estB["oracle"])
-    out["shared_draws"] = {"frames": nB, "iters_per_frame": oracle_iters, "pixels_per_iter": oracle_pixels}
+        out["shared_draws_fused_vs_oracle"] = dict(pose_diff(estB["fused"], estB["oracle"]), **trace_diff(trB["fused"], trB["oracle"]))
+        out["shared_draws_composed_vs_oracle"] = dict(pose_diff(estB["composed"], estB["oracle"]), **trace_diff(trB["composed"], trB["oracle"]))
+    out["shared_draws"] = {"frames": nB, "iters_per_frame": oracle_iters, "pixels_per_iter": oracle_pixels,
+                           "note": "identical pixels and sampler draws: iteration 0 of frame 1 compares one forward + backward; later "
+                                   "iterations compound fp32-level gradient differences through Adam (lr 0.005 = 1.7 frame steps per "
+                                   "unit m/sqrt(v)) and the arg-min-loss candidate picks an ITERATION, which is discontinuous in the "
+                                   "losses -- final poses of two engines differ at the level of the tracker's own scatter"}
     out["wall_s"] = round(time.perf_counter() - t_all, 1)
     return out
 

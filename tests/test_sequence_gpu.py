@@ -70,6 +70,8 @@ def test_synthetic_sequence_fused_vs_composed_vs_oracle(capsys):
     # After that Adam (lr 0.005 = 1.4 frame steps per unit of m / sqrt(v)) compounds the gradient differences, and the frame's
     # pose is the arg-min-loss ITERATE -- discontinuous in the losses: final poses agree at the level of the tracker's own scatter.
     for d in (d_fc, d_fo):
-        assert d["iter0_loss_rel_diff"] < 1e-4 and d["iter0_grad_diff_of_largest_component"] < 5e-3, d
-        assert d["max_cam_diff_first_5_iters"] < 0.1 * step, d
+        # (measured on MI355X: loss 3e-7 .. 6e-6, gradient 1e-6 .. 3e-4 of the largest component, camera drift over five
+        #  iterations 8e-9 .. 5e-6; final poses 0.0011-0.0015 apart at an ATE of 0.0009-0.0010)
+        assert d["iter0_loss_rel_diff"] < 5e-5 and d["iter0_grad_diff_of_largest_component"] < 2e-3, d
+        assert d["max_cam_diff_first_5_iters"] < 5e-5, d
         assert d["max_trans_diff_scene_units"] < 0.6 * step and d["max_rot_diff_deg"] < 0.15, d

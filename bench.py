@@ -39,14 +39,16 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak = the peak for this config'
 # instruction per SIMD this gives the matrix-pipe busy time, reported beside the fp32-equivalent `frac`.  The quad tiling issues
 # twice as many v_mfma_f32_16x16x32_bf16 of half the duration -- the same busy cycles (profiles/r02_pmc_per_kernel_*.csv).
 MFMA_PER_TILE = {"k_sampler_sdf": 216, "k_sdfnet_fwd<coarse>": 180, "k_sdfnet_fwd<fine>": 372, "k_sdfnet_fwd<pair>": 552, "k_sdfnet_bwd<coarse>": 288,
-                 "k_sdfnet_bwd<fine>": 672, "k_colour_fwd": 156, "k_colour_bwd": 324, "k_colour_coarse_bwd": 324 + 288}
+                 "k_sdfnet_bwd<fine>": 672, "k_colour_fwd": 156, "k_colour_bwd": 168, "k_colour_coarse_bwd": 168 + 288}
+# (round 5: the data-path colour backward no longer recomputes its forward -- ReLU masks and sigmoid outputs come from the save area --
+#  so its count is the two reverse GEMMs only: 12 544 MAC, 168 MFMAs per 32 points; round 4: 25 088 / 324)
 N_SIMD, NOMINAL_GHZ = 1024, 2.4
 
 ALGO_MAC = {
     "k_sampler_sdf": 17408,            # coarse (4544+64) + fine (4544+2*4096+64): sdf rows only
     "k_sdfnet_fwd<coarse>": 13248, "k_sdfnet_fwd<fine>": 29632, "k_sdfnet_fwd<pair>": 13248 + 29632,
     "k_sdfnet_bwd<coarse>": 22400, "k_sdfnet_bwd<fine>": 55168,
-    "k_colour_fwd": 12544, "k_colour_bwd": 25088, "k_colour_coarse_bwd": 25088 + 22400,
+    "k_colour_fwd": 12544, "k_colour_bwd": 12544, "k_colour_coarse_bwd": 12544 + 22400,
 }
 
 

@@ -149,7 +149,10 @@ int nsa_rays_pose_backward(const float *uv, const float *pose, const float *K, u
 
 /* Colour network at the composite points: rgb = sigmoid(MLP([x, PE4(view dir), grad sdf, feature, colour grid])).
  * replaces RenderingNetwork.forward, mode "idr" (code/model/base_networks.py:333-395).  `save` (optional,
- * ceil(P/32)*4096 floats) receives what the backward needs from the 1 GiB colour table (features + Jacobian). */
+ * ceil(P/32)*(4096 + 256) floats) receives what the backward needs: from the 1 GiB colour table the features + Jacobian (4096 floats per
+ * 32-point tile), and of the MLP itself the ReLU masks of both hidden layers and the sigmoid outputs (256 floats per tile, behind the
+ * ceil(P/32)*4096 block) -- the data-path backward (nsa_colour_backward, nsa_colour_coarse_backward) reads those instead of
+ * recomputing the forward; the mapping backward (nsa_colour_backward_params) recomputes it (its activations are gradient operands). */
 int nsa_colour_forward(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, const float *grad,
                        const float *feat_hl, float *rgb, float *save, nsa_stream_t stream);
 

@@ -49,6 +49,33 @@ struct ColOps {
     }
 };
 
+// Staged parts of a backward launch: the mapping form (MAP) recomputes the forward (all six parts); the data-path form needs the
+// reverse GEMMs only (W1^T, W0^T in two parts) -- round 5: ReLU masks and the sigmoid outputs come from the forward's save area.
+template <bool MAP>
+struct ColBwdOps {
+    static constexpr int n = MAP ? 6 : 3;
+    static constexpr int kRev = MAP ? 3 : 0;                  // index of the W1^T part
+    __host__ __device__ static constexpr StageOp op(int i) { return ColOps<true>::op(MAP ? i : i + 3); }
+};
+
+// Extension of the save area behind its ceil(P/32) x 4096 floats (features + Jacobian): per 32-point tile 256 floats --
+//   [0..63] ReLU mask of layer 1 (bit 16 t + r of lane l = a1[t][r] > 0), [64..127] the same for layer 2, [128 + 32 j + p] rgb_j of
+//   point p (the sigmoid outputs).  The data-path backward reads these instead of recomputing the forward MLP: it never needs the
+//   first-layer input vector again (torch: relu'(a) = a > 0, sigmoid' = rgb (1 - rgb), base_networks.py:375-394).
+constexpr int kSaveTile = 4096, kSaveExt = 256;
+__device__ __forceinline__ float* save_ext(float* save, uint32_t P, uint32_t tile) {
+    return save + (size_t)((P + 31) / 32) * kSaveTile + (size_t)tile * kSaveExt;
+}
+
+__device__ __forceinline__ uint32_t relu_mask(const f32x16 (&a)[2]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m |= a[t][r] > 0.0f ? (1u << (16 * t + r)) : 0u;
+    return m;
+}
+
 struct ColourArgs {
     PointSrc src;
     const float* table;
@@ -194,7 +221,8 @@ __device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeo
 // table and measured 3 us SLOWER with the staging barriers, so it streams its fragments from L2 per wave.
 template <class Seq, bool STAGED>
 __device__ __forceinline__ void colour_mlp(float* stage, const float* __restrict__ wp, int lane, int h,
-                                           const float (&in)[COL_IN_STEPS], f32x16 (&a1)[2], f32x16 (&a2)[2], float (&rgb)[3]) {
+                                           const float (&in)[COL_IN_STEPS], f32x16 (&a1)[2], f32x16 (&a2)[2], float (&rgb)[3],
+                                           uint32_t* masks = nullptr) {
     load_vec<2>(wp + ColPack::kB0, h, a1);
     if (STAGED) {
         gemm_staged_part<Seq, kColStage, COL_IN_STEPS, 2, 0, 5>(stage, wp, 0, lane, in, a1);
@@ -207,9 +235,11 @@ __device__ __forceinline__ void colour_mlp(float* stage, const float* __restrict
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) h1[16 * t + r] = relu_f(a1[t][r]);
+    if (masks) masks[0] = relu_mask(a1);         // (taken where a1 dies: the forward keeps no pre-activation alive for it)
     load_vec<2>(wp + ColPack::kB1, h, a2);
     if (STAGED) gemm_staged_part<Seq, kColStage, HS, 2, 0, 4>(stage, wp, 2, lane, h1, a2);
     else        gemm_op<HS, 2>(wp + ColPack::kW1, lane, h1, a2);
+    if (masks) masks[1] = relu_mask(a2);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         f32x16 wv[2];
@@ -224,11 +254,11 @@ __device__ __forceinline__ void colour_mlp(float* stage, const float* __restrict
     }
 }
 
-// The colour forward lives on memory-level parallelism (1 GiB table, HBM gather): four waves per SIMD.  The fp32 build's generic form
-// needs 123 registers either way; the bf16-operand build allocated 133 under a two-wave target and lost a wave per SIMD (round 5).
+// The colour forward lives on memory-level parallelism (1 GiB table, HBM gather): four waves per SIMD.  Under a two-wave target the
+// bf16-operand build allocated 133 registers and, with the ReLU masks of round 5, the fp32 build 134: a wave per SIMD lost.
 // The x-pair form (XP > 0, off by default) needs 218 registers and keeps the two-wave target.
 #ifndef NSA_OCC_COL_FWD
-#define NSA_OCC_COL_FWD (NSA_PIECES == 1 ? 4 : 2)      // (the fp32 build lands at 123-126 registers = four waves under either target)
+#define NSA_OCC_COL_FWD 4
 #endif
 template <int XP>
 __global__ __launch_bounds__(256, XP > 0 ? 2 : NSA_OCC_COL_FWD) void k_colour_fwd(ColourArgs a, GridGeom16 geom) {
@@ -251,7 +281,7 @@ static __device__ unsigned long long* g_ts_c = nullptr;
 #endif
 template <bool MAP>
 __global__ __launch_bounds__(256, 2) void k_colour_bwd(ColourArgs a, GridGeom16 geom) {
-    using Seq = ColOps<true>;
+    using Seq = ColBwdOps<MAP>;
     __shared__ __attribute__((aligned(16))) float stage[2 * kColStage];
     CTS_BEGIN
 #define NSA_BODY_NW 4
@@ -283,7 +313,7 @@ __global__ __launch_bounds__(64 * NSA_CC_NW, 2) void k_colour_coarse_bwd(ColourA
     static_assert(kStageFloats >= kColStage, "the colour phase stages its parts in the SDF kernel's buffers");
     {   // phase 1: k_colour_bwd<false>
         constexpr bool MAP = false;
-        using Seq = ColOps<true>;
+        using Seq = ColBwdOps<false>;
         const ColourArgs& a = ca;
         const GridGeom16& geom = cgeom;
 #include "colour_bwd_body.inc"

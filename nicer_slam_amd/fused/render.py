@@ -19,6 +19,12 @@ def hl_size(P):
     return ((P + 31) // 32) * 2048
 
 
+def save_size(P):
+    """floats of the colour forward's save area: per 32-point tile 4096 (16 features + 48 Jacobian entries per lane) + 256 (ReLU masks of
+    both hidden layers and the sigmoid outputs: what the data-path backward needs instead of recomputing the MLP; csrc/render_colour.hip)"""
+    return ((P + 31) // 32) * (4096 + 256)
+
+
 def hl_index(P, device):
     """[P,64] gather index into an HL buffer (tests / debugging)."""
     pid = torch.arange(P, device=device).unsqueeze(1)
@@ -87,7 +93,7 @@ def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd, sort_p
     order = morton_order(_pts(rays_o, rays_d, z_vals), P, dev) if sort_points else None
     pts = _pts(rays_o, rays_d, z_vals, order)
     b = dict(order=order, sdf=torch.empty(P, device=dev), grad=torch.empty(P, 3, device=dev), feat=torch.empty(hl_size(P), device=dev),
-             rgb=torch.empty(P, 3, device=dev), save=torch.empty(hl_size(P) * 2, device=dev) if need_bwd else None,
+             rgb=torch.empty(P, 3, device=dev), save=torch.empty(save_size(P), device=dev) if need_bwd else None,
              weights=torch.empty(R, S, device=dev), rgb_values=torch.empty(R, 3, device=dev),
              depth=torch.empty(R, device=dev), nmap=torch.empty(R, 3, device=dev), entropy=torch.empty(R, device=dev),
              vox=model.voxels.contiguous(), packs=(pc, pf, pr), keep=(keep_c, keep_f, keep_r))

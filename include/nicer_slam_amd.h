@@ -168,7 +168,9 @@ int nsa_colour_forward_composite(const nsa_points_t *pts, const nsa_grid_t *grid
  * ray (P a multiple of 128, no launch order): a workgroup of the colour forward holds exactly one ray, and when its colours are stored
  * its first wave forms the ray's rendered colour, the L1 cotangent and the composite backward (arguments as for nsa_composite_track;
  * R = P / 128).  The same statements as the two kernels: identical results; the per-ray kernel's launch disappears into the tail of
- * the colour forward. */
+ * the colour forward.  This entry leaves the 16 FEATURE slots per lane of `save` unwritten (the Jacobian, the ReLU masks and the outputs
+ * are written): what follows it is the data-path backward; nsa_colour_backward_params needs a save area written by nsa_colour_forward
+ * or nsa_colour_forward_composite. */
 int nsa_colour_forward_track(const nsa_points_t *pts, const nsa_grid_t *grid, const float *packed, const float *grad,
                              const float *feat_hl, float *rgb, float *save, const float *sdf, const float *voxels,
                              uint32_t voxel_res, const float *gt, uint32_t n_total, float *rgb_values, float *ray_loss,

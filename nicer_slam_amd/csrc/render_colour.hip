@@ -84,7 +84,9 @@ struct ColourArgs {
     const float* grad;      // [P,3] grad sdf (input "normals")
     const float* feat;      // HL
     float* rgb;             // [P,3] out
-    float* save;            // per-lane save area [tiles][64 floats][64 lanes] or nullptr (16 features + 48 Jacobian)
+    float* save;            // per-lane save area [tiles][64 floats][64 lanes] or nullptr (16 features + 48 Jacobian) + save_ext
+    int save_no_features;   // 1: leave the 16 feature slots of the save area unwritten (only the mapping backward reads them, and the
+                            //    tracker's forward entry is never followed by one): 16.8 MB less to write per 1024 x 128 batch
     // backward
     const float* g_rgb;     // [P,3]
     float* g_feat;          // HL out
@@ -119,14 +121,16 @@ struct ColEmitter {
 
 // features of one colour-grid level into the first-layer slots and, with a save area, features + Jacobian for the backward
 __device__ __forceinline__ void colour_level_out(const float (&v)[8][CC], const float (&w)[3], const float (&dw)[3], float scale,
-                                                 bool inside, int jl, float (&in)[COL_IN_STEPS], float* sv) {
+                                                 bool inside, int jl, float (&in)[COL_IN_STEPS], float* sv, bool sv_features = true) {
     float f[CC];
     blend<3, CC>(v, w, f);
 #pragma unroll
     for (int c = 0; c < CC; ++c) in[49 + jl * CC + c] = inside ? f[c] : 0.0f;
     if (sv) {
+        if (sv_features) {
 #pragma unroll
-        for (int c = 0; c < CC; ++c) sv[(jl * CC + c) * 64] = in[49 + jl * CC + c];
+            for (int c = 0; c < CC; ++c) sv[(jl * CC + c) * 64] = in[49 + jl * CC + c];
+        }
 #pragma unroll
         for (int gd = 0; gd < 3; ++gd) {
             float jr[CC];
@@ -200,7 +204,7 @@ __device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeo
         } else {
             gather_corners<3, CC>(a.table, lg, cell, v);
         }
-        colour_level_out(v, w, dw, lg.scale, inside, jl, in, sv);
+        colour_level_out(v, w, dw, lg.scale, inside, jl, in, sv, !a.save_no_features);
     }
     if (XP > 0 && __any(redo)) {
 #pragma unroll
@@ -211,7 +215,7 @@ __device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeo
             const bool inside = locate<3>(u, lg.scale, cell, w, dw);
             float v[8][CC];
             gather_corners<3, CC>(a.table, lg, cell, v);
-            colour_level_out(v, w, dw, lg.scale, inside, jl, in, sv);
+            colour_level_out(v, w, dw, lg.scale, inside, jl, in, sv, !a.save_no_features);
         }
     }
 }
@@ -485,6 +489,9 @@ int NSA_ENTRY(nsa_colour_forward_track)(const nsa_points_t* pts, const nsa_grid_
     // one workgroup = one ray: ray samples in ray order, 128 per ray
     if (pts->points || pts->order || pts->S != 128 || pts->P % 128 != 0 || n_total < pts->P / 128) return NSA_EBADARG;
     a.wp = packed; a.grad = grad; a.feat = feat_hl; a.rgb = rgb; a.save = save;
+#ifndef NSA_X_SAVE_FEATURES      // (experiment builds: A/B of the feature stores)
+    a.save_no_features = 1;      // this entry is the tracker's: its backward is the data-path one (ReLU masks, outputs, Jacobian)
+#endif
     CompositeArgs t{};
     t.rays_o = pts->rays_o; t.rays_d = pts->rays_d; t.z_vals = pts->z_vals; t.sdf = sdf; t.rgb = rgb; t.voxels = voxels;
     t.voxel_res = voxel_res; t.R = pts->P / 128; t.S = 128;

@@ -1,5 +1,6 @@
 """A/B timing of the sampler's SDF pass (nsa_sampler_sdf) at the bench shape for several tile codes, on ONE box:
-   python tools/ab_sampler.py [--rays=R] [tiles ...]      (default 1024 rays, tiles 64 96)
+   python tools/ab_sampler.py [--rays=R] [tiles ...]      (default 1024 rays, tiles 64 32; 96 / 97 need the experiment build:
+   NSA_BUILD_TAG=ws NSA_X_WS=1 python -m nicer_slam_amd.build ; NSA_LIB_TAG=ws python tools/ab_sampler.py 64 96 97)
 HIP events around back-to-back launches (the kernel runs 100+ us: launch overhead is hidden), GEMM clock pre-warm, three rounds,
 the variants interleaved so that clock drift hits them alike.  Also checks that every variant returns the same bits as tile 32."""
 import sys
@@ -16,7 +17,7 @@ from nicer_slam_amd.fused import sampler as fs
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--rays=")]
     rays = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--rays=")]
-    tiles = [int(t) for t in args] or [64, 96]
+    tiles = [int(t) for t in args] or [64, 32]
     torch.manual_seed(0)
     model = SLAMNetwork(replica_model_conf(94, 640, 32, use_warp_loss=False), n_images=1).cuda().train()
     g = torch.Generator(device="cuda").manual_seed(3)

@@ -294,6 +294,17 @@ def run(frames=50, iters=100, pixels=1024, H=340, W=600, oracle_frames=3, oracle
         a, b = out["free_running_fused"]["ate_rmse_scene_units"], out["free_running_composed"]["ate_rmse_scene_units"]
         out["free_running_ate_ratio_fused_over_composed"] = a / b
         out["free_running_pose_difference"] = pose_diff(res["fused"], res["composed"])
+        # the optional reduced-precision modes of BASELINE configs[2] / [4] on the same frames (fp32 teacher, bf16-operand tracker)
+        for prec in ("bf16", "bf16_colour"):
+            teacher.mlp_precision = prec
+            teacher.__dict__.pop("_track_graphs", None)
+            t0 = time.perf_counter()
+            est = track_sequence("fused", teacher, imgs, K, gt, H, W, iters, pixels, log=log)
+            torch.cuda.synchronize()
+            out["free_running_fused_" + prec] = dict(summarise(gt, est), wall_s=round(time.perf_counter() - t0, 1),
+                                                     ms_per_iteration=round((time.perf_counter() - t0) / ((frames - 1) * iters) * 1e3, 3))
+        teacher.mlp_precision = "fp32"
+        teacher.__dict__.pop("_track_graphs", None)
     # (B) shared draws, reduced pixel count so that the CPU oracle can take part
     nB = max(2, oracle_frames + 1)
     estB, trB = {}, {}

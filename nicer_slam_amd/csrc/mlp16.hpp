@@ -257,12 +257,54 @@ __device__ __forceinline__ void gemm16_staged_part(float* stage, const float* __
 #endif
 }
 
+// ---- resident weights (bf16-operand build, round 5) ---------------------------------------------------------------------------
+// With one piece per fragment the packed blocks of a whole kernel fit into LDS at once (paired forward: 96 KiB, fine backward: 64 KiB):
+// a persistent workgroup copies every DISTINCT block of its sequence once, and its waves then loop over their tiles with no barrier
+// and no staging traffic at all -- the waves of a SIMD drift apart instead of meeting at a barrier per GEMM.  ResidentSeq<Seq> marks
+// a sequence as resident: gemm16_staged then multiplies straight out of the resident image (blocks laid out [mt][kg][piece][lane]).
+template <class Seq>
+struct ResidentSeq : Seq { static constexpr bool kResident = true; };
+template <class Seq, class = void>
+struct seq_resident { static constexpr bool value = false; };
+template <class Seq>
+struct seq_resident<Seq, decltype((void)Seq::kResident)> { static constexpr bool value = true; };
+
+// the first op of the sequence that uses the same packed block as `op` (a backward names its forward and reverse blocks twice)
+template <class Seq>
+__host__ __device__ constexpr int res_first(int op) {
+    for (int j = 0; j < op; ++j)
+        if (Seq::off(j) == Seq::off(op) && seq_net<Seq>(j) == seq_net<Seq>(op)) return j;
+    return op;
+}
+template <class Seq>
+__host__ __device__ constexpr int res_size(int op) { return Seq::mt(op) * Seq::kg(op) * 256 * kLdsPieces; }
+// LDS offset (floats) of op's block in the resident image; op == Seq::n: the image's size
+template <class Seq>
+__host__ __device__ constexpr int res_off(int op) {
+    const int f = op < Seq::n ? res_first<Seq>(op) : op;
+    int o = 0;
+    for (int j = 0; j < f; ++j)
+        if (res_first<Seq>(j) == j) o += res_size<Seq>(j);
+    return o;
+}
+template <class Seq, int NW>
+__device__ __forceinline__ void resident_load(float* lds, const float* __restrict__ wp, const float* __restrict__ wp1 = nullptr) {
+#pragma unroll
+    for (int op = 0; op < Seq::n; ++op)
+        if (res_first<Seq>(op) == op)
+            stage_issue_part<NW>(wp, StagePart{Seq::off(op), Seq::mt(op), Seq::kg(op), 0, Seq::kg(op), seq_net<Seq>(op)},
+                                 lds + res_off<Seq>(op), wp1);
+}
+
 // logical GEMM `opi` of Seq (KG k-groups, MT output tiles): all its parts (at most two).  `wp1`: base of the second packed block
 // of a sequence that runs two networks (Seq::net).
 template <class Seq, int NW, int BUF, int KG, int MT>
 __device__ __forceinline__ void gemm16_staged(float* stage, const float* __restrict__ wp, int opi, int lane,
                                               const float (&b)[8 * KG], f32x4v (&acc)[MT], const float* __restrict__ wp1 = nullptr) {
-
+    if constexpr (seq_resident<Seq>::value) {        // `stage` = the resident image: no wait, no copy, no barrier
+        gemm16_lds_part<KG, MT, 0, KG>(stage + res_off<Seq>(opi), lane, b, acc);
+        return;
+    }
     constexpr int M = max_groups<BUF>(MT);
     constexpr int NP = (KG + M - 1) / M;
     static_assert(NP <= 3, "a staged GEMM is split into at most three parts");

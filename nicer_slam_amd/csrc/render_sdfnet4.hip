@@ -6,6 +6,7 @@
 //   k_sdfnet4_bwd   value path + double backward through the reverse pass (grid-Hessian term dropped, hashgrid.py:134);
 //                   MAP = true adds table gradients (run-merged atomics) and the emission rows of the weight gradients
 // Reference: ImplicitNetworkGrid.get_outputs/gradient (code/model/base_networks.py:195-221), ImplicitNetworkGrid_COMBINE (:7-47).
+#include <cstdlib>
 #include "sdf_net4.hpp"
 
 namespace nsa {
@@ -324,46 +325,9 @@ __global__ __launch_bounds__(64 * NSA_NW4_PAIR, NSA_OCC4_FWD) void k_sdfnet4_fwd
     const uint32_t n_tiles = (a.src.P + 15) / 16;
     const bool wave_live = tile < n_tiles;
     if (!wave_live) tile = n_tiles - 1;
-    uint32_t pid = tile * 16 + j;
-    const bool live = wave_live && pid < a.src.P;
-    if (pid >= a.src.P) pid = a.src.P - 1;
-    const uint32_t pt = point_of(a.src, pid);
-    float x[3], z;
-    uint32_t ray;
-    load_point(a.src, pt, x, ray, z);
-    __syncthreads();                                         // s_geom
-    static_assert((8 / CC) * 3 * CC == (8 / CF) * 3 * CF, "one Jacobian column serves both grids");
-    constexpr int kJac = (8 / CC) * 3 * CC;
-    __shared__ float jac_lds[Seq::NW * kJac * 64];
-    float* jstore = jac_lds + (threadIdx.x >> 6) * (kJac * 64) + lane;
-    float in[QIN], dl[QIN];
-    pe_slots4(x, q, in);                                     // slots 0..15: shared by the two networks
-    // coarse network
-    grid_slots4<LC, CC>(x, a.df_c, a.table_c, s_geom, q, in, jstore);
-    float sdf_c, g_c[3];
-    f32x4v fo_c[4];
-    net_forward4<NHC, Seq>(stage, 0, a.wp_c, a.wp_c, a.wp_f, lane, q, in, sdf_c, fo_c, dl);
-    slots_to_x_jac4<LC, CC>(a.df_c, jstore, q, in, dl, g_c);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) g_c[d] = quad_sum(g_c[d]);
-    // fine network (the Jacobian column and the grid slots are reused; the coarse ones have been consumed)
-    grid_slots4<LF, CF>(x, a.df_f, a.table_f, s_geom + 16, q, in, jstore);
-    float sdf_f, g_f[3];
-    f32x4v fo_f[4];
-    net_forward4<NHF, Seq>(stage, Seq::A::n, a.wp_f, a.wp_c, a.wp_f, lane, q, in, sdf_f, fo_f, dl);
-    slots_to_x_jac4<LF, CF>(a.df_f, jstore, q, in, dl, g_f);
-    if (wave_live) {
-        float* fdst = a.feat + hl_base4(tile, j, q);
-#pragma unroll
-        for (int s = 0; s < QHS; ++s) fdst[hl_step4(s)] = fo_f[s >> 2][s & 3] + fo_c[s >> 2][s & 3];
-    }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) g_f[d] = quad_sum(g_f[d]);
-    if (live && q == 0) {
-        a.sdf[pt] = sdf_f + sdf_c;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) a.grad[(size_t)pt * 3 + d] = g_f[d] + g_c[d];
-    }
+#define NSA_BODY_SYNC __syncthreads();
+#include "sdfnet4_pair_body.inc"
+#undef NSA_BODY_SYNC
 }
 
 template <int L, int C, int NH, bool MAP>
@@ -382,149 +346,81 @@ __global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd(
     const uint32_t n_tiles = (a.src.P + 15) / 16;
     const bool wave_live = tile < n_tiles;
     if (!wave_live) tile = n_tiles - 1;
-    uint32_t pid = tile * 16 + j;
-    const bool live = wave_live && pid < a.src.P;
-    if (pid >= a.src.P) pid = a.src.P - 1;
-    const uint32_t pt = point_of(a.src, pid);
-    float x[3], z;
-    uint32_t ray;
-    load_point(a.src, pt, x, ray, z);
-    __syncthreads();                                         // s_geom
-    TS_MARK(4)
-    // the grid Jacobian of this lane's levels stays in lane-private LDS: the backward needs no second and third corner gather
-    constexpr int kJac = (8 / C) * 3 * C;                    // 24 floats per lane
-    __shared__ float jac_lds[Seq::NW * kJac * 64];
-    float* jstore = jac_lds + (threadIdx.x >> 6) * (kJac * 64) + lane;
-    float in[QIN];
-    pe_slots4(x, q, in);
-    grid_slots4<L, C>(x, a.divide_factor, a.table, s_geom, q, in, jstore);
-    const bool emit = MAP && a.emit != nullptr && wave_live;   // (a clamped wave must not touch the last tile's rows)
-    const Emitter4 em{emit ? a.emit + (size_t)tile * 16 + j : nullptr, a.emit_ld, live};
-    float sg[NH][QHS], hl[QHS];
-    TS_MARK(5)
-    hidden_forward4<NH, Seq>(stage, 0, a.wp, lane, q, in, sg, hl, emit ? &em : nullptr);
-    TS_MARK(6)
-    float dh[NH > 1 ? NH - 1 : 1][QHS], dl[QIN];
-    reverse_pass4<NH, Seq>(stage, NH, a.wp, lane, q, sg, dh, dl, emit ? &em : nullptr);
-    TS_MARK(7)
-    if (emit) {
-#pragma unroll
-        for (int s = 0; s < QIN; ++s) em.slot(E::H0, s, q, in[s]);
-    }
-
-    float nbar[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) nbar[d] = a.g_grad ? a.g_grad[(size_t)pt * 3 + d] : 0.0f;
-    const float sbar = a.g_sdf ? a.g_sdf[pt] : 0.0f;
-
-    // ---- tangent sweep: e_k = sp''(a_k) dh_k ta_k (kept in e[k-1]) ----
-    float e[NH][QHS];
-    float xb2[3];
-    {
-        float tin[QIN];
-        tangent_from_jac4<L, C>(a.divide_factor, jstore, q, in, nbar, dl, tin, xb2);
-        if (emit) {
-#pragma unroll
-            for (int s = 0; s < QIN; ++s) em.slot(E::TIN, s, q, tin[s]);
-        }
-        f32x4v acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        gemm16_staged<Seq, Seq::NW, Seq::BUF, QIN_G, 4>(stage, a.wp, 2 * NH, lane, tin, acc);
-        f32x4v ws[4];
-        load_vec16(a.wp + P::kWSDF, q, ws);
-        float th[QHS];
-#pragma unroll
-        for (int k = 1; k <= NH; ++k) {
-#pragma unroll
-            for (int s = 0; s < QHS; ++s) {
-                const float s1 = sg[k - 1][s];
-                const float s2 = 100.0f * s1 * (1.0f - s1);          // 0 in the linear region (s1 == 1)
-                const float dhk = (k == NH) ? ws[s >> 2][s & 3] : dh[k - 1][s];
-                const float ta = acc[s >> 2][s & 3];
-                e[k - 1][s] = s2 * dhk * ta;
-                th[s] = s1 * ta;
-                if (emit) em.hid(E::TH(k), s, q, th[s]);
-            }
-            if (k < NH) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-                gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, a.wp, 2 * NH + k, lane, th, acc);
-            }
-        }
-    }
-    TS_MARK(8)
-    // ---- reverse sweep ----
-    float ab[QHS];
-    {
-        float fb[QHS];
-        const float* fsrc = a.g_feat ? a.g_feat + hl_base4(tile, j, q) : nullptr;
-#pragma unroll
-        for (int s = 0; s < QHS; ++s) fb[s] = fsrc ? fsrc[hl_step4(s)] : 0.0f;
-        if (emit) {
-#pragma unroll
-            for (int s = 0; s < QHS; ++s) em.hid(E::FB, s, q, fb[s]);
-        }
-        f32x4v acc[4], ws[4];
-        load_vec16(a.wp + P::kWSDF, q, ws);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)        // (element by element: a vector * scalar here becomes v_pk_mul_f32, see build.py::isa_check)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[t][r] = sbar * ws[t][r];
-        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, a.wp, 3 * NH, lane, fb, acc);
-#pragma unroll
-        for (int s = 0; s < QHS; ++s) ab[s] = sg[NH - 1][s] * acc[s >> 2][s & 3] + e[NH - 1][s];
-    }
-#pragma unroll
-    for (int k = NH - 1; k >= 1; --k) {
-        if (emit) {
-#pragma unroll
-            for (int s = 0; s < QHS; ++s) em.hid(E::AB(k + 1), s, q, ab[s]);
-        }
-        f32x4v acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, a.wp, 3 * NH + 1 + (NH - 1 - k), lane, ab, acc);
-#pragma unroll
-        for (int s = 0; s < QHS; ++s) ab[s] = sg[k - 1][s] * acc[s >> 2][s & 3] + e[k - 1][s];
-    }
-    if (emit) {
-#pragma unroll
-        for (int s = 0; s < QHS; ++s) em.hid(E::AB(1), s, q, ab[s]);
-    }
-    TS_MARK(9)
-    float hb0[QIN];
-    {
-        f32x4v a6[6];
-#pragma unroll
-        for (int t = 0; t < 6; ++t) a6[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 6>(stage, a.wp, 4 * NH, lane, ab, a6);
-#pragma unroll
-        for (int s = 0; s < QIN; ++s) hb0[s] = a6[s >> 2][s & 3];
-    }
-    float gx[3];
-    slots_to_x_jac4<L, C>(a.divide_factor, jstore, q, in, hb0, gx);
-    // scatter scratch: the stage buffer the last GEMM part does NOT read; every wave passed the barrier of that part and
-    // nothing is fetched after it, so nobody touches that buffer any more
-    constexpr int kIdle = (Seq::n_parts() - 1) & 1 ? 0 : 1;
-    if (MAP && a.g_table)
-        table_grad_scatter4<L, C>(x, a.divide_factor, s_geom, q, lane, live, hb0, dl, nbar, a.g_table,
-                                  stage + kIdle * Seq::BUF + (threadIdx.x >> 6) * 64 * (2 * C + 1));
-#pragma unroll
-    for (int d = 0; d < 3; ++d) gx[d] = quad_sum(gx[d] + xb2[d]);
-    if (live && q == 0) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            float v = gx[d];
-            if (a.accumulate) v += a.g_x[(size_t)pt * 3 + d];
-            a.g_x[(size_t)pt * 3 + d] = v;
-        }
-    }
+#define NSA_BODY_SYNC __syncthreads();
+#include "sdfnet4_bwd_body.inc"
+#undef NSA_BODY_SYNC
     TS_MARK(10)
     TS_END
 }
 
 static_assert(NSA_NW4_BWD * 64 * (2 * 8 + 1) <= stage_floats4(NSA_NW4_BWD), "scatter scratch must fit the idle stage buffer");
+
+// ---- resident-weight persistent forms (bf16-operand build; mlp16.hpp::ResidentSeq) -------------------------------------------------
+// One 8-wave workgroup per CU copies every distinct packed block of the sequence into LDS once (single piece per fragment: paired
+// forward 96 KiB, fine backward 64 KiB) and its waves loop over their tiles with no barrier and no staging: the statements of a tile
+// are the staged kernels' own (sdfnet4_pair_body.inc / sdfnet4_bwd_body.inc), so the results are bit-identical to them.
+#if NSA_PIECES == 1
+template <int LC, int CC, int NHC, int LF, int CF, int NHF>
+__global__ __launch_bounds__(64 * NSA_NW4_PAIR, NSA_OCC4_FWD) void k_sdfnet4_fwd_pair_res(SdfNet4PairArgs a, GridGeom16 gc, GridGeom16 gf) {
+    using Seq = ResidentSeq<SdfOpsPair<NHC, NHF>>;
+    __shared__ __attribute__((aligned(16))) float stage[res_off<Seq>(Seq::n)];
+    __shared__ LevelGeom s_geom[32];
+    resident_load<Seq, Seq::NW>(stage, a.wp_c, a.wp_f);
+    if (threadIdx.x < 16) s_geom[threadIdx.x] = gc.lv[threadIdx.x];
+    else if (threadIdx.x < 32) s_geom[threadIdx.x] = gf.lv[threadIdx.x - 16];
+    stage_wait();                                            // vmcnt(0) + workgroup barrier: weights and geometry are in LDS
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const uint32_t n_tiles = (a.src.P + 15) / 16;
+    constexpr bool wave_live = true;
+    for (uint32_t tile = blockIdx.x * Seq::NW + (threadIdx.x >> 6); tile < n_tiles; tile += gridDim.x * Seq::NW) {
+#define NSA_BODY_SYNC
+#include "sdfnet4_pair_body.inc"
+#undef NSA_BODY_SYNC
+    }
+}
+
+template <int L, int C, int NH>
+__global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd_res(SdfNet4Args a, GridGeom16 geom) {
+    constexpr bool MAP = false;
+    using P = SdfPack4<NH>;
+    using Seq = ResidentSeq<SdfOps4<NH, true>>;
+    using E = SE4<NH>;
+    __shared__ __attribute__((aligned(16))) float stage[res_off<Seq>(Seq::n)];
+    __shared__ LevelGeom s_geom[16];
+    resident_load<Seq, Seq::NW>(stage, a.wp);
+    geom_to_lds(geom, s_geom);
+    stage_wait();
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const uint32_t n_tiles = (a.src.P + 15) / 16;
+    constexpr bool wave_live = true;
+    for (uint32_t tile = blockIdx.x * Seq::NW + (threadIdx.x >> 6); tile < n_tiles; tile += gridDim.x * Seq::NW) {
+#define NSA_BODY_SYNC
+#pragma push_macro("TS_MARK")             // (the per-phase cycle stamps of the profiling build belong to the staged kernel)
+#undef TS_MARK
+#define TS_MARK(slot)
+#include "sdfnet4_bwd_body.inc"
+#pragma pop_macro("TS_MARK")
+#undef NSA_BODY_SYNC
+    }
+}
+
+// workgroups of a persistent launch: one per CU
+static int persistent_blocks4() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus : 256;
+    }
+    return n;
+}
+// NSA_BF16_RESIDENT=0: the staged forms (A/B runs)
+static bool bf16_resident() {
+    static const bool on = [] { const char* e = getenv("NSA_BF16_RESIDENT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+#endif
 
 static int launch_sdfnet4(bool bwd, const nsa_grid_t* grid, const SdfNet4Args& a, hipStream_t st) {
     const bool map = a.g_table != nullptr || a.emit != nullptr;
@@ -540,6 +436,12 @@ static int launch_sdfnet4(bool bwd, const nsa_grid_t* grid, const SdfNet4Args& a
         else            hipLaunchKernelGGL((k_sdfnet4_fwd<4, 8, 1>), g, b, 0, st, a, geom);
     } else if (grid->L == 8 && grid->C == 4 && grid->n_hidden == 3) {
         if (bwd && map) hipLaunchKernelGGL((k_sdfnet4_bwd<8, 4, 3, true>), g, b, 0, st, a, geom);
+#if NSA_PIECES == 1
+        else if (bwd && bf16_resident()) {
+            const uint32_t wgs = (tiles + nw - 1) / nw, cap = (uint32_t)persistent_blocks4();
+            hipLaunchKernelGGL((k_sdfnet4_bwd_res<8, 4, 3>), dim3(wgs < cap ? wgs : cap), b, 0, st, a, geom);
+        }
+#endif
         else if (bwd)   hipLaunchKernelGGL((k_sdfnet4_bwd<8, 4, 3, false>), g, b, 0, st, a, geom);
         else            hipLaunchKernelGGL((k_sdfnet4_fwd<8, 4, 3>), g, b, 0, st, a, geom);
     } else {
@@ -593,6 +495,14 @@ int NSA_ENTRY(nsa_sdfnet4_forward_pair)(const nsa_points_t* pts, const nsa_grid_
     if (int rc = make_grid_geom16(fine->offsets_host, fine->L, fine->S, fine->H, &gf, fine->C)) return rc;
     const uint32_t tiles = (a.src.P + 15) / 16;
     launch_begin();
+#if NSA_PIECES == 1
+    if (bf16_resident()) {
+        const uint32_t wgs = (tiles + NSA_NW4_PAIR - 1) / NSA_NW4_PAIR, cap = (uint32_t)persistent_blocks4();
+        hipLaunchKernelGGL((k_sdfnet4_fwd_pair_res<4, 8, 1, 8, 4, 3>), dim3(wgs < cap ? wgs : cap), dim3(64 * NSA_NW4_PAIR), 0,
+                           (hipStream_t)stream, a, gc, gf);
+        return launch_end();
+    }
+#endif
     hipLaunchKernelGGL((k_sdfnet4_fwd_pair<4, 8, 1, 8, 4, 3>), dim3((tiles + NSA_NW4_PAIR - 1) / NSA_NW4_PAIR), dim3(64 * NSA_NW4_PAIR), 0,
                        (hipStream_t)stream, a, gc, gf);
     return launch_end();

@@ -256,51 +256,11 @@ __device__ __forceinline__ void gemm_lds(const float* lds_block, int lane, const
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// ---- resident weights (bf16-operand build, round 5; see mlp16.hpp for the quad tiling's form) ---------------------------------------
-// With one piece per fragment the packed blocks of a whole backward launch fit into LDS at once: a persistent workgroup copies them
-// once and its waves loop over their tiles with no barrier and no staging.  ResidentBlocks<Seq, BASE> / ResidentParts<Seq, BASE> mark
-// a block sequence (gemm_staged) resp. a part sequence (gemm_staged_part) as resident in an LDS image starting BASE floats in.
-template <class Seq, int BASE>
-struct ResidentBlocks : Seq { static constexpr bool kResident = true; static constexpr int kBase = BASE; };
-template <class Seq, int BASE>
-struct ResidentParts : Seq { static constexpr bool kResident = true; static constexpr int kBase = BASE; };
-template <class Seq, class = void>
-struct seq_is_resident { static constexpr bool value = false; };
-template <class Seq>
-struct seq_is_resident<Seq, decltype((void)Seq::kResident)> { static constexpr bool value = true; };
-// block sequences: op i uses the packed block at Seq::off(i), Seq::size(i) floats (three pieces); a block named twice is kept once
-template <class Seq>
-__host__ __device__ constexpr int resb_first(int op) {
-    for (int j = 0; j < op; ++j)
-        if (Seq::off(j) == Seq::off(op)) return j;
-    return op;
-}
-template <class Seq>
-__host__ __device__ constexpr int resb_off(int op) {        // op == Seq::n: end of the sequence's image
-    const int f = op < Seq::n ? resb_first<Seq>(op) : op;
-    int o = Seq::kBase;
-    for (int j = 0; j < f; ++j)
-        if (resb_first<Seq>(j) == j) o += Seq::size(j) / 3 * kLdsPieces;
-    return o;
-}
-// part sequences: part i = Seq::op(i) (StageOp), laid out [mt][ng][piece][lane]
-template <class Seq>
-__host__ __device__ constexpr int resp_off(int part) {      // part == Seq::n: end of the sequence's image
-    int o = Seq::kBase;
-    for (int j = 0; j < part; ++j) o += Seq::op(j).mt * Seq::op(j).ng * 256 * kLdsPieces;
-    return o;
-}
-
 // GEMM number `opi` of the kernel's sequence Seq (Seq::n ops; Seq::off(i) / Seq::size(i) = packed block of op i, in
 // floats from `wp`): wait for its block, start fetching the next one into the other buffer, multiply from LDS.
 template <class Seq, int KS, int MT>
 __device__ __forceinline__ void gemm_staged(float* stage, const float* __restrict__ wp, int opi, int lane,
                                             const float (&b)[KS], f32x16 (&acc)[MT]) {
-    if constexpr (seq_is_resident<Seq>::value) {      // `stage` = the resident image: no wait, no copy, no barrier
-        __builtin_amdgcn_sched_barrier(0);            // (where the staged form has its workgroup barrier: later phases' loads stay below)
-        gemm_lds<KS, MT>(stage + resb_off<Seq>(opi), lane, b, acc);
-        return;
-    }
     stage_wait();
     if (opi + 1 < Seq::n) stage_issue(wp + Seq::off(opi + 1), Seq::size(opi + 1), stage + ((opi + 1) & 1) * kStageFloats);
     gemm_lds<KS, MT>(stage + (opi & 1) * kStageFloats, lane, b, acc);
@@ -370,11 +330,6 @@ __device__ __forceinline__ void gemm_lds_part(const float* lds_block, int lane, 
 template <class Seq, int BUF, int KS, int MT, int G0, int NG>
 __device__ __forceinline__ void gemm_staged_part(float* stage, const float* __restrict__ wp, int opi, int lane,
                                                  const float (&b)[KS], f32x16 (&acc)[MT]) {
-    if constexpr (seq_is_resident<Seq>::value) {      // `stage` = the resident image
-        __builtin_amdgcn_sched_barrier(0);
-        gemm_lds_part<KS, MT, G0, NG>(stage + resp_off<Seq>(opi), lane, b, acc);
-        return;
-    }
     stage_wait();
     if (opi + 1 < Seq::n) stage_issue_op(wp, Seq::op(opi + 1), stage + ((opi + 1) & 1) * BUF);
     gemm_lds_part<KS, MT, G0, NG>(stage + (opi & 1) * BUF, lane, b, acc);

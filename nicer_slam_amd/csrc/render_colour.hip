@@ -336,95 +336,6 @@ __global__ __launch_bounds__(64 * NSA_CC_NW, 2) void k_colour_coarse_bwd(ColourA
 }
 #undef NSA_BODY_NW
 
-// ---- resident-weight persistent forms of the two data-path backward launches (bf16-operand build; mlp_common.hpp::Resident*) ----------
-// The three reverse parts of the colour network (28 KiB at one piece per fragment) and the three distinct blocks of the coarse SDF
-// backward (30 KiB) are copied into LDS once per workgroup; its waves then loop over 32-point tiles with no barrier and no staging --
-// the waves of a SIMD drift apart instead of meeting at every GEMM (bf16: paired forward / fine backward -18 % with the same change in the
-// quad tiling, profiles/r05_ab_experiments.txt r5i).  The statements of a tile are the staged kernels' own bodies: identical results.
-#if NSA_PIECES == 1
-#define NSA_BODY_NW 4
-using ColResSeq = ResidentParts<ColBwdOps<false>, 0>;
-constexpr int kColResFloats = resp_off<ColResSeq>(ColResSeq::n);
-using CoarseResSeq = ResidentBlocks<SdfOps<1, true>, kColResFloats>;
-constexpr int kColCoarseResFloats = resb_off<CoarseResSeq>(CoarseResSeq::n);
-
-__device__ __forceinline__ void colour_resident_load(float* image, const float* __restrict__ wp) {
-#pragma unroll
-    for (int i = 0; i < ColResSeq::n; ++i) stage_issue_op(wp, ColResSeq::op(i), image + resp_off<ColResSeq>(i));
-}
-
-__global__ __launch_bounds__(256, 2) void k_colour_bwd_res(ColourArgs a, GridGeom16 geom) {
-    constexpr bool MAP = false;
-    using Seq = ColResSeq;
-    __shared__ __attribute__((aligned(16))) float stage[kColResFloats];
-    colour_resident_load(stage, a.wp);
-    stage_wait();
-    const uint32_t n_tiles_all = (a.src.P + 31) / 32;
-    for (uint32_t tile_it = blockIdx.x * 4 + (threadIdx.x >> 6); tile_it < n_tiles_all; tile_it += gridDim.x * 4) {
-#define NSA_BODY_RESIDENT tile_it
-#include "colour_bwd_body.inc"
-#undef NSA_BODY_RESIDENT
-    }
-}
-
-__global__ __launch_bounds__(256, 2) void k_colour_coarse_bwd_res(ColourArgs ca, GridGeom16 cgeom, SdfNetArgs sa, GridGeom16 sgeom) {
-    __shared__ __attribute__((aligned(16))) float stage[kColCoarseResFloats];
-    colour_resident_load(stage, ca.wp);
-#pragma unroll
-    for (int i = 0; i < CoarseResSeq::n; ++i)
-        if (resb_first<CoarseResSeq>(i) == i)
-            stage_issue(sa.wp + CoarseResSeq::off(i), CoarseResSeq::size(i), stage + resb_off<CoarseResSeq>(i));
-    stage_wait();
-    const uint32_t n_tiles_all = (ca.src.P + 31) / 32;
-    for (uint32_t tile_it = blockIdx.x * 4 + (threadIdx.x >> 6); tile_it < n_tiles_all; tile_it += gridDim.x * 4) {
-#define NSA_BODY_RESIDENT tile_it
-        // (the packed-parameter pointers are laundered once per tile: as loop invariants, the per-feature vectors read through them --
-        //  biases, output rows, ~200 registers' worth -- would be hoisted out of the loop and spilled)
-        ColourArgs ca_it = ca;
-        SdfNetArgs sa_it = sa;
-        asm volatile("" : "+s"(ca_it.wp), "+s"(sa_it.wp));
-        {   // phase 1: the colour backward of the tile
-            constexpr bool MAP = false;
-            using Seq = ColResSeq;
-            const ColourArgs& a = ca_it;
-            const GridGeom16& geom = cgeom;
-#include "colour_bwd_body.inc"
-        }
-        __builtin_amdgcn_sched_barrier(0);       // (no statement of one phase is scheduled into the other: register pressure)
-        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's cotangent stores have left before it reads them back below
-        __builtin_amdgcn_sched_barrier(0);
-        {   // phase 2: the coarse SDF backward of the same tile
-            constexpr int L = 4, C = 8, NH = 1;
-            constexpr bool MAP = false;
-            using P = SdfPack<NH>;
-            using Seq = CoarseResSeq;
-            const SdfNetArgs& a = sa_it;
-            const GridGeom16& geom = sgeom;
-#include "sdfnet_bwd_body.inc"
-        }
-#undef NSA_BODY_RESIDENT
-    }
-}
-#undef NSA_BODY_NW
-
-static int colour_persistent_blocks() {          // two 4-wave workgroups per CU
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, cus = 0;
-        n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? 2 * cus : 512;
-    }
-    return n;
-}
-static bool colour_bf16_resident() {             // NSA_BF16_RESIDENT=0 or NSA_BF16_RESIDENT_CC=0: the staged forms (A/B runs)
-    static const bool on = [] {
-        const char* e = getenv("NSA_BF16_RESIDENT");
-        const char* c = getenv("NSA_BF16_RESIDENT_CC");
-        return !(e && e[0] == '0') && !(c && c[0] == '0');
-    }();
-    return on;
-}
-#endif
-
 }  // namespace nsa
 
 // ---- colour forward + the ray's composite / L1 / composite backward as two phases of ONE launch (tracker, 128 samples per ray) -------
@@ -607,13 +518,6 @@ int NSA_ENTRY(nsa_colour_backward)(const nsa_points_t* pts, const nsa_grid_t* gr
     a.g_feat = g_feat_hl; a.g_grad = g_grad; a.g_x = g_x; a.g_dir = g_dir; a.grid_grad = grid_grad;
     const uint32_t tiles = (pts->P + 31) / 32;
     launch_begin();
-#if NSA_PIECES == 1
-    if (colour_bf16_resident()) {
-        const uint32_t wgs = (tiles + 3) / 4, cap = (uint32_t)colour_persistent_blocks();
-        hipLaunchKernelGGL(k_colour_bwd_res, dim3(wgs < cap ? wgs : cap), dim3(256), 0, (hipStream_t)stream, a, geom);
-        return launch_end();
-    }
-#endif
     hipLaunchKernelGGL(k_colour_bwd<false>, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
     return launch_end();
 }
@@ -646,13 +550,6 @@ int NSA_ENTRY(nsa_colour_coarse_backward)(const nsa_points_t* pts, const nsa_gri
     sa.g_sdf = g_sdf; sa.g_feat = g_feat_hl; sa.g_grad = g_grad; sa.g_x = g_x;
     const uint32_t tiles = (pts->P + 31) / 32;
     launch_begin();
-#if NSA_PIECES == 1
-    if (colour_bf16_resident()) {
-        const uint32_t wgs = (tiles + 3) / 4, cap = (uint32_t)colour_persistent_blocks();
-        hipLaunchKernelGGL(k_colour_coarse_bwd_res, dim3(wgs < cap ? wgs : cap), dim3(256), 0, (hipStream_t)stream, a, geom, sa, sgeom);
-        return launch_end();
-    }
-#endif
     hipLaunchKernelGGL(k_colour_coarse_bwd, dim3((tiles + NSA_CC_NW - 1) / NSA_CC_NW), dim3(64 * NSA_CC_NW), 0, (hipStream_t)stream, a, geom, sa, sgeom);
     return launch_end();
 }

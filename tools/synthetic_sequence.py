@@ -235,6 +235,184 @@ def track_sequence(engine, model, frames, K, gt_poses, H, W, iters=100, pixels=1
     return torch.stack([e.cpu() for e in est])
 
 
+# ------------------------------------------------------------------------------------------------- tracking AND mapping (mini SLAM)
+def render_cues(model, poses, K, H, W):
+    """colour, depth and (camera-frame) normal images [n, H*W, C] of the teacher: the synthetic stand-ins for a dataset's RGB frames
+    and its monocular depth / normal cues (scene_dataset.py:185-205)."""
+    from nicer_slam_amd.inference import render_image
+    dev = model.voxels.device
+    uv = all_pixels(H, W, dev).unsqueeze(0)
+    was = model.training
+    model.eval()
+    rgb, depth, normal = [], [], []
+    with torch.no_grad():
+        for c2w in poses:
+            res = render_image(model, {"intrinsics": K[None], "uv": uv, "pose": c2w.to(dev)[None]}, n_pixels=65536)
+            rgb.append(res["rgb_values"].reshape(H * W, 3).clone())
+            depth.append(res["depth_values"].reshape(H * W, 1).clone())
+            normal.append(res["normal_map"].reshape(H * W, 3).clone())
+    model.train(was)
+    return torch.stack(rgb), torch.stack(depth), torch.stack(normal)
+
+
+def make_student(teacher, H, W, n_images, colour_grid=None):
+    """The map to be learned: a SLAMNetwork at the reference's initialisation (tables U(-1e-4, 1e-4), geometric MLPs) -- except the
+    fine SDF MLP, which the reference loads from `pretrain.pth` and never optimises (volsdf_train.py:139-173): here the teacher's."""
+    from nicer_slam_amd.model.network import SLAMNetwork
+    from nicer_slam_amd.utils.conf import replica_model_conf
+    torch.manual_seed(11)
+    kw = {} if colour_grid is None else {"colour_grid": colour_grid}
+    student = SLAMNetwork(replica_model_conf(64, 640, 32, use_warp_loss=False), dataset=_DS(H, W), n_images=n_images, **kw)
+    sd = teacher.state_dict()
+    with torch.no_grad():
+        for name, p in student.named_parameters():
+            if name.startswith("implicit_network.fine.lin"):
+                p.copy_(sd[name].to(p.device))
+    student.train_dataset, student.keyframe_every = None, 10
+    return student.to(teacher.voxels.device)
+
+
+def run_slam(engine, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_grid=None, map_every=5, map_iters=100, track_iters=100,
+             map_pixels=8192, track_pixels=1024, lr=0.002, cam_lr=0.005, ba_lr=0.001, window=15, log=None):
+    """Tracking AND mapping in the reference's loop shape (volsdf_train.py:363-613) on `engine`: frame 0 at its ground-truth pose and
+    `map_iters` mapping iterations on it; every later frame tracked from the constant-speed initialisation against the map learned so far;
+    every `map_every`-th frame a mapping round over the keyframe window (every 10th frame + the current one; the frames since the last
+    keyframe join half-way), coarse -> fine and base -> highfreq schedules, bundle adjustment of the window's cameras in the last 30 % of a
+    round (poses written back as :584-594 does).  Objective: the shipped SLAMLoss weights without the warp / flow terms; the monocular
+    depth / normal cues are the teacher's renderings.  -> final pose estimates [frames,4,4] (CPU), seconds spent in (tracking, mapping)."""
+    from nicer_slam_amd.feed import FrameFeed
+    from nicer_slam_amd.model.loss import SLAMLoss
+    from nicer_slam_amd.optim import Adam as HipAdam
+    from nicer_slam_amd.utils.general import get_camera_from_tensor, get_tensor_from_camera
+    dev = teacher.voxels.device
+    student = make_student(teacher, H, W, frames, colour_grid)
+    student.engine = engine
+    student.train()
+    imp, rn = student.implicit_network, student.rendering_network
+    para_list = [     # volsdf_train.py:150-173
+        {"name": "encoding", "params": list(imp.fine.grid_parameters()), "lr": lr * 20.0},
+        {"name": "encoding", "params": list(imp.coarse.grid_parameters()), "lr": lr * 20.0},
+        {"name": "net", "params": list(rn.grid_parameters()), "lr": lr * 5.0},
+        {"name": "net", "params": list(rn.mlp_parameters()), "lr": lr},
+        {"name": "density", "params": list(student.density.parameters()), "lr": 2e-3},
+        {"name": "coarse_mlp_parameters", "params": list(imp.coarse.mlp_parameters()), "lr": lr},
+    ]
+    para_list = [g for g in para_list if len(g["params"])]
+    optimizer = HipAdam(para_list, betas=(0.9, 0.99), eps=1e-15)       # (= torch.optim.Adam's semantics, one pass per tensor)
+    loss_fn = SLAMLoss(model=student, rgb_loss="torch.nn.L1Loss", assign_scale_shift_init=True, eikonal_weight=0.1, smooth_weight=0.005,
+                       depth_weight=0.1, normal_l1_weight=0.05, normal_cos_weight=0.05)          # runconf_replica_1.conf:45-57
+    tracking_loss = SLAMLoss(model=student, rgb_loss="torch.nn.L1Loss", eikonal_weight=0, smooth_weight=0, depth_weight=0,
+                             normal_l1_weight=0, normal_cos_weight=0)
+    feed = FrameFeed((H, W), device=dev, capacity=frames)
+    t_track = t_map = 0.0
+
+    def mapping(frame_idx):
+        local = [0] if frame_idx == 0 else list(range(0, frame_idx, 10)) + [frame_idx]
+        for it in range(map_iters):
+            if frame_idx != 0 and it == map_iters // 2:                                       # :493-495
+                local = sorted(set(local + list(range(frame_idx // 10 * 10, frame_idx))))
+            kf = list(local)
+            feed.change_sampling_idx(max(1, map_pixels // len(kf)))
+            indices, model_input, ground_truth = feed.batch(kf, full="store")
+            ba = frame_idx != 0 and it > int(map_iters * 0.7)
+            if ba:
+                cams = torch.stack([get_tensor_from_camera((gt[0] if k == 0 else feed.frames[k]["pose"]).cpu()) for k in kf])
+                cams = cams.to(dev).requires_grad_(True)
+                opt_ba = torch.optim.Adam([cams], lr=ba_lr)
+                model_input["pose"] = get_camera_from_tensor(cams)
+            optimizer.zero_grad()
+            if frame_idx > 1:
+                stage = "coarse" if it < int(map_iters * 0.25) else "fine"
+                color_stage = "base" if it < int(map_iters * 0.7) else "highfreq"
+            else:
+                stage, color_stage = "fine", "highfreq"
+            out = student(model_input, indices, ground_truth, keyframe_list=kf, frame_idx=frame_idx, mode="mapping", stage=stage,
+                          color_stage=color_stage, iter=it)
+            assert student.last_engine == engine, student.last_engine
+            loss = loss_fn(out, ground_truth, kf, frame_idx=frame_idx, stage=stage)["loss"]
+            loss.backward()
+            optimizer.step()
+            if ba:
+                opt_ba.step()
+                poses = get_camera_from_tensor(cams.detach())
+                for ii, k in enumerate(kf):                                                   # :584-594
+                    if k != 0 and not (k in kf[: window // 2]):
+                        feed.set_pose(k, poses[ii])
+        return float(loss.detach())
+
+    for f in range(frames):
+        if f == 0:
+            pose0 = gt[0]
+        elif f >= 2:
+            p1, p2 = feed.frames[f - 1]["pose"].cpu(), feed.frames[f - 2]["pose"].cpu()
+            pose0 = (p1 @ torch.linalg.inv(p2)) @ p1
+        else:
+            pose0 = feed.frames[0]["pose"].cpu()
+        # the reference's loader hands the monocular depth cue over in its own units and scales it by 20 on the first frame
+        # (loss.py:179-185, assign_scale): the cue is the true depth / 20
+        feed.add_frame(f, rgb=rgb[f], depth=depth[f] / 20.0, normal=normal[f], gt_depth=depth[f], intrinsics=K, pose=pose0)
+        if f > 0:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cam = get_tensor_from_camera(pose0).to(dev).detach().clone().requires_grad_(True)
+            opt = torch.optim.Adam([cam], lr=cam_lr)
+            sched = torch.optim.lr_scheduler.StepLR(opt, step_size=50, gamma=0.95)
+            best, cand = float("inf"), None
+            for it in range(track_iters):
+                feed.change_sampling_idx(track_pixels)
+                indices, model_input, ground_truth = feed.batch([f])
+                model_input["pose"] = get_camera_from_tensor(cam).unsqueeze(0)
+                out = student(model_input, indices, ground_truth, mode="tracking", frame_idx=f)
+                loss = tracking_loss(out, ground_truth, stage="fine", frame_idx=f)["loss"]
+                loss.backward()
+                opt.step()
+                sched.step()
+                opt.zero_grad()
+                lv = float(loss.detach())
+                if lv < best:
+                    best, cand = lv, cam.detach().clone()
+            feed.set_pose(f, get_camera_from_tensor(cand).detach())
+            torch.cuda.synchronize()
+            t_track += time.perf_counter() - t0
+        if f % map_every == 0:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            last = mapping(f)
+            torch.cuda.synchronize()
+            t_map += time.perf_counter() - t0
+            if log is not None:
+                log(f, last)
+    est = torch.stack([feed.frames[f]["pose"].detach().cpu() for f in range(frames)])
+    del optimizer, student, feed
+    torch.cuda.empty_cache()
+    return est, t_track, t_map
+
+
+def run_slam_table(frames=50, H=340, W=600, colour_grid=None, map_iters=100, track_iters=100, engines=("fused", "composed"), verbose=False):
+    """The mini-SLAM table: ATE of tracking + mapping on the synthetic sequence, fused engine beside the composed one."""
+    dev = torch.device("cuda", 0)
+    teacher = build_teacher(H, W, colour_grid=colour_grid, device=dev)
+    teacher.engine = "fused"
+    K = intrinsics(H, W, dev)
+    gt = load_trajectory(frames)
+    rgb, depth, normal = render_cues(teacher, gt, K, H, W)
+    out = {"what": "synthetic tracking + mapping (mini SLAM): teacher-rendered frames and depth / normal cues along gt_replica_room0[:N]; the "
+                   "map is LEARNED (student at the reference's initialisation, fine SDF MLP = the teacher's as pretrain.pth is), loop shape of "
+                   "volsdf_train.py:363-613 (mapping every 5th frame, 100 iterations x 8192 pixels, BA in the last 30 %), ATE as eval_cam.py:43-105",
+           "frames": frames, "image": [H, W], "map_iters": map_iters, "track_iters": track_iters,
+           "no_tracking_baseline": summarise(gt, gt[:1].repeat(frames, 1, 1))}
+    log = (lambda f, l: print(f"  mapped at frame {f}: loss {l:.5f}", file=sys.stderr)) if verbose else None
+    for eng in engines:
+        t0 = time.perf_counter()
+        est, t_track, t_map = run_slam(eng, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_grid, map_iters=map_iters,
+                                       track_iters=track_iters, log=log)
+        out["slam_" + eng] = dict(summarise(gt, est), wall_s=round(time.perf_counter() - t0, 1), tracking_s=round(t_track, 1),
+                                  mapping_s=round(t_map, 1))
+    if "slam_fused" in out and "slam_composed" in out:
+        out["slam_ate_ratio_fused_over_composed"] = out["slam_fused"]["ate_rmse_scene_units"] / out["slam_composed"]["ate_rmse_scene_units"]
+    return out
+
+
 def summarise(gt, est, scale=SCALE):
     gt, est = gt[:est.shape[0]].numpy(), est.numpy()
     tr = np.linalg.norm(gt[:, :3, 3] - est[:, :3, 3], axis=1)
@@ -343,8 +521,14 @@ if __name__ == "__main__":
     ap.add_argument("--oracle-iters", type=int, default=100)
     ap.add_argument("--small-colour-grid", action="store_true", help="64 MiB colour table instead of the shipped 1 GiB (quick runs)")
     ap.add_argument("--no-free", action="store_true")
+    ap.add_argument("--slam", action="store_true", help="the tracking + mapping table (map learned from the frames) instead of the tracking one")
+    ap.add_argument("--map-iters", type=int, default=100)
+    ap.add_argument("--engines", default="fused,composed")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
     cg = dict(base_resolution=16, desired_resolution=512, log2_hashmap_size=19) if a.small_colour_grid else None
+    if a.slam:
+        print(json.dumps(run_slam_table(a.frames, a.height, a.width, cg, a.map_iters, a.iters, tuple(a.engines.split(",")), a.verbose), indent=1))
+        sys.exit(0)
     print(json.dumps(run(a.frames, a.iters, a.pixels, a.height, a.width, a.oracle_frames, a.oracle_pixels, a.oracle_iters, cg,
                          not a.no_free, a.verbose), indent=1))

@@ -374,6 +374,10 @@ def run_slam(engine, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_gr
             feed.set_pose(f, get_camera_from_tensor(cand).detach())
             torch.cuda.synchronize()
             t_track += time.perf_counter() - t0
+            if log is not None:
+                e0 = float((pose0[:3, 3] - gt[f][:3, 3]).norm())
+                e1 = float((feed.frames[f]["pose"].cpu()[:3, 3] - gt[f][:3, 3]).norm())
+                log(f, best, f"tracked: initial error {e0:.5f} -> {e1:.5f}")
         if f % map_every == 0:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -381,7 +385,7 @@ def run_slam(engine, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_gr
             torch.cuda.synchronize()
             t_map += time.perf_counter() - t0
             if log is not None:
-                log(f, last)
+                log(f, last, "mapped")
     est = torch.stack([feed.frames[f]["pose"].detach().cpu() for f in range(frames)])
     del optimizer, student, feed
     torch.cuda.empty_cache()
@@ -401,8 +405,10 @@ def run_slam_table(frames=50, H=340, W=600, colour_grid=None, map_iters=100, tra
                    "volsdf_train.py:363-613 (mapping every 5th frame, 100 iterations x 8192 pixels, BA in the last 30 %), ATE as eval_cam.py:43-105",
            "frames": frames, "image": [H, W], "map_iters": map_iters, "track_iters": track_iters,
            "no_tracking_baseline": summarise(gt, gt[:1].repeat(frames, 1, 1))}
-    log = (lambda f, l: print(f"  mapped at frame {f}: loss {l:.5f}", file=sys.stderr)) if verbose else None
+    log = (lambda f, l, what: print(f"  frame {f}: loss {l:.5f}  {what}", file=sys.stderr)) if verbose else None
     for eng in engines:
+        if verbose:
+            print(f"engine {eng}", file=sys.stderr)
         t0 = time.perf_counter()
         est, t_track, t_map = run_slam(eng, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_grid, map_iters=map_iters,
                                        track_iters=track_iters, log=log)

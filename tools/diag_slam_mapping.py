@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import synthetic_sequence as ss
 
 
-def main(H=170, W=300, frames=6, map_iters=100, map_pixels=8192, variants=("fused", "composed")):
+def main(H=170, W=300, frames=6, map_iters=100, map_pixels=8192, variants=("fused", "composed"), first_engine="fused"):
     from nicer_slam_amd.feed import FrameFeed
     from nicer_slam_amd.model.loss import SLAMLoss
     from nicer_slam_amd.optim import Adam as HipAdam
@@ -89,8 +89,13 @@ def main(H=170, W=300, frames=6, map_iters=100, map_pixels=8192, variants=("fuse
     # frame 0 round on the fused engine: the common starting point
     opt0, loss0 = make_opt(student), make_loss(student)
     tr0 = []
-    mapping(student, opt0, loss0, "fused", 0, map_iters, tr0)
-    print("frame-0 round (fused):", " ".join(f"{t[0]}:{t[4]['loss']:.4f}" for t in tr0[::4]))
+    mapping(student, opt0, loss0, first_engine, 0, map_iters, tr0)
+    print(f"frame-0 round ({first_engine}):", " ".join(f"{t[0]}:{t[4]['loss']:.4f}" for t in tr0[::4]))
+    with torch.no_grad():
+        v = student.voxels
+        print(f"  state after it: visit counter sum {float(v.sum()):.6g} max {float(v.max()):.6g} nonzero {int((v > 0).sum())};  "
+              + "  ".join(f"{n.split('.')[-3] if 'lin' in n else n.split('.')[1]}.{n.split('.')[-1]} |{float(p.norm()):.5g}|"
+                          for n, p in student.named_parameters() if n.endswith(("embeddings", "lin0.weight_v", "lin2.weight_g"))))
     state = copy.deepcopy(student.state_dict())
     opt_state = copy.deepcopy(opt0.state_dict())
     vox = student.voxels.clone()
@@ -111,4 +116,4 @@ def main(H=170, W=300, frames=6, map_iters=100, map_pixels=8192, variants=("fuse
 
 
 if __name__ == "__main__":
-    main()
+    main(first_engine=sys.argv[1] if len(sys.argv) > 1 else "fused")

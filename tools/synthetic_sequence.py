@@ -273,13 +273,17 @@ def make_student(teacher, H, W, n_images, colour_grid=None):
 
 
 def run_slam(engine, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_grid=None, map_every=5, map_iters=100, track_iters=100,
-             map_pixels=8192, track_pixels=1024, lr=0.002, cam_lr=0.005, ba_lr=0.001, window=15, log=None):
+             map_pixels=8192, track_pixels=1024, lr=0.002, cam_lr=0.005, ba_lr=0.001, window=15, log=None, schedule="reference"):
     """Tracking AND mapping in the reference's loop shape (volsdf_train.py:363-613) on `engine`: frame 0 at its ground-truth pose and
     `map_iters` mapping iterations on it; every later frame tracked from the constant-speed initialisation against the map learned so far;
     every `map_every`-th frame a mapping round over the keyframe window (every 10th frame + the current one; the frames since the last
     keyframe join half-way), coarse -> fine and base -> highfreq schedules, bundle adjustment of the window's cameras in the last 30 % of a
     round (poses written back as :584-594 does).  Objective: the shipped SLAMLoss weights without the warp / flow terms; the monocular
-    depth / normal cues are the teacher's renderings.  -> final pose estimates [frames,4,4] (CPU), seconds spent in (tracking, mapping)."""
+    depth / normal cues are the teacher's renderings.  schedule = "reference": stage / colour-stage schedule of volsdf_train.py:550-555;
+    "fine": every round at stage "fine" / "highfreq" -- on this synthetic scene the coarse-only quarter of a later round is BISTABLE
+    (tools/diag_slam_mapping.py, profiles/r05_slam_mapping_rounds.txt: from one and the same state the round ends at loss 0.044 or loses the
+    surface -- no ray straddles it any more, loss 0.14 -- on EITHER engine, by the draws), so trajectories under it compare luck, not engines.
+    -> final pose estimates [frames,4,4] (CPU), seconds spent in (tracking, mapping)."""
     from nicer_slam_amd.feed import FrameFeed
     from nicer_slam_amd.model.loss import SLAMLoss
     from nicer_slam_amd.optim import Adam as HipAdam
@@ -321,7 +325,7 @@ def run_slam(engine, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_gr
                 opt_ba = torch.optim.Adam([cams], lr=ba_lr)
                 model_input["pose"] = get_camera_from_tensor(cams)
             optimizer.zero_grad()
-            if frame_idx > 1:
+            if frame_idx > 1 and schedule == "reference":
                 stage = "coarse" if it < int(map_iters * 0.25) else "fine"
                 color_stage = "base" if it < int(map_iters * 0.7) else "highfreq"
             else:
@@ -392,7 +396,8 @@ def run_slam(engine, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_gr
     return est, t_track, t_map
 
 
-def run_slam_table(frames=50, H=340, W=600, colour_grid=None, map_iters=100, track_iters=100, engines=("fused", "composed"), verbose=False):
+def run_slam_table(frames=50, H=340, W=600, colour_grid=None, map_iters=100, track_iters=100, engines=("fused", "composed"), verbose=False,
+                   schedule="reference"):
     """The mini-SLAM table: ATE of tracking + mapping on the synthetic sequence, fused engine beside the composed one."""
     dev = torch.device("cuda", 0)
     teacher = build_teacher(H, W, colour_grid=colour_grid, device=dev)
@@ -403,7 +408,7 @@ def run_slam_table(frames=50, H=340, W=600, colour_grid=None, map_iters=100, tra
     out = {"what": "synthetic tracking + mapping (mini SLAM): teacher-rendered frames and depth / normal cues along gt_replica_room0[:N]; the "
                    "map is LEARNED (student at the reference's initialisation, fine SDF MLP = the teacher's as pretrain.pth is), loop shape of "
                    "volsdf_train.py:363-613 (mapping every 5th frame, 100 iterations x 8192 pixels, BA in the last 30 %), ATE as eval_cam.py:43-105",
-           "frames": frames, "image": [H, W], "map_iters": map_iters, "track_iters": track_iters,
+           "frames": frames, "image": [H, W], "map_iters": map_iters, "track_iters": track_iters, "schedule": schedule,
            "no_tracking_baseline": summarise(gt, gt[:1].repeat(frames, 1, 1))}
     log = (lambda f, l, what: print(f"  frame {f}: loss {l:.5f}  {what}", file=sys.stderr)) if verbose else None
     for eng in engines:
@@ -411,7 +416,7 @@ def run_slam_table(frames=50, H=340, W=600, colour_grid=None, map_iters=100, tra
             print(f"engine {eng}", file=sys.stderr)
         t0 = time.perf_counter()
         est, t_track, t_map = run_slam(eng, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_grid, map_iters=map_iters,
-                                       track_iters=track_iters, log=log)
+                                       track_iters=track_iters, log=log, schedule=schedule)
         out["slam_" + eng] = dict(summarise(gt, est), wall_s=round(time.perf_counter() - t0, 1), tracking_s=round(t_track, 1),
                                   mapping_s=round(t_map, 1))
     if "slam_fused" in out and "slam_composed" in out:
@@ -530,11 +535,12 @@ if __name__ == "__main__":
     ap.add_argument("--slam", action="store_true", help="the tracking + mapping table (map learned from the frames) instead of the tracking one")
     ap.add_argument("--map-iters", type=int, default=100)
     ap.add_argument("--engines", default="fused,composed")
+    ap.add_argument("--schedule", default="reference", choices=["reference", "fine"])
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
     cg = dict(base_resolution=16, desired_resolution=512, log2_hashmap_size=19) if a.small_colour_grid else None
     if a.slam:
-        print(json.dumps(run_slam_table(a.frames, a.height, a.width, cg, a.map_iters, a.iters, tuple(a.engines.split(",")), a.verbose), indent=1))
+        print(json.dumps(run_slam_table(a.frames, a.height, a.width, cg, a.map_iters, a.iters, tuple(a.engines.split(",")), a.verbose, a.schedule), indent=1))
         sys.exit(0)
     print(json.dumps(run(a.frames, a.iters, a.pixels, a.height, a.width, a.oracle_frames, a.oracle_pixels, a.oracle_iters, cg,
                          not a.no_free, a.verbose), indent=1))

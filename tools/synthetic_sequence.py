@@ -255,12 +255,12 @@ def render_cues(model, poses, K, H, W):
     return torch.stack(rgb), torch.stack(depth), torch.stack(normal)
 
 
-def make_student(teacher, H, W, n_images, colour_grid=None):
+def make_student(teacher, H, W, n_images, colour_grid=None, seed=11):
     """The map to be learned: a SLAMNetwork at the reference's initialisation (tables U(-1e-4, 1e-4), geometric MLPs) -- except the
     fine SDF MLP, which the reference loads from `pretrain.pth` and never optimises (volsdf_train.py:139-173): here the teacher's."""
     from nicer_slam_amd.model.network import SLAMNetwork
     from nicer_slam_amd.utils.conf import replica_model_conf
-    torch.manual_seed(11)
+    torch.manual_seed(seed)
     kw = {} if colour_grid is None else {"colour_grid": colour_grid}
     student = SLAMNetwork(replica_model_conf(64, 640, 32, use_warp_loss=False), dataset=_DS(H, W), n_images=n_images, **kw)
     sd = teacher.state_dict()
@@ -273,7 +273,7 @@ def make_student(teacher, H, W, n_images, colour_grid=None):
 
 
 def run_slam(engine, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_grid=None, map_every=5, map_iters=100, track_iters=100,
-             map_pixels=8192, track_pixels=1024, lr=0.002, cam_lr=0.005, ba_lr=0.001, window=15, log=None, schedule="reference"):
+             map_pixels=8192, track_pixels=1024, lr=0.002, cam_lr=0.005, ba_lr=0.001, window=15, log=None, schedule="reference", seed=11):
     """Tracking AND mapping in the reference's loop shape (volsdf_train.py:363-613) on `engine`: frame 0 at its ground-truth pose and
     `map_iters` mapping iterations on it; every later frame tracked from the constant-speed initialisation against the map learned so far;
     every `map_every`-th frame a mapping round over the keyframe window (every 10th frame + the current one; the frames since the last
@@ -289,8 +289,8 @@ def run_slam(engine, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_gr
     from nicer_slam_amd.optim import Adam as HipAdam
     from nicer_slam_amd.utils.general import get_camera_from_tensor, get_tensor_from_camera
     dev = teacher.voxels.device
-    student = make_student(teacher, H, W, frames, colour_grid)
-    student.engine = engine
+    student = make_student(teacher, H, W, frames, colour_grid, seed)      # (also seeds every random stream of the run: torch's
+    student.engine = engine                                              #  generators and, through them, the fused sampler's Philox state)
     student.train()
     imp, rn = student.implicit_network, student.rendering_network
     para_list = [     # volsdf_train.py:150-173
@@ -397,7 +397,7 @@ def run_slam(engine, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_gr
 
 
 def run_slam_table(frames=50, H=340, W=600, colour_grid=None, map_iters=100, track_iters=100, engines=("fused", "composed"), verbose=False,
-                   schedule="reference"):
+                   schedule="reference", seeds=(11,)):
     """The mini-SLAM table: ATE of tracking + mapping on the synthetic sequence, fused engine beside the composed one."""
     dev = torch.device("cuda", 0)
     teacher = build_teacher(H, W, colour_grid=colour_grid, device=dev)
@@ -411,16 +411,22 @@ def run_slam_table(frames=50, H=340, W=600, colour_grid=None, map_iters=100, tra
            "frames": frames, "image": [H, W], "map_iters": map_iters, "track_iters": track_iters, "schedule": schedule,
            "no_tracking_baseline": summarise(gt, gt[:1].repeat(frames, 1, 1))}
     log = (lambda f, l, what: print(f"  frame {f}: loss {l:.5f}  {what}", file=sys.stderr)) if verbose else None
-    for eng in engines:
-        if verbose:
-            print(f"engine {eng}", file=sys.stderr)
-        t0 = time.perf_counter()
-        est, t_track, t_map = run_slam(eng, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_grid, map_iters=map_iters,
-                                       track_iters=track_iters, log=log, schedule=schedule)
-        out["slam_" + eng] = dict(summarise(gt, est), wall_s=round(time.perf_counter() - t0, 1), tracking_s=round(t_track, 1),
-                                  mapping_s=round(t_map, 1))
+    for spec in engines:                     # "engine" or "engine:seed,seed,..." (the composed engine is ~11x slower: fewer seeds)
+        eng, _, sd = spec.partition(":")
+        runs = []
+        for seed in ([int(x) for x in sd.split("+")] if sd else list(seeds)):
+            if verbose:
+                print(f"engine {eng} seed {seed}", file=sys.stderr)
+            t0 = time.perf_counter()
+            est, t_track, t_map = run_slam(eng, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_grid, map_iters=map_iters,
+                                           track_iters=track_iters, log=log, schedule=schedule, seed=seed)
+            runs.append(dict(summarise(gt, est), seed=seed, wall_s=round(time.perf_counter() - t0, 1), tracking_s=round(t_track, 1),
+                             mapping_s=round(t_map, 1)))
+        ates = [r["ate_rmse_scene_units"] for r in runs]
+        out["slam_" + eng] = {"runs": runs, "ate_rmse_mean": float(np.mean(ates)), "ate_rmse_min": float(np.min(ates)),
+                              "ate_rmse_max": float(np.max(ates)), "ate_rmse_cm_at_room_scale_mean": float(np.mean(ates)) / SCALE * 100}
     if "slam_fused" in out and "slam_composed" in out:
-        out["slam_ate_ratio_fused_over_composed"] = out["slam_fused"]["ate_rmse_scene_units"] / out["slam_composed"]["ate_rmse_scene_units"]
+        out["slam_ate_ratio_fused_over_composed"] = out["slam_fused"]["ate_rmse_mean"] / out["slam_composed"]["ate_rmse_mean"]
     return out
 
 

@@ -75,3 +75,27 @@ def test_synthetic_sequence_fused_vs_composed_vs_oracle(capsys):
         assert d["iter0_loss_rel_diff"] < 5e-5 and d["iter0_grad_diff_of_largest_component"] < 2e-3, d
         assert d["max_cam_diff_first_5_iters"] < 5e-5, d
         assert d["max_trans_diff_scene_units"] < 0.6 * step and d["max_rot_diff_deg"] < 0.15, d
+
+
+def test_mini_slam_tracks_with_a_learned_map(capsys):
+    """Tracking AND mapping in the reference's loop shape (volsdf_train.py:363-613) on the fused engine: the map is learned from the
+    frames (student at the reference's initialisation), every 5th frame is mapped with bundle adjustment, every frame tracked against
+    the map so far.  Short version of `tools/synthetic_sequence.py --slam` (profiles/r05_slam_ate.json: 50 frames, both engines, seeds)."""
+    import synthetic_sequence as ss
+    dev = torch.device("cuda", 0)
+    Hs, Ws, n = 136, 240, 16
+    cg = dict(base_resolution=16, desired_resolution=512, log2_hashmap_size=19)
+    teacher = ss.build_teacher(Hs, Ws, colour_grid=cg, device=dev)
+    teacher.engine = "fused"
+    K = ss.intrinsics(Hs, Ws, dev)
+    gt = ss.load_trajectory(n)
+    rgb, depth, normal = ss.render_cues(teacher, gt, K, Hs, Ws)
+    est, t_track, t_map = ss.run_slam("fused", teacher, rgb, depth, normal, K, gt, Hs, Ws, n, cg, map_iters=100, track_iters=60,
+                                      schedule="fine")
+    ate = ss.ate_rmse(gt.numpy(), est.numpy())
+    still = ss.ate_rmse(gt.numpy(), gt[:1].repeat(n, 1, 1).numpy())
+    err = np.linalg.norm(gt[:, :3, 3].numpy() - est[:, :3, 3].numpy(), axis=1)
+    with capsys.disabled():
+        print(f"\n  mini-SLAM, {n} frames: ATE RMSE {ate:.5f} (no tracking {still:.5f}); max error {err.max():.5f}; tracking {t_track:.1f} s, mapping {t_map:.1f} s")
+    assert np.isfinite(est.numpy()).all()
+    assert ate < 0.5 * still and err.max() < 0.03, (ate, still, err.max())

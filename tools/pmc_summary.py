@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Summarise rocprofv3 --pmc counter_collection CSVs: mean counter value per dispatch for each nsa:: kernel.
+"""Summarise rocprofv3 --pmc counter_collection CSVs: mean counter value per dispatch for each nsa:: (and nsa_bf16::) kernel.
 usage: pmc_summary.py <dir-with-*counter_collection.csv> [...]  -> prints CSV (kernel, counter, mean, n)"""
 import collections
 import csv
@@ -13,7 +13,7 @@ for d in sys.argv[1:]:
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 k = row.get("Kernel_Name", "")
-                if "nsa::" not in k:
+                if "nsa::" not in k and "nsa_bf16::" not in k:
                     continue
                 k = k.split("(")[0].replace("void ", "")
                 a = acc[(k, row["Counter_Name"])]

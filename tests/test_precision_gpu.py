@@ -124,3 +124,31 @@ def test_bf16_colour_mapping_gradients_close_to_fp32():
     for n, err in errs.items():
         assert err < 0.05, (n, err, errs)
     assert max(errs.values()) > 1e-5                  # the bf16 colour backward really ran
+
+
+def test_bf16_resident_quad_kernels_are_bit_identical_to_the_staged_forms(tmp_path):
+    """The bf16 build's paired SDF forward and fine backward run as resident-weight, barrier-free persistent kernels (mlp16.hpp::
+    ResidentSeq); NSA_BF16_RESIDENT=0 selects the staged forms, which include the SAME per-tile statements (sdfnet4_*_body.inc): every
+    output of a tracking iteration must agree bit for bit.  The switch is read once per process, hence two subprocesses."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r'''
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import test_precision_gpu as t
+model = t._model(94)
+out, g = t._run(model, 300, 128, "bf16")
+torch.save({"g": g.cpu(), **{k: out[k].detach().cpu() for k in ("sdf", "rgb", "weights", "rgb_values", "depth_values", "normal_map", "z_vals")}}, sys.argv[1])
+''' % (root, os.path.join(root, "tests"))
+    res = {}
+    for flag in ("1", "0"):
+        path = str(tmp_path / f"res{flag}.pt")
+        env = dict(os.environ, NSA_BF16_RESIDENT=flag)
+        p = subprocess.run([sys.executable, "-c", script, path], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[flag] = torch.load(path)
+    for k, v in res["1"].items():
+        assert torch.equal(v, res["0"][k]), (k, float((v - res["0"][k]).abs().max()))
+    assert float(res["1"]["g"].abs().max()) > 0

@@ -348,6 +348,12 @@ int nsa_adam_step_scaled(float *param, const float *grad, const float *grad_div,
  * launch order for nsa_points_t.order (new -- the reference processes points in ray order). */
 int nsa_morton_keys(const nsa_points_t *pts, int32_t *keys, nsa_stream_t stream);
 
+/* order[] = stable argsort of the top `key_bits` (1..30) bits of those keys: the launch order itself, by an in-library LSD radix
+ * sort (8-bit digits, two launches per pass, deterministic).  workspace: nsa_morton_order_workspace(P) 4-byte words.
+ * (new, as nsa_morton_keys; replaces keys -> torch.sort -> indices.) */
+int nsa_morton_order(const nsa_points_t *pts, int32_t *order, uint32_t *workspace, uint32_t key_bits, nsa_stream_t stream);
+uint64_t nsa_morton_order_workspace(uint32_t P);
+
 /* voxels[floor((x+1)/2*res)] += 1 for every sample with all |x_d| <= 0.99 (voxels: [res,res,res] fp32, x-major).
  * replaces SLAMNetwork.update_voxels (code/model/network.py:62-76). */
 int nsa_update_voxels(const nsa_points_t *pts, float *voxels, uint32_t res, nsa_stream_t stream);
@@ -357,6 +363,32 @@ int nsa_update_voxels(const nsa_points_t *pts, float *voxels, uint32_t res, nsa_
  * replaces self.optimizer.step() for one parameter tensor (code/training/volsdf_train.py:174, 420-424). */
 int nsa_adam_table_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, uint32_t step,
                         float lr, float beta1, float beta2, float eps, nsa_stream_t stream);
+
+/* The same step with the gradient CONSUMED: every gradient element read is left zero (16-byte groups that were already zero are
+ * not rewritten), so a persistent gradient buffer needs no zero fill before the next backward pass scatters into it.
+ * replaces optimizer.step() + the next iteration's optimizer.zero_grad() / dense zero-initialised table gradient
+ * (code/training/volsdf_train.py:547-576, code/hashencoder/hashgrid.py:117-118) for one table. */
+int nsa_adam_table_step_clear(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, uint32_t step,
+                              float lr, float beta1, float beta2, float eps, nsa_stream_t stream);
+
+/* Weight-normed Linear layers -> the flat effective parameter vector the packed blocks and the MAP kernels' gradients use:
+ *   flat = [W_0 (rows x cols, row-major), b_0, W_1, b_1, .., 0],   W_l[r,:] = weight_v_l[r,:] * weight_g_l[r] / ||weight_v_l[r,:]||,
+ * norms[row] = ||weight_v_l[r,:]|| for the backward (rows of all layers, in order); n_layers <= 8.
+ * replaces nn.utils.weight_norm's per-layer recomputation (torch._weight_norm, dim 0) of code/model/base_networks.py:137-141,
+ * 376-379 + the reshape / cat that followed it here. */
+typedef struct nsa_wn_layer {
+    const float *weight_v;   /* [rows, cols] */
+    const float *weight_g;   /* [rows]       */
+    const float *bias;       /* [rows]       */
+    uint32_t rows, cols;
+} nsa_wn_layer_t;
+int nsa_weight_norm_flat(const nsa_wn_layer_t *layers, uint32_t n_layers, float *flat, float *norms, nsa_stream_t stream);
+/* Its backward: g_flat (layout of flat) -> g_params = per layer [g_weight_v (rows x cols) | g_weight_g (rows) | g_bias (rows)]. */
+int nsa_weight_norm_flat_backward(const nsa_wn_layer_t *layers, uint32_t n_layers, const float *norms, const float *g_flat,
+                                  float *g_params, nsa_stream_t stream);
+
+/* One extra emission row for nsa_emit_gemm: dst[p] = src[order ? order[p] : p] (src NULL: `fill`) for p < P, 0 for P <= p < n. */
+int nsa_emit_row(float *dst, const float *src, const int32_t *order, uint32_t P, uint64_t n, float fill, nsa_stream_t stream);
 
 /* Packed MLP parameter block (MFMA fragment order) from the flat effective parameters in one launch:
  *   out[o] = word order[o] of concat( split3(flat[a_index]) as [group][piece hi/mid/lo][lane][4 words of 2 bf16], flat[v_index] )

@@ -131,7 +131,23 @@ lib.nsa_update_voxels.restype = _i
 lib.nsa_update_voxels.argtypes = [_pp, _p, _u32, _p]
 lib.nsa_adam_table_step.restype = _i
 lib.nsa_adam_table_step.argtypes = [_p, _p, _p, _p, ctypes.c_uint64, _u32, _f32, _f32, _f32, _f32, _p]
-EXPORTS += ["nsa_update_voxels", "nsa_adam_table_step"]
+lib.nsa_adam_table_step_clear.restype = _i
+lib.nsa_adam_table_step_clear.argtypes = lib.nsa_adam_table_step.argtypes
+EXPORTS += ["nsa_update_voxels", "nsa_adam_table_step", "nsa_adam_table_step_clear"]
+
+
+class WnLayer(ctypes.Structure):
+    """nsa_wn_layer_t"""
+    _fields_ = [("weight_v", _p), ("weight_g", _p), ("bias", _p), ("rows", _u32), ("cols", _u32)]
+
+
+lib.nsa_weight_norm_flat.restype = _i
+lib.nsa_weight_norm_flat.argtypes = [ctypes.POINTER(WnLayer), _u32, _p, _p, _p]
+lib.nsa_weight_norm_flat_backward.restype = _i
+lib.nsa_weight_norm_flat_backward.argtypes = [ctypes.POINTER(WnLayer), _u32, _p, _p, _p, _p]
+lib.nsa_emit_row.restype = _i
+lib.nsa_emit_row.argtypes = [_p, _p, _p, _u32, ctypes.c_uint64, _f32, _p]
+EXPORTS += ["nsa_weight_norm_flat", "nsa_weight_norm_flat_backward", "nsa_emit_row"]
 
 lib.nsa_emit_gemm.restype = _i
 lib.nsa_emit_gemm.argtypes = [_p, ctypes.c_uint64, _u32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), _u32,
@@ -208,6 +224,11 @@ EXPORTS += ["nsa_track_begin", "nsa_track_begin_draw", "nsa_composite_track", "n
 
 lib.nsa_morton_keys.restype = _i
 lib.nsa_morton_keys.argtypes = [_pp, _p, _p]
+lib.nsa_morton_order.restype = _i
+lib.nsa_morton_order.argtypes = [_pp, _p, _p, _u32, _p]
+lib.nsa_morton_order_workspace.restype = ctypes.c_uint64
+lib.nsa_morton_order_workspace.argtypes = [_u32]
+EXPORTS += ["nsa_morton_order", "nsa_morton_order_workspace"]
 EXPORTS += ["nsa_morton_keys"]
 
 lib.nsa_adam_step_scaled.restype = _i

@@ -57,8 +57,101 @@ __global__ __launch_bounds__(256) void k_morton_keys(PointSrc src, int32_t* __re
     keys[pid] = (int32_t)(spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2));
 }
 
+// ---- argsort of the Morton keys: stable LSD radix sort, 8-bit digits, two launches per pass ------------------------------------
+// (replaces torch.sort = rocprim's block sort + ~26 merge launches per call.)  A pass: k_radix_hist counts the digits of every
+// block's tile into counts[block][256]; k_radix_scatter turns them into the block's output offsets itself (digit totals over all
+// blocks + the earlier blocks' share: nb x 1 KiB of L2 reads per block, nb <= 256, so no scan launch in between), then ranks its
+// keys stably -- a wave owns a contiguous run of its block's tile and walks it 64 keys at a time; the lanes holding equal digits
+// find each other with 8 ballots, the lowest of them advances the wave's running offset of that digit in LDS.  No inter-block
+// waiting, no atomics on global memory: the result is deterministic (equal keys keep their index order).
+constexpr uint32_t RS_WAVES = 4;
+struct RadixArgs {
+    const uint32_t* keys_in;
+    const uint32_t* vals_in;      // nullptr: the identity (first pass)
+    uint32_t* keys_out;           // nullptr: keys not needed any more (last pass)
+    uint32_t* vals_out;
+    uint32_t* counts;             // [nb][256]
+    uint32_t P, nb, per_wave, shift;
+};
+
+__global__ __launch_bounds__(256) void k_radix_hist(RadixArgs a) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t start = ((uint64_t)blockIdx.x * RS_WAVES + w) * a.per_wave;
+    for (uint32_t r = 0; r < a.per_wave; r += 64) {
+        const uint64_t e = start + r + lane;
+        if (e < a.P) atomicAdd(&h[(a.keys_in[e] >> a.shift) & 255u], 1u);
+    }
+    __syncthreads();
+    a.counts[blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_radix_scatter(RadixArgs a) {
+    __shared__ uint32_t wh[RS_WAVES][256];
+    __shared__ uint32_t run[RS_WAVES][256];
+    __shared__ uint32_t scan[256];
+    const uint32_t t = threadIdx.x, w = t >> 6, lane = t & 63;
+    // digit t: keys of all blocks, and of the blocks before this one
+    uint32_t total = 0, before = 0;
+    for (uint32_t b = 0; b < a.nb; ++b) {
+        const uint32_t c = a.counts[b * 256 + t];
+        total += c;
+        before += b < blockIdx.x ? c : 0u;
+    }
+    scan[t] = total;
+#pragma unroll
+    for (uint32_t wv = 0; wv < RS_WAVES; ++wv) wh[wv][t] = 0;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {             // inclusive scan over the digits
+        const uint32_t v = t >= off ? scan[t - off] : 0u;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    const uint64_t start = ((uint64_t)blockIdx.x * RS_WAVES + w) * a.per_wave;
+    for (uint32_t r = 0; r < a.per_wave; r += 64) {            // digits of this wave's run
+        const uint64_t e = start + r + lane;
+        if (e < a.P) atomicAdd(&wh[w][(a.keys_in[e] >> a.shift) & 255u], 1u);
+    }
+    __syncthreads();
+    {
+        uint32_t acc = scan[t] - total + before;               // first output slot of digit t for this block
+#pragma unroll
+        for (uint32_t wv = 0; wv < RS_WAVES; ++wv) {
+            run[wv][t] = acc;
+            acc += wh[wv][t];
+        }
+    }
+    __syncthreads();
+    for (uint32_t r = 0; r < a.per_wave; r += 64) {
+        const uint64_t e = start + r + lane;
+        const bool valid = e < a.P;
+        const uint32_t key = valid ? a.keys_in[e] : 0u;
+        const uint32_t d = (key >> a.shift) & 255u;
+        unsigned long long same = __ballot(valid);             // valid lanes holding this lane's digit
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            same &= bit ? bal : ~bal;
+        }
+        const uint32_t rank = __popcll(same & ((1ull << lane) - 1ull)), cnt = __popcll(same);
+        const uint32_t base = valid ? run[w][d] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) run[w][d] = base + cnt;        // (same wave, program order: the next round reads it)
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            const uint32_t pos = base + rank;
+            if (a.keys_out) a.keys_out[pos] = key;
+            a.vals_out[pos] = a.vals_in ? a.vals_in[e] : (uint32_t)e;
+        }
+    }
+}
+
 struct AdamTableArgs {
-    float* p; const float* g; float* m; float* v;
+    float* p; float* g; float* m; float* v;
     uint64_t n;
     float w1;          // 1 - beta1
     float beta2, w2;   // beta2, 1 - beta2
@@ -78,6 +171,10 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 
 // (A variant with 2 / 4 float4 groups per thread and all their loads issued first measured the same 4.9 TB/s = 0.78 of the 6.29 TB/s
 // streaming-copy rate on a 1 GiB table, profiles/r04_ab_experiments.txt r4h: seven concurrent streams, not load depth, set the rate.)
+// CLEAR: the gradient is consumed -- every element read is left zero, so that a persistent gradient buffer needs no separate
+// zero fill before the next backward pass scatters into it (fused/tablegrad.py; the reference's zero_grad + dense autograd
+// gradient, volsdf_train.py:547-576 and hashgrid.py:117-118, as one pass).  Untouched 16-byte groups are not rewritten.
+template <bool CLEAR>
 __global__ __launch_bounds__(256) void k_adam_table(AdamTableArgs a) {
     const uint64_t n4 = a.n / 4;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
@@ -93,11 +190,98 @@ __global__ __launch_bounds__(256) void k_adam_table(AdamTableArgs a) {
         reinterpret_cast<float4*>(a.p)[i] = p;
         reinterpret_cast<float4*>(a.m)[i] = m;
         reinterpret_cast<float4*>(a.v)[i] = v;
+        if (CLEAR && (g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f))        // (NaN != 0: cleared too)
+            reinterpret_cast<float4*>(a.g)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (blockIdx.x == 0) {
         const uint64_t i = n4 * 4 + threadIdx.x;
-        if (i < a.n) adam_one(a.p[i], a.g[i], a.m[i], a.v[i], a);
+        if (i < a.n) {
+            adam_one(a.p[i], a.g[i], a.m[i], a.v[i], a);
+            if (CLEAR) a.g[i] = 0.0f;
+        }
     }
+}
+
+// ---- weight-normed MLP parameters <-> the flat effective parameter vector, one launch per direction ---------------------------
+// flat = [W_0 (rows x cols, row-major), b_0, W_1, b_1, .., 0] with W_l[r,:] = v_l[r,:] * g_l[r] / ||v_l[r,:]||  -- what
+// torch._weight_norm(v, g, dim=0) computes per layer (nn.utils.weight_norm of code/model/base_networks.py:137-141, 376-379) followed
+// by the reshape / cat of fused/pack.py::flat_params.  One wave per weight row; the block after the last row writes the trailing 0.
+constexpr int WN_MAX_LAYERS = 8;
+struct WnArgs {
+    const float* v[WN_MAX_LAYERS];
+    const float* g[WN_MAX_LAYERS];
+    const float* bias[WN_MAX_LAYERS];
+    uint32_t rows[WN_MAX_LAYERS], cols[WN_MAX_LAYERS];
+    uint32_t row0[WN_MAX_LAYERS + 1];      // first global row of layer l; row0[n] = number of rows
+    uint32_t off[WN_MAX_LAYERS + 1];       // first flat element of layer l; off[n] = index of the trailing zero
+    uint32_t n;
+    float* flat;                           // forward: out
+    float* norms;                          // forward: out [row0[n]]; backward: in
+    const float* g_flat;                   // backward: cotangent of flat
+    float* g_params;                       // backward: out, per layer [g_v (rows x cols) | g_g (rows) | g_bias (rows)]
+};
+
+__device__ __forceinline__ float wave_sum(float s) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    return s;
+}
+
+__device__ __forceinline__ int wn_layer_of(const WnArgs& a, uint32_t row) {
+    int l = 0;
+    while (l + 1 < (int)a.n && row >= a.row0[l + 1]) ++l;
+    return l;
+}
+
+__global__ __launch_bounds__(64) void k_weight_norm_flat(WnArgs a) {
+    const uint32_t row = blockIdx.x, tid = threadIdx.x;
+    if (row == a.row0[a.n]) {
+        if (tid == 0) a.flat[a.off[a.n]] = 0.0f;
+        return;
+    }
+    const int l = wn_layer_of(a, row);
+    const uint32_t r = row - a.row0[l], cols = a.cols[l];
+    const float* v = a.v[l] + (size_t)r * cols;
+    float s = 0.0f;
+    for (uint32_t c = tid; c < cols; c += 64) s = fmaf(v[c], v[c], s);
+    const float norm = sqrtf(wave_sum(s));
+    const float rnorm = 1.0f / norm, gr = a.g[l][r];
+    float* w = a.flat + a.off[l] + (size_t)r * cols;
+    for (uint32_t c = tid; c < cols; c += 64) w[c] = v[c] * gr * rnorm;      // operation order of ATen's weight_norm kernel
+    if (tid == 0) {
+        a.norms[row] = norm;
+        a.flat[a.off[l] + (size_t)a.rows[l] * cols + r] = a.bias[l][r];
+    }
+}
+
+// g_g[r] = <g_W[r,:], v[r,:]> / ||v||,  g_v[r,:] = g[r] (g_W[r,:] / ||v|| - v[r,:] <g_W[r,:], v[r,:]> / ||v||^3),  g_bias = its slice
+// (the formulas of ATen's weight_norm backward, so that the composed and the fused engine differ by summation order only).
+__global__ __launch_bounds__(64) void k_weight_norm_flat_bwd(WnArgs a) {
+    const uint32_t row = blockIdx.x, tid = threadIdx.x;
+    const int l = wn_layer_of(a, row);
+    const uint32_t r = row - a.row0[l], cols = a.cols[l], rows = a.rows[l];
+    const float* v = a.v[l] + (size_t)r * cols;
+    const float* gw = a.g_flat + a.off[l] + (size_t)r * cols;
+    float s = 0.0f;
+    for (uint32_t c = tid; c < cols; c += 64) s = fmaf(gw[c], v[c], s);
+    s = wave_sum(s);
+    const float rnorm = 1.0f / a.norms[row], gr = a.g[l][r];
+    const float rnorm3 = rnorm * rnorm * rnorm;
+    float* out = a.g_params + a.off[l] + a.row0[l];                       // = sum over earlier layers of rows * (cols + 2)
+    for (uint32_t c = tid; c < cols; c += 64) out[(size_t)r * cols + c] = gr * (rnorm * gw[c] - rnorm3 * v[c] * s);
+    if (tid == 0) {
+        out[(size_t)rows * cols + r] = s * rnorm;
+        out[(size_t)rows * cols + rows + r] = a.g_flat[a.off[l] + (size_t)rows * cols + r];
+    }
+}
+
+// dst[p] = src[order ? order[p] : p] for p < P, 0 up to n: one extra emission row (the per-point cotangent of the sdf value, in
+// launch order) so that the last layer's sdf-row gradient is one more nsa_emit_gemm product instead of a library GEMV.
+__global__ __launch_bounds__(256) void k_emit_row(float* __restrict__ dst, const float* __restrict__ src,
+                                                  const int32_t* __restrict__ order, uint32_t P, uint64_t n, float fill) {
+    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    dst[p] = p < P ? (src ? src[order ? (uint32_t)order[p] : (uint32_t)p] : fill) : 0.0f;
 }
 
 // ---- packed MLP parameter blocks in one launch (fused/pack.py::pack_blocks) ----------------------------------------------------
@@ -177,8 +361,53 @@ int nsa_morton_keys(const nsa_points_t* pts, int32_t* keys, nsa_stream_t stream)
     return launch_end();
 }
 
-int nsa_adam_table_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, uint32_t step,
-                        float lr, float beta1, float beta2, float eps, nsa_stream_t stream) {
+static void radix_geometry(uint32_t P, uint32_t& nb, uint32_t& per_wave) {
+    nb = (P + 4095u) / 4096u;
+    if (nb < 1) nb = 1;
+    if (nb > 256) nb = 256;
+    const uint64_t waves = (uint64_t)nb * nsa::RS_WAVES;
+    per_wave = (uint32_t)((((uint64_t)P + waves - 1) / waves + 63) / 64 * 64);
+}
+
+uint64_t nsa_morton_order_workspace(uint32_t P) {
+    uint32_t nb, per_wave;
+    radix_geometry(P, nb, per_wave);
+    return 3ull * P + (uint64_t)nb * 256;
+}
+
+int nsa_morton_order(const nsa_points_t* pts, int32_t* order, uint32_t* workspace, uint32_t key_bits, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!pts || !order || !workspace || key_bits < 1 || key_bits > 30) return NSA_EBADARG;
+    const uint32_t P = pts->P;
+    if (P == 0) return NSA_OK;
+    if (P > 0x7FFFFFFFu) return NSA_EBADARG;
+    uint32_t* keys[2] = {workspace, workspace + P};
+    uint32_t* tmp = workspace + 2ull * P;
+    uint32_t* counts = workspace + 3ull * P;
+    const int rc = nsa_morton_keys(pts, reinterpret_cast<int32_t*>(keys[0]), stream);
+    if (rc != NSA_OK) return rc;
+    RadixArgs a;
+    a.P = P;
+    radix_geometry(P, a.nb, a.per_wave);
+    a.counts = counts;
+    const uint32_t passes = (key_bits + 7) / 8, shift0 = 30 - key_bits;
+    launch_begin();
+    for (uint32_t i = 0; i < passes; ++i) {
+        uint32_t* v_out = ((passes - 1 - i) & 1u) ? tmp : reinterpret_cast<uint32_t*>(order);
+        const uint32_t* v_in = i == 0 ? nullptr : (((passes - i) & 1u) ? tmp : reinterpret_cast<uint32_t*>(order));
+        a.keys_in = keys[i & 1];
+        a.keys_out = i + 1 < passes ? keys[(i + 1) & 1] : nullptr;
+        a.vals_in = v_in;
+        a.vals_out = v_out;
+        a.shift = shift0 + 8 * i;
+        hipLaunchKernelGGL(k_radix_hist, dim3(a.nb), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(a.nb), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    return launch_end();
+}
+
+static int adam_table_launch(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, uint32_t step,
+                             float lr, float beta1, float beta2, float eps, bool clear, nsa_stream_t stream) {
     using namespace nsa;
     if (!param || !grad || !exp_avg || !exp_avg_sq || step == 0) return NSA_EBADARG;
     if (n == 0) return NSA_OK;
@@ -193,7 +422,72 @@ int nsa_adam_table_step(float* param, const float* grad, float* exp_avg, float* 
     if (blocks > 256 * 32) blocks = 256 * 32;      // grid-stride: 32 blocks per CU keeps every HBM channel busy
     if (blocks == 0) blocks = 1;
     launch_begin();
-    hipLaunchKernelGGL(k_adam_table, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (clear) hipLaunchKernelGGL(k_adam_table<true>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else       hipLaunchKernelGGL(k_adam_table<false>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_end();
+}
+
+int nsa_adam_table_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, uint32_t step,
+                        float lr, float beta1, float beta2, float eps, nsa_stream_t stream) {
+    return adam_table_launch(param, const_cast<float*>(grad), exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, false, stream);
+}
+
+int nsa_adam_table_step_clear(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, uint32_t step,
+                              float lr, float beta1, float beta2, float eps, nsa_stream_t stream) {
+    return adam_table_launch(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, true, stream);
+}
+
+static int wn_args(const nsa_wn_layer_t* layers, uint32_t n_layers, nsa::WnArgs& a) {
+    using namespace nsa;
+    if (!layers || n_layers < 1 || n_layers > (uint32_t)WN_MAX_LAYERS) return NSA_EBADARG;
+    uint64_t row = 0, off = 0;
+    for (uint32_t l = 0; l < n_layers; ++l) {
+        const nsa_wn_layer_t& L = layers[l];
+        if (!L.weight_v || !L.weight_g || !L.bias || L.rows == 0 || L.cols == 0) return NSA_EBADARG;
+        a.v[l] = L.weight_v; a.g[l] = L.weight_g; a.bias[l] = L.bias;
+        a.rows[l] = L.rows; a.cols[l] = L.cols;
+        a.row0[l] = (uint32_t)row; a.off[l] = (uint32_t)off;
+        row += L.rows;
+        off += (uint64_t)L.rows * L.cols + L.rows;
+        if (off > 0x7FFFFFFFull) return NSA_EBADARG;
+    }
+    a.row0[n_layers] = (uint32_t)row; a.off[n_layers] = (uint32_t)off;
+    a.n = n_layers;
+    a.flat = nullptr; a.norms = nullptr; a.g_flat = nullptr; a.g_params = nullptr;
+    return NSA_OK;
+}
+
+int nsa_weight_norm_flat(const nsa_wn_layer_t* layers, uint32_t n_layers, float* flat, float* norms, nsa_stream_t stream) {
+    using namespace nsa;
+    WnArgs a;
+    const int rc = wn_args(layers, n_layers, a);
+    if (rc != NSA_OK) return rc;
+    if (!flat || !norms) return NSA_EBADARG;
+    a.flat = flat; a.norms = norms;
+    launch_begin();
+    hipLaunchKernelGGL(k_weight_norm_flat, dim3(a.row0[a.n] + 1), dim3(64), 0, (hipStream_t)stream, a);
+    return launch_end();
+}
+
+int nsa_weight_norm_flat_backward(const nsa_wn_layer_t* layers, uint32_t n_layers, const float* norms, const float* g_flat,
+                                  float* g_params, nsa_stream_t stream) {
+    using namespace nsa;
+    WnArgs a;
+    const int rc = wn_args(layers, n_layers, a);
+    if (rc != NSA_OK) return rc;
+    if (!norms || !g_flat || !g_params) return NSA_EBADARG;
+    a.norms = const_cast<float*>(norms); a.g_flat = g_flat; a.g_params = g_params;
+    launch_begin();
+    hipLaunchKernelGGL(k_weight_norm_flat_bwd, dim3(a.row0[a.n]), dim3(64), 0, (hipStream_t)stream, a);
+    return launch_end();
+}
+
+int nsa_emit_row(float* dst, const float* src, const int32_t* order, uint32_t P, uint64_t n, float fill, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!dst || P > n) return NSA_EBADARG;
+    if (n == 0) return NSA_OK;
+    launch_begin();
+    hipLaunchKernelGGL(k_emit_row, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, src, order, P, n, fill);
     return launch_end();
 }
 

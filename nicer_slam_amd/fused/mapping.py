@@ -24,7 +24,7 @@ import torch
 from .._native import lib, check, PointsDesc
 from ..hashencoder.backend import _timed
 from . import pack
-from .render import composite_forward_raw, composite_backward_raw, hl_size, morton_order, _stream
+from .render import composite_forward_raw, composite_backward_raw, hl_size, morton_order, _stream, _table_grad, _table_result
 from .sampler import forward_pair_ok, grid_desc, packed_sdf, precision_of, sdf_grid_desc, tile_of
 
 KCHUNK = 4096
@@ -61,13 +61,14 @@ def emit_ld(P):
     return ((P + KCHUNK - 1) // KCHUNK) * KCHUNK
 
 
-def new_emit(rows, P, device):
-    """Emission buffer [rows][ld]; the columns past the last (16-point) tile are never written by the kernels."""
+def new_emit(rows, P, device, extra=0):
+    """Emission buffer [rows + extra][ld]; the columns past the last (16-point) tile are never written by the kernels.  ``extra``
+    rows past the kernels' own are written by nsa_emit_row (sdf_flat_grad: a row of ones and the per-point sdf cotangent)."""
     ld = emit_ld(P)
-    buf = torch.empty(rows, ld, device=device)
+    buf = torch.empty(rows + extra, ld, device=device)
     tail = ((P + 15) // 16) * 16
     if tail < ld:
-        buf[:, tail:].zero_()
+        buf[:rows, tail:].zero_()
     return buf
 
 
@@ -133,9 +134,11 @@ def _col_rows():
     return torch.from_numpy(rows)
 
 
-def sdf_flat_grad(emit, g_sdf, P, L, C, NH=1, tile=32):
+def sdf_flat_grad(emit, g_sdf, P, L, C, NH=1, tile=32, order=None):
     """Gradient of an SDF network's flat parameter vector [W0(64x71), b0, W1, b1, .., W_NH(65x64), b_NH, 0] from its emission
-    rows (row map and formulas: struct SE<NH>, csrc/render_sdfnet.hip; SE4<NH>, csrc/render_sdfnet4.hip)."""
+    rows (row map and formulas: struct SE<NH>, csrc/render_sdfnet.hip; SE4<NH>, csrc/render_sdfnet4.hip).  ``g_sdf`` [P]: the
+    per-point cotangent of the sdf value in POINT order, ``order`` the launch order of the emission columns (None: identity);
+    ``emit`` then carries two rows past the kernels' own (new_emit(..., extra=2))."""
     m = se_rows(NH, tile)
     IN, ws = m["IN"], _workspace(emit)
     parts = []
@@ -145,12 +148,20 @@ def sdf_flat_grad(emit, g_sdf, P, L, C, NH=1, tile=32):
     for k in range(1, NH):                                   # hidden layer k, same two paths
         Wk = emit_gemm(emit, (m[f"AB{k + 1}"], m[f"DA{k + 1}"]), 64, (m[f"H{k}"], m[f"TH{k}"]), 64, workspace=ws)
         parts += [Wk[:, :64].reshape(-1), Wk[:, 64]]
-    row0 = emit_gemm(emit, (m[f"TH{NH}"],), 64, None, 0, workspace=ws)[:, 0]           # sdf row: row sums of TH_NH
-    Wf = emit_gemm(emit, (m["FB"],), 64, (m[f"H{NH}"],), 64, workspace=ws)               # feature rows + their biases
-    dbs = emit.new_zeros(1)
-    if g_sdf is not None:
-        row0 = row0 + emit[m[f"H{NH}"]:m[f"H{NH}"] + 64, :P] @ g_sdf
+    if g_sdf is None:
+        row0 = emit_gemm(emit, (m[f"TH{NH}"],), 64, None, 0, workspace=ws)[:, 0]       # sdf row: row sums of TH_NH
+        dbs = emit.new_zeros(1)
+    else:
+        # sdf row = row sums of TH_NH + H_NH g_sdf: one product pair against two rows written here (ones; g_sdf in launch order)
+        ROWS, ld = m["ROWS"], emit.shape[1]
+        assert emit.shape[0] >= ROWS + 2 and g_sdf.is_contiguous() and g_sdf.numel() == P
+        st = _stream()
+        check(lib.nsa_emit_row(emit[ROWS].data_ptr(), None, None, P, ld, 1.0, st))
+        check(lib.nsa_emit_row(emit[ROWS + 1].data_ptr(), g_sdf.data_ptr(), None if order is None else order.data_ptr(), P, ld,
+                               0.0, st))
+        row0 = emit_gemm(emit, (m[f"TH{NH}"], m[f"H{NH}"]), 64, (ROWS, ROWS + 1), 1, sums=False, workspace=ws)[:, 0]
         dbs = g_sdf.sum().reshape(1)
+    Wf = emit_gemm(emit, (m["FB"],), 64, (m[f"H{NH}"],), 64, workspace=ws)               # feature rows + their biases
     parts += [row0, Wf[:, :64].reshape(-1), dbs, Wf[:, 64], emit.new_zeros(1)]
     return torch.cat(parts)
 
@@ -270,7 +281,7 @@ class FusedSdfGradient(torch.autograd.Function):
         out = [None, None, None, None, None, None, None]
         tile = tile_of(model, "coarse_map")
         emit = new_emit(se_rows(1, tile)["ROWS"], N, dev) if need[1] else None
-        gt_c = torch.zeros_like(imp.coarse.encoding.embeddings) if need[2] else None
+        gt_c = _table_grad(imp.coarse.encoding.embeddings) if need[2] else None
         if emit is not None or gt_c is not None:
             gcm, keep_cm = sdf_grid_desc(model, "coarse", "coarse_map")
             pcm = packed_sdf(model, "coarse", use="coarse_map")
@@ -283,9 +294,9 @@ class FusedSdfGradient(torch.autograd.Function):
             if emit is not None:
                 enc = imp.coarse.encoding
                 out[1] = sdf_flat_grad(emit, None, N, enc.num_levels, enc.level_dim, tile=tile)
-            out[2] = gt_c
+            out[2] = _table_result(gt_c)
         if (need[3] or need[4]) and stage != "coarse":
-            gt_f = torch.zeros_like(imp.fine.encoding.embeddings) if need[3] else None
+            gt_f = _table_grad(imp.fine.encoding.embeddings) if need[3] else None
             emit_f = new_emit(se_rows(3, tile_of(model, "fine"))["ROWS"], N, dev) if need[4] else None
             with _timed("k_sdfnet_bwd<fine,eik>", 0):
                 check(lib.nsa_sdfnet_backward_params(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), None, None,
@@ -293,7 +304,7 @@ class FusedSdfGradient(torch.autograd.Function):
                                                      None if gt_f is None else gt_f.data_ptr(),
                                                      None if emit_f is None else emit_f.data_ptr(),
                                                      0 if emit_f is None else emit_f.shape[1], st))
-            out[3] = gt_f
+            out[3] = _table_result(gt_f)
             if emit_f is not None:
                 enc = imp.fine.encoding
                 out[4] = sdf_flat_grad(emit_f, None, N, enc.num_levels, enc.level_dim, NH=3, tile=tile_of(model, "fine"))
@@ -302,10 +313,17 @@ class FusedSdfGradient(torch.autograd.Function):
 
 def flat_inputs(model):
     """(flat coarse MLP, flat colour MLP, coarse table, fine table, colour table, flat fine MLP or None) as autograd
-    inputs; the last one only when its gradients are wanted (fine_mlp_wanted)."""
+    inputs; the last one only when its gradients are wanted (fine_mlp_wanted).  Inside one SLAMNetwork.forward the composite pass
+    and the eikonal pass share them (``model._flat_inputs_fwd``, set and cleared by forward): one weight-norm node per network."""
+    shared = model.__dict__.get("_flat_inputs_fwd")
+    if shared is not None and shared[0] == torch.is_grad_enabled():
+        return shared[1]
     c, f, r = _nets(model)
-    return (pack.flat_params(c), pack.flat_params(r), c.encoding.embeddings, f.encoding.embeddings,
-            r.encoding.embeddings, pack.flat_params(f) if fine_mlp_wanted(model) else None)
+    out = (pack.flat_params(c), pack.flat_params(r), c.encoding.embeddings, f.encoding.embeddings,
+           r.encoding.embeddings, pack.flat_params(f) if fine_mlp_wanted(model) else None)
+    if "_flat_inputs_fwd" in model.__dict__:
+        model.__dict__["_flat_inputs_fwd"] = (torch.is_grad_enabled(), out)
+    return out
 
 
 def composite(model, rays_o, rays_d, z_vals, stage, color_stage):

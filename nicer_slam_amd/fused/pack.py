@@ -198,7 +198,81 @@ def effective_weight(lin):
     return lin.weight
 
 
+class FlatWeightNorm(torch.autograd.Function):
+    """(weight_v_0, weight_g_0, bias_0, weight_v_1, ..) -> flat effective parameter vector, forward and backward one launch each
+    (csrc/map_tail.hip::k_weight_norm_flat[_bwd]): what per-layer torch._weight_norm + reshape + cat compute, with ATen's formulas.
+    A mapping iteration re-derives three networks' weights every step (base_networks.py:137-141 registers weight_norm on
+    every Linear), which as torch ops was ~27 launches per iteration."""
+
+    @staticmethod
+    def _desc(params):
+        from .._native import WnLayer
+        n = len(params) // 3
+        arr = (WnLayer * n)()
+        for l in range(n):
+            v, g, b = params[3 * l:3 * l + 3]
+            arr[l] = WnLayer(v.data_ptr(), g.data_ptr(), b.data_ptr(), v.shape[0], v.shape[1])
+        return arr, n
+
+    @staticmethod
+    def forward(ctx, *params):
+        from .._native import lib, check
+        params = tuple(p.detach().contiguous() for p in params)
+        arr, n = FlatWeightNorm._desc(params)
+        rows = sum(int(params[3 * l].shape[0]) for l in range(n))
+        size = sum(int(params[3 * l].numel()) + int(params[3 * l].shape[0]) for l in range(n))
+        dev = params[0].device
+        flat = torch.empty(size + 1, device=dev)
+        norms = torch.empty(rows, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.nsa_weight_norm_flat(arr, n, flat.data_ptr(), norms.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        ctx.save_for_backward(norms, *params)
+        return flat
+
+    @staticmethod
+    def backward(ctx, g_flat):
+        from .._native import lib, check
+        norms, *params = ctx.saved_tensors
+        arr, n = FlatWeightNorm._desc(params)
+        g_flat = g_flat.contiguous()
+        out = torch.empty(sum(p.numel() for p in params), device=g_flat.device)
+        with torch.cuda.device(g_flat.device):
+            check(lib.nsa_weight_norm_flat_backward(arr, n, norms.data_ptr(), g_flat.data_ptr(), out.data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream))
+        grads, o = [], 0
+        for l in range(n):
+            for i, p in enumerate(params[3 * l:3 * l + 3]):
+                grads.append(out[o:o + p.numel()].view(p.shape) if ctx.needs_input_grad[3 * l + i] else None)
+                o += p.numel()
+        return tuple(grads)
+
+
+def _wn_params(net):
+    """[weight_v, weight_g, bias] per layer when every Linear of ``net`` is a weight-normed float32 CUDA layer, else None."""
+    out = []
+    for l in range(net.num_layers - 1):
+        lin = getattr(net, "lin" + str(l))
+        if not (hasattr(lin, "weight_g") and hasattr(lin, "weight_v") and lin.bias is not None):
+            return None
+        ps = [lin.weight_v, lin.weight_g, lin.bias]
+        if not all(p.is_cuda and p.dtype == torch.float32 for p in ps) or lin.weight_v.dim() != 2:
+            return None
+        out += ps
+    return out if 3 <= len(out) <= 24 else None
+
+
 def flat_params(net):
+    """Flat effective parameter vector [W_0, b_0, W_1, b_1, .., 0] of an MLP (differentiable)."""
+    wn = _wn_params(net)
+    if wn is not None:
+        if torch.is_grad_enabled():
+            return FlatWeightNorm.apply(*wn)
+        # detached (the packs of every tiling of this network ask for it): once per parameter version
+        key = tuple((p.data_ptr(), p._version) for p in wn)
+        hit = net.__dict__.get("_flat_detached")
+        if hit is None or hit[0] != key:
+            hit = net.__dict__["_flat_detached"] = (key, FlatWeightNorm.apply(*wn))
+        return hit[1]
     parts = []
     for l in range(net.num_layers - 1):
         lin = getattr(net, "lin" + str(l))

@@ -6,6 +6,7 @@ between the sampler and the output dict (reference code/model/network.py:112-151
 (mapping) still go through the composed engine.
 """
 import ctypes
+import os
 
 import torch
 
@@ -67,11 +68,31 @@ def _pts(rays_o, rays_d, z_vals, order=None):
                       None if order is None else order.data_ptr())
 
 
+def _table_grad(param):
+    """Where a MAP kernel adds a table's gradient: the table's persistent in-place buffer (fused/tablegrad.py) or, with
+    NSA_TABLE_GRADS=autograd, a fresh zero-filled tensor handed back through autograd."""
+    from . import tablegrad
+    return tablegrad.target(param) if tablegrad.IN_PLACE else torch.zeros_like(param)
+
+
+def _table_result(gt):
+    from . import tablegrad
+    return None if tablegrad.IN_PLACE else gt
+
+
+# bits of the 30-bit Morton code the launch order is sorted on (24 = a 256^3 lattice: three radix passes instead of four; points
+# of one such cell keep their ray order)
+MORTON_BITS = int(os.environ.get("NSA_MORTON_BITS", "30"))
+
+
 def morton_order(pts_desc, P, device):
     """int32 [P] spatially coherent launch order of the points described by ``pts_desc`` (argsort of Morton keys)."""
-    keys = torch.empty(P, device=device, dtype=torch.int32)
-    check(lib.nsa_morton_keys(ctypes.byref(pts_desc), keys.data_ptr(), _stream()))
-    return torch.sort(keys).indices.to(torch.int32)
+    order = torch.empty(P, device=device, dtype=torch.int32)
+    if P == 0:
+        return order
+    ws = torch.empty(int(lib.nsa_morton_order_workspace(P)), device=device, dtype=torch.int32)
+    check(lib.nsa_morton_order(ctypes.byref(pts_desc), order.data_ptr(), ws.data_ptr(), MORTON_BITS, _stream()))
+    return order
 
 
 def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd, sort_points=False, composite=True, track=None):
@@ -197,7 +218,7 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
     if want.get("flat_r") or want.get("tab_r"):
         from . import mapping
         emit = mapping.new_emit(mapping.CE["ROWS"], P, dev) if want.get("flat_r") else None
-        gt = torch.zeros_like(model.rendering_network.encoding.embeddings) if want.get("tab_r") else None
+        gt = _table_grad(model.rendering_network.encoding.embeddings) if want.get("tab_r") else None
         with _timed("k_colour_bwd<map>", P * 512):
             check(lib.nsa_colour_backward_params(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
                                                  b["feat"].data_ptr(), b["save"].data_ptr(), g_rgb.data_ptr(), grid_grad,
@@ -206,7 +227,7 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
         if emit is not None:
             pg["flat_r"] = mapping.colour_flat_grad(emit)
             del emit
-        pg["tab_r"] = gt
+        pg["tab_r"] = _table_result(gt)
     elif merged:        # colour backward + coarse SDF backward: two phases of one launch (same 32-point tiles)
         with _timed("k_colour_coarse_bwd", P * (512 + 3 * 4 * 8 * 8 * 4)):
             check(lib.nsa_colour_coarse_backward(ctypes.byref(pts), ctypes.byref(gr), pr.data_ptr(), b["grad"].data_ptr(),
@@ -225,17 +246,17 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
         tile_m = tile_of(model, "coarse_map")
         gcm, keep_cm = sdf_grid_desc(model, "coarse", "coarse_map")
         pcm = packed_sdf(model, "coarse", use="coarse_map")
-        emit = mapping.new_emit(mapping.se_rows(1, tile_m)["ROWS"], P, dev) if want.get("flat_c") else None
-        gt = torch.zeros_like(enc.embeddings) if want.get("tab_c") else None
+        emit = mapping.new_emit(mapping.se_rows(1, tile_m)["ROWS"], P, dev, extra=2) if want.get("flat_c") else None
+        gt = _table_grad(enc.embeddings) if want.get("tab_c") else None
         with _timed("k_sdfnet_bwd<coarse,map>", P * 3 * 4 * 8 * 8 * 4):
             check(lib.nsa_sdfnet_backward_params(ctypes.byref(pts), ctypes.byref(gcm), pcm.data_ptr(), g_sdf.data_ptr(),
                                                  g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(), ptr(gt),
                                                  ptr(emit), 0 if emit is None else emit.shape[1], st))
         if emit is not None:
-            g_sdf_w = g_sdf if order is None else g_sdf[order.long()]       # emission columns are work items
-            pg["flat_c"] = mapping.sdf_flat_grad(emit, g_sdf_w, P, enc.num_levels, enc.level_dim, tile=tile_m)
+            pg["flat_c"] = mapping.sdf_flat_grad(emit, g_sdf, P, enc.num_levels, enc.level_dim, tile=tile_m,
+                                                 order=order)       # (emission columns are work items)
             del emit
-        pg["tab_c"] = gt
+        pg["tab_c"] = _table_result(gt)
     elif not merged:
         with _timed("k_sdfnet_bwd<coarse>", P * 3 * 4 * 8 * 8 * 4):
             check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gc), pc.data_ptr(), g_sdf.data_ptr(),
@@ -244,17 +265,18 @@ def composite_backward_raw(model, rays_o, rays_d, z_vals, b, stage, color_stage,
         if want.get("tab_f") or want.get("flat_f"):
             from . import mapping
             enc = imp.fine.encoding
-            gt = torch.zeros_like(enc.embeddings) if want.get("tab_f") else None
-            emit = mapping.new_emit(mapping.se_rows(3, tile_of(model, "fine"))["ROWS"], P, dev) if want.get("flat_f") else None
+            gt = _table_grad(enc.embeddings) if want.get("tab_f") else None
+            emit = (mapping.new_emit(mapping.se_rows(3, tile_of(model, "fine"))["ROWS"], P, dev, extra=2)
+                    if want.get("flat_f") else None)
             with _timed("k_sdfnet_bwd<fine,map>", P * 3 * 8 * 8 * 4 * 4):
                 check(lib.nsa_sdfnet_backward_params(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), g_sdf.data_ptr(),
                                                      g_feat.data_ptr(), g_grad.data_ptr(), 1, g_x.data_ptr(),
                                                      ptr(gt), ptr(emit), 0 if emit is None else emit.shape[1], st))
             if emit is not None:
-                g_sdf_w = g_sdf if order is None else g_sdf[order.long()]
-                pg["flat_f"] = mapping.sdf_flat_grad(emit, g_sdf_w, P, enc.num_levels, enc.level_dim, NH=3, tile=tile_of(model, "fine"))
+                pg["flat_f"] = mapping.sdf_flat_grad(emit, g_sdf, P, enc.num_levels, enc.level_dim, NH=3,
+                                                     tile=tile_of(model, "fine"), order=order)
                 del emit
-            pg["tab_f"] = gt
+            pg["tab_f"] = _table_result(gt)
         else:
             with _timed("k_sdfnet_bwd<fine>", P * 3 * 8 * 8 * 4 * 4):
                 check(lib.nsa_sdfnet_backward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), g_sdf.data_ptr(),

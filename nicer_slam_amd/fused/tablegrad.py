@@ -1,0 +1,76 @@
+"""Persistent, in-place gradient buffers of the hash-grid tables for the fused mapping engine.
+
+The reference's mapping iteration (code/training/volsdf_train.py:547-576) runs optimizer.zero_grad(), a backward whose grid
+encoder allocates a zero-filled dense gradient per table and atomically adds into it (code/hashencoder/hashgrid.py:85,117-118),
+and a dense Adam step.  With a 1 GiB colour table the zero fill and autograd's sum of the two passes' table gradients (composite
+pass + eikonal pass) are pure HBM streaming.  Here every table owns ONE persistent gradient buffer:
+
+* the MAP backward kernels scatter straight into ``param.grad`` -- which is this buffer whenever ``param.grad`` was None (the
+  state optimizer.zero_grad() leaves) -- so both passes of an iteration accumulate in place and autograd has nothing to add;
+* ``nicer_slam_amd.optim.Adam`` reads the buffer and leaves it zero behind itself (nsa_adam_table_step_clear), so the next
+  iteration starts from a clean buffer without a fill.
+
+Observable semantics: after ``loss.backward()`` ``param.grad`` holds the accumulated gradient exactly as with autograd
+(including accumulation over several backward calls, and into a ``.grad`` tensor the caller put there).  Differences, both
+documented in INTEGRATION.md: the table gradients do not travel through autograd (``torch.autograd.grad(loss, table)`` raises;
+tensor hooks on the tables do not fire), and after ``nicer_slam_amd.optim.Adam.step()`` a table's ``.grad`` reads zero until
+the next backward (the gradient was consumed).  ``NSA_TABLE_GRADS=autograd`` (or ``IN_PLACE = False``) restores fresh
+zero-filled gradients returned through autograd.
+"""
+import os
+from torch.utils.weak import WeakTensorKeyDictionary
+
+import torch
+
+IN_PLACE = os.environ.get("NSA_TABLE_GRADS", "inplace") != "autograd"
+
+
+class _Entry:
+    __slots__ = ("buf", "clean")
+
+    def __init__(self, param):
+        self.buf = torch.zeros_like(param, memory_format=torch.contiguous_format)
+        self.clean = True
+
+
+_pool = WeakTensorKeyDictionary()
+
+
+def _entry(param):
+    e = _pool.get(param)
+    if e is None or e.buf.shape != param.shape or e.buf.device != param.device:
+        e = _pool[param] = _Entry(param)
+    return e
+
+
+def target(param):
+    """The tensor the MAP kernels of this backward pass add ``param``'s gradient into (float32, contiguous, param's shape);
+    afterwards it is (part of) ``param.grad``.  Called inside autograd.Function.backward; the Function returns None for the table."""
+    g = param.grad
+    if g is not None:
+        if g.dtype == torch.float32 and g.is_contiguous() and g.shape == param.shape and g.device == param.device and not g.is_sparse:
+            e = _pool.get(param)
+            if e is not None and e.buf.data_ptr() == g.data_ptr():
+                e.clean = False
+            return g                       # accumulate where the gradient already lives (ours or the caller's)
+        raise RuntimeError("fused mapping engine: a table's .grad must be a dense contiguous float32 tensor of the table's shape "
+                           "(set NSA_TABLE_GRADS=autograd for gradients returned through autograd)")
+    e = _entry(param)
+    if not e.clean:                        # left dirty: zero_grad() without our Adam step, or another optimizer consumed it
+        e.buf.zero_()
+    e.clean = False
+    with torch.no_grad():
+        param.grad = e.buf
+    return e.buf
+
+
+def consumable(param, grad):
+    """True when ``grad`` is this module's buffer of ``param`` (the optimizer may then consume it: read it and leave it zero)."""
+    e = _pool.get(param)
+    return e is not None and grad.data_ptr() == e.buf.data_ptr()
+
+
+def mark_clean(param):
+    e = _pool.get(param)
+    if e is not None:
+        e.clean = True

@@ -154,6 +154,7 @@ class SLAMNetwork(nn.Module):
             self.patchsizes = self.mapping_patchsizes
         intrinsics, uv, pose = input["intrinsics"], input["uv"], input["pose"]
         self.last_engine = "composed"
+        self.__dict__.pop("_flat_inputs_fwd", None)
         bs, num_pixels, _ = uv.shape
         fused_kind = self._fused_composite_ok(mode, ground_truth)
         fused = fused_kind is not None
@@ -199,6 +200,8 @@ class SLAMNetwork(nn.Module):
             from ..fused import render as fused_render, mapping as fused_mapping
             self.last_engine = "fused"
             engine = fused_mapping if fused_kind == "params" else fused_render
+            if fused_kind == "params":
+                self.__dict__["_flat_inputs_fwd"] = None      # composite + eikonal pass of this call share their autograd inputs
             rgb_values, depth, nmap_w, weights, ent_ray, sdf, rgb, gradients = engine.composite(
                 self, cam_flat, dirs, z_vals, stage, color_stage)
         else:
@@ -210,8 +213,12 @@ class SLAMNetwork(nn.Module):
             rgb_values = torch.sum(weights.unsqueeze(-1) * rgb, 1)
             depth = torch.sum(weights * z_vals, 1, keepdims=True) / (weights.sum(dim=1, keepdims=True) + 1e-8)
             nmap_w, ent_ray = None, None
-        return self._assemble(mode, bs, num_pixels, uv, pose, intrinsics, ground_truth, stage, fused, fused_kind, depth_scale,
-                              cam_flat, dirs, z_vals, z_samples_eik, rgb_values, depth, nmap_w, weights, ent_ray, sdf, rgb, gradients)
+        try:
+            return self._assemble(mode, bs, num_pixels, uv, pose, intrinsics, ground_truth, stage, fused, fused_kind, depth_scale,
+                                  cam_flat, dirs, z_vals, z_samples_eik, rgb_values, depth, nmap_w, weights, ent_ray, sdf, rgb,
+                                  gradients)
+        finally:
+            self.__dict__.pop("_flat_inputs_fwd", None)
 
     def _assemble(self, mode, bs, num_pixels, uv, pose, intrinsics, ground_truth, stage, fused, fused_kind, depth_scale, cam_flat,
                   dirs, z_vals, z_samples_eik, rgb_values, depth, nmap_w, weights, ent_ray, sdf, rgb, gradients):

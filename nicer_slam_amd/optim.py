@@ -3,6 +3,10 @@
 the two small MLPs).  One HIP pass per parameter tensor (csrc/map_tail.hip: 4 reads + 3 writes per element, the HBM
 floor of a dense Adam step) instead of torch's seven multi-tensor passes.
 
+``consume_table_grads`` (default on): a grid table whose ``.grad`` is the fused mapping engine's persistent buffer
+(fused/tablegrad.py) has that gradient CONSUMED by ``step()`` -- read and left zero in the same pass -- so that the next
+backward needs no zero fill; such a ``.grad`` reads zero after ``step()``.  Every other gradient is left untouched, as torch does.
+
 Same semantics, operation order and state layout as torch.optim.Adam without weight decay / amsgrad / maximize:
 ``state[p] = {"step": tensor(float), "exp_avg", "exp_avg_sq"}``, so state_dicts are interchangeable.  CUDA float32
 contiguous parameters only; anything else raises (no fallback).
@@ -11,14 +15,16 @@ import torch
 
 from ._native import lib, check
 from ._version import bump_version
+from .fused import tablegrad
 
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, consume_table_grads=True):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.consume_table_grads = consume_table_grads
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -44,9 +50,14 @@ class Adam(torch.optim.Optimizer):
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state["step"] += 1
-                check(lib.nsa_adam_table_step(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(),
-                                              state["exp_avg_sq"].data_ptr(), p.numel(), int(state["step"]),
-                                              float(group["lr"]), float(b1), float(b2), float(group["eps"]), st))
+                # a table gradient living in the fused engine's persistent buffer is consumed: read and left zero, so the next
+                # backward scatters into it without a fill (fused/tablegrad.py)
+                consume = self.consume_table_grads and tablegrad.consumable(p, g)
+                step_fn = lib.nsa_adam_table_step_clear if consume else lib.nsa_adam_table_step
+                check(step_fn(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(), p.numel(),
+                              int(state["step"]), float(group["lr"]), float(b1), float(b2), float(group["eps"]), st))
+                if consume:
+                    tablegrad.mark_clean(p)
                 # the kernel wrote p behind autograd's back: bump its version counter like an in-place op would
                 # (the packed-weight caches of the fused engine key on it)
                 bump_version(p)

@@ -452,3 +452,151 @@ def test_emit_gemm_vs_float64(case):
     err = (out.double().cpu() - ref).abs() / scale.clamp_min(1e-30)
     print("emit_gemm max error / sum|ab|:", float(err.max()))
     assert float(err.max()) < 1e-6, float(err.max())      # fp32 accumulation over ~11k terms (x2 pairs)
+
+
+def test_flat_weight_norm_kernels_vs_torch_weight_norm():
+    """fused/pack.py::FlatWeightNorm (nsa_weight_norm_flat / _backward: one launch per direction) vs per-layer torch._weight_norm
+    + reshape + cat and its autograd, on the three MLP shapes of the model (base_networks.py:137-141, 376-379)."""
+    from nicer_slam_amd.fused import pack
+    fx = load("full_mapping")
+    model = build_model(fx).cuda()
+    nets = [model.implicit_network.coarse, model.implicit_network.fine, model.rendering_network]
+    torch.manual_seed(3)
+    for net in nets:
+        with torch.no_grad():
+            for p in net.mlp_parameters():
+                p.add_(0.1 * torch.randn_like(p))
+        wn = pack._wn_params(net)
+        assert wn is not None and len(wn) == 3 * (net.num_layers - 1)
+        flat = pack.flat_params(net)
+        parts = []
+        for l in range(net.num_layers - 1):
+            lin = getattr(net, "lin" + str(l))
+            parts += [torch._weight_norm(lin.weight_v, lin.weight_g, 0).reshape(-1), lin.bias.reshape(-1)]
+        ref = torch.cat(parts + [parts[0].new_zeros(1)])
+        assert flat.shape == ref.shape and float(flat[-1]) == 0.0
+        assert_close(flat.detach(), ref.detach().cpu().numpy(), 1e-7, 2e-6, "flat effective parameters")
+        c = torch.randn_like(ref)
+        params = list(net.mlp_parameters())
+        g_kernel = torch.autograd.grad(flat, params, c)
+        g_torch = torch.autograd.grad(ref, params, c)
+        for p, a, b in zip(params, g_kernel, g_torch):
+            assert a.shape == p.shape
+            assert_close(a, b.cpu().numpy(), 2e-6 * float(b.abs().max()) + 1e-9, 2e-5, "weight-norm backward")
+        # detached: computed once per parameter version, recomputed after an in-place update
+        with torch.no_grad():
+            d0 = pack.flat_params(net)
+            assert pack.flat_params(net) is d0
+            params[0].mul_(1.5)
+            d1 = pack.flat_params(net)
+        assert d1 is not d0 and not torch.equal(d0, d1)
+
+
+def test_adam_consumes_the_persistent_table_gradient_buffer():
+    """fused/tablegrad.py + nsa_adam_table_step_clear: the table's .grad is the engine's persistent buffer; the HIP Adam steps like
+    torch.optim.Adam on it and leaves it zero, so the next backward needs no fill; a gradient that is NOT that buffer is left
+    untouched (torch semantics)."""
+    from nicer_slam_amd.optim import Adam
+    from nicer_slam_amd.fused import tablegrad
+    torch.manual_seed(5)
+    n = (1 << 18) + 6
+    p0 = torch.randn(n, 2, device="cuda") * 0.1
+    a, b = torch.nn.Parameter(p0.clone()), torch.nn.Parameter(p0.clone())
+    oa = Adam([{"params": [a], "lr": 0.04}], betas=(0.9, 0.99), eps=1e-15)
+    ob = torch.optim.Adam([{"params": [b], "lr": 0.04}], betas=(0.9, 0.99), eps=1e-15)
+    ptr = None
+    for it in range(4):
+        oa.zero_grad()
+        assert a.grad is None
+        buf = tablegrad.target(a)                       # what a MAP backward kernel is handed
+        assert a.grad is buf and buf.shape == a.shape
+        assert float(buf.abs().max()) == 0.0, "the buffer must come back clean without a fill"
+        assert ptr is None or buf.data_ptr() == ptr
+        ptr = buf.data_ptr()
+        g = torch.randn(n, 2, device="cuda") * (10.0 ** (it - 2))
+        g[::3] = 0.0
+        buf.add_(g)
+        assert tablegrad.target(a) is buf               # second pass of the same iteration accumulates in place
+        b.grad = g.clone()
+        oa.step()
+        ob.step()
+        assert_close(a.detach(), b.detach().cpu().numpy(), 1e-7, 2e-6, f"param after step {it + 1}")
+        assert float(buf.abs().max()) == 0.0            # consumed
+    # a caller-owned gradient is stepped on but not cleared
+    oa.zero_grad()
+    a.grad = torch.ones_like(a)
+    oa.step()
+    assert float(a.grad.min()) == 1.0
+    # left dirty (no step): the next acquisition clears it
+    oa.zero_grad()
+    tablegrad.target(a).add_(1.0)
+    oa.zero_grad()
+    assert float(tablegrad.target(a).abs().max()) == 0.0
+
+
+def test_table_gradients_in_place_vs_through_autograd():
+    """The default in-place table gradients (MAP kernels scatter into param.grad = a persistent buffer) against the
+    NSA_TABLE_GRADS=autograd form (fresh zero-filled gradients returned through autograd) on the full mapping golden: same
+    gradients up to the atomics' summation order; two backward passes without zero_grad accumulate; autograd.grad raises."""
+    from nicer_slam_amd.fused import tablegrad
+    fx = load("full_mapping")
+    tables = ("implicit_network.coarse.encoding.embeddings", "implicit_network.fine.encoding.embeddings",
+              "rendering_network.encoding.embeddings")
+    grads = {}
+    assert tablegrad.IN_PLACE
+    try:
+        for mode in (True, False):
+            tablegrad.IN_PLACE = mode
+            model, cam, out = _run(fx, "fused")
+            golden_objective(out, fx, "mapping").backward()
+            named = dict(model.named_parameters())
+            grads[mode] = {k: named[k].grad.clone() for k in tables}
+            for k in tables:
+                assert tablegrad.consumable(named[k], named[k].grad) == mode, k
+            if mode:          # a second forward + backward without zero_grad: gradients accumulate like autograd's
+                model.voxels = tt(fx["in_voxels"]).cuda()
+                model.draws = draws_of(fx, "cuda")
+                model.draws["z_vals_override"] = tt(fx["out_z_vals"]).cuda()
+                from nicer_slam_amd.utils.general import camera_from_tensor_torch
+                out2 = model({"intrinsics": tt(fx["in_K"]).cuda(), "uv": tt(fx["in_uv"]).cuda(),
+                              "pose": camera_from_tensor_torch(cam.detach())},
+                             torch.arange(out["rgb_values"].shape[0], device="cuda"), {}, mode="mapping",
+                             stage=str(fx["meta_stage"]), color_stage=str(fx["meta_color_stage"]), frame_idx=1)
+                golden_objective(out2, fx, "mapping").backward()
+                for k in tables:
+                    ref = 2.0 * grads[True][k]
+                    assert_close(named[k].grad, ref.cpu().numpy(), 1e-6 + 2e-4 * float(ref.abs().max()), 1e-3, "accumulated " + k)
+                out3 = model({"intrinsics": tt(fx["in_K"]).cuda(), "uv": tt(fx["in_uv"]).cuda(),
+                              "pose": camera_from_tensor_torch(cam.detach())},
+                             torch.arange(out["rgb_values"].shape[0], device="cuda"), {}, mode="mapping",
+                             stage=str(fx["meta_stage"]), color_stage=str(fx["meta_color_stage"]), frame_idx=1)
+                with pytest.raises(RuntimeError):
+                    torch.autograd.grad(golden_objective(out3, fx, "mapping"), [named[tables[2]]])
+    finally:
+        tablegrad.IN_PLACE = True
+    for k in tables:
+        ref = grads[False][k]
+        assert float(ref.abs().max()) > 0
+        assert_close(grads[True][k], ref.cpu().numpy(), 1e-6 + 2e-5 * float(ref.abs().max()), 1e-3, k)
+
+
+@pytest.mark.parametrize("P", [1, 63, 4097, 100003, 8192 * 98])
+@pytest.mark.parametrize("bits", [30, 24, 9])
+def test_morton_order_radix_sort_vs_torch_stable_sort(P, bits):
+    """nsa_morton_order (in-library LSD radix sort of the Morton keys) = the stable argsort of the keys' top `bits` bits."""
+    import ctypes
+    from nicer_slam_amd._native import lib, check, PointsDesc
+    g = torch.Generator(device="cuda").manual_seed(P + bits)
+    pts = (torch.rand(P, 3, device="cuda", generator=g) * 2.2 - 1.1)
+    if P > 100:
+        pts[::5] = pts[7]                                     # many equal keys: stability matters
+    desc = PointsDesc(None, None, None, pts.data_ptr(), P, 0, None)
+    st = torch.cuda.current_stream().cuda_stream
+    keys = torch.empty(P, device="cuda", dtype=torch.int32)
+    check(lib.nsa_morton_keys(ctypes.byref(desc), keys.data_ptr(), st))
+    order = torch.full((P,), -1, device="cuda", dtype=torch.int32)
+    ws = torch.empty(int(lib.nsa_morton_order_workspace(P)), device="cuda", dtype=torch.int32)
+    check(lib.nsa_morton_order(ctypes.byref(desc), order.data_ptr(), ws.data_ptr(), bits, st))
+    ref = torch.sort(keys.long() >> (30 - bits), stable=True).indices
+    assert torch.equal(order.long(), ref)
+    assert lib.nsa_morton_order(ctypes.byref(desc), order.data_ptr(), ws.data_ptr(), 31, st) != 0

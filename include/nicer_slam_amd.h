@@ -359,7 +359,8 @@ uint64_t nsa_morton_order_workspace(uint32_t P);
 int nsa_update_voxels(const nsa_points_t *pts, float *voxels, uint32_t res, nsa_stream_t stream);
 
 /* One torch.optim.Adam step (no weight decay / amsgrad) over n parameters in a single pass; `step` = this step's
- * number t >= 1 (bias corrections are computed on the host in double, like torch).  All pointers 16-byte aligned.
+ * number t >= 1 (bias corrections are computed on the host in double, like torch).  16-byte aligned pointers take the
+ * 16-byte path; anything less (4-byte aligned at least) a one-element-per-thread form with the same arithmetic.
  * replaces self.optimizer.step() for one parameter tensor (code/training/volsdf_train.py:174, 420-424). */
 int nsa_adam_table_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, uint32_t step,
                         float lr, float beta1, float beta2, float eps, nsa_stream_t stream);

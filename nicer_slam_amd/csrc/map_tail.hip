@@ -202,6 +202,16 @@ __global__ __launch_bounds__(256) void k_adam_table(AdamTableArgs a) {
     }
 }
 
+// any alignment (gradients that are views into a larger buffer, e.g. FlatWeightNorm's): one element per thread
+template <bool CLEAR>
+__global__ __launch_bounds__(256) void k_adam_table_scalar(AdamTableArgs a) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) {
+        adam_one(a.p[i], a.g[i], a.m[i], a.v[i], a);
+        if (CLEAR) a.g[i] = 0.0f;
+    }
+}
+
 // ---- weight-normed MLP parameters <-> the flat effective parameter vector, one launch per direction ---------------------------
 // flat = [W_0 (rows x cols, row-major), b_0, W_1, b_1, .., 0] with W_l[r,:] = v_l[r,:] * g_l[r] / ||v_l[r,:]||  -- what
 // torch._weight_norm(v, g, dim=0) computes per layer (nn.utils.weight_norm of code/model/base_networks.py:137-141, 376-379) followed
@@ -411,8 +421,10 @@ static int adam_table_launch(float* param, float* grad, float* exp_avg, float* e
     using namespace nsa;
     if (!param || !grad || !exp_avg || !exp_avg_sq || step == 0) return NSA_EBADARG;
     if (n == 0) return NSA_OK;
-    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
-         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15u) return NSA_EBADARG;            // float4 path
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) |
+                           reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq);
+    if (bits & 3u) return NSA_EBADARG;
+    const bool vec = (bits & 15u) == 0;                                                  // float4 path
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     AdamTableArgs a{param, grad, exp_avg, exp_avg_sq, n, 1.0f - beta1, beta2, 1.0f - beta2,
@@ -422,8 +434,13 @@ static int adam_table_launch(float* param, float* grad, float* exp_avg, float* e
     if (blocks > 256 * 32) blocks = 256 * 32;      // grid-stride: 32 blocks per CU keeps every HBM channel busy
     if (blocks == 0) blocks = 1;
     launch_begin();
-    if (clear) hipLaunchKernelGGL(k_adam_table<true>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, a);
-    else       hipLaunchKernelGGL(k_adam_table<false>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (!vec) {
+        uint64_t sb = (n + 255) / 256;
+        if (sb > 256 * 32) sb = 256 * 32;
+        if (clear) hipLaunchKernelGGL(k_adam_table_scalar<true>, dim3((uint32_t)sb), dim3(256), 0, (hipStream_t)stream, a);
+        else       hipLaunchKernelGGL(k_adam_table_scalar<false>, dim3((uint32_t)sb), dim3(256), 0, (hipStream_t)stream, a);
+    } else if (clear) hipLaunchKernelGGL(k_adam_table<true>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else              hipLaunchKernelGGL(k_adam_table<false>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return launch_end();
 }
 

@@ -372,6 +372,11 @@ int nsa_adam_table_step(float *param, const float *grad, float *exp_avg, float *
 int nsa_adam_table_step_clear(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, uint32_t step,
                               float lr, float beta1, float beta2, float eps, nsa_stream_t stream);
 
+/* p[0..n) = 0 (p 16-byte aligned): the zero fill of a table-gradient buffer as a library launch, so that it can run on a side
+ * stream under the next iteration's forward kernels (nicer_slam_amd/fused/tablegrad.py).  replaces optimizer.zero_grad() +
+ * the zero-initialised dense gradient of code/hashencoder/hashgrid.py:117-118. */
+int nsa_fill_zero(float *p, uint64_t n, nsa_stream_t stream);
+
 /* Weight-normed Linear layers -> the flat effective parameter vector the packed blocks and the MAP kernels' gradients use:
  *   flat = [W_0 (rows x cols, row-major), b_0, W_1, b_1, .., 0],   W_l[r,:] = weight_v_l[r,:] * weight_g_l[r] / ||weight_v_l[r,:]||,
  * norms[row] = ||weight_v_l[r,:]|| for the backward (rows of all layers, in order); n_layers <= 8.

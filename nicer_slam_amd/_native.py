@@ -147,7 +147,9 @@ lib.nsa_weight_norm_flat_backward.restype = _i
 lib.nsa_weight_norm_flat_backward.argtypes = [ctypes.POINTER(WnLayer), _u32, _p, _p, _p, _p]
 lib.nsa_emit_row.restype = _i
 lib.nsa_emit_row.argtypes = [_p, _p, _p, _u32, ctypes.c_uint64, _f32, _p]
-EXPORTS += ["nsa_weight_norm_flat", "nsa_weight_norm_flat_backward", "nsa_emit_row"]
+lib.nsa_fill_zero.restype = _i
+lib.nsa_fill_zero.argtypes = [_p, ctypes.c_uint64, _p]
+EXPORTS += ["nsa_weight_norm_flat", "nsa_weight_norm_flat_backward", "nsa_emit_row", "nsa_fill_zero"]
 
 lib.nsa_emit_gemm.restype = _i
 lib.nsa_emit_gemm.argtypes = [_p, ctypes.c_uint64, _u32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), _u32,

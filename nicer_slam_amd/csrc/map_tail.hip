@@ -74,15 +74,37 @@ struct RadixArgs {
     uint32_t P, nb, per_wave, shift;
 };
 
+constexpr int RS_CHUNK = 16;      // rounds (of 64 keys) a wave loads before it ranks them: the loads of a chunk are in flight together
+
+// keys (and, with `vals`, their payloads) of one chunk of this wave's run; slots past the run / past P hold `valid` = false
+struct RadixChunk {
+    uint32_t key[RS_CHUNK], val[RS_CHUNK];
+    bool valid[RS_CHUNK];
+};
+__device__ __forceinline__ void radix_load(const RadixArgs& a, uint64_t start, uint32_t r0, uint32_t lane, bool vals, RadixChunk& c) {
+#pragma unroll
+    for (int j = 0; j < RS_CHUNK; ++j) {
+        const uint32_t r = r0 + 64u * j;
+        const uint64_t e = start + r + lane;
+        c.valid[j] = r < a.per_wave && e < a.P;
+        c.key[j] = c.valid[j] ? a.keys_in[e] : 0u;
+        c.val[j] = (uint32_t)e;
+        if (vals && a.vals_in) c.val[j] = c.valid[j] ? a.vals_in[e] : 0u;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_radix_hist(RadixArgs a) {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint64_t start = ((uint64_t)blockIdx.x * RS_WAVES + w) * a.per_wave;
-    for (uint32_t r = 0; r < a.per_wave; r += 64) {
-        const uint64_t e = start + r + lane;
-        if (e < a.P) atomicAdd(&h[(a.keys_in[e] >> a.shift) & 255u], 1u);
+    for (uint32_t r0 = 0; r0 < a.per_wave; r0 += 64u * RS_CHUNK) {
+        RadixChunk c;
+        radix_load(a, start, r0, lane, false, c);
+#pragma unroll
+        for (int j = 0; j < RS_CHUNK; ++j)
+            if (c.valid[j]) atomicAdd(&h[(c.key[j] >> a.shift) & 255u], 1u);
     }
     __syncthreads();
     a.counts[blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
@@ -95,6 +117,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(RadixArgs a) {
     const uint32_t t = threadIdx.x, w = t >> 6, lane = t & 63;
     // digit t: keys of all blocks, and of the blocks before this one
     uint32_t total = 0, before = 0;
+#pragma unroll 8
     for (uint32_t b = 0; b < a.nb; ++b) {
         const uint32_t c = a.counts[b * 256 + t];
         total += c;
@@ -111,9 +134,13 @@ __global__ __launch_bounds__(256) void k_radix_scatter(RadixArgs a) {
         __syncthreads();
     }
     const uint64_t start = ((uint64_t)blockIdx.x * RS_WAVES + w) * a.per_wave;
-    for (uint32_t r = 0; r < a.per_wave; r += 64) {            // digits of this wave's run
-        const uint64_t e = start + r + lane;
-        if (e < a.P) atomicAdd(&wh[w][(a.keys_in[e] >> a.shift) & 255u], 1u);
+    const bool single = a.per_wave <= 64u * RS_CHUNK;          // the whole run in one chunk: loaded once, kept in registers
+    RadixChunk c;
+    for (uint32_t r0 = 0; r0 < a.per_wave; r0 += 64u * RS_CHUNK) {      // digits of this wave's run
+        radix_load(a, start, r0, lane, true, c);
+#pragma unroll
+        for (int j = 0; j < RS_CHUNK; ++j)
+            if (c.valid[j]) atomicAdd(&wh[w][(c.key[j] >> a.shift) & 255u], 1u);
     }
     __syncthreads();
     {
@@ -125,27 +152,29 @@ __global__ __launch_bounds__(256) void k_radix_scatter(RadixArgs a) {
         }
     }
     __syncthreads();
-    for (uint32_t r = 0; r < a.per_wave; r += 64) {
-        const uint64_t e = start + r + lane;
-        const bool valid = e < a.P;
-        const uint32_t key = valid ? a.keys_in[e] : 0u;
-        const uint32_t d = (key >> a.shift) & 255u;
-        unsigned long long same = __ballot(valid);             // valid lanes holding this lane's digit
+    for (uint32_t r0 = 0; r0 < a.per_wave; r0 += 64u * RS_CHUNK) {
+        if (!single) radix_load(a, start, r0, lane, true, c);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long bal = __ballot(bit);
-            same &= bit ? bal : ~bal;
-        }
-        const uint32_t rank = __popcll(same & ((1ull << lane) - 1ull)), cnt = __popcll(same);
-        const uint32_t base = valid ? run[w][d] : 0u;
-        __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) run[w][d] = base + cnt;        // (same wave, program order: the next round reads it)
-        __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            const uint32_t pos = base + rank;
-            if (a.keys_out) a.keys_out[pos] = key;
-            a.vals_out[pos] = a.vals_in ? a.vals_in[e] : (uint32_t)e;
+        for (int j = 0; j < RS_CHUNK; ++j) {
+            const bool valid = c.valid[j];
+            const uint32_t d = (c.key[j] >> a.shift) & 255u;
+            unsigned long long same = __ballot(valid);         // valid lanes holding this lane's digit
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                same &= bit ? bal : ~bal;
+            }
+            const uint32_t rank = __popcll(same & ((1ull << lane) - 1ull)), cnt = __popcll(same);
+            const uint32_t base = valid ? run[w][d] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rank == 0) run[w][d] = base + cnt;    // (same wave, program order: the next round reads it)
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                const uint32_t pos = base + rank;
+                if (a.keys_out) a.keys_out[pos] = c.key[j];
+                a.vals_out[pos] = c.val[j];
+            }
         }
     }
 }
@@ -200,6 +229,13 @@ __global__ __launch_bounds__(256) void k_adam_table(AdamTableArgs a) {
             if (CLEAR) a.g[i] = 0.0f;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_fill_zero(float* __restrict__ p, uint64_t n) {
+    const uint64_t n4 = n / 4, stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<float4*>(p)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (blockIdx.x == 0 && n4 * 4 + threadIdx.x < n) p[n4 * 4 + threadIdx.x] = 0.0f;
 }
 
 // any alignment (gradients that are views into a larger buffer, e.g. FlatWeightNorm's): one element per thread
@@ -452,6 +488,18 @@ int nsa_adam_table_step(float* param, const float* grad, float* exp_avg, float* 
 int nsa_adam_table_step_clear(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, uint32_t step,
                               float lr, float beta1, float beta2, float eps, nsa_stream_t stream) {
     return adam_table_launch(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, true, stream);
+}
+
+int nsa_fill_zero(float* p, uint64_t n, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!p || (reinterpret_cast<uintptr_t>(p) & 15u)) return NSA_EBADARG;
+    if (n == 0) return NSA_OK;
+    uint64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks == 0) blocks = 1;
+    launch_begin();
+    hipLaunchKernelGGL(k_fill_zero, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, p, n);
+    return launch_end();
 }
 
 static int wn_args(const nsa_wn_layer_t* layers, uint32_t n_layers, nsa::WnArgs& a) {

@@ -7,8 +7,11 @@ pass + eikonal pass) are pure HBM streaming.  Here every table owns ONE persiste
 
 * the MAP backward kernels scatter straight into ``param.grad`` -- which is this buffer whenever ``param.grad`` was None (the
   state optimizer.zero_grad() leaves) -- so both passes of an iteration accumulate in place and autograd has nothing to add;
-* ``nicer_slam_amd.optim.Adam`` reads the buffer and leaves it zero behind itself (nsa_adam_table_step_clear), so the next
-  iteration starts from a clean buffer without a fill.
+* ``nicer_slam_amd.optim.Adam`` consumes the buffer: once its step kernel has read the gradient, the zero fill for the NEXT
+  iteration is issued on a side stream (nsa_fill_zero), where it streams to HBM underneath the next forward pass's gather- and
+  ALU-bound kernels instead of in front of the backward; the first MAP kernel that scatters into the buffer waits for it.
+  (Clearing inside the Adam kernel -- nsa_adam_table_step_clear, ``consume_table_grads="fused"`` -- measured SLOWER than fill +
+  step: an eighth concurrent stream costs the 1 GiB step more than the separate fill does, profiles/r05_ab_experiments.txt r5w.)
 
 Observable semantics: after ``loss.backward()`` ``param.grad`` holds the accumulated gradient exactly as with autograd
 (including accumulation over several backward calls, and into a ``.grad`` tensor the caller put there).  Differences, both
@@ -26,11 +29,34 @@ IN_PLACE = os.environ.get("NSA_TABLE_GRADS", "inplace") != "autograd"
 
 
 class _Entry:
-    __slots__ = ("buf", "clean")
+    __slots__ = ("buf", "clean", "done")
 
     def __init__(self, param):
         self.buf = torch.zeros_like(param, memory_format=torch.contiguous_format)
         self.clean = True
+        self.done = None          # event of a zero fill in flight on the side stream
+
+
+_side = {}
+
+
+def _side_stream(device):
+    s = _side.get(device)
+    if s is None:
+        s = _side[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def _fill(buf, stream):
+    from .._native import lib, check
+    check(lib.nsa_fill_zero(buf.data_ptr(), buf.numel(), stream.cuda_stream))
+
+
+def _settle(e):
+    """make the current stream wait for a fill in flight"""
+    if e.done is not None:
+        torch.cuda.current_stream(e.buf.device).wait_event(e.done)
+        e.done = None
 
 
 _pool = WeakTensorKeyDictionary()
@@ -51,13 +77,16 @@ def target(param):
         if g.dtype == torch.float32 and g.is_contiguous() and g.shape == param.shape and g.device == param.device and not g.is_sparse:
             e = _pool.get(param)
             if e is not None and e.buf.data_ptr() == g.data_ptr():
+                _settle(e)
                 e.clean = False
             return g                       # accumulate where the gradient already lives (ours or the caller's)
         raise RuntimeError("fused mapping engine: a table's .grad must be a dense contiguous float32 tensor of the table's shape "
                            "(set NSA_TABLE_GRADS=autograd for gradients returned through autograd)")
     e = _entry(param)
+    _settle(e)
     if not e.clean:                        # left dirty: zero_grad() without our Adam step, or another optimizer consumed it
-        e.buf.zero_()
+        with torch.cuda.device(e.buf.device):
+            _fill(e.buf, torch.cuda.current_stream())
     e.clean = False
     with torch.no_grad():
         param.grad = e.buf
@@ -71,6 +100,25 @@ def consumable(param, grad):
 
 
 def mark_clean(param):
+    """the optimizer cleared the buffer itself (nsa_adam_table_step_clear)"""
     e = _pool.get(param)
     if e is not None:
         e.clean = True
+
+
+def clear_async(param):
+    """The optimizer has read ``param``'s buffer on the current stream: zero it on the side stream, behind that read.  Until the next
+    backward the buffer's contents are unspecified (being cleared)."""
+    e = _pool.get(param)
+    if e is None:
+        return
+    dev = e.buf.device
+    with torch.cuda.device(dev):
+        main, side = torch.cuda.current_stream(), _side_stream(dev)
+        side.wait_stream(main)
+        _fill(e.buf, side)
+        if e.done is None:
+            e.done = torch.cuda.Event()
+        e.done.record(side)
+        e.buf.record_stream(side)
+    e.clean = True

@@ -4,8 +4,10 @@ the two small MLPs).  One HIP pass per parameter tensor (csrc/map_tail.hip: 4 re
 floor of a dense Adam step) instead of torch's seven multi-tensor passes.
 
 ``consume_table_grads`` (default on): a grid table whose ``.grad`` is the fused mapping engine's persistent buffer
-(fused/tablegrad.py) has that gradient CONSUMED by ``step()`` -- read and left zero in the same pass -- so that the next
-backward needs no zero fill; such a ``.grad`` reads zero after ``step()``.  Every other gradient is left untouched, as torch does.
+(fused/tablegrad.py) has that gradient CONSUMED by ``step()`` -- once read it is zero-filled on a side stream, underneath the
+next forward pass, so that the next backward finds a clean buffer without a fill in its way; such a ``.grad`` must not be read
+after ``step()`` (it is being cleared; zero once the next backward has started).  ``"fused"`` clears inside the step kernel
+instead (zero right after ``step()``, but a slower step).  Every other gradient is left untouched, as torch does.
 
 Same semantics, operation order and state layout as torch.optim.Adam without weight decay / amsgrad / maximize:
 ``state[p] = {"step": tensor(float), "exp_avg", "exp_avg_sq"}``, so state_dicts are interchangeable.  CUDA float32
@@ -52,12 +54,14 @@ class Adam(torch.optim.Optimizer):
                 state["step"] += 1
                 # a table gradient living in the fused engine's persistent buffer is consumed: read and left zero, so the next
                 # backward scatters into it without a fill (fused/tablegrad.py)
-                consume = self.consume_table_grads and tablegrad.consumable(p, g)
-                step_fn = lib.nsa_adam_table_step_clear if consume else lib.nsa_adam_table_step
+                consume = self.consume_table_grads if tablegrad.consumable(p, g) else False
+                step_fn = lib.nsa_adam_table_step_clear if consume == "fused" else lib.nsa_adam_table_step
                 check(step_fn(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(), p.numel(),
                               int(state["step"]), float(group["lr"]), float(b1), float(b2), float(group["eps"]), st))
-                if consume:
+                if consume == "fused":
                     tablegrad.mark_clean(p)
+                elif consume:
+                    tablegrad.clear_async(p)
                 # the kernel wrote p behind autograd's back: bump its version counter like an in-place op would
                 # (the packed-weight caches of the fused engine key on it)
                 bump_version(p)

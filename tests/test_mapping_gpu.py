@@ -492,17 +492,18 @@ def test_flat_weight_norm_kernels_vs_torch_weight_norm():
         assert d1 is not d0 and not torch.equal(d0, d1)
 
 
-def test_adam_consumes_the_persistent_table_gradient_buffer():
-    """fused/tablegrad.py + nsa_adam_table_step_clear: the table's .grad is the engine's persistent buffer; the HIP Adam steps like
-    torch.optim.Adam on it and leaves it zero, so the next backward needs no fill; a gradient that is NOT that buffer is left
-    untouched (torch semantics)."""
+@pytest.mark.parametrize("consume", [True, "fused"])
+def test_adam_consumes_the_persistent_table_gradient_buffer(consume):
+    """fused/tablegrad.py: the table's .grad is the engine's persistent buffer; the HIP Adam steps like torch.optim.Adam on it and
+    has it zeroed behind the read (side-stream nsa_fill_zero, or nsa_adam_table_step_clear with "fused"), so the next backward
+    finds it clean; a gradient that is NOT that buffer is left untouched (torch semantics)."""
     from nicer_slam_amd.optim import Adam
     from nicer_slam_amd.fused import tablegrad
     torch.manual_seed(5)
     n = (1 << 18) + 6
     p0 = torch.randn(n, 2, device="cuda") * 0.1
     a, b = torch.nn.Parameter(p0.clone()), torch.nn.Parameter(p0.clone())
-    oa = Adam([{"params": [a], "lr": 0.04}], betas=(0.9, 0.99), eps=1e-15)
+    oa = Adam([{"params": [a], "lr": 0.04}], betas=(0.9, 0.99), eps=1e-15, consume_table_grads=consume)
     ob = torch.optim.Adam([{"params": [b], "lr": 0.04}], betas=(0.9, 0.99), eps=1e-15)
     ptr = None
     for it in range(4):
@@ -521,7 +522,10 @@ def test_adam_consumes_the_persistent_table_gradient_buffer():
         oa.step()
         ob.step()
         assert_close(a.detach(), b.detach().cpu().numpy(), 1e-7, 2e-6, f"param after step {it + 1}")
-        assert float(buf.abs().max()) == 0.0            # consumed
+        if consume == "fused":
+            assert float(buf.abs().max()) == 0.0        # cleared by the step kernel itself
+    torch.cuda.synchronize()
+    assert float(buf.abs().max()) == 0.0                # consumed
     # a caller-owned gradient is stepped on but not cleared
     oa.zero_grad()
     a.grad = torch.ones_like(a)
@@ -574,10 +578,10 @@ def test_table_gradients_in_place_vs_through_autograd():
                     torch.autograd.grad(golden_objective(out3, fx, "mapping"), [named[tables[2]]])
     finally:
         tablegrad.IN_PLACE = True
+    assert float(grads[False][tables[2]].abs().max()) > 0
     for k in tables:
         ref = grads[False][k]
-        assert float(ref.abs().max()) > 0
-        assert_close(grads[True][k], ref.cpu().numpy(), 1e-6 + 2e-5 * float(ref.abs().max()), 1e-3, k)
+        assert_close(grads[True][k], ref.cpu().numpy(), 1e-7 + 2e-5 * float(ref.abs().max()), 1e-3, k)
 
 
 @pytest.mark.parametrize("P", [1, 63, 4097, 100003, 8192 * 98])

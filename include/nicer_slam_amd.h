@@ -372,6 +372,17 @@ int nsa_adam_table_step(float *param, const float *grad, float *exp_avg, float *
 int nsa_adam_table_step_clear(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, uint32_t step,
                               float lr, float beta1, float beta2, float eps, nsa_stream_t stream);
 
+/* The same Adam step over up to 24 SMALL tensors (n <= 2^24 each) in one launch: the weight_v / weight_g / bias tensors of the
+ * trained MLPs.  Per-tensor lr and step count; beta1, beta2, eps shared.  4-byte aligned pointers suffice. */
+typedef struct nsa_adam_seg {
+    float *param;
+    const float *grad;
+    float *exp_avg, *exp_avg_sq;
+    uint32_t n, step;
+    float lr;
+} nsa_adam_seg_t;
+int nsa_adam_multi_step(const nsa_adam_seg_t *segs, uint32_t count, float beta1, float beta2, float eps, nsa_stream_t stream);
+
 /* p[0..n) = 0 (p 16-byte aligned): the zero fill of a table-gradient buffer as a library launch, so that it can run on a side
  * stream under the next iteration's forward kernels (nicer_slam_amd/fused/tablegrad.py).  replaces optimizer.zero_grad() +
  * the zero-initialised dense gradient of code/hashencoder/hashgrid.py:117-118. */

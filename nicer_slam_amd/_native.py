@@ -147,6 +147,14 @@ lib.nsa_weight_norm_flat_backward.restype = _i
 lib.nsa_weight_norm_flat_backward.argtypes = [ctypes.POINTER(WnLayer), _u32, _p, _p, _p, _p]
 lib.nsa_emit_row.restype = _i
 lib.nsa_emit_row.argtypes = [_p, _p, _p, _u32, ctypes.c_uint64, _f32, _p]
+class AdamSeg(ctypes.Structure):
+    """nsa_adam_seg_t"""
+    _fields_ = [("param", _p), ("grad", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("n", _u32), ("step", _u32), ("lr", _f32)]
+
+
+lib.nsa_adam_multi_step.restype = _i
+lib.nsa_adam_multi_step.argtypes = [ctypes.POINTER(AdamSeg), _u32, _f32, _f32, _f32, _p]
+EXPORTS += ["nsa_adam_multi_step"]
 lib.nsa_fill_zero.restype = _i
 lib.nsa_fill_zero.argtypes = [_p, ctypes.c_uint64, _p]
 EXPORTS += ["nsa_weight_norm_flat", "nsa_weight_norm_flat_backward", "nsa_emit_row", "nsa_fill_zero"]

@@ -248,6 +248,30 @@ __global__ __launch_bounds__(256) void k_adam_table_scalar(AdamTableArgs a) {
     }
 }
 
+// Adam over up to ADAM_MULTI_MAX small tensors in ONE launch (the ~15 weight_v / weight_g / bias tensors of the two trained MLPs:
+// a launch each was 13 x ~4.5 us of device time per mapping iteration for a few thousand floats).  Block b works on 256 elements
+// of segment seg_of(b); per-segment step sizes (lr and step count may differ between parameter groups).
+constexpr int ADAM_MULTI_MAX = 24;
+struct AdamMultiArgs {
+    float* p[ADAM_MULTI_MAX]; float* g[ADAM_MULTI_MAX]; float* m[ADAM_MULTI_MAX]; float* v[ADAM_MULTI_MAX];
+    uint32_t n[ADAM_MULTI_MAX];
+    uint32_t block0[ADAM_MULTI_MAX + 1];      // first block of every segment
+    float step_size[ADAM_MULTI_MAX], bc2_sqrt[ADAM_MULTI_MAX];
+    float w1, beta2, w2, eps;
+    uint32_t count;
+};
+
+__global__ __launch_bounds__(256) void k_adam_multi(AdamMultiArgs a) {
+    uint32_t s = 0;
+    while (s + 1 < a.count && blockIdx.x >= a.block0[s + 1]) ++s;
+    const uint32_t i = (blockIdx.x - a.block0[s]) * 256 + threadIdx.x;
+    if (i >= a.n[s]) return;
+    AdamTableArgs one;
+    one.w1 = a.w1; one.beta2 = a.beta2; one.w2 = a.w2; one.eps = a.eps;
+    one.step_size = a.step_size[s]; one.bc2_sqrt = a.bc2_sqrt[s];
+    adam_one(a.p[s][i], a.g[s][i], a.m[s][i], a.v[s][i], one);
+}
+
 // ---- weight-normed MLP parameters <-> the flat effective parameter vector, one launch per direction ---------------------------
 // flat = [W_0 (rows x cols, row-major), b_0, W_1, b_1, .., 0] with W_l[r,:] = v_l[r,:] * g_l[r] / ||v_l[r,:]||  -- what
 // torch._weight_norm(v, g, dim=0) computes per layer (nn.utils.weight_norm of code/model/base_networks.py:137-141, 376-379) followed
@@ -490,12 +514,40 @@ int nsa_adam_table_step_clear(float* param, float* grad, float* exp_avg, float* 
     return adam_table_launch(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, true, stream);
 }
 
+int nsa_adam_multi_step(const nsa_adam_seg_t* segs, uint32_t count, float beta1, float beta2, float eps, nsa_stream_t stream) {
+    using namespace nsa;
+    if (count == 0) return NSA_OK;
+    if (!segs || count > (uint32_t)ADAM_MULTI_MAX) return NSA_EBADARG;
+    AdamMultiArgs a;
+    uint32_t blocks = 0;
+    for (uint32_t s = 0; s < count; ++s) {
+        const nsa_adam_seg_t& g = segs[s];
+        if (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq || g.step == 0 || g.n == 0 || g.n > (1u << 24)) return NSA_EBADARG;
+        if ((reinterpret_cast<uintptr_t>(g.param) | reinterpret_cast<uintptr_t>(g.grad) | reinterpret_cast<uintptr_t>(g.exp_avg) |
+             reinterpret_cast<uintptr_t>(g.exp_avg_sq)) & 3u) return NSA_EBADARG;
+        a.p[s] = g.param; a.g[s] = const_cast<float*>(g.grad); a.m[s] = g.exp_avg; a.v[s] = g.exp_avg_sq;
+        a.n[s] = g.n;
+        a.block0[s] = blocks;
+        blocks += (g.n + 255) / 256;
+        const double bc1 = 1.0 - pow((double)beta1, (double)g.step);
+        const double bc2 = 1.0 - pow((double)beta2, (double)g.step);
+        a.step_size[s] = (float)((double)g.lr / bc1);
+        a.bc2_sqrt[s] = (float)sqrt(bc2);
+    }
+    a.block0[count] = blocks;
+    a.w1 = 1.0f - beta1; a.beta2 = beta2; a.w2 = 1.0f - beta2; a.eps = eps;
+    a.count = count;
+    launch_begin();
+    hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_end();
+}
+
 int nsa_fill_zero(float* p, uint64_t n, nsa_stream_t stream) {
     using namespace nsa;
     if (!p || (reinterpret_cast<uintptr_t>(p) & 15u)) return NSA_EBADARG;
     if (n == 0) return NSA_OK;
     uint64_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > 256 * 32) blocks = 256 * 32;
     if (blocks == 0) blocks = 1;
     launch_begin();
     hipLaunchKernelGGL(k_fill_zero, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, p, n);

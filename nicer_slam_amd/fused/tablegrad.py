@@ -7,23 +7,24 @@ pass + eikonal pass) are pure HBM streaming.  Here every table owns ONE persiste
 
 * the MAP backward kernels scatter straight into ``param.grad`` -- which is this buffer whenever ``param.grad`` was None (the
   state optimizer.zero_grad() leaves) -- so both passes of an iteration accumulate in place and autograd has nothing to add;
-* ``nicer_slam_amd.optim.Adam`` consumes the buffer: once its step kernel has read the gradient, the zero fill for the NEXT
-  iteration is issued on a side stream (nsa_fill_zero), where it streams to HBM underneath the next forward pass's gather- and
-  ALU-bound kernels instead of in front of the backward; the first MAP kernel that scatters into the buffer waits for it.
-  (Clearing inside the Adam kernel -- nsa_adam_table_step_clear, ``consume_table_grads="fused"`` -- measured SLOWER than fill +
-  step: an eighth concurrent stream costs the 1 GiB step more than the separate fill does, profiles/r05_ab_experiments.txt r5w.)
+* the buffer is zero-filled by the engine right before the first MAP kernel of a backward pass adds into it (nsa_fill_zero on
+  the launch stream -- it also leaves the buffer's lines warm in the cache for the atomics that follow).  Two other clearing
+  policies exist for nicer_slam_amd.optim.Adam(consume_table_grads=...) and both measured slower on MI355X
+  (profiles/r05_ab_experiments.txt r5w): the fill on a side stream behind the optimizer's read, underneath the next forward pass
+  (True), and clearing inside the step kernel (nsa_adam_table_step_clear, "fused").
 
 Observable semantics: after ``loss.backward()`` ``param.grad`` holds the accumulated gradient exactly as with autograd
-(including accumulation over several backward calls, and into a ``.grad`` tensor the caller put there).  Differences, both
-documented in INTEGRATION.md: the table gradients do not travel through autograd (``torch.autograd.grad(loss, table)`` raises;
-tensor hooks on the tables do not fire), and after ``nicer_slam_amd.optim.Adam.step()`` a table's ``.grad`` reads zero until
-the next backward (the gradient was consumed).  ``NSA_TABLE_GRADS=autograd`` (or ``IN_PLACE = False``) restores fresh
+(including accumulation over several backward calls, and into a ``.grad`` tensor the caller put there).  Differences
+(INTEGRATION.md): the table gradients do not travel through autograd (``torch.autograd.grad(loss, table)`` raises;
+tensor hooks on the tables do not fire), the gradient tensor is the SAME storage every iteration (a ``.grad`` kept across
+iterations is overwritten by the next backward), and with a consuming optimizer policy a table's ``.grad`` must not be read
+after ``step()``.  ``NSA_TABLE_GRADS=autograd`` (or ``IN_PLACE = False``) restores fresh
 zero-filled gradients returned through autograd.
 """
 import os
-from torch.utils.weak import WeakTensorKeyDictionary
 
 import torch
+from torch.utils.weak import WeakTensorKeyDictionary
 
 IN_PLACE = os.environ.get("NSA_TABLE_GRADS", "inplace") != "autograd"
 

@@ -3,30 +3,50 @@
 the two small MLPs).  One HIP pass per parameter tensor (csrc/map_tail.hip: 4 reads + 3 writes per element, the HBM
 floor of a dense Adam step) instead of torch's seven multi-tensor passes.
 
-``consume_table_grads`` (default on): a grid table whose ``.grad`` is the fused mapping engine's persistent buffer
-(fused/tablegrad.py) has that gradient CONSUMED by ``step()`` -- once read it is zero-filled on a side stream, underneath the
-next forward pass, so that the next backward finds a clean buffer without a fill in its way; such a ``.grad`` must not be read
-after ``step()`` (it is being cleared; zero once the next backward has started).  ``"fused"`` clears inside the step kernel
-instead (zero right after ``step()``, but a slower step).  Every other gradient is left untouched, as torch does.
+``consume_table_grads``: what happens to a grid table's gradient that lives in the fused mapping engine's persistent buffer
+(fused/tablegrad.py) once ``step()`` has read it.  ``False`` (default): nothing -- the engine zero-fills the buffer right before
+the next backward scatters into it (nsa_fill_zero), which also leaves its lines warm in the cache for the atomics.  ``True``: the
+fill is issued on a side stream behind the read, underneath the next forward pass; ``"fused"``: cleared inside the step kernel
+(nsa_adam_table_step_clear).  Both measured SLOWER than the default on MI355X (profiles/r05_ab_experiments.txt r5w: the scatter
+misses the cache, and an eighth concurrent stream slows the 1 GiB step more than a separate fill costs); with either, such a
+``.grad`` must not be read after ``step()``.  Every other gradient is left untouched, as torch does.
+Tensors of up to 65536 elements (the MLP parameters) are stepped 24 per launch (nsa_adam_multi_step).
 
 Same semantics, operation order and state layout as torch.optim.Adam without weight decay / amsgrad / maximize:
 ``state[p] = {"step": tensor(float), "exp_avg", "exp_avg_sq"}``, so state_dicts are interchangeable.  CUDA float32
 contiguous parameters only; anything else raises (no fallback).
 """
+import os
+
 import torch
 
-from ._native import lib, check
+from ._native import lib, check, AdamSeg
 from ._version import bump_version
 from .fused import tablegrad
 
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, consume_table_grads=True):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, consume_table_grads=None):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        if consume_table_grads is None:      # NSA_TABLE_GRAD_CLEAR = acquire (default) | async | fused: A/B switch of the clearing policy
+            consume_table_grads = {"acquire": False, "async": True, "fused": "fused"}[os.environ.get("NSA_TABLE_GRAD_CLEAR", "acquire")]
         self.consume_table_grads = consume_table_grads
+
+    SMALL = 1 << 16        # tensors up to this many elements share launches (nsa_adam_multi_step, 24 per launch)
+
+    def _flush(self, batch, key, st):
+        if not batch:
+            return
+        b1, b2, eps = key[1:]
+        segs = (AdamSeg * len(batch))(*[AdamSeg(p.data_ptr(), g.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(),
+                                                p.numel(), int(s["step"]), lr) for p, g, s, lr in batch])
+        check(lib.nsa_adam_multi_step(segs, len(batch), b1, b2, eps, st))
+        for p, _, _, _ in batch:
+            bump_version(p)
+        batch.clear()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -35,6 +55,7 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         st = torch.cuda.current_stream().cuda_stream
+        batch, batch_key = [], None
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -52,8 +73,15 @@ class Adam(torch.optim.Optimizer):
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state["step"] += 1
-                # a table gradient living in the fused engine's persistent buffer is consumed: read and left zero, so the next
-                # backward scatters into it without a fill (fused/tablegrad.py)
+                if 0 < p.numel() <= self.SMALL:
+                    key = (p.device, float(b1), float(b2), float(group["eps"]))
+                    if key != batch_key or len(batch) == 24:
+                        self._flush(batch, batch_key, st)
+                        batch_key = key
+                    batch.append((p, g, state, float(group["lr"])))      # g: kept alive until the launch
+                    continue
+                # a table gradient living in the fused engine's persistent buffer can be consumed: zero-filled behind the read
+                # (fused/tablegrad.py)
                 consume = self.consume_table_grads if tablegrad.consumable(p, g) else False
                 step_fn = lib.nsa_adam_table_step_clear if consume == "fused" else lib.nsa_adam_table_step
                 check(step_fn(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(), p.numel(),
@@ -65,4 +93,5 @@ class Adam(torch.optim.Optimizer):
                 # the kernel wrote p behind autograd's back: bump its version counter like an in-place op would
                 # (the packed-weight caches of the fused engine key on it)
                 bump_version(p)
+        self._flush(batch, batch_key, st)
         return loss

@@ -26,6 +26,8 @@ import os
 import torch
 from torch.utils.weak import WeakTensorKeyDictionary
 
+from .. import _streams
+
 IN_PLACE = os.environ.get("NSA_TABLE_GRADS", "inplace") != "autograd"
 
 
@@ -36,16 +38,6 @@ class _Entry:
         self.buf = torch.zeros_like(param, memory_format=torch.contiguous_format)
         self.clean = True
         self.done = None          # event of a zero fill in flight on the side stream
-
-
-_side = {}
-
-
-def _side_stream(device):
-    s = _side.get(device)
-    if s is None:
-        s = _side[device] = torch.cuda.Stream(device=device)
-    return s
 
 
 def _fill(buf, stream):
@@ -73,6 +65,7 @@ def _entry(param):
 def target(param):
     """The tensor the MAP kernels of this backward pass add ``param``'s gradient into (float32, contiguous, param's shape);
     afterwards it is (part of) ``param.grad``.  Called inside autograd.Function.backward; the Function returns None for the table."""
+    _streams.settle(param)                 # an overlapped optimizer step still reading the previous gradient
     g = param.grad
     if g is not None:
         if g.dtype == torch.float32 and g.is_contiguous() and g.shape == param.shape and g.device == param.device and not g.is_sparse:
@@ -115,7 +108,7 @@ def clear_async(param):
         return
     dev = e.buf.device
     with torch.cuda.device(dev):
-        main, side = torch.cuda.current_stream(), _side_stream(dev)
+        main, side = torch.cuda.current_stream(), _streams.side_stream(dev)
         side.wait_stream(main)
         _fill(e.buf, side)
         if e.done is None:

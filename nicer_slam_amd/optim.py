@@ -12,6 +12,11 @@ misses the cache, and an eighth concurrent stream slows the 1 GiB step more than
 ``.grad`` must not be read after ``step()``.  Every other gradient is left untouched, as torch does.
 Tensors of up to 65536 elements (the MLP parameters) are stepped 24 per launch (nsa_adam_multi_step).
 
+``overlap_min_numel``: tensors at least this large are stepped on a side stream (nicer_slam_amd/_streams.py): ``step()`` returns
+with the update in flight, the fused engine's kernels that read the tensor wait for it, and the ray sampler / SDF forward of the
+next iteration -- which read only the SDF tables -- run meanwhile.  Opt-in: code outside the engine that reads such a parameter
+must call ``optimizer.synchronize()`` first.
+
 Same semantics, operation order and state layout as torch.optim.Adam without weight decay / amsgrad / maximize:
 ``state[p] = {"step": tensor(float), "exp_avg", "exp_avg_sq"}``, so state_dicts are interchangeable.  CUDA float32
 contiguous parameters only; anything else raises (no fallback).
@@ -20,6 +25,7 @@ import os
 
 import torch
 
+from . import _streams
 from ._native import lib, check, AdamSeg
 from ._version import bump_version
 from .fused import tablegrad
@@ -27,13 +33,20 @@ from .fused import tablegrad
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, consume_table_grads=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, consume_table_grads=None, overlap_min_numel=None):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         if consume_table_grads is None:      # NSA_TABLE_GRAD_CLEAR = acquire (default) | async | fused: A/B switch of the clearing policy
             consume_table_grads = {"acquire": False, "async": True, "fused": "fused"}[os.environ.get("NSA_TABLE_GRAD_CLEAR", "acquire")]
         self.consume_table_grads = consume_table_grads
+        if overlap_min_numel is None and os.environ.get("NSA_ADAM_OVERLAP"):
+            overlap_min_numel = int(os.environ["NSA_ADAM_OVERLAP"])
+        self.overlap_min_numel = overlap_min_numel
+
+    def synchronize(self):
+        """The current stream waits for every overlapped step still in flight (before reading parameters outside the engine)."""
+        _streams.settle_all()
 
     SMALL = 1 << 16        # tensors up to this many elements share launches (nsa_adam_multi_step, 24 per launch)
 
@@ -84,8 +97,21 @@ class Adam(torch.optim.Optimizer):
                 # (fused/tablegrad.py)
                 consume = self.consume_table_grads if tablegrad.consumable(p, g) else False
                 step_fn = lib.nsa_adam_table_step_clear if consume == "fused" else lib.nsa_adam_table_step
+                overlap = self.overlap_min_numel is not None and p.numel() >= self.overlap_min_numel and consume is False
+                run_on = st
+                if overlap:       # this table's step streams to HBM underneath the next forward's sampler (see _streams.py)
+                    main, side = torch.cuda.current_stream(p.device), _streams.side_stream(p.device)
+                    _streams.settle(p)
+                    side.wait_stream(main)
+                    run_on = side.cuda_stream
                 check(step_fn(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(), p.numel(),
-                              int(state["step"]), float(group["lr"]), float(b1), float(b2), float(group["eps"]), st))
+                              int(state["step"]), float(group["lr"]), float(b1), float(b2), float(group["eps"]), run_on))
+                if overlap:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    _streams.defer(p, ev)
+                    for t in (p, g, state["exp_avg"], state["exp_avg_sq"]):
+                        t.record_stream(side)
                 if consume == "fused":
                     tablegrad.mark_clean(p)
                 elif consume:

@@ -3,6 +3,7 @@
 //   k_adam_table      torch.optim.Adam over a (large) parameter tensor in one pass
 // Reference: SLAMNetwork.update_voxels (code/model/network.py:62-76); torch.optim.Adam as configured by
 // code/training/volsdf_train.py:174 (betas (0.9, 0.99), eps 1e-15, no weight decay, no amsgrad).
+#include <cstdlib>
 #include "sdf_net.hpp"
 
 namespace nsa {
@@ -546,8 +547,11 @@ int nsa_fill_zero(float* p, uint64_t n, nsa_stream_t stream) {
     using namespace nsa;
     if (!p || (reinterpret_cast<uintptr_t>(p) & 15u)) return NSA_EBADARG;
     if (n == 0) return NSA_OK;
+    // 8 resident blocks per CU, grid-stride: every sweep of the grid writes one contiguous 8 MiB region
+    // (NSA_FILL_BLOCKS: A/B override, tools/micro/fill_bench.py)
+    static const uint64_t cap = [] { const char* e = getenv("NSA_FILL_BLOCKS"); return e && atoll(e) > 0 ? (uint64_t)atoll(e) : 2048ull; }();
     uint64_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
     launch_begin();
     hipLaunchKernelGGL(k_fill_zero, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, p, n);

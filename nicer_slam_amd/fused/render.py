@@ -10,7 +10,6 @@ import os
 
 import torch
 
-from .. import _streams
 from .._native import lib, check, PointsDesc
 from ..hashencoder.backend import _timed
 from . import pack
@@ -81,9 +80,10 @@ def _table_result(gt):
     return None if tablegrad.IN_PLACE else gt
 
 
-# bits of the 30-bit Morton code the launch order is sorted on (24 = a 256^3 lattice: three radix passes instead of four; points
-# of one such cell keep their ray order)
-MORTON_BITS = int(os.environ.get("NSA_MORTON_BITS", "30"))
+# bits of the 30-bit Morton code the launch order is sorted on: 24 = a 256^3 lattice, three radix passes; the points of one such
+# cell keep their ray order.  (Interleaved A/B of a mapping iteration, tools/ab_mapping.py: 23-25 bits 0.05-0.15 ms faster than the
+# full 30 -- one pass less, and the MAP kernels do not lose by it; profiles/r05_ab_experiments.txt r5y/r5z.)
+MORTON_BITS = int(os.environ.get("NSA_MORTON_BITS", "24"))
 
 
 def morton_order(pts_desc, P, device):
@@ -110,8 +110,7 @@ def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd, sort_p
     imp = model.implicit_network
     gc, keep_c = sdf_grid_desc(model, "coarse")
     gf, keep_f = sdf_grid_desc(model, "fine")
-    gr, keep_r = grid_desc(model.rendering_network.encoding, model.rendering_network.divide_factor, 2, precision_of(model, "colour"),
-                           settle=False)          # (the colour table's pending optimizer step is waited for below, not here)
+    gr, keep_r = grid_desc(model.rendering_network.encoding, model.rendering_network.divide_factor, 2, precision_of(model, "colour"))
     pc, pf, pr = packed_sdf(model, "coarse"), packed_sdf(model, "fine"), packed_colour(model)
     order = morton_order(_pts(rays_o, rays_d, z_vals), P, dev) if sort_points else None
     pts = _pts(rays_o, rays_d, z_vals, order)
@@ -136,7 +135,6 @@ def composite_forward_raw(model, rays_o, rays_d, z_vals, stage, need_bwd, sort_p
             with _timed("k_sdfnet_fwd<fine>", P * 8 * 8 * 4 * 4):
                 check(lib.nsa_sdfnet_forward(ctypes.byref(pts), ctypes.byref(gf), pf.data_ptr(), 1, b["sdf"].data_ptr(),
                                              b["grad"].data_ptr(), b["feat"].data_ptr(), st))
-    _streams.settle(model.rendering_network.encoding.embeddings)      # first reader of the colour table in this pass
     if track is not None and not composite and COLOUR_FWD_TRACK and S == 128 and order is None:
         t_out = dict(g_sdf=torch.empty(P, device=dev), g_rgb=torch.empty(P, 3, device=dev), g_grad=torch.empty(P, 3, device=dev))
         with _timed("k_colour_fwd", P * 16 * 8 * 2 * 4):

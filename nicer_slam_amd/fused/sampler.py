@@ -8,7 +8,6 @@ import os
 import numpy as np
 import torch
 
-from .. import _streams
 from .._native import lib, check, GridDesc
 from ..hashencoder.backend import _offsets_host, _timed
 from . import pack
@@ -82,10 +81,8 @@ def forward_pair_ok(model):
     return FWD_PAIR and tile_of(model, "fine") == 16 and tile_of(model, "coarse_pair") == 16
 
 
-def grid_desc(net_or_enc, divide_factor, n_hidden, precision=0, tile=0, settle=True):
+def grid_desc(net_or_enc, divide_factor, n_hidden, precision=0, tile=0):
     enc = net_or_enc
-    if settle:                             # an optimizer step of this table overlapped on the side stream (optim.Adam): the
-        _streams.settle(enc.embeddings)    # caller's launches wait for it (settle=False: the caller does so at its first use)
     off = _offsets_host(enc.offsets)
     d = GridDesc(enc.embeddings.data_ptr(), off.data_ptr(), enc.num_levels, enc.level_dim,
                  float(np.log2(enc.per_level_scale)), enc.base_resolution, float(divide_factor), n_hidden, precision, tile)

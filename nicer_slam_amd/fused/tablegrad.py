@@ -8,17 +8,17 @@ pass + eikonal pass) are pure HBM streaming.  Here every table owns ONE persiste
 * the MAP backward kernels scatter straight into ``param.grad`` -- which is this buffer whenever ``param.grad`` was None (the
   state optimizer.zero_grad() leaves) -- so both passes of an iteration accumulate in place and autograd has nothing to add;
 * the buffer is zero-filled by the engine right before the first MAP kernel of a backward pass adds into it (nsa_fill_zero on
-  the launch stream -- it also leaves the buffer's lines warm in the cache for the atomics that follow).  Two other clearing
-  policies exist for nicer_slam_amd.optim.Adam(consume_table_grads=...) and both measured slower on MI355X
-  (profiles/r05_ab_experiments.txt r5w): the fill on a side stream behind the optimizer's read, underneath the next forward pass
-  (True), and clearing inside the step kernel (nsa_adam_table_step_clear, "fused").
+  the launch stream).  Alternatives measured and not kept (profiles/r05_ab_experiments.txt r5w-r5z): clearing inside the Adam
+  kernel (kept as an option, nsa_adam_table_step_clear: the eighth stream slows the 1 GiB step by more than the fill costs), the
+  fill on a side stream underneath the next forward pass, and the 1 GiB table's Adam step itself on a side stream underneath the
+  next iteration's ray sampler (no gain either: the forward kernels slow down by what the overlap hides).
 
 Observable semantics: after ``loss.backward()`` ``param.grad`` holds the accumulated gradient exactly as with autograd
 (including accumulation over several backward calls, and into a ``.grad`` tensor the caller put there).  Differences
 (INTEGRATION.md): the table gradients do not travel through autograd (``torch.autograd.grad(loss, table)`` raises;
 tensor hooks on the tables do not fire), the gradient tensor is the SAME storage every iteration (a ``.grad`` kept across
-iterations is overwritten by the next backward), and with a consuming optimizer policy a table's ``.grad`` must not be read
-after ``step()``.  ``NSA_TABLE_GRADS=autograd`` (or ``IN_PLACE = False``) restores fresh
+iterations is overwritten by the next backward), and with ``optim.Adam(consume_table_grads=True)`` a table's ``.grad`` reads
+zero after ``step()``.  ``NSA_TABLE_GRADS=autograd`` (or ``IN_PLACE = False``) restores fresh
 zero-filled gradients returned through autograd.
 """
 import os
@@ -26,30 +26,20 @@ import os
 import torch
 from torch.utils.weak import WeakTensorKeyDictionary
 
-from .. import _streams
-
 IN_PLACE = os.environ.get("NSA_TABLE_GRADS", "inplace") != "autograd"
 
 
 class _Entry:
-    __slots__ = ("buf", "clean", "done")
+    __slots__ = ("buf", "clean")
 
     def __init__(self, param):
         self.buf = torch.zeros_like(param, memory_format=torch.contiguous_format)
         self.clean = True
-        self.done = None          # event of a zero fill in flight on the side stream
 
 
 def _fill(buf, stream):
     from .._native import lib, check
     check(lib.nsa_fill_zero(buf.data_ptr(), buf.numel(), stream.cuda_stream))
-
-
-def _settle(e):
-    """make the current stream wait for a fill in flight"""
-    if e.done is not None:
-        torch.cuda.current_stream(e.buf.device).wait_event(e.done)
-        e.done = None
 
 
 _pool = WeakTensorKeyDictionary()
@@ -65,20 +55,17 @@ def _entry(param):
 def target(param):
     """The tensor the MAP kernels of this backward pass add ``param``'s gradient into (float32, contiguous, param's shape);
     afterwards it is (part of) ``param.grad``.  Called inside autograd.Function.backward; the Function returns None for the table."""
-    _streams.settle(param)                 # an overlapped optimizer step still reading the previous gradient
     g = param.grad
     if g is not None:
         if g.dtype == torch.float32 and g.is_contiguous() and g.shape == param.shape and g.device == param.device and not g.is_sparse:
             e = _pool.get(param)
             if e is not None and e.buf.data_ptr() == g.data_ptr():
-                _settle(e)
                 e.clean = False
             return g                       # accumulate where the gradient already lives (ours or the caller's)
         raise RuntimeError("fused mapping engine: a table's .grad must be a dense contiguous float32 tensor of the table's shape "
                            "(set NSA_TABLE_GRADS=autograd for gradients returned through autograd)")
     e = _entry(param)
-    _settle(e)
-    if not e.clean:                        # left dirty: zero_grad() without our Adam step, or another optimizer consumed it
+    if not e.clean:                        # holds the previous pass's gradient (clean only when new, or cleared by the optimizer)
         with torch.cuda.device(e.buf.device):
             _fill(e.buf, torch.cuda.current_stream())
     e.clean = False
@@ -98,21 +85,3 @@ def mark_clean(param):
     e = _pool.get(param)
     if e is not None:
         e.clean = True
-
-
-def clear_async(param):
-    """The optimizer has read ``param``'s buffer on the current stream: zero it on the side stream, behind that read.  Until the next
-    backward the buffer's contents are unspecified (being cleared)."""
-    e = _pool.get(param)
-    if e is None:
-        return
-    dev = e.buf.device
-    with torch.cuda.device(dev):
-        main, side = torch.cuda.current_stream(), _streams.side_stream(dev)
-        side.wait_stream(main)
-        _fill(e.buf, side)
-        if e.done is None:
-            e.done = torch.cuda.Event()
-        e.done.record(side)
-        e.buf.record_stream(side)
-    e.clean = True

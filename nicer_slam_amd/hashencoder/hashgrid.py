@@ -21,7 +21,6 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
-from .. import _streams
 from .backend import _backend  # noqa: F401  (module attribute = native seam; tests may swap it)
 
 
@@ -141,7 +140,6 @@ class HashEncoder(nn.Module):
                 f"params={tuple(self.embeddings.shape)}")
 
     def forward(self, inputs, size=1):
-        _streams.settle(self.embeddings)        # an optimizer step of this table overlapped on a side stream (optim.Adam)
         inputs = (inputs + size) / (2 * size)   # [-size, size] -> [0, 1]
         prefix_shape = list(inputs.shape[:-1])
         inputs = inputs.view(-1, self.input_dim)

@@ -5,17 +5,10 @@ floor of a dense Adam step) instead of torch's seven multi-tensor passes.
 
 ``consume_table_grads``: what happens to a grid table's gradient that lives in the fused mapping engine's persistent buffer
 (fused/tablegrad.py) once ``step()`` has read it.  ``False`` (default): nothing -- the engine zero-fills the buffer right before
-the next backward scatters into it (nsa_fill_zero), which also leaves its lines warm in the cache for the atomics.  ``True``: the
-fill is issued on a side stream behind the read, underneath the next forward pass; ``"fused"``: cleared inside the step kernel
-(nsa_adam_table_step_clear).  Both measured SLOWER than the default on MI355X (profiles/r05_ab_experiments.txt r5w: the scatter
-misses the cache, and an eighth concurrent stream slows the 1 GiB step more than a separate fill costs); with either, such a
-``.grad`` must not be read after ``step()``.  Every other gradient is left untouched, as torch does.
+the next backward scatters into it (nsa_fill_zero).  ``True``: cleared inside the step kernel (nsa_adam_table_step_clear; such a
+``.grad`` reads zero after ``step()``) -- measured SLOWER on MI355X: an eighth concurrent stream slows the 1 GiB step by more than
+the separate fill costs (profiles/r05_ab_experiments.txt r5w).  Every other gradient is left untouched, as torch does.
 Tensors of up to 65536 elements (the MLP parameters) are stepped 24 per launch (nsa_adam_multi_step).
-
-``overlap_min_numel``: tensors at least this large are stepped on a side stream (nicer_slam_amd/_streams.py): ``step()`` returns
-with the update in flight, the fused engine's kernels that read the tensor wait for it, and the ray sampler / SDF forward of the
-next iteration -- which read only the SDF tables -- run meanwhile.  Opt-in: code outside the engine that reads such a parameter
-must call ``optimizer.synchronize()`` first.
 
 Same semantics, operation order and state layout as torch.optim.Adam without weight decay / amsgrad / maximize:
 ``state[p] = {"step": tensor(float), "exp_avg", "exp_avg_sq"}``, so state_dicts are interchangeable.  CUDA float32
@@ -25,7 +18,6 @@ import os
 
 import torch
 
-from . import _streams
 from ._native import lib, check, AdamSeg
 from ._version import bump_version
 from .fused import tablegrad
@@ -33,20 +25,13 @@ from .fused import tablegrad
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, consume_table_grads=None, overlap_min_numel=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, consume_table_grads=None):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
-        if consume_table_grads is None:      # NSA_TABLE_GRAD_CLEAR = acquire (default) | async | fused: A/B switch of the clearing policy
-            consume_table_grads = {"acquire": False, "async": True, "fused": "fused"}[os.environ.get("NSA_TABLE_GRAD_CLEAR", "acquire")]
+        if consume_table_grads is None:      # NSA_TABLE_GRAD_CLEAR = acquire (default) | fused: A/B switch of the clearing policy
+            consume_table_grads = {"acquire": False, "fused": True}[os.environ.get("NSA_TABLE_GRAD_CLEAR", "acquire")]
         self.consume_table_grads = consume_table_grads
-        if overlap_min_numel is None and os.environ.get("NSA_ADAM_OVERLAP"):
-            overlap_min_numel = int(os.environ["NSA_ADAM_OVERLAP"])
-        self.overlap_min_numel = overlap_min_numel
-
-    def synchronize(self):
-        """The current stream waits for every overlapped step still in flight (before reading parameters outside the engine)."""
-        _streams.settle_all()
 
     SMALL = 1 << 16        # tensors up to this many elements share launches (nsa_adam_multi_step, 24 per launch)
 
@@ -95,27 +80,12 @@ class Adam(torch.optim.Optimizer):
                     continue
                 # a table gradient living in the fused engine's persistent buffer can be consumed: zero-filled behind the read
                 # (fused/tablegrad.py)
-                consume = self.consume_table_grads if tablegrad.consumable(p, g) else False
-                step_fn = lib.nsa_adam_table_step_clear if consume == "fused" else lib.nsa_adam_table_step
-                overlap = self.overlap_min_numel is not None and p.numel() >= self.overlap_min_numel and consume is False
-                run_on = st
-                if overlap:       # this table's step streams to HBM underneath the next forward's sampler (see _streams.py)
-                    main, side = torch.cuda.current_stream(p.device), _streams.side_stream(p.device)
-                    _streams.settle(p)
-                    side.wait_stream(main)
-                    run_on = side.cuda_stream
+                consume = bool(self.consume_table_grads) and tablegrad.consumable(p, g)
+                step_fn = lib.nsa_adam_table_step_clear if consume else lib.nsa_adam_table_step
                 check(step_fn(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(), p.numel(),
-                              int(state["step"]), float(group["lr"]), float(b1), float(b2), float(group["eps"]), run_on))
-                if overlap:
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    _streams.defer(p, ev)
-                    for t in (p, g, state["exp_avg"], state["exp_avg_sq"]):
-                        t.record_stream(side)
-                if consume == "fused":
+                              int(state["step"]), float(group["lr"]), float(b1), float(b2), float(group["eps"]), st))
+                if consume:
                     tablegrad.mark_clean(p)
-                elif consume:
-                    tablegrad.clear_async(p)
                 # the kernel wrote p behind autograd's back: bump its version counter like an in-place op would
                 # (the packed-weight caches of the fused engine key on it)
                 bump_version(p)

@@ -492,11 +492,11 @@ def test_flat_weight_norm_kernels_vs_torch_weight_norm():
         assert d1 is not d0 and not torch.equal(d0, d1)
 
 
-@pytest.mark.parametrize("consume", [False, True, "fused"])
+@pytest.mark.parametrize("consume", [False, True])
 def test_adam_consumes_the_persistent_table_gradient_buffer(consume):
     """fused/tablegrad.py: the table's .grad is the engine's persistent buffer; the HIP Adam steps like torch.optim.Adam on it and
-    has it zeroed behind the read (side-stream nsa_fill_zero, or nsa_adam_table_step_clear with "fused"), so the next backward
-    finds it clean; with the default policy (False) the engine clears it when the next backward acquires it.  A gradient that is
+    either clears it itself (nsa_adam_table_step_clear) or leaves that to the engine (default: nsa_fill_zero when the next backward
+    acquires it); either way the next backward finds it clean.  A gradient that is
     NOT that buffer is left untouched (torch semantics)."""
     from nicer_slam_amd.optim import Adam
     from nicer_slam_amd.fused import tablegrad
@@ -523,10 +523,7 @@ def test_adam_consumes_the_persistent_table_gradient_buffer(consume):
         oa.step()
         ob.step()
         assert_close(a.detach(), b.detach().cpu().numpy(), 1e-7, 2e-6, f"param after step {it + 1}")
-        if consume == "fused":
-            assert float(buf.abs().max()) == 0.0        # cleared by the step kernel itself
-    torch.cuda.synchronize()
-    assert (float(buf.abs().max()) == 0.0) == bool(consume)      # consumed / left for the engine to clear at the next backward
+        assert (float(buf.abs().max()) == 0.0) == consume      # cleared by the step kernel / left for the engine to clear
     # a caller-owned gradient is stepped on but not cleared
     oa.zero_grad()
     a.grad = torch.ones_like(a)

@@ -10,12 +10,9 @@ from nicer_slam_amd.fused import tablegrad, render
 
 ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-VARIANTS = [("acquire30", dict(inplace=True, consume=False, bits=30)), ("acquire24", dict(inplace=True, consume=False, bits=24)),
-            ("autograd24", dict(inplace=False, consume=False, bits=24)),
-            ("overlap24", dict(inplace=True, consume=False, bits=24, overlap=1 << 24)),
-            ("overlap24_autograd", dict(inplace=False, consume=False, bits=24, overlap=1 << 24)),
-            ("acquire25", dict(inplace=True, consume=False, bits=25)), ("acquire23", dict(inplace=True, consume=False, bits=23)),
-            ("overlap24_all", dict(inplace=True, consume=False, bits=24, overlap=1 << 20))]
+VARIANTS = [("acquire24", dict(inplace=True, consume=False, bits=24)), ("fused24", dict(inplace=True, consume=True, bits=24)),
+            ("autograd24", dict(inplace=False, consume=False, bits=24)), ("acquire30", dict(inplace=True, consume=False, bits=30)),
+            ("acquire21", dict(inplace=True, consume=False, bits=21))]
 
 
 def hook(step):
@@ -23,10 +20,7 @@ def hook(step):
     res = {n: [] for n, _ in VARIANTS}
     for rnd in range(ROUNDS):
         for name, v in VARIANTS:
-            torch.cuda.synchronize()
-            opt.synchronize()
             tablegrad.IN_PLACE, opt.consume_table_grads, render.MORTON_BITS = v["inplace"], v["consume"], v["bits"]
-            opt.overlap_min_numel = v.get("overlap")
             for _ in range(3):
                 step()
             torch.cuda.synchronize()

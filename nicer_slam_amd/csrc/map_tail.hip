@@ -232,11 +232,58 @@ __global__ __launch_bounds__(256) void k_adam_table(AdamTableArgs a) {
     }
 }
 
+// One block = 16 KiB, no loop: the dispatcher walks the buffer front to back, so HBM sees one linear write stream (6.8 TB/s on a
+// 1 GiB buffer; a grid capped at 8 blocks per CU that strides through the buffer reached 4.8 -- tools/micro/fill_bench.py, r5A).
+constexpr int FILL_GROUPS = 4;
 __global__ __launch_bounds__(256) void k_fill_zero(float* __restrict__ p, uint64_t n) {
-    const uint64_t n4 = n / 4, stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
-        reinterpret_cast<float4*>(p)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const uint64_t n4 = n / 4;
+    const uint64_t i0 = (uint64_t)blockIdx.x * (256 * FILL_GROUPS) + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < FILL_GROUPS; ++j) {
+        const uint64_t i = i0 + 256u * j;
+        if (i < n4) reinterpret_cast<float4*>(p)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     if (blockIdx.x == 0 && n4 * 4 + threadIdx.x < n) p[n4 * 4 + threadIdx.x] = 0.0f;
+}
+
+// k_adam_table with the same front-to-back block order: block b owns float4 groups [b * 256 G, (b + 1) * 256 G)
+template <bool CLEAR, int G>
+__global__ __launch_bounds__(256) void k_adam_table_linear(AdamTableArgs a) {
+    const uint64_t n4 = a.n / 4;
+    const uint64_t i0 = (uint64_t)blockIdx.x * (256 * G) + threadIdx.x;
+    float4 p[G], g[G], m[G], v[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const uint64_t i = i0 + 256u * j;
+        if (i < n4) {
+            p[j] = reinterpret_cast<float4*>(a.p)[i];
+            g[j] = reinterpret_cast<const float4*>(a.g)[i];
+            m[j] = reinterpret_cast<float4*>(a.m)[i];
+            v[j] = reinterpret_cast<float4*>(a.v)[i];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const uint64_t i = i0 + 256u * j;
+        if (i < n4) {
+            adam_one(p[j].x, g[j].x, m[j].x, v[j].x, a);
+            adam_one(p[j].y, g[j].y, m[j].y, v[j].y, a);
+            adam_one(p[j].z, g[j].z, m[j].z, v[j].z, a);
+            adam_one(p[j].w, g[j].w, m[j].w, v[j].w, a);
+            reinterpret_cast<float4*>(a.p)[i] = p[j];
+            reinterpret_cast<float4*>(a.m)[i] = m[j];
+            reinterpret_cast<float4*>(a.v)[i] = v[j];
+            if (CLEAR && (g[j].x != 0.0f || g[j].y != 0.0f || g[j].z != 0.0f || g[j].w != 0.0f))
+                reinterpret_cast<float4*>(a.g)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    }
+    if (blockIdx.x == 0) {
+        const uint64_t i = n4 * 4 + threadIdx.x;
+        if (i < a.n) {
+            adam_one(a.p[i], a.g[i], a.m[i], a.v[i], a);
+            if (CLEAR) a.g[i] = 0.0f;
+        }
+    }
 }
 
 // any alignment (gradients that are views into a larger buffer, e.g. FlatWeightNorm's): one element per thread
@@ -477,6 +524,16 @@ int nsa_morton_order(const nsa_points_t* pts, int32_t* order, uint32_t* workspac
     return launch_end();
 }
 
+// NSA_ADAM_GRID = stride | linear1 | linear2 (A/B switch, tools/ab_adam.py): 0 = the grid-stride kernel, G = k_adam_table_linear<G>
+static int adam_grid_mode() {
+    static const int mode = [] {
+        const char* e = getenv("NSA_ADAM_GRID");
+        if (!e) return 1;
+        return e[0] == 's' ? 0 : (e[6] == '2' ? 2 : 1);
+    }();
+    return mode;
+}
+
 static int adam_table_launch(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, uint32_t step,
                              float lr, float beta1, float beta2, float eps, bool clear, nsa_stream_t stream) {
     using namespace nsa;
@@ -500,6 +557,18 @@ static int adam_table_launch(float* param, float* grad, float* exp_avg, float* e
         if (sb > 256 * 32) sb = 256 * 32;
         if (clear) hipLaunchKernelGGL(k_adam_table_scalar<true>, dim3((uint32_t)sb), dim3(256), 0, (hipStream_t)stream, a);
         else       hipLaunchKernelGGL(k_adam_table_scalar<false>, dim3((uint32_t)sb), dim3(256), 0, (hipStream_t)stream, a);
+    } else if (adam_grid_mode() > 0) {
+        const int G = adam_grid_mode();
+        const uint64_t lb = (n4 + 256 * G - 1) / (256 * G) ? (n4 + 256 * G - 1) / (256 * G) : 1;
+        if (lb > 0x7FFFFFFFull) return NSA_EBADARG;
+        const dim3 grid((uint32_t)lb), block(256);
+        if (G == 1) {
+            if (clear) hipLaunchKernelGGL((k_adam_table_linear<true, 1>), grid, block, 0, (hipStream_t)stream, a);
+            else       hipLaunchKernelGGL((k_adam_table_linear<false, 1>), grid, block, 0, (hipStream_t)stream, a);
+        } else {
+            if (clear) hipLaunchKernelGGL((k_adam_table_linear<true, 2>), grid, block, 0, (hipStream_t)stream, a);
+            else       hipLaunchKernelGGL((k_adam_table_linear<false, 2>), grid, block, 0, (hipStream_t)stream, a);
+        }
     } else if (clear) hipLaunchKernelGGL(k_adam_table<true>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else              hipLaunchKernelGGL(k_adam_table<false>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return launch_end();
@@ -547,12 +616,9 @@ int nsa_fill_zero(float* p, uint64_t n, nsa_stream_t stream) {
     using namespace nsa;
     if (!p || (reinterpret_cast<uintptr_t>(p) & 15u)) return NSA_EBADARG;
     if (n == 0) return NSA_OK;
-    // 8 resident blocks per CU, grid-stride: every sweep of the grid writes one contiguous 8 MiB region
-    // (NSA_FILL_BLOCKS: A/B override, tools/micro/fill_bench.py)
-    static const uint64_t cap = [] { const char* e = getenv("NSA_FILL_BLOCKS"); return e && atoll(e) > 0 ? (uint64_t)atoll(e) : 2048ull; }();
-    uint64_t blocks = (n / 4 + 255) / 256;
-    if (blocks > cap) blocks = cap;
+    uint64_t blocks = (n / 4 + 256 * FILL_GROUPS - 1) / (256 * FILL_GROUPS);
     if (blocks == 0) blocks = 1;
+    if (blocks > 0x7FFFFFFFull) return NSA_EBADARG;
     launch_begin();
     hipLaunchKernelGGL(k_fill_zero, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, p, n);
     return launch_end();

@@ -232,9 +232,9 @@ __global__ __launch_bounds__(256) void k_adam_table(AdamTableArgs a) {
     }
 }
 
-// One block = 16 KiB, no loop: the dispatcher walks the buffer front to back, so HBM sees one linear write stream (6.8 TB/s on a
+// One block = one contiguous chunk (4 KiB per float4 group), no loop: the dispatcher walks the buffer front to back, so HBM sees one linear write stream (6.8 TB/s on a
 // 1 GiB buffer; a grid capped at 8 blocks per CU that strides through the buffer reached 4.8 -- tools/micro/fill_bench.py, r5A).
-constexpr int FILL_GROUPS = 4;
+template <int FILL_GROUPS>
 __global__ __launch_bounds__(256) void k_fill_zero(float* __restrict__ p, uint64_t n) {
     const uint64_t n4 = n / 4;
     const uint64_t i0 = (uint64_t)blockIdx.x * (256 * FILL_GROUPS) + threadIdx.x;
@@ -616,11 +616,16 @@ int nsa_fill_zero(float* p, uint64_t n, nsa_stream_t stream) {
     using namespace nsa;
     if (!p || (reinterpret_cast<uintptr_t>(p) & 15u)) return NSA_EBADARG;
     if (n == 0) return NSA_OK;
-    uint64_t blocks = (n / 4 + 256 * FILL_GROUPS - 1) / (256 * FILL_GROUPS);
+    // float4 groups per thread (NSA_FILL_GROUPS = 1 | 2 | 4: A/B override, tools/micro/fill_bench.py)
+    static const int G = [] { const char* e = getenv("NSA_FILL_GROUPS"); return e ? atoi(e) : 1; }();
+    uint64_t blocks = (n / 4 + 256 * G - 1) / (256 * G);
     if (blocks == 0) blocks = 1;
     if (blocks > 0x7FFFFFFFull) return NSA_EBADARG;
+    const dim3 grid((uint32_t)blocks), block(256);
     launch_begin();
-    hipLaunchKernelGGL(k_fill_zero, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, p, n);
+    if (G == 4)      hipLaunchKernelGGL(k_fill_zero<4>, grid, block, 0, (hipStream_t)stream, p, n);
+    else if (G == 2) hipLaunchKernelGGL(k_fill_zero<2>, grid, block, 0, (hipStream_t)stream, p, n);
+    else             hipLaunchKernelGGL(k_fill_zero<1>, grid, block, 0, (hipStream_t)stream, p, n);
     return launch_end();
 }
 

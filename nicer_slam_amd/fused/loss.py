@@ -33,9 +33,16 @@ class _FusedSlamLoss(torch.autograd.Function):
         keep = [rgb_, depth_, normal_, gth, gnei, c(rgb_gt).reshape(R, 3), c(depth_mono).reshape(R), c(depth_real).reshape(R),
                 c(depth_real_mask).reshape(R), c(mask_gt).reshape(R), c(sdf).reshape(R, -1), c(normal_gt).reshape(R, 3)]
         S = keep[10].shape[1]
-        g_rgb, g_depth, g_normal = torch.empty_like(rgb_), torch.empty_like(depth_), torch.empty_like(normal_)
-        g_theta = torch.empty_like(gth) if E else None
-        g_nei = torch.empty_like(gnei) if gnei is not None else None
+        # the five gradients live in ONE buffer: one launch scales them by the incoming cotangent in backward, and the two eikonal
+        # halves stay adjacent, as fused/mapping.py::FusedSdfGradient.backward wants them (no cat of the halves)
+        sizes = [R * 3, R, R * 3, E * 3 if E else 0, E * 3 if gnei is not None else 0]
+        gbuf = torch.empty(sum(sizes), device=dev)
+        o = [0]
+        for n_ in sizes:
+            o.append(o[-1] + n_)
+        g_rgb, g_depth, g_normal = gbuf[o[0]:o[1]].view(R, 3), gbuf[o[1]:o[2]], gbuf[o[2]:o[3]].view(R, 3)
+        g_theta = gbuf[o[3]:o[4]].view(E, 3) if E else None
+        g_nei = gbuf[o[4]:o[5]].view(E, 3) if gnei is not None else None
         terms = torch.empty(8, device=dev)
         ws = torch.empty((int(lib.nsa_slam_loss_workspace(bs, n, E)) + 1) // 2, device=dev, dtype=torch.float64)
         p = lambda t: None if t is None else t.data_ptr()
@@ -43,22 +50,20 @@ class _FusedSlamLoss(torch.autograd.Function):
                      p(normal_), p(keep[11]), p(gth), p(gnei), *[float(w) for w in weights], int(bool(whole)),
                      p(g_rgb), p(g_depth), p(g_normal), p(g_theta), p(g_nei), p(terms))
         check(lib.nsa_slam_loss(ctypes.byref(d), ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
-        ctx.shapes = (rgb.shape, depth.shape, normal.shape)
-        ctx.save_for_backward(*[t for t in (g_rgb, g_depth, g_normal, g_theta, g_nei) if t is not None])
-        ctx.have = (g_theta is not None, g_nei is not None)
+        ctx.shapes = (rgb.shape, depth.shape, normal.shape, (E, 3))
+        ctx.save_for_backward(gbuf)
+        ctx.offsets, ctx.have = o, (g_theta is not None, g_nei is not None)
         ctx.mark_non_differentiable(terms)
         return terms[7].clone(), terms
 
     @staticmethod
     def backward(ctx, g_total, _g_terms):
-        saved = list(ctx.saved_tensors)
-        g_rgb, g_depth, g_normal = saved[:3]
-        rest = saved[3:]
-        g_theta = rest.pop(0) if ctx.have[0] else None
-        g_nei = rest.pop(0) if ctx.have[1] else None
-        s_rgb, s_depth, s_normal = ctx.shapes
-        sc = lambda t, shape=None: None if t is None else (t * g_total).reshape(shape if shape is not None else t.shape)
-        return (sc(g_rgb, s_rgb), sc(g_depth, s_depth), sc(g_normal, s_normal), sc(g_theta), sc(g_nei)) + (None,) * 9
+        (gbuf,) = ctx.saved_tensors
+        g = gbuf * g_total
+        o = ctx.offsets
+        s_rgb, s_depth, s_normal, s_theta = ctx.shapes
+        return (g[o[0]:o[1]].view(s_rgb), g[o[1]:o[2]].view(s_depth), g[o[2]:o[3]].view(s_normal),
+                g[o[3]:o[4]].view(s_theta) if ctx.have[0] else None, g[o[4]:o[5]].view(s_theta) if ctx.have[1] else None) + (None,) * 9
 
 
 def fused_terms(model_outputs, rgb_gt, depth_mono, depth_real, depth_real_mask, mask_gt, normal_gt, weights, whole=False,

@@ -57,6 +57,12 @@ assert se_rows(1, 16)["ROWS"] == 512 and se_rows(3, 16)["ROWS"] == 1024
 CE = dict(IN=0, H1=130, H2=194, AB1=258, AB2=322, OB=386, ROWS=389)              # = enum CE_* (render_colour.hip)
 
 
+@functools.lru_cache(maxsize=None)
+def _zero1(device):
+    """a [1] zero on ``device``, made once (the flat gradient vectors end in one; it is only ever read)"""
+    return torch.zeros(1, device=device)
+
+
 def emit_ld(P):
     return ((P + KCHUNK - 1) // KCHUNK) * KCHUNK
 
@@ -150,7 +156,7 @@ def sdf_flat_grad(emit, g_sdf, P, L, C, NH=1, tile=32, order=None):
         parts += [Wk[:, :64].reshape(-1), Wk[:, 64]]
     if g_sdf is None:
         row0 = emit_gemm(emit, (m[f"TH{NH}"],), 64, None, 0, workspace=ws)[:, 0]       # sdf row: row sums of TH_NH
-        dbs = emit.new_zeros(1)
+        dbs = _zero1(emit.device)
     else:
         # sdf row = row sums of TH_NH + H_NH g_sdf: one product pair against two rows written here (ones; g_sdf in launch order)
         ROWS, ld = m["ROWS"], emit.shape[1]
@@ -162,7 +168,7 @@ def sdf_flat_grad(emit, g_sdf, P, L, C, NH=1, tile=32, order=None):
         row0 = emit_gemm(emit, (m[f"TH{NH}"], m[f"H{NH}"]), 64, (ROWS, ROWS + 1), 1, sums=False, workspace=ws)[:, 0]
         dbs = g_sdf.sum().reshape(1)
     Wf = emit_gemm(emit, (m["FB"],), 64, (m[f"H{NH}"],), 64, workspace=ws)               # feature rows + their biases
-    parts += [row0, Wf[:, :64].reshape(-1), dbs, Wf[:, 64], emit.new_zeros(1)]
+    parts += [row0, Wf[:, :64].reshape(-1), dbs, Wf[:, 64], _zero1(emit.device)]
     return torch.cat(parts)
 
 
@@ -173,7 +179,7 @@ def colour_flat_grad(emit):
     W1 = emit_gemm(emit, (CE["AB2"],), 64, (CE["H1"],), 64, workspace=ws)
     W2 = emit_gemm(emit, (CE["OB"],), 3, (CE["H2"],), 64, workspace=ws)
     return torch.cat([W0[:, :130][:, _on(emit.device, _col_rows)].reshape(-1), W0[:, 130], W1[:, :64].reshape(-1), W1[:, 64],
-                      W2[:, :64].reshape(-1), W2[:, 64], emit.new_zeros(1)])
+                      W2[:, :64].reshape(-1), W2[:, 64], _zero1(emit.device)])
 
 
 def _nets(model):
@@ -230,9 +236,11 @@ class FusedSdfGradient(torch.autograd.Function):
     of network.py:313-336) with gradients for (flat coarse MLP, coarse table, fine table)."""
 
     @staticmethod
-    def forward(ctx, points, flat_c, tab_c, tab_f, flat_f, model, stage):
+    def forward(ctx, points, flat_c, tab_c, tab_f, flat_f, model, stage, halves=False):
         points = points.contiguous()
         N = points.shape[0]
+        halves = bool(halves) and N % 2 == 0
+        ctx.halves = halves
         dev = points.device
         imp = model.implicit_network
         gc, keep_c = sdf_grid_desc(model, "coarse")
@@ -260,11 +268,25 @@ class FusedSdfGradient(torch.autograd.Function):
                                                  grad.data_ptr(), feat.data_ptr(), st))
         ctx.save_for_backward(points)
         ctx.model, ctx.stage, ctx.packs, ctx.order = model, stage, (pc, pf), order
+        if halves:          # the two halves as two outputs: the loss's cotangents come back as two tensors, not through slice_backward
+            ctx.set_materialize_grads(False)
+            return grad[:N // 2], grad[N // 2:]
         return grad
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g2=None):
         (points,) = ctx.saved_tensors
+        if ctx.halves:
+            n_half = points.shape[0] // 2
+            if g is None and g2 is None:
+                return (None,) * 8
+            if (g is not None and g2 is not None and g.is_contiguous() and g2.is_contiguous()
+                    and g2.data_ptr() == g.data_ptr() + g.numel() * g.element_size()
+                    and g.untyped_storage().data_ptr() == g2.untyped_storage().data_ptr()):
+                g = torch.as_strided(g, (2 * n_half, 3), (3, 1))          # adjacent halves of one buffer (fused/loss.py): no copy
+            else:
+                z = lambda t: torch.zeros(n_half, 3, device=points.device) if t is None else t
+                g = torch.cat([z(g), z(g2)], 0)
         model, stage = ctx.model, ctx.stage
         N = points.shape[0]
         dev = points.device
@@ -278,7 +300,7 @@ class FusedSdfGradient(torch.autograd.Function):
         g_x = torch.empty(N, 3, device=dev)
         need = ctx.needs_input_grad
         st = _stream()
-        out = [None, None, None, None, None, None, None]
+        out = [None, None, None, None, None, None, None, None]
         tile = tile_of(model, "coarse_map")
         emit = new_emit(se_rows(1, tile)["ROWS"], N, dev) if need[1] else None
         gt_c = _table_grad(imp.coarse.encoding.embeddings) if need[2] else None
@@ -332,9 +354,11 @@ def composite(model, rays_o, rays_d, z_vals, stage, color_stage):
                                       color_stage)
 
 
-def sdf_gradient(model, points, stage):
+def sdf_gradient(model, points, stage, halves=False):
+    """grad sdf at ``points``; ``halves``: returned as (first half, second half) -- the eikonal samples and their jittered neighbours
+    (network.py:313-336) -- as two outputs of the Function."""
     flat_c, _, tab_c, tab_f, _, flat_f = flat_inputs(model)
-    return FusedSdfGradient.apply(points, flat_c, tab_c, tab_f, flat_f, model, stage)
+    return FusedSdfGradient.apply(points, flat_c, tab_c, tab_f, flat_f, model, stage, halves)
 
 
 def update_voxels(model, rays_o, rays_d, z_vals):

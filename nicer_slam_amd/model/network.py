@@ -266,11 +266,11 @@ class SLAMNetwork(nn.Module):
             eik = torch.cat([eik, eik + (self.draw("eik_jitter", eik.shape) - 0.5) * 0.01], 0)
             if fused_kind == "params":
                 from ..fused import mapping as fused_mapping
-                grad_theta = fused_mapping.sdf_gradient(self, eik, stage)
+                output["grad_theta"], output["grad_theta_nei"] = fused_mapping.sdf_gradient(self, eik, stage, halves=True)
             else:
                 grad_theta = self.implicit_network.gradient(eik, stage=stage)
-            half = grad_theta.shape[0] // 2
-            output["grad_theta"], output["grad_theta_nei"] = grad_theta[:half], grad_theta[half:]
+                half = grad_theta.shape[0] // 2
+                output["grad_theta"], output["grad_theta_nei"] = grad_theta[:half], grad_theta[half:]
         if fused:
             normal_map = nmap_w.reshape(bs, -1, 3)
         else:

@@ -421,7 +421,9 @@ def mapping_signature(rays=8192, frames=8, samples=98):
     """What a committed atomic-request profile (profiles/rNN_mapping_pmc_per_kernel.csv) must have been taken with to be quoted
     beside a launch time of THIS run: the batch shape and the kernels' tilings (tools/profile_mapping.sh stores it next to the CSV)."""
     from nicer_slam_amd.fused.sampler import DEFAULT_TILES
-    return {"rays": rays, "keyframes": frames, "samples_per_ray": samples, "tiles": dict(sorted(DEFAULT_TILES.items()))}
+    from nicer_slam_amd.fused.render import MORTON_BITS
+    return {"rays": rays, "keyframes": frames, "samples_per_ray": samples, "tiles": dict(sorted(DEFAULT_TILES.items())),
+            "morton_bits": MORTON_BITS}      # (the launch order decides how many rows merge into one atomic request)
 
 
 def mapping_leg(device, rays=8192, frames=8, iters=5, cpu=True, step_hook=None):

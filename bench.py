@@ -569,12 +569,29 @@ def mapping_leg(device, rays=8192, frames=8, iters=5, cpu=True, step_hook=None):
                     "algorithmic_bytes_per_iteration": nbytes, "algorithmic_GBps": round(ach, 1),
                     "algorithmic_frac_of_hbm": round(ach / HBM_PEAK_GBS, 4), "atomic_scatter": atomic}
     return {"ms": round(dt * 1e3, 2), "rays": rays, "keyframes": frames, "samples_per_ray": S,
+            "device_time_in_library": mapping_library_share(),
             "objective": "SLAMLoss with the weights of code/confs/replica/runconf_replica_1.conf (rgb, eikonal, smooth, ssi depth, "
                          "normals, patch warp [patch 1], flow over %d edges); stage fine / highfreq" % len(pairs),
             "eikonal_points": 22 * rays, "rays_per_s": round(rays / dt, 1), "engine": model.last_engine,
             "optimizer": "nicer_slam_amd.optim.Adam (1.1 GiB of parameters, dense)", "iters": iters,
             "final_loss": round(float(last), 6), "kernels_ms": {k: round(v, 3) for k, v in sorted(agg.items())},
             "roofline": roof, "cpu_baseline": cpu_mapping_baseline(model) if cpu else None}
+
+
+def mapping_library_share():
+    """Share of a mapping iteration's device time spent in this library's kernels (names in namespace nsa::) and launches per iteration,
+    quoted from the newest committed rocprofv3 kernel summary of this leg (tools/profile_mapping.sh: 10 timed iterations) -- a profile
+    cannot be taken from inside the run, so the file is named."""
+    import csv
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_mapping_kernel_stats.csv")), reverse=True)
+    if not paths:
+        return None
+    rows = list(csv.DictReader(open(paths[0])))
+    total = sum(int(r["TotalDurationNs"]) for r in rows)
+    ours = sum(int(r["TotalDurationNs"]) for r in rows if "nsa::" in r["Name"])
+    return {"share": round(ours / total, 4), "launches_per_iteration": round(sum(int(r["Calls"]) for r in rows) / 10, 1),
+            "source": os.path.relpath(paths[0], ROOT)}
 
 
 def cpu_mapping_baseline(model, n=256, frames=8):

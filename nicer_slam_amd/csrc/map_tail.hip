@@ -247,6 +247,40 @@ __global__ __launch_bounds__(256) void k_fill_zero(float* __restrict__ p, uint64
 }
 
 // k_adam_table with the same front-to-back block order: block b owns float4 groups [b * 256 G, (b + 1) * 256 G)
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+    float4 r;
+    r.x = __builtin_nontemporal_load(&p->x); r.y = __builtin_nontemporal_load(&p->y);
+    r.z = __builtin_nontemporal_load(&p->z); r.w = __builtin_nontemporal_load(&p->w);
+    return r;
+}
+__device__ __forceinline__ void nt_store4(float4* p, const float4& v) {
+    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+    __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+}
+
+// experiment (NSA_ADAM_GRID=nt): the linear kernel with non-temporal loads and stores on all seven streams
+__global__ __launch_bounds__(256) void k_adam_table_linear_nt(AdamTableArgs a) {
+    const uint64_t n4 = a.n / 4;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        float4 p = nt_load4(reinterpret_cast<const float4*>(a.p) + i);
+        const float4 g = nt_load4(reinterpret_cast<const float4*>(a.g) + i);
+        float4 m = nt_load4(reinterpret_cast<const float4*>(a.m) + i);
+        float4 v = nt_load4(reinterpret_cast<const float4*>(a.v) + i);
+        adam_one(p.x, g.x, m.x, v.x, a);
+        adam_one(p.y, g.y, m.y, v.y, a);
+        adam_one(p.z, g.z, m.z, v.z, a);
+        adam_one(p.w, g.w, m.w, v.w, a);
+        nt_store4(reinterpret_cast<float4*>(a.p) + i, p);
+        nt_store4(reinterpret_cast<float4*>(a.m) + i, m);
+        nt_store4(reinterpret_cast<float4*>(a.v) + i, v);
+    }
+    if (blockIdx.x == 0) {
+        const uint64_t t = n4 * 4 + threadIdx.x;
+        if (t < a.n) adam_one(a.p[t], a.g[t], a.m[t], a.v[t], a);
+    }
+}
+
 template <bool CLEAR, int G>
 __global__ __launch_bounds__(256) void k_adam_table_linear(AdamTableArgs a) {
     const uint64_t n4 = a.n / 4;
@@ -529,6 +563,7 @@ static int adam_grid_mode() {
     static const int mode = [] {
         const char* e = getenv("NSA_ADAM_GRID");
         if (!e) return 1;
+        if (e[0] == 'n') return 3;
         return e[0] == 's' ? 0 : (e[6] == '2' ? 2 : 1);
     }();
     return mode;
@@ -558,11 +593,14 @@ static int adam_table_launch(float* param, float* grad, float* exp_avg, float* e
         if (clear) hipLaunchKernelGGL(k_adam_table_scalar<true>, dim3((uint32_t)sb), dim3(256), 0, (hipStream_t)stream, a);
         else       hipLaunchKernelGGL(k_adam_table_scalar<false>, dim3((uint32_t)sb), dim3(256), 0, (hipStream_t)stream, a);
     } else if (adam_grid_mode() > 0) {
-        const int G = adam_grid_mode();
+        const int mode = adam_grid_mode();
+        const int G = mode == 3 ? 1 : mode;
         const uint64_t lb = (n4 + 256 * G - 1) / (256 * G) ? (n4 + 256 * G - 1) / (256 * G) : 1;
         if (lb > 0x7FFFFFFFull) return NSA_EBADARG;
         const dim3 grid((uint32_t)lb), block(256);
-        if (G == 1) {
+        if (mode == 3 && !clear) {
+            hipLaunchKernelGGL(k_adam_table_linear_nt, grid, block, 0, (hipStream_t)stream, a);
+        } else if (G == 1) {
             if (clear) hipLaunchKernelGGL((k_adam_table_linear<true, 1>), grid, block, 0, (hipStream_t)stream, a);
             else       hipLaunchKernelGGL((k_adam_table_linear<false, 1>), grid, block, 0, (hipStream_t)stream, a);
         } else {

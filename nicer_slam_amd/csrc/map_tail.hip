@@ -234,14 +234,22 @@ __global__ __launch_bounds__(256) void k_adam_table(AdamTableArgs a) {
 
 // One block = one contiguous chunk (4 KiB per float4 group), no loop: the dispatcher walks the buffer front to back, so HBM sees one linear write stream (6.8 TB/s on a
 // 1 GiB buffer; a grid capped at 8 blocks per CU that strides through the buffer reached 4.8 -- tools/micro/fill_bench.py, r5A).
-template <int FILL_GROUPS>
+template <int FILL_GROUPS, bool NT = false>
 __global__ __launch_bounds__(256) void k_fill_zero(float* __restrict__ p, uint64_t n) {
     const uint64_t n4 = n / 4;
     const uint64_t i0 = (uint64_t)blockIdx.x * (256 * FILL_GROUPS) + threadIdx.x;
 #pragma unroll
     for (int j = 0; j < FILL_GROUPS; ++j) {
         const uint64_t i = i0 + 256u * j;
-        if (i < n4) reinterpret_cast<float4*>(p)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (i < n4) {
+            if (NT) {
+                float* q = p + 4 * i;
+                __builtin_nontemporal_store(0.0f, q); __builtin_nontemporal_store(0.0f, q + 1);
+                __builtin_nontemporal_store(0.0f, q + 2); __builtin_nontemporal_store(0.0f, q + 3);
+            } else {
+                reinterpret_cast<float4*>(p)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
     }
     if (blockIdx.x == 0 && n4 * 4 + threadIdx.x < n) p[n4 * 4 + threadIdx.x] = 0.0f;
 }
@@ -258,22 +266,39 @@ __device__ __forceinline__ void nt_store4(float4* p, const float4& v) {
     __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
 }
 
-// experiment (NSA_ADAM_GRID=nt): the linear kernel with non-temporal loads and stores on all seven streams
+// The linear kernel with non-temporal accesses (gfx950: the `nt` bit on global_load / global_store_dwordx4 -- streamed lines are not
+// kept in L2): 5-8 % faster again on the 1 GiB table (1355 -> 1265 us on the slower of two boxes; tools/ab_adam.py, r5E).  LD / ST
+// select the hint for the four loads / three stores (NSA_ADAM_GRID = nt | ntl | nts for A/B).
+template <bool LD, bool ST>
 __global__ __launch_bounds__(256) void k_adam_table_linear_nt(AdamTableArgs a) {
     const uint64_t n4 = a.n / 4;
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n4) {
-        float4 p = nt_load4(reinterpret_cast<const float4*>(a.p) + i);
-        const float4 g = nt_load4(reinterpret_cast<const float4*>(a.g) + i);
-        float4 m = nt_load4(reinterpret_cast<const float4*>(a.m) + i);
-        float4 v = nt_load4(reinterpret_cast<const float4*>(a.v) + i);
+        float4 p, g, m, v;
+        if (LD) {
+            p = nt_load4(reinterpret_cast<const float4*>(a.p) + i);
+            g = nt_load4(reinterpret_cast<const float4*>(a.g) + i);
+            m = nt_load4(reinterpret_cast<const float4*>(a.m) + i);
+            v = nt_load4(reinterpret_cast<const float4*>(a.v) + i);
+        } else {
+            p = reinterpret_cast<const float4*>(a.p)[i];
+            g = reinterpret_cast<const float4*>(a.g)[i];
+            m = reinterpret_cast<const float4*>(a.m)[i];
+            v = reinterpret_cast<const float4*>(a.v)[i];
+        }
         adam_one(p.x, g.x, m.x, v.x, a);
         adam_one(p.y, g.y, m.y, v.y, a);
         adam_one(p.z, g.z, m.z, v.z, a);
         adam_one(p.w, g.w, m.w, v.w, a);
-        nt_store4(reinterpret_cast<float4*>(a.p) + i, p);
-        nt_store4(reinterpret_cast<float4*>(a.m) + i, m);
-        nt_store4(reinterpret_cast<float4*>(a.v) + i, v);
+        if (ST) {
+            nt_store4(reinterpret_cast<float4*>(a.p) + i, p);
+            nt_store4(reinterpret_cast<float4*>(a.m) + i, m);
+            nt_store4(reinterpret_cast<float4*>(a.v) + i, v);
+        } else {
+            reinterpret_cast<float4*>(a.p)[i] = p;
+            reinterpret_cast<float4*>(a.m)[i] = m;
+            reinterpret_cast<float4*>(a.v)[i] = v;
+        }
     }
     if (blockIdx.x == 0) {
         const uint64_t t = n4 * 4 + threadIdx.x;
@@ -558,12 +583,13 @@ int nsa_morton_order(const nsa_points_t* pts, int32_t* order, uint32_t* workspac
     return launch_end();
 }
 
-// NSA_ADAM_GRID = stride | linear1 | linear2 (A/B switch, tools/ab_adam.py): 0 = the grid-stride kernel, G = k_adam_table_linear<G>
+// NSA_ADAM_GRID = stride | linear1 | linear2 | nt (default) | ntl | nts (A/B switch, tools/ab_adam.py): 0 = the grid-stride kernel,
+// 1 / 2 = k_adam_table_linear<G>, 3 / 4 / 5 = k_adam_table_linear_nt with the hint on loads + stores / loads / stores
 static int adam_grid_mode() {
     static const int mode = [] {
         const char* e = getenv("NSA_ADAM_GRID");
-        if (!e) return 1;
-        if (e[0] == 'n') return 3;
+        if (!e) return 3;
+        if (e[0] == 'n') return e[2] == 'l' ? 4 : (e[2] == 's' ? 5 : 3);
         return e[0] == 's' ? 0 : (e[6] == '2' ? 2 : 1);
     }();
     return mode;
@@ -594,12 +620,16 @@ static int adam_table_launch(float* param, float* grad, float* exp_avg, float* e
         else       hipLaunchKernelGGL(k_adam_table_scalar<false>, dim3((uint32_t)sb), dim3(256), 0, (hipStream_t)stream, a);
     } else if (adam_grid_mode() > 0) {
         const int mode = adam_grid_mode();
-        const int G = mode == 3 ? 1 : mode;
+        const int G = mode >= 3 ? 1 : mode;
         const uint64_t lb = (n4 + 256 * G - 1) / (256 * G) ? (n4 + 256 * G - 1) / (256 * G) : 1;
         if (lb > 0x7FFFFFFFull) return NSA_EBADARG;
         const dim3 grid((uint32_t)lb), block(256);
-        if (mode == 3 && !clear) {
-            hipLaunchKernelGGL(k_adam_table_linear_nt, grid, block, 0, (hipStream_t)stream, a);
+        // non-temporal only where nothing of the tensor could stay cached anyway: a table that fits the 256 MB of MALL (the SDF
+        // tables, 4 and 36 MiB) is gathered from by the very next forward pass and should stay there
+        if (mode >= 3 && !clear && n >= (1ull << 26)) {
+            if (mode == 3)      hipLaunchKernelGGL((k_adam_table_linear_nt<true, true>), grid, block, 0, (hipStream_t)stream, a);
+            else if (mode == 4) hipLaunchKernelGGL((k_adam_table_linear_nt<true, false>), grid, block, 0, (hipStream_t)stream, a);
+            else                hipLaunchKernelGGL((k_adam_table_linear_nt<false, true>), grid, block, 0, (hipStream_t)stream, a);
         } else if (G == 1) {
             if (clear) hipLaunchKernelGGL((k_adam_table_linear<true, 1>), grid, block, 0, (hipStream_t)stream, a);
             else       hipLaunchKernelGGL((k_adam_table_linear<false, 1>), grid, block, 0, (hipStream_t)stream, a);
@@ -656,12 +686,14 @@ int nsa_fill_zero(float* p, uint64_t n, nsa_stream_t stream) {
     if (n == 0) return NSA_OK;
     // float4 groups per thread (NSA_FILL_GROUPS = 1 | 2 | 4: A/B override, tools/micro/fill_bench.py)
     static const int G = [] { const char* e = getenv("NSA_FILL_GROUPS"); return e ? atoi(e) : 1; }();
-    uint64_t blocks = (n / 4 + 256 * G - 1) / (256 * G);
+    const int gg = G == 9 ? 1 : G;
+    uint64_t blocks = (n / 4 + 256 * gg - 1) / (256 * gg);
     if (blocks == 0) blocks = 1;
     if (blocks > 0x7FFFFFFFull) return NSA_EBADARG;
     const dim3 grid((uint32_t)blocks), block(256);
     launch_begin();
-    if (G == 4)      hipLaunchKernelGGL(k_fill_zero<4>, grid, block, 0, (hipStream_t)stream, p, n);
+    if (G == 9)      hipLaunchKernelGGL((k_fill_zero<1, true>), grid, block, 0, (hipStream_t)stream, p, n);      // A/B: non-temporal
+    else if (G == 4) hipLaunchKernelGGL(k_fill_zero<4>, grid, block, 0, (hipStream_t)stream, p, n);
     else if (G == 2) hipLaunchKernelGGL(k_fill_zero<2>, grid, block, 0, (hipStream_t)stream, p, n);
     else             hipLaunchKernelGGL(k_fill_zero<1>, grid, block, 0, (hipStream_t)stream, p, n);
     return launch_end();

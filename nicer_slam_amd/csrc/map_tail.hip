@@ -234,22 +234,14 @@ __global__ __launch_bounds__(256) void k_adam_table(AdamTableArgs a) {
 
 // One block = one contiguous chunk (4 KiB per float4 group), no loop: the dispatcher walks the buffer front to back, so HBM sees one linear write stream (6.8 TB/s on a
 // 1 GiB buffer; a grid capped at 8 blocks per CU that strides through the buffer reached 4.8 -- tools/micro/fill_bench.py, r5A).
-template <int FILL_GROUPS, bool NT = false>
+template <int FILL_GROUPS>
 __global__ __launch_bounds__(256) void k_fill_zero(float* __restrict__ p, uint64_t n) {
     const uint64_t n4 = n / 4;
     const uint64_t i0 = (uint64_t)blockIdx.x * (256 * FILL_GROUPS) + threadIdx.x;
 #pragma unroll
     for (int j = 0; j < FILL_GROUPS; ++j) {
         const uint64_t i = i0 + 256u * j;
-        if (i < n4) {
-            if (NT) {
-                float* q = p + 4 * i;
-                __builtin_nontemporal_store(0.0f, q); __builtin_nontemporal_store(0.0f, q + 1);
-                __builtin_nontemporal_store(0.0f, q + 2); __builtin_nontemporal_store(0.0f, q + 3);
-            } else {
-                reinterpret_cast<float4*>(p)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-        }
+        if (i < n4) reinterpret_cast<float4*>(p)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // (non-temporal stores: 3 % slower, r5E)
     }
     if (blockIdx.x == 0 && n4 * 4 + threadIdx.x < n) p[n4 * 4 + threadIdx.x] = 0.0f;
 }
@@ -686,14 +678,12 @@ int nsa_fill_zero(float* p, uint64_t n, nsa_stream_t stream) {
     if (n == 0) return NSA_OK;
     // float4 groups per thread (NSA_FILL_GROUPS = 1 | 2 | 4: A/B override, tools/micro/fill_bench.py)
     static const int G = [] { const char* e = getenv("NSA_FILL_GROUPS"); return e ? atoi(e) : 1; }();
-    const int gg = G == 9 ? 1 : G;
-    uint64_t blocks = (n / 4 + 256 * gg - 1) / (256 * gg);
+    uint64_t blocks = (n / 4 + 256 * G - 1) / (256 * G);
     if (blocks == 0) blocks = 1;
     if (blocks > 0x7FFFFFFFull) return NSA_EBADARG;
     const dim3 grid((uint32_t)blocks), block(256);
     launch_begin();
-    if (G == 9)      hipLaunchKernelGGL((k_fill_zero<1, true>), grid, block, 0, (hipStream_t)stream, p, n);      // A/B: non-temporal
-    else if (G == 4) hipLaunchKernelGGL(k_fill_zero<4>, grid, block, 0, (hipStream_t)stream, p, n);
+    if (G == 4)      hipLaunchKernelGGL(k_fill_zero<4>, grid, block, 0, (hipStream_t)stream, p, n);
     else if (G == 2) hipLaunchKernelGGL(k_fill_zero<2>, grid, block, 0, (hipStream_t)stream, p, n);
     else             hipLaunchKernelGGL(k_fill_zero<1>, grid, block, 0, (hipStream_t)stream, p, n);
     return launch_end();

@@ -44,14 +44,9 @@ __host__ __device__ inline uint32_t emit_kw(uint64_t ld) {
 }
 
 __device__ __forceinline__ void load8(const float* __restrict__ p, float (&x)[8]) {
-#if NSA_EMIT_NT
-#pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = __builtin_nontemporal_load(p + i);      // (merged into two global_load_dwordx4 ... nt)
-#else
     const float4 u = reinterpret_cast<const float4*>(p)[0];
     const float4 v = reinterpret_cast<const float4*>(p)[1];
     x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
-#endif
 }
 
 template <int MT, int NT>

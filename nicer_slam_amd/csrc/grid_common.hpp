@@ -98,19 +98,6 @@ inline bool has_generic_level(const LevelGeom* lv, uint32_t L) {
 
 // hipGetLastError() also reports stale non-errors left by OTHER runtime calls on this host thread (e.g. PyTorch's
 // hipEventQuery -> hipErrorNotReady), so every entry point clears it before launching and reads it after.
-// Emission rows (MAP backward kernels -> nsa_emit_gemm) are written once and read once, gigabytes per launch: streamed past the
-// cache (`nt`) they do not evict the gradient-table lines the same kernels' atomics work on.  NSA_EMIT_NT=0: plain accesses (A/B).
-#ifndef NSA_EMIT_NT
-#define NSA_EMIT_NT 1
-#endif
-__device__ __forceinline__ void emit_store(float* p, float v) {
-#if NSA_EMIT_NT
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-
 inline void launch_begin() { (void)hipGetLastError(); }
 inline int launch_end() { return hipGetLastError() == hipSuccess ? NSA_OK : NSA_ELAUNCH; }
 

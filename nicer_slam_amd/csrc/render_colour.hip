@@ -111,11 +111,11 @@ struct ColEmitter {
     uint32_t ld;
     bool live;
     __device__ __forceinline__ void slot(int region, int s, int h, float v) const {
-        emit_store(&base[(size_t)(region + 2 * s + h) * ld], live ? v : 0.0f);
+        base[(size_t)(region + 2 * s + h) * ld] = live ? v : 0.0f;
     }
     __device__ __forceinline__ void hid(int region, int q, int h, float v) const {
         const int f = 32 * (q >> 4) + (q & 3) + 8 * ((q & 15) >> 2) + 4 * h;
-        emit_store(&base[(size_t)(region + f) * ld], live ? v : 0.0f);
+        base[(size_t)(region + f) * ld] = live ? v : 0.0f;
     }
 };
 

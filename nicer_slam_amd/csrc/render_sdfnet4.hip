@@ -67,10 +67,10 @@ struct Emitter4 {
     uint32_t ld;
     bool live;
     __device__ __forceinline__ void slot(int region, int s, int q, float v) const {
-        emit_store(&base[(size_t)(region + 4 * s + q) * ld], live ? v : 0.0f);
+        base[(size_t)(region + 4 * s + q) * ld] = live ? v : 0.0f;
     }
     __device__ __forceinline__ void hid(int region, int s, int q, float v) const {
-        emit_store(&base[(size_t)(region + 16 * (s >> 2) + 4 * q + (s & 3)) * ld], live ? v : 0.0f);
+        base[(size_t)(region + 16 * (s >> 2) + 4 * q + (s & 3)) * ld] = live ? v : 0.0f;
     }
 };
 

@@ -507,15 +507,18 @@ def mapping_leg(device, rays=8192, frames=8, iters=5, cpu=True, step_hook=None):
     assert model.last_engine == "fused"
     if step_hook is not None:          # tools/profile_mapping_host.py: the warmed-up iteration, handed out for a profiler
         return step_hook(step)
-    # per-kernel durations of one more iteration (event pairs on the launch stream) and the roofline of its dominant kernel
+    # per-kernel durations of four more iterations (event pairs on the launch stream; means per iteration -- a single iteration's
+    # reading of the dominant kernel moved by 10 % between runs) and the roofline of the dominant kernel
     import nicer_slam_amd.hashencoder.backend as be
+    PROF_ITERS = 4
     be.PROFILE = []
-    step()
+    for _ in range(PROF_ITERS):
+        step()
     torch.cuda.synchronize()
     prof, be.PROFILE = be.PROFILE, None
     agg = {}
     for name, _, e0, e1 in prof:
-        agg[name] = agg.get(name, 0.0) + e0.elapsed_time(e1)
+        agg[name] = agg.get(name, 0.0) + e0.elapsed_time(e1) / PROF_ITERS
     S = 98
     P = rays * S
     roof = None
@@ -553,7 +556,7 @@ def mapping_leg(device, rays=8192, frames=8, iters=5, cpu=True, step_hook=None):
                     break
             if reqs and "sdfnet" in name:      # the counter's per-dispatch mean covers this kernel's two launches per iteration
                 reqs = reqs * 2 * P / (P + 22 * rays)      # (composite points and eikonal points): the composite launch's share
-            launches = sum(1 for n_, _, _, _ in prof if n_ == name)
+            launches = sum(1 for n_, _, _, _ in prof if n_ == name) // PROF_ITERS
             per_launch_s = tms * 1e-3 / max(launches, 1)
             ATOMIC_CEILING = 20e9
             atomic = {"table_rows_per_launch": rows // max(launches, 1), "atomic_requests_per_launch": reqs,

@@ -36,7 +36,24 @@ struct EmitGemmArgs {
     uint32_t pairs, M, N, sums;       // out is [M][N + sums]; column N = row sums of A (pair 0)
     uint32_t kw;                      // columns per slice (multiple of KSUB)
     float* partial;                   // [slices][M][N + sums]
+    uint32_t slices, groups;          // grid = slices x groups workgroups, numbered by emit_block()
 };
+
+// Workgroup id -> (slice, column group).  The waves of one slice share its A rows; workgroups are dealt round-robin to the 8 XCDs, each
+// with its own L2, so the groups of a slice are numbered 8 apart (same XCD) and back to back in dispatch order: the second group's
+// A fragments are L2 hits instead of a second trip to HBM.  (With the former (slices, groups) grid they ran on the same XCD too, but a
+// whole sweep of 1024 slices apart.)
+__device__ __forceinline__ void emit_block(const EmitGemmArgs& g, uint32_t& slice, uint32_t& grp) {
+    const uint32_t id = blockIdx.x;
+    if ((g.slices & 7u) == 0) {
+        const uint32_t per = 8u * g.groups;
+        slice = (id / per) * 8u + (id & 7u);
+        grp = (id >> 3) % g.groups;
+    } else {
+        slice = id / g.groups;
+        grp = id % g.groups;
+    }
+}
 
 __host__ __device__ inline uint32_t emit_kw(uint64_t ld) {
     const uint64_t n = ld / KSUB;
@@ -87,13 +104,15 @@ __device__ __forceinline__ void emit_step(const EmitFrags<MT, NT>& f, f32x16 (&a
     }
 }
 
-// grid: (slices, groups of NT output tiles); one wave per block
+// grid: slices x (groups of NT output tiles) workgroups in emit_block() order; one wave per block
 template <int MT, int NT>
 __global__ __launch_bounds__(64) void k_emit_gemm(EmitGemmArgs g) {
     const int lane = threadIdx.x, i = lane & 31, kq = lane >> 5;
     const uint32_t N1 = g.N + g.sums;
-    const uint32_t n0 = blockIdx.y * (32u * NTW);              // first output column of this wave
-    const uint64_t c0 = (uint64_t)blockIdx.x * g.kw;
+    uint32_t slice, grp;
+    emit_block(g, slice, grp);
+    const uint32_t n0 = grp * (32u * NTW);                     // first output column of this wave
+    const uint64_t c0 = (uint64_t)slice * g.kw;
     const uint64_t c1 = c0 + g.kw < g.ld ? c0 + g.kw : g.ld;
     f32x16 total[MT][NT];
     float asum[MT];
@@ -152,7 +171,7 @@ __global__ __launch_bounds__(64) void k_emit_gemm(EmitGemmArgs g) {
         }
     }
     // D[row][col]: col = lane & 31 (the B row n), row = 8 (r >> 2) + 4 (lane >> 5) + (r & 3) (the A row within the m-tile)
-    float* out = g.partial + (uint64_t)blockIdx.x * g.M * N1;
+    float* out = g.partial + (uint64_t)slice * g.M * N1;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const uint32_t n = n0 + 32u * nt + i;
@@ -166,7 +185,7 @@ __global__ __launch_bounds__(64) void k_emit_gemm(EmitGemmArgs g) {
                 }
         }
     }
-    if (g.sums && blockIdx.y == 0) {
+    if (g.sums && grp == 0) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const float s = asum[mt] + __shfl_xor(asum[mt], 32);
@@ -208,12 +227,13 @@ __global__ __launch_bounds__(256) void k_emit_reduce(const float* __restrict__ p
 }
 
 template <int MT>
-static void emit_launch(const EmitGemmArgs& g, uint32_t slices, uint32_t tiles, hipStream_t st) {
+static void emit_launch(EmitGemmArgs g, uint32_t slices, uint32_t tiles, hipStream_t st) {
     const uint32_t groups = tiles ? (tiles + NTW - 1) / NTW : 1;
+    g.slices = slices; g.groups = groups;
     const uint32_t last = tiles ? tiles - (groups - 1) * NTW : 0;        // tiles of the last group
     // all groups but the last are full; instantiate by the widest group present (narrower groups clamp their rows)
     const uint32_t nt = groups > 1 ? NTW : (last ? last : 1);
-    const dim3 grid(slices, groups), block(64);
+    const dim3 grid(slices * groups), block(64);
     if (nt == 1) hipLaunchKernelGGL((k_emit_gemm<MT, 1>), grid, block, 0, st, g);
     else if (nt == 2) hipLaunchKernelGGL((k_emit_gemm<MT, 2>), grid, block, 0, st, g);
     else hipLaunchKernelGGL((k_emit_gemm<MT, 3>), grid, block, 0, st, g);

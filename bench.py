@@ -583,7 +583,7 @@ def mapping_leg(device, rays=8192, frames=8, iters=5, cpu=True, step_hook=None):
 
 def mapping_library_share():
     """Share of a mapping iteration's device time spent in this library's kernels (names in namespace nsa::) and launches per iteration,
-    quoted from the newest committed rocprofv3 kernel summary of this leg (tools/profile_mapping.sh: 10 timed iterations) -- a profile
+    quoted from the newest committed rocprofv3 kernel summary of this leg (tools/profile_mapping.sh) -- a profile
     cannot be taken from inside the run, so the file is named."""
     import csv
     import glob
@@ -593,7 +593,8 @@ def mapping_library_share():
     rows = list(csv.DictReader(open(paths[0])))
     total = sum(int(r["TotalDurationNs"]) for r in rows)
     ours = sum(int(r["TotalDurationNs"]) for r in rows if "nsa::" in r["Name"])
-    return {"share": round(ours / total, 4), "launches_per_iteration": round(sum(int(r["Calls"]) for r in rows) / 10, 1),
+    iters = max([int(r["Calls"]) for r in rows if "k_colour_bwd<true>" in r["Name"]] or [10])     # one launch of it per iteration
+    return {"share": round(ours / total, 4), "launches_per_iteration": round(sum(int(r["Calls"]) for r in rows) / iters, 1),
             "source": os.path.relpath(paths[0], ROOT)}
 
 

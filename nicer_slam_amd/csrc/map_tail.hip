@@ -4,6 +4,7 @@
 // Reference: SLAMNetwork.update_voxels (code/model/network.py:62-76); torch.optim.Adam as configured by
 // code/training/volsdf_train.py:174 (betas (0.9, 0.99), eps 1e-15, no weight decay, no amsgrad).
 #include <cstdlib>
+#include <cstring>
 #include "sdf_net.hpp"
 
 namespace nsa {
@@ -580,9 +581,13 @@ int nsa_morton_order(const nsa_points_t* pts, int32_t* order, uint32_t* workspac
 static int adam_grid_mode() {
     static const int mode = [] {
         const char* e = getenv("NSA_ADAM_GRID");
-        if (!e) return 3;
-        if (e[0] == 'n') return e[2] == 'l' ? 4 : (e[2] == 's' ? 5 : 3);
-        return e[0] == 's' ? 0 : (e[6] == '2' ? 2 : 1);
+        if (!e || !strcmp(e, "nt")) return 3;
+        if (!strcmp(e, "stride")) return 0;
+        if (!strcmp(e, "linear1")) return 1;
+        if (!strcmp(e, "linear2")) return 2;
+        if (!strcmp(e, "ntl")) return 4;
+        if (!strcmp(e, "nts")) return 5;
+        return 3;
     }();
     return mode;
 }

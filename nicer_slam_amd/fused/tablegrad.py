@@ -55,6 +55,8 @@ def _entry(param):
 def target(param):
     """The tensor the MAP kernels of this backward pass add ``param``'s gradient into (float32, contiguous, param's shape);
     afterwards it is (part of) ``param.grad``.  Called inside autograd.Function.backward; the Function returns None for the table."""
+    if not (param.is_cuda and param.dtype == torch.float32):
+        raise RuntimeError("fused mapping engine: grid tables must be float32 CUDA tensors")
     g = param.grad
     if g is not None:
         if g.dtype == torch.float32 and g.is_contiguous() and g.shape == param.shape and g.device == param.device and not g.is_sparse:

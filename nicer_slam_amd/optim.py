@@ -30,7 +30,11 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         if consume_table_grads is None:      # NSA_TABLE_GRAD_CLEAR = acquire (default) | fused: A/B switch of the clearing policy
-            consume_table_grads = {"acquire": False, "fused": True}[os.environ.get("NSA_TABLE_GRAD_CLEAR", "acquire")]
+            policy = os.environ.get("NSA_TABLE_GRAD_CLEAR", "acquire")
+            if policy not in ("acquire", "fused"):
+                raise ValueError(f"NSA_TABLE_GRAD_CLEAR={policy!r}: expected 'acquire' or 'fused' (the side-stream policy 'async' of "
+                                 "profiles/r05_ab_experiments.txt r5y was measured and removed)")
+            consume_table_grads = policy == "fused"
         self.consume_table_grads = consume_table_grads
 
     SMALL = 1 << 16        # tensors up to this many elements share launches (nsa_adam_multi_step, 24 per launch)

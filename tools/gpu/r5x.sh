@@ -8,7 +8,7 @@ tail -3 $O/tests.log
 B="python bench.py --only-mapping 10 --no-cpu-baseline"
 run() { name=$1; shift; env "$@" timeout 300 $B > $O/map_$name.json 2> $O/map_$name.err; echo "$name rc=$? $(python -c "import json;print(json.load(open('$O/map_$name.json')).get('rays_per_s'))" 2>/dev/null)"; }
 run acquire30 NSA_X=0
-run async30 NSA_TABLE_GRAD_CLEAR=async
+# run async30 NSA_TABLE_GRAD_CLEAR=async      (policy removed after this run)
 run fused30 NSA_TABLE_GRAD_CLEAR=fused
 run autograd30 NSA_TABLE_GRADS=autograd
 run acquire27 NSA_MORTON_BITS=27

@@ -41,3 +41,20 @@ def test_config_presets_expand_and_reject_contradictions():
     assert run("--config", "1").stdout.split() == ["1", "0", "128", "fp32"]
     bad = run("--config", "2", "--gpus", "4")
     assert bad.returncode != 0 and "means --gpus 8" in bad.stderr
+
+
+def test_mapping_leg_quotes_committed_profiles_consistently():
+    """The mapping leg's context numbers read committed files: the in-library share comes from the newest rNN_mapping_kernel_stats.csv
+    (normalised by the once-per-iteration kernel, whatever number of iterations the profile held), and the atomic-request counters are
+    only quoted when their signature file matches the batch shape, tilings and key bits of the run."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    share = bench.mapping_library_share()
+    assert share is not None and share["source"].startswith("profiles/r") and 0.9 < share["share"] <= 1.0
+    assert 100 < share["launches_per_iteration"] < 400
+    sig = bench.mapping_signature()
+    assert sig["rays"] == 8192 and sig["morton_bits"] in range(1, 31) and "fine" in sig["tiles"]
+    metas = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_mapping_pmc_meta.json"))
+    newest = json.load(open(os.path.join(ROOT, "profiles", metas[-1])))
+    assert newest == sig, "the newest committed atomic-request profile was taken with another shape / tiling / key width"

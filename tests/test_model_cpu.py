@@ -190,3 +190,32 @@ def test_backend_rejects_cpu_tensors():
     enc = HashEncoder(num_levels=2, level_dim=2, base_resolution=4, desired_resolution=8, log2_hashmap_size=8)
     with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
         enc(torch.zeros(4, 3))
+
+
+def test_mapping_host_guards_without_a_gpu():
+    """Host-side refusals of the round-5 mapping helpers: the in-place table-gradient buffers are for CUDA float32 tables only (no
+    CPU path to fall into), and a clearing policy that no longer exists is named, not silently mapped."""
+    import os
+    import pytest
+    import torch
+    from nicer_slam_amd.fused import tablegrad
+    with pytest.raises(RuntimeError, match="CUDA"):
+        tablegrad.target(torch.nn.Parameter(torch.zeros(8, 2)))
+    assert tablegrad.consumable(torch.nn.Parameter(torch.zeros(2)), torch.zeros(2)) is False
+    from nicer_slam_amd.optim import Adam
+    old = os.environ.get("NSA_TABLE_GRAD_CLEAR")
+    try:
+        os.environ["NSA_TABLE_GRAD_CLEAR"] = "async"
+        with pytest.raises(ValueError, match="async"):
+            Adam([torch.nn.Parameter(torch.zeros(3))])
+        os.environ["NSA_TABLE_GRAD_CLEAR"] = "fused"
+        assert Adam([torch.nn.Parameter(torch.zeros(3))]).consume_table_grads is True
+    finally:
+        if old is None:
+            os.environ.pop("NSA_TABLE_GRAD_CLEAR", None)
+        else:
+            os.environ["NSA_TABLE_GRAD_CLEAR"] = old
+    with pytest.raises(RuntimeError):                    # the optimizer itself: no CPU fallback either (no GPU / not a CUDA tensor)
+        p = torch.nn.Parameter(torch.zeros(3))
+        p.grad = torch.ones(3)
+        Adam([p]).step()

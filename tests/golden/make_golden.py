@@ -66,17 +66,26 @@ def capture_draws(log):
 
 
 # ------------------------------------------------------------------ configs
-def model_conf(coarse_grid, fine_grid, n_samples, n_eval, n_extra, warp=False):
-    def sdf(dims, g):
-        return dict(d_in=3, d_out=1, dims=dims, geometric_init=True, bias=0.6, skip_in=[],
-                    weight_norm=True, multires=6, inside_outside=True, use_grid_feature=True,
-                    base_size=g[0], end_size=g[1], logmap=g[2], num_levels=g[3], level_dim=g[4],
-                    divide_factor=1.0, embedding_method="nerf")
+# the model subtree differs between the shipped conf families in exactly these keys (confs/replica/runconf_replica_1.conf:96,118
+# vs confs/7scenes/runconf_7scenes_1.conf:98,111,114,122,136 = confs/azure/*.conf)
+FAMILY = {"replica": dict(coarse=dict(bias=0.6), fine=dict(geometric_init=True)),
+          "7scenes": dict(coarse=dict(bias=1.0, concat_coarse_feature=False),
+                          fine=dict(geometric_init=False, clamp=False, concat_coarse_feature=False))}
+
+
+def model_conf(coarse_grid, fine_grid, n_samples, n_eval, n_extra, warp=False, family="replica"):
+    def sdf(dims, g, which):
+        d = dict(d_in=3, d_out=1, dims=dims, geometric_init=True, bias=0.6, skip_in=[],
+                 weight_norm=True, multires=6, inside_outside=True, use_grid_feature=True,
+                 base_size=g[0], end_size=g[1], logmap=g[2], num_levels=g[3], level_dim=g[4],
+                 divide_factor=1.0, embedding_method="nerf")
+        d.update(FAMILY[family][which])
+        return d
     return ref_shims.Conf(
         feature_vector_size=64, scene_bounding_sphere=1.0, use_warp_loss=bool(warp),
         mapping_patchsizes=[1, 5] if warp else [1], tracking_patchsizes=[1], sampling_method="important",
         density_method="volsdf_gridpredefined",
-        implicit_network=dict(coarse=sdf([64], coarse_grid), fine=sdf([64, 64, 64], fine_grid)),
+        implicit_network=dict(coarse=sdf([64], coarse_grid, "coarse"), fine=sdf([64, 64, 64], fine_grid, "fine")),
         rendering_network=dict(mode="idr", d_in=9, d_out=3, dims=[64, 64], weight_norm=True,
                                multires_view=4, per_image_code=False, use_grid_feature=True),
         gridpredefinedensity={},
@@ -88,13 +97,17 @@ class _DS:
     img_res = (680, 1200)
 
 
+class _DS7:                      # confs/7scenes/runconf_7scenes_1.conf:68-71
+    img_res = (480, 640)
+
+
 def build_model(seed, coarse_grid, fine_grid, colour_grid, n_samples, n_eval, n_extra, emb_scale, warp=False, ds=None,
-                rand_v=0.0):
+                rand_v=0.0, family="replica"):
     """Reference SLAMNetwork with reduced-size tables.  The colour encoder is hard-coded to a
     1 GiB table (base_networks.py:265-284); it is swapped for the reference's own HashEncoder
     class with a small geometry that keeps 16 levels x 2 features."""
     torch.manual_seed(seed)
-    conf = model_conf(coarse_grid, fine_grid, n_samples, n_eval, n_extra, warp)
+    conf = model_conf(coarse_grid, fine_grid, n_samples, n_eval, n_extra, warp, family)
     # build with a throw-away tiny colour grid to avoid allocating 1 GiB: patch the class default
     RN = ref_shims.import_ref("model.base_networks").RenderingNetwork
     HE = hg.HashEncoder
@@ -133,12 +146,12 @@ def build_model(seed, coarse_grid, fine_grid, colour_grid, n_samples, n_eval, n_
     return model, conf
 
 
-def synth_inputs(seed, bs, n_pix):
+def synth_inputs(seed, bs, n_pix, res=_DS.img_res, cam_k=(600.0, 599.5, 339.5)):
     g = torch.Generator().manual_seed(seed)
-    H, W = _DS.img_res
+    H, W = res
     K = torch.eye(4)
-    K[0, 0] = K[1, 1] = 600.0
-    K[0, 2], K[1, 2] = 599.5, 339.5
+    K[0, 0] = K[1, 1] = cam_k[0]
+    K[0, 2], K[1, 2] = cam_k[1], cam_k[2]
     K[0, 1] = 0.3  # exercise the skew term of lift()
     idx = torch.randint(H * W, (bs, n_pix), generator=g)
     uv = torch.stack([(idx % W).float(), (idx // W).float()], -1)
@@ -177,12 +190,17 @@ def objective(out, gt, mode):
 
 
 def full_case(name, seed, mode, stage, color_stage, bs, n_pix, training=True, poisson=False,
-              grids=None, samples=(10, 32, 6), rand_v=0.0):
+              grids=None, samples=(10, 32, 6), rand_v=0.0, family="replica"):
+    """family = "7scenes": the model subtree of the 7-Scenes / Azure confs (coarse sphere radius 1.0, fine SDF MLP at nn.Linear's
+    default initialisation -- which, unlike the geometric one, feeds every positional-encoding and grid column from the start),
+    480 x 640 frames and the Kinect camera (f = 585, principal point (320, 240))."""
     coarse_grid, fine_grid, colour_grid = grids or ((4, 4, 8, 4, 8), (4, 32, 10, 8, 4), (4, 64, 10))
+    seven = family == "7scenes"
     model, conf = build_model(seed, coarse_grid, fine_grid, colour_grid, *samples,
-                              emb_scale=(0.05, 0.05, 0.5) if not rand_v else (0.3, 0.3, 0.5), rand_v=rand_v)
+                              emb_scale=(0.05, 0.05, 0.5) if not rand_v else (0.3, 0.3, 0.5), rand_v=rand_v, family=family,
+                              ds=_DS7() if seven else None)
     model.train(training)
-    uv, cam, K = synth_inputs(seed + 1, bs, n_pix)
+    uv, cam, K = synth_inputs(seed + 1, bs, n_pix, *((_DS7.img_res, (585.0, 320.0, 240.0)) if seven else ()))
     g = torch.Generator().manual_seed(seed + 2)
     if poisson:
         model.voxels.copy_(torch.poisson(torch.full(model.voxels.shape, 50.0), generator=g))
@@ -200,7 +218,8 @@ def full_case(name, seed, mode, stage, color_stage, bs, n_pix, training=True, po
            "meta_mode": mode, "meta_stage": stage, "meta_color_stage": color_stage,
            "meta_training": int(training), "meta_samples": np.array(samples),
            "meta_coarse_grid": np.array(coarse_grid), "meta_fine_grid": np.array(fine_grid),
-           "meta_colour_grid": np.array(colour_grid)}
+           "meta_colour_grid": np.array(colour_grid), "meta_family": family,
+           "meta_frame_res": np.array(_DS7.img_res if seven else _DS.img_res)}
     kinds = [k for k, _ in log.draws]
     if training:
         assert kinds[:3] == ["rand", "randperm", "randint"], kinds
@@ -513,9 +532,10 @@ def reproj_case(name, seed, bs=3, n_pix=10):
           {k: tuple(v.shape) for k, v in rec.items() if k.startswith("grad_")})
 
 
-def loss_case(name, seed, frame_idx, stage, bs=2, n=12, S=6):
+def loss_case(name, seed, frame_idx, stage, bs=2, n=12, S=6, family="replica"):
     """SLAMLoss.forward (model/loss.py:113-233 + utils/MiDaS.py) with the shipped Replica weights
-    (confs/replica/runconf_replica_1.conf:45-56) on random model outputs: every term and d loss / d output."""
+    (confs/replica/runconf_replica_1.conf:45-56; family "7scenes": confs/7scenes/runconf_7scenes_1.conf:46-58, smooth_weight 0.05)
+    on random model outputs: every term and d loss / d output."""
     ref_loss = ref_shims.import_ref("model.loss")
     g = torch.Generator().manual_seed(seed)
     rnd = lambda *shape: torch.rand(*shape, generator=g)
@@ -536,13 +556,15 @@ def loss_case(name, seed, frame_idx, stage, bs=2, n=12, S=6):
           "flow": (rnd(3, n, 2) - 0.5) * 8, "flow_mask": rnd(3, n) > 0.4}
 
     class DS:
-        data_dir = "../Datasets/processed/Replica"
+        data_dir = "../Datasets/processed/Replica" if family == "replica" else "../Datasets/processed/7Scenes"
+    smooth_weight = 0.005 if family == "replica" else 0.05
     crit = ref_loss.SLAMLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, train_dataset=DS(), scan_id=1,
-                             assign_scale_shift_init=True, smooth_weight=0.005, warp_loss_type="l1", depth_weight=0.1,
+                             assign_scale_shift_init=True, smooth_weight=smooth_weight, warp_loss_type="l1", depth_weight=0.1,
                              normal_l1_weight=0.05, normal_cos_weight=0.05, flow_weight=0.001, warp_loss_weight=0.5)
     res = crit(out, gt, keyframe_list=None, frame_idx=frame_idx, stage=stage)
     res["loss"].backward()
-    rec = {"meta_frame_idx": np.array(frame_idx), "meta_stage": np.array(stage)}
+    rec = {"meta_frame_idx": np.array(frame_idx), "meta_stage": np.array(stage), "meta_smooth_weight": np.array(smooth_weight),
+           "meta_data_dir": np.array(DS.data_dir)}
     for k, v in out.items():
         if isinstance(v, torch.Tensor):
             rec["in_" + k] = v.detach()
@@ -676,6 +698,13 @@ def rw_cases():
     full_case("full_mapping_rw_coarse", 18, "mapping", "coarse", "highfreq", bs=2, n_pix=8, rand_v=0.04)
 
 
+def family_cases():
+    """the second conf family (7-Scenes / Azure model subtree + 7-Scenes frame size and camera): tracking, both mapping schedules"""
+    full_case("full_tracking_7scenes", 61, "tracking", "fine", "highfreq", bs=1, n_pix=24, poisson=True, family="7scenes")
+    full_case("full_mapping_7scenes", 62, "mapping", "fine", "highfreq", bs=2, n_pix=8, poisson=True, family="7scenes")
+    full_case("full_mapping_7scenes_coarse_base", 63, "mapping", "coarse", "base", bs=2, n_pix=8, family="7scenes")
+
+
 def twin_cases():
     twin_case("twin_dense", 4, L=5, C=4, base=8, end=24, n_pts=128)
     twin_case("twin_dense_c8", 6, L=3, C=8, base=8, end=19, n_pts=96)
@@ -688,6 +717,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--rw-only" in sys.argv:
         rw_cases()
+        sys.exit(0)
+    if "--family-only" in sys.argv:
+        family_cases()
+        loss_case("loss_mapping_7scenes", 23, frame_idx=7, stage="fine", family="7scenes")
         sys.exit(0)
     if "--reproj-only" in sys.argv:
         reproj_case("reproj_blocks", 51)
@@ -716,3 +749,5 @@ if __name__ == "__main__":
     full_case("full_mapping_coarse_base", 13, "mapping", "coarse", "base", bs=2, n_pix=8)
     full_case("full_vis_eval", 14, "vis", "fine", "highfreq", bs=1, n_pix=16, training=False)
     rw_cases()
+    family_cases()
+    loss_case("loss_mapping_7scenes", 23, frame_idx=7, stage="fine", family="7scenes")

@@ -31,7 +31,8 @@ def _setup(name):
     return fx, model, cam, pose, rays_o, rays_d
 
 
-@pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_vis_eval", "full_tracking_rw"])
+@pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_vis_eval", "full_tracking_rw",
+                                  "full_tracking_7scenes"])
 def test_stage_by_stage_forward(name):
     """sdf / grad sdf / feature / rgb / weights of the fused kernels at the reference's own sample positions."""
     from oracle import render_ref as R
@@ -80,7 +81,7 @@ def test_feature_vector_hl_layout():
     assert_close(dense, f_o, 2e-5 * float(f_o.abs().max()), 1e-4, "feature vector")
 
 
-@pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_tracking_rw"])
+@pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_tracking_rw", "full_tracking_7scenes"])
 def test_model_fused_engine_vs_reference_goldens(name):
     """SLAMNetwork with engine='fused': output dict and the pose gradient of the tracking objective."""
     fx, model, cam, pose, _, _ = _setup(name)
@@ -100,7 +101,8 @@ def test_model_fused_engine_vs_reference_goldens(name):
 
 @pytest.mark.parametrize("name,stage,cstage", [("full_tracking", "fine", "highfreq"), ("full_tracking_poisson", "fine", "base"),
                                                ("full_mapping", "coarse", "highfreq"), ("full_tracking_rw", "fine", "highfreq"),
-                                               ("full_mapping_rw", "fine", "highfreq")])
+                                               ("full_mapping_rw", "fine", "highfreq"), ("full_tracking_7scenes", "fine", "highfreq"),
+                                               ("full_mapping_7scenes", "coarse", "base")])
 def test_backward_all_cotangents_vs_oracle(name, stage, cstage):
     """Every differentiable output (rgb, depth, normal map, entropy, weights) pulled back to the pose and compared
     with the CPU oracle (torch autograd over the restated reference graph) -- both stages / colour stages."""

@@ -26,9 +26,18 @@ def check_slam_loss(name, device="cpu", atol=1e-6, gtol=1e-7, engine="auto"):
     out["warp_output"] = warp
     gt = {k[3:]: dv(k) for k in fx if k.startswith("gt_")}
     gt["flow_mask"] = gt["flow_mask"].bool()
-    crit = SLAMLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, train_dataset=_DS(), scan_id=1,
-                    assign_scale_shift_init=True, smooth_weight=0.005, warp_loss_type="l1", depth_weight=0.1,
-                    normal_l1_weight=0.05, normal_cos_weight=0.05, flow_weight=0.001, warp_loss_weight=0.5)
+    if "meta_data_dir" in fx:        # a second conf family: its loss block comes from the shipped preset (utils/conf.py::run_conf)
+        from nicer_slam_amd.utils.conf import run_conf
+        rc = next(c for c in map(run_conf, ("replica", "7scenes", "azure")) if c["data_dir"] == str(fx["meta_data_dir"]))
+        assert rc["loss"]["smooth_weight"] == float(fx["meta_smooth_weight"])
+
+        class ds:
+            data_dir = rc["data_dir"]
+        crit = SLAMLoss(train_dataset=ds(), scan_id=1, **rc["loss"])
+    else:
+        crit = SLAMLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, train_dataset=_DS(), scan_id=1,
+                        assign_scale_shift_init=True, smooth_weight=0.005, warp_loss_type="l1", depth_weight=0.1,
+                        normal_l1_weight=0.05, normal_cos_weight=0.05, flow_weight=0.001, warp_loss_weight=0.5)
     crit.engine = engine
     assert crit._fused_ok(out) == (device == "cuda" and engine == "auto")      # GPU: the HIP loss kernels, not the torch ops
     res = crit(out, gt, keyframe_list=None, frame_idx=int(fx["meta_frame_idx"]), stage=str(fx["meta_stage"]))
@@ -47,7 +56,7 @@ def check_slam_loss(name, device="cpu", atol=1e-6, gtol=1e-7, engine="auto"):
             assert_close(warp[ps][1].grad, fx[key], gtol, 1e-4, key)
 
 
-@pytest.mark.parametrize("name", ["loss_mapping_first_frame", "loss_mapping_fine"])
+@pytest.mark.parametrize("name", ["loss_mapping_first_frame", "loss_mapping_fine", "loss_mapping_7scenes"])
 def test_slam_loss_vs_reference_golden(name):
     check_slam_loss(name)
 

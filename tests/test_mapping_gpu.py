@@ -31,7 +31,8 @@ def _run(fx, engine, ground_truth=None):
     return model, cam, out
 
 
-@pytest.mark.parametrize("name", ["full_mapping", "full_mapping_coarse_base", "full_mapping_rw", "full_mapping_rw_coarse"])
+@pytest.mark.parametrize("name", ["full_mapping", "full_mapping_coarse_base", "full_mapping_rw", "full_mapping_rw_coarse",
+                                  "full_mapping_7scenes", "full_mapping_7scenes_coarse_base"])
 def test_fused_mapping_vs_reference_goldens(name):
     fx = load(name)
     model, cam, out = _run(fx, "fused")
@@ -69,7 +70,8 @@ def test_fused_mapping_vs_reference_goldens(name):
 
 
 @pytest.mark.parametrize("name", ["full_tracking", "full_mapping", "full_mapping_coarse_base", "full_tracking_rw",
-                                  "full_mapping_rw", "full_mapping_rw_coarse"])
+                                  "full_mapping_rw", "full_mapping_rw_coarse", "full_tracking_7scenes", "full_mapping_7scenes",
+                                  "full_mapping_7scenes_coarse_base"])
 def test_fused_engine_every_parameter_gradient_like_the_reference(name):
     """The model exactly as volsdf_train.py builds it -- every parameter requires grad, nothing frozen -- with the two
     skip-policies switched off (tracking_param_grads, fine_mlp_grads): the fused engine then produces what the reference's

@@ -18,11 +18,12 @@ def oracle_seam(monkeypatch):
 
 def build_model(fx):
     from nicer_slam_amd.model.network import SLAMNetwork
-    from nicer_slam_amd.utils.conf import replica_model_conf
+    from nicer_slam_amd.utils.conf import model_conf
     cg, fg, col = fx["meta_coarse_grid"], fx["meta_fine_grid"], fx["meta_colour_grid"]
     ns, ne, nx = [int(v) for v in fx["meta_samples"]]
     warp = "meta_img_res" in fx
-    conf = replica_model_conf(ns, ne, nx, use_warp_loss=warp)
+    family = str(fx["meta_family"]) if "meta_family" in fx else "replica"      # 7-Scenes / Azure model subtree (utils/conf.py)
+    conf = model_conf(family, ns, ne, nx, use_warp_loss=warp)
     if warp:
         conf["mapping_patchsizes"] = [1, 5]
     for net, g in (("coarse", cg), ("fine", fg)):
@@ -30,7 +31,8 @@ def build_model(fx):
                                              num_levels=int(g[3]), level_dim=int(g[4]))
 
     class DS:
-        img_res = tuple(int(v) for v in fx["meta_img_res"]) if warp else (680, 1200)
+        img_res = tuple(int(v) for v in fx["meta_img_res" if warp else "meta_frame_res"]) if (warp or "meta_frame_res" in fx) \
+            else (680, 1200)
     model = SLAMNetwork(conf, dataset=DS(), n_images=4,
                         colour_grid=dict(base_resolution=int(col[0]), desired_resolution=int(col[1]),
                                          log2_hashmap_size=int(col[2])))
@@ -39,7 +41,7 @@ def build_model(fx):
 
 
 @pytest.mark.parametrize("name", ["full_tracking", "full_mapping", "full_mapping_coarse_base", "full_vis_eval",
-                                  "full_tracking_rw", "full_mapping_rw"])
+                                  "full_tracking_rw", "full_mapping_rw", "full_tracking_7scenes", "full_mapping_7scenes_coarse_base"])
 def test_model_layer_matches_reference(oracle_seam, name):
     from nicer_slam_amd.utils.general import get_camera_from_tensor
     fx = load(name)

@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("engine", ["composed"])
 @pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_mapping", "full_mapping_coarse_base",
-                                  "full_vis_eval", "full_tracking_rw", "full_mapping_rw", "full_mapping_rw_coarse"])
+                                  "full_vis_eval", "full_tracking_rw", "full_mapping_rw", "full_mapping_rw_coarse",
+                                  "full_tracking_7scenes", "full_mapping_7scenes", "full_mapping_7scenes_coarse_base"])
 def test_forward_and_grads_vs_reference_goldens(name, engine):
     from nicer_slam_amd.utils.general import camera_from_tensor_torch as get_camera_from_tensor   # the reference's op order: golden comparison (on-face far samples)
     fx = load(name)

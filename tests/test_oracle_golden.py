@@ -104,7 +104,9 @@ def check_samples(z, z_ref, bins, cdf, tight=1e-5, u_tol=1e-5, min_tight=0.97):
 # "_rw": every weight_v of the SDF networks perturbed, so that positional-encoding and grid-feature columns of the first layer
 # (zero after the geometric initialisation) carry signal: table gradients and the double backward are non-trivial there
 FULL = ["full_tracking", "full_tracking_poisson", "full_mapping", "full_mapping_coarse_base", "full_vis_eval",
-        "full_tracking_rw", "full_mapping_rw", "full_mapping_rw_coarse"]
+        "full_tracking_rw", "full_mapping_rw", "full_mapping_rw_coarse",
+        # the 7-Scenes / Azure conf family: coarse sphere radius 1.0, fine SDF MLP at nn.Linear's default initialisation, 480 x 640
+        "full_tracking_7scenes", "full_mapping_7scenes", "full_mapping_7scenes_coarse_base"]
 
 
 @pytest.mark.parametrize("name", FULL)

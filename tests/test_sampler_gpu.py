@@ -20,7 +20,7 @@ def _rays(fx, model):
 
 
 @pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_mapping", "full_vis_eval", "full_tracking_rw",
-                                  "full_mapping_rw"])
+                                  "full_mapping_rw", "full_tracking_7scenes", "full_mapping_7scenes"])
 def test_coarse_stage_sdf_and_z(name):
     """z (stratified) and coarse+fine SDF at the R*E coarse samples vs the oracle restatement."""
     from oracle import render_ref as R
@@ -46,7 +46,7 @@ def test_coarse_stage_sdf_and_z(name):
 
 
 @pytest.mark.parametrize("name", ["full_tracking", "full_tracking_poisson", "full_mapping", "full_vis_eval", "full_tracking_rw",
-                                  "full_mapping_rw"])
+                                  "full_mapping_rw", "full_tracking_7scenes", "full_mapping_7scenes"])
 def test_full_sampler_vs_reference_samples(name):
     """End-to-end fused sampler vs the reference's own z_vals (goldens), compared in CDF space."""
     from oracle import render_ref as R

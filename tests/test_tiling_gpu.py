@@ -33,7 +33,8 @@ def _run(fx, tile, z=None):
     return out, cam.grad, {n: p.grad for n, p in model.named_parameters()}
 
 
-@pytest.mark.parametrize("name", ["full_tracking_rw", "full_mapping_rw", "full_mapping_rw_coarse", "full_tracking_poisson"])
+@pytest.mark.parametrize("name", ["full_tracking_rw", "full_mapping_rw", "full_mapping_rw_coarse", "full_tracking_poisson",
+                                  "full_tracking_7scenes", "full_mapping_7scenes"])
 def test_quad_and_32_point_tilings_agree(name):
     fx = load(name)
     o16, c16, g16 = _run(fx, 16)

@@ -372,6 +372,14 @@ int nsa_adam_table_step(float *param, const float *grad, float *exp_avg, float *
 int nsa_adam_table_step_clear(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, uint32_t step,
                               float lr, float beta1, float beta2, float eps, nsa_stream_t stream);
 
+/* The step of a parameter that received NO gradient this iteration, as the reference's environment takes it: under torch 1.11
+ * (env_yamls/nicer-slam.yaml:62) optimizer.zero_grad() (code/training/volsdf_train.py:547) leaves zero TENSORS, so Adam still decays both
+ * moments and moves the parameter along its momentum (the fine table during stage "coarse", the colour table during color_stage "base",
+ * :550-555); torch >= 2.0 sets .grad = None and skips such a parameter.  Arithmetic of nsa_adam_table_step with grad == 0, no gradient
+ * read (3 reads + 3 writes per element).  replaces zero_grad() + optimizer.step() for one un-touched tensor (volsdf_train.py:547,576). */
+int nsa_adam_table_step_zero_grad(float *param, float *exp_avg, float *exp_avg_sq, uint64_t n, uint32_t step, float lr, float beta1,
+                                  float beta2, float eps, nsa_stream_t stream);
+
 /* The same Adam step over up to 24 SMALL tensors (n <= 2^24 each) in one launch: the weight_v / weight_g / bias tensors of the
  * trained MLPs.  Per-tensor lr and step count; beta1, beta2, eps shared.  4-byte aligned pointers suffice. */
 typedef struct nsa_adam_seg {
@@ -383,8 +391,8 @@ typedef struct nsa_adam_seg {
 } nsa_adam_seg_t;
 int nsa_adam_multi_step(const nsa_adam_seg_t *segs, uint32_t count, float beta1, float beta2, float eps, nsa_stream_t stream);
 
-/* p[0..n) = 0 (p 16-byte aligned): the zero fill of a table-gradient buffer as a library launch, so that it can run on a side
- * stream under the next iteration's forward kernels (nicer_slam_amd/fused/tablegrad.py).  replaces optimizer.zero_grad() +
+/* p[0..n) = 0 (p 16-byte aligned): the zero fill of a table-gradient buffer as a library launch, issued on the launch stream right
+ * before the first backward kernel of a pass scatters into the buffer (nicer_slam_amd/fused/tablegrad.py).  replaces optimizer.zero_grad() +
  * the zero-initialised dense gradient of code/hashencoder/hashgrid.py:117-118. */
 int nsa_fill_zero(float *p, uint64_t n, nsa_stream_t stream);
 

@@ -133,7 +133,9 @@ lib.nsa_adam_table_step.restype = _i
 lib.nsa_adam_table_step.argtypes = [_p, _p, _p, _p, ctypes.c_uint64, _u32, _f32, _f32, _f32, _f32, _p]
 lib.nsa_adam_table_step_clear.restype = _i
 lib.nsa_adam_table_step_clear.argtypes = lib.nsa_adam_table_step.argtypes
-EXPORTS += ["nsa_update_voxels", "nsa_adam_table_step", "nsa_adam_table_step_clear"]
+lib.nsa_adam_table_step_zero_grad.restype = _i
+lib.nsa_adam_table_step_zero_grad.argtypes = [_p, _p, _p, ctypes.c_uint64, _u32, _f32, _f32, _f32, _f32, _p]
+EXPORTS += ["nsa_update_voxels", "nsa_adam_table_step", "nsa_adam_table_step_clear", "nsa_adam_table_step_zero_grad"]
 
 
 class WnLayer(ctypes.Structure):

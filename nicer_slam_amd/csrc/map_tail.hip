@@ -338,6 +338,51 @@ __global__ __launch_bounds__(256) void k_adam_table_linear(AdamTableArgs a) {
     }
 }
 
+// The step torch 1.11 (the reference's environment, env_yamls/nicer-slam.yaml:62) takes for a parameter that received NO gradient in
+// this iteration: there optimizer.zero_grad() (volsdf_train.py:547) leaves a ZERO tensor, so Adam still decays both moments and moves the
+// parameter along its momentum -- the fine table during stage "coarse", the colour table during color_stage "base" (:550-555).  Same
+// arithmetic as adam_one with g = 0 (m + w1 (0 - m); v beta2 + w2 0 0), without reading a gradient: 3 reads + 3 writes per element
+// instead of a zero fill + 4 reads + 3 writes.  NT: non-temporal accesses for tables beyond the MALL, as k_adam_table_linear_nt.
+template <bool NT>
+__global__ __launch_bounds__(256) void k_adam_table_zero_grad(AdamTableArgs a) {
+    const uint64_t n4 = a.n / 4;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        float4 p, m, v;
+        if (NT) {
+            p = nt_load4(reinterpret_cast<const float4*>(a.p) + i);
+            m = nt_load4(reinterpret_cast<const float4*>(a.m) + i);
+            v = nt_load4(reinterpret_cast<const float4*>(a.v) + i);
+        } else {
+            p = reinterpret_cast<const float4*>(a.p)[i];
+            m = reinterpret_cast<const float4*>(a.m)[i];
+            v = reinterpret_cast<const float4*>(a.v)[i];
+        }
+        adam_one(p.x, 0.0f, m.x, v.x, a);
+        adam_one(p.y, 0.0f, m.y, v.y, a);
+        adam_one(p.z, 0.0f, m.z, v.z, a);
+        adam_one(p.w, 0.0f, m.w, v.w, a);
+        if (NT) {
+            nt_store4(reinterpret_cast<float4*>(a.p) + i, p);
+            nt_store4(reinterpret_cast<float4*>(a.m) + i, m);
+            nt_store4(reinterpret_cast<float4*>(a.v) + i, v);
+        } else {
+            reinterpret_cast<float4*>(a.p)[i] = p;
+            reinterpret_cast<float4*>(a.m)[i] = m;
+            reinterpret_cast<float4*>(a.v)[i] = v;
+        }
+    }
+    if (blockIdx.x == 0) {
+        const uint64_t t = n4 * 4 + threadIdx.x;
+        if (t < a.n) adam_one(a.p[t], 0.0f, a.m[t], a.v[t], a);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_adam_table_zero_grad_scalar(AdamTableArgs a) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) adam_one(a.p[i], 0.0f, a.m[i], a.v[i], a);
+}
+
 // any alignment (gradients that are views into a larger buffer, e.g. FlatWeightNorm's): one element per thread
 template <bool CLEAR>
 __global__ __launch_bounds__(256) void k_adam_table_scalar(AdamTableArgs a) {
@@ -649,6 +694,30 @@ int nsa_adam_table_step_clear(float* param, float* grad, float* exp_avg, float* 
     return adam_table_launch(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, true, stream);
 }
 
+int nsa_adam_table_step_zero_grad(float* param, float* exp_avg, float* exp_avg_sq, uint64_t n, uint32_t step, float lr, float beta1,
+                                  float beta2, float eps, nsa_stream_t stream) {
+    using namespace nsa;
+    if (!param || !exp_avg || !exp_avg_sq || step == 0) return NSA_EBADARG;
+    if (n == 0) return NSA_OK;
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq);
+    if (bits & 3u) return NSA_EBADARG;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamTableArgs a{param, nullptr, exp_avg, exp_avg_sq, n, 1.0f - beta1, beta2, 1.0f - beta2, (float)((double)lr / bc1), (float)sqrt(bc2), eps};
+    launch_begin();
+    if (bits & 15u) {
+        uint64_t sb = (n + 255) / 256;
+        if (sb > 256 * 32) sb = 256 * 32;
+        hipLaunchKernelGGL(k_adam_table_zero_grad_scalar, dim3((uint32_t)sb), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        const uint64_t lb = (n / 4 + 255) / 256 ? (n / 4 + 255) / 256 : 1;
+        if (lb > 0x7FFFFFFFull) return NSA_EBADARG;
+        if (n >= (1ull << 26)) hipLaunchKernelGGL(k_adam_table_zero_grad<true>, dim3((uint32_t)lb), dim3(256), 0, (hipStream_t)stream, a);
+        else                   hipLaunchKernelGGL(k_adam_table_zero_grad<false>, dim3((uint32_t)lb), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    return launch_end();
+}
+
 int nsa_adam_multi_step(const nsa_adam_seg_t* segs, uint32_t count, float beta1, float beta2, float eps, nsa_stream_t stream) {
     using namespace nsa;
     if (count == 0) return NSA_OK;
@@ -682,7 +751,11 @@ int nsa_fill_zero(float* p, uint64_t n, nsa_stream_t stream) {
     if (!p || (reinterpret_cast<uintptr_t>(p) & 15u)) return NSA_EBADARG;
     if (n == 0) return NSA_OK;
     // float4 groups per thread (NSA_FILL_GROUPS = 1 | 2 | 4: A/B override, tools/micro/fill_bench.py)
-    static const int G = [] { const char* e = getenv("NSA_FILL_GROUPS"); return e ? atoi(e) : 1; }();
+    static const int G = [] {
+        const char* e = getenv("NSA_FILL_GROUPS");
+        const int g = e ? atoi(e) : 1;
+        return (g == 2 || g == 4) ? g : 1;        // anything else would size the grid for a template that is not launched
+    }();
     uint64_t blocks = (n / 4 + 256 * G - 1) / (256 * G);
     if (blocks == 0) blocks = 1;
     if (blocks > 0x7FFFFFFFull) return NSA_EBADARG;

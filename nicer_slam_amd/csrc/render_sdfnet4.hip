@@ -408,12 +408,15 @@ __global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd_
 
 // workgroups of a persistent launch: one per CU
 static int persistent_blocks4() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, cus = 0;
-        n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus : 256;
+    // per device id (a process may drive GPUs with different CU counts, and the current device may change between launches)
+    static int n[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (n[dev] == 0) {
+        int cus = 0;
+        n[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus : 256;
     }
-    return n;
+    return n[dev];
 }
 // NSA_BF16_RESIDENT=0: the staged forms (A/B runs)
 static bool bf16_resident() {

@@ -56,6 +56,10 @@ def _hip_adam(p, g, exp_avg, exp_avg_sq, step, lr, betas, eps):
     from ._native import lib, check
     if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
         raise RuntimeError("ShardedAdam: the built-in stepper needs float32 contiguous CUDA tensors")
+    if g is None:            # the zero-gradient step of none_grad="zeros" (optim.py): no gradient is read
+        check(lib.nsa_adam_table_step_zero_grad(p.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), p.numel(), int(step), float(lr),
+                                                float(betas[0]), float(betas[1]), float(eps), torch.cuda.current_stream().cuda_stream))
+        return
     check(lib.nsa_adam_table_step(p.data_ptr(), g.contiguous().data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                                   p.numel(), int(step), float(lr), float(betas[0]), float(betas[1]), float(eps),
                                   torch.cuda.current_stream().cuda_stream))
@@ -75,6 +79,10 @@ class ShardedAdam(torch.optim.Optimizer):
     the SUM so that ranks with different ray counts still produce the gradient of the global mean.
     Hyper-parameters/semantics as nicer_slam_amd.optim.Adam / torch.optim.Adam (no weight decay, no amsgrad).
     ``stepper`` = callable(p, g, exp_avg, exp_avg_sq, step, lr, betas, eps) updating p in place; default: the HIP kernel.
+    ``none_grad`` as nicer_slam_amd.optim.Adam: "skip" (installed torch) or "zeros" (torch 1.11, the reference's environment) -- a
+    parameter whose ``.grad`` is None on this step but which has been stepped before takes a zero-gradient step (``stepper`` is called
+    with ``g = None``).  Which parameters receive gradients is decided by the mapping schedule (stage / color_stage), i.e. identically on
+    every rank, so no collective is needed for the gradient: each rank steps its slice, the slices are all-gathered as usual.
 
     ``p.grad`` is CONSUMED by ``step()``: it is scaled by ``weight`` in place and the collectives run on its storage (the
     reduce-scatter reads it; under gloo the fallback all-reduces into it), so after the step it no longer holds this rank's
@@ -85,8 +93,12 @@ class ShardedAdam(torch.optim.Optimizer):
     list fallbacks of the same methods, and a 1-rank RCCL group exercises the in-place forms with world = 1 only.
     """
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, shard_min_numel=1 << 16, stepper=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, shard_min_numel=1 << 16, stepper=None,
+                 none_grad="skip"):
+        if none_grad not in ("skip", "zeros"):
+            raise ValueError(f"none_grad={none_grad!r}: expected 'skip' or 'zeros'")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.none_grad = none_grad
         self.group, self.shard_min_numel, self.stepper = group, shard_min_numel, stepper or _hip_adam
         on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
@@ -124,6 +136,27 @@ class ShardedAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             for p in group["params"]:
                 if p.grad is None:
+                    state = self.state.get(p)
+                    if getattr(self, "none_grad", "skip") != "zeros" or not state:
+                        continue
+                    state["step"] += 1
+                    if state["sharded"]:
+                        n, numel = state["shard_numel"], p.numel()
+                        if state["padded"]:
+                            flat = state["flat"]
+                            flat[:numel].copy_(p.view(-1))
+                        else:
+                            flat = p.view(-1)
+                        p_shard = flat[self.rank * n:(self.rank + 1) * n]
+                        self.stepper(p_shard, None, state["exp_avg"], state["exp_avg_sq"], state["step"], group["lr"], group["betas"],
+                                     group["eps"])
+                        self._all_gather(flat, p_shard)
+                        if state["padded"]:
+                            p.view(-1).copy_(flat[:numel])
+                    else:
+                        self.stepper(p.view(-1), None, state["exp_avg"], state["exp_avg_sq"], state["step"], group["lr"], group["betas"],
+                                     group["eps"])
+                    bump_version(p)
                     continue
                 state = self.state[p]
                 if not state:

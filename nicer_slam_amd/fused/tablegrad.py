@@ -30,11 +30,12 @@ IN_PLACE = os.environ.get("NSA_TABLE_GRADS", "inplace") != "autograd"
 
 
 class _Entry:
-    __slots__ = ("buf", "clean")
+    __slots__ = ("buf", "clean", "clean_version")
 
     def __init__(self, param):
         self.buf = torch.zeros_like(param, memory_format=torch.contiguous_format)
         self.clean = True
+        self.clean_version = self.buf._version      # the buffer's autograd version counter when it was last known to be all zero
 
 
 def _fill(buf, stream):
@@ -67,7 +68,10 @@ def target(param):
         raise RuntimeError("fused mapping engine: a table's .grad must be a dense contiguous float32 tensor of the table's shape "
                            "(set NSA_TABLE_GRADS=autograd for gradients returned through autograd)")
     e = _entry(param)
-    if not e.clean:                        # holds the previous pass's gradient (clean only when new, or cleared by the optimizer)
+    # holds the previous pass's gradient unless new or cleared by the optimizer (consume_table_grads) -- and, in that case, only if no
+    # torch op wrote the buffer since (it stays reachable as param.grad after the step: AccumulateGrad's `+=` of the composed engine
+    # or a caller's in-place add bump its version counter; the library's own kernels go through target(), which un-cleans)
+    if not e.clean or e.buf._version != e.clean_version:
         with torch.cuda.device(e.buf.device):
             _fill(e.buf, torch.cuda.current_stream())
     e.clean = False
@@ -87,3 +91,4 @@ def mark_clean(param):
     e = _pool.get(param)
     if e is not None:
         e.clean = True
+        e.clean_version = e.buf._version

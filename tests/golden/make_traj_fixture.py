@@ -1,15 +1,17 @@
-"""Build-container script (needs /root/reference): the first 64 poses of the reference's ground-truth trajectory of Replica room0
-(`gt_trajs/gt_replica_room0.txt`: one line per frame, `stamp tx ty tz qx qy qz qw`, what code/evaluation/eval_cam.py:456-459 compares
-an estimate against) -> tests/golden/replica_room0_traj64.txt.  A data fixture (numbers), used by tools/synthetic_sequence.py as the
-camera path of the synthetic multi-frame tracking run ("poses from gt_trajs/gt_replica_room0.txt recentred / scaled
-into the unit cube")."""
+"""Build-container script (needs /root/reference): the first 64 poses of the reference's ground-truth trajectories of Replica room0 and
+7-Scenes office (`gt_trajs/gt_replica_room0.txt`, `gt_trajs/gt_7scenes_office.txt`: one line per frame, `stamp tx ty tz qx qy qz qw`, what
+code/evaluation/eval_cam.py:456-459 compares an estimate against) -> tests/golden/replica_room0_traj64.txt, scenes7_office_traj64.txt.
+Data fixtures (numbers), used by tools/synthetic_sequence.py as the camera paths of the synthetic multi-frame runs ("poses from
+gt_trajs/gt_replica_room0.txt recentred / scaled into the unit cube"; BASELINE configs[3] names the 7-Scenes office sequence)."""
 import os
 
-SRC = "/root/reference/gt_trajs/gt_replica_room0.txt"
-DST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "replica_room0_traj64.txt")
+HERE = os.path.dirname(os.path.abspath(__file__))
+PAIRS = (("/root/reference/gt_trajs/gt_replica_room0.txt", "replica_room0_traj64.txt"),
+         ("/root/reference/gt_trajs/gt_7scenes_office.txt", "scenes7_office_traj64.txt"))
 
 if __name__ == "__main__":
-    rows = [ln for ln in open(SRC).read().splitlines() if ln.strip()][:64]
-    assert len(rows) == 64 and all(len(r.split()) == 8 for r in rows)
-    open(DST, "w").write("\n".join(rows) + "\n")
-    print(DST, len(rows))
+    for src, name in PAIRS:
+        rows = [ln for ln in open(src).read().splitlines() if ln.strip()][:64]
+        assert len(rows) == 64 and all(len(r.split()) == 8 for r in rows)
+        open(os.path.join(HERE, name), "w").write("\n".join(rows) + "\n")
+        print(name, len(rows))

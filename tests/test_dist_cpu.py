@@ -88,6 +88,8 @@ def _torch_math_adam(p, g, m, v, step, lr, betas, eps):
     """Test-only stepper (torch.optim.Adam's update written out) so ShardedAdam's collectives can run on CPU tensors;
     the product default is the HIP kernel."""
     b1, b2 = betas
+    if g is None:                # none_grad="zeros": the zero-gradient step (what torch 1.11 does after zero_grad())
+        g = torch.zeros_like(p)
     m.lerp_(g, 1 - b1)
     v.mul_(b2).addcmul_(g, g, value=1 - b2)
     denom = (v.sqrt() / (1 - b2 ** step) ** 0.5).add_(eps)
@@ -102,6 +104,10 @@ def _rank_grads(rank, it, shapes):
 _SHAPES = [(37,), (70001, 3), (5, 7), (40000, 2)]   # small, sharded (odd size -> padded staging buffer), small, sharded (even:
                                                    # collectives run straight on the gradient / parameter storage)
 _WEIGHTS = [0.25, 0.75]                          # unequal ray shares
+_ITERS = 5
+# (iteration, parameter) pairs without a gradient -- a table outside its stage (volsdf_train.py:550-555): one sharded + padded tensor, one
+# small one.  With none_grad="zeros" they take torch 1.11's zero-gradient step; the single-process reference is fed explicit zeros.
+_NO_GRAD = {(3, 1), (3, 2)}
 
 
 def _map_worker(rank, world, port, out_q):
@@ -115,11 +121,11 @@ def _map_worker(rank, world, port, out_q):
     torch.manual_seed(0)
     params = [torch.nn.Parameter(torch.randn(*s)) for s in _SHAPES]
     opt = nd.ShardedAdam([{"params": params[:2], "lr": 0.04}, {"params": params[2:], "lr": 0.002}], betas=(0.9, 0.99),
-                         eps=1e-15, stepper=_torch_math_adam, shard_min_numel=1 << 16)
+                         eps=1e-15, stepper=_torch_math_adam, shard_min_numel=1 << 16, none_grad="zeros")
     ptrs = None
-    for it in range(3):
-        for p, g in zip(params, _rank_grads(rank, it, _SHAPES)):
-            p.grad = g
+    for it in range(_ITERS):
+        for i, (p, g) in enumerate(zip(params, _rank_grads(rank, it, _SHAPES))):
+            p.grad = None if (it, i) in _NO_GRAD else g          # (what zero_grad() leaves under torch >= 2.0)
         opt.step(weight=_WEIGHTS[rank])
         # no buffer churn: every persistent buffer of the sharded tensors keeps its storage from the first step on
         now = [opt.state[params[i]][k].data_ptr() for i in (1, 3) for k in ("exp_avg", "exp_avg_sq", "g_shard")]
@@ -152,10 +158,10 @@ def test_two_rank_sharded_adam_matches_single_process_adam():
     torch.manual_seed(0)
     ref = [torch.nn.Parameter(torch.randn(*s)) for s in _SHAPES]
     opt = torch.optim.Adam([{"params": ref[:2], "lr": 0.04}, {"params": ref[2:], "lr": 0.002}], betas=(0.9, 0.99), eps=1e-15)
-    for it in range(3):
+    for it in range(_ITERS):
         gs = [_rank_grads(r, it, _SHAPES) for r in range(2)]
         for i, p in enumerate(ref):
-            p.grad = _WEIGHTS[0] * gs[0][i] + _WEIGHTS[1] * gs[1][i]
+            p.grad = torch.zeros_like(p) if (it, i) in _NO_GRAD else _WEIGHTS[0] * gs[0][i] + _WEIGHTS[1] * gs[1][i]
         opt.step()
     for a, b, r in zip(res[0][1], res[1][1], ref):
         np.testing.assert_array_equal(a, b)                                   # replicas stay bit-identical

@@ -272,6 +272,62 @@ def test_fused_adam_vs_torch_adam(n):
                  "exp_avg_sq")
 
 
+@pytest.mark.parametrize("n", [5, 1027, (1 << 20) + 3, (1 << 26) + 8])
+def test_adam_none_grad_zeros_is_the_reference_environments_zero_grad(n):
+    """optim.Adam(none_grad="zeros"): a parameter whose .grad is None (what optimizer.zero_grad() leaves under torch >= 2.0) but which was
+    stepped before takes the step torch 1.11 -- the reference's environment, env_yamls/nicer-slam.yaml:62 -- takes on the ZERO tensor its
+    zero_grad() leaves (volsdf_train.py:547): moments decay, the parameter moves along its momentum.  Expected values: torch.optim.Adam fed
+    explicit zero gradients.  Sizes: multi-tensor launch (5, 1027), table kernel (2^20 + 3), non-temporal table kernel (2^26 + 8).
+    "skip" (default) must leave such a parameter and its state untouched, and a never-stepped parameter is skipped in both modes."""
+    from nicer_slam_amd.optim import Adam
+    torch.manual_seed(n % 1000)
+    p0 = torch.randn(n, device="cuda") * 0.1
+    a, b, c = (torch.nn.Parameter(p0.clone()) for _ in range(3))
+    fresh = torch.nn.Parameter(p0[:7].clone())
+    oa = Adam([{"params": [a, fresh], "lr": 0.04}], betas=(0.9, 0.99), eps=1e-15, none_grad="zeros")
+    ob = torch.optim.Adam([{"params": [b], "lr": 0.04}], betas=(0.9, 0.99), eps=1e-15)
+    oc = Adam([{"params": [c], "lr": 0.04}], betas=(0.9, 0.99), eps=1e-15)
+    assert oc.none_grad == "skip"
+    with pytest.raises(ValueError):
+        Adam([a], none_grad="zero")
+    oa.step()                                                 # nothing has a gradient or a state yet: nothing happens
+    assert torch.equal(a.detach(), p0) and not oa.state.get(a) and not oa.state.get(fresh)
+    schedule = [True, True, False, False, False, True, False]     # gradient this step?
+    for it, has in enumerate(schedule):
+        g = torch.randn(n, device="cuda") * (10.0 ** (it % 3 - 2))
+        g[::3] = 0.0
+        a.grad, c.grad = (g.clone(), g.clone()) if has else (None, None)
+        b.grad = g.clone() if has else torch.zeros_like(b)
+        c_before = c.detach().clone()
+        v0 = a._version
+        oa.step()
+        ob.step()
+        oc.step()
+        assert a._version > v0
+        assert_close(a.detach(), b.detach().cpu().numpy(), 1e-7, 2e-6, f"param after step {it + 1}")
+        if not has:
+            assert torch.equal(c.detach(), c_before)          # "skip": untouched
+            assert float((a.detach() - c_before).abs().max()) > 0 or it == 0
+    sa, sb, sc = oa.state[a], ob.state[b], oc.state[c]
+    assert float(sa["step"]) == float(sb["step"]) == len(schedule) and float(sc["step"]) == sum(schedule)
+    assert not oa.state.get(fresh)
+    assert_close(sa["exp_avg"], sb["exp_avg"].cpu().numpy(), 3e-7 * float(sb["exp_avg"].abs().max()), 2e-6, "exp_avg")
+    assert_close(sa["exp_avg_sq"], sb["exp_avg_sq"].cpu().numpy(), 3e-7 * float(sb["exp_avg_sq"].abs().max()), 2e-6, "exp_avg_sq")
+    # the options survive pickling and a state_dict round trip (device `step` tensors of a capturable torch state are moved to the host)
+    import pickle
+    o2 = pickle.loads(pickle.dumps(oa))
+    assert o2.none_grad == "zeros" and o2.consume_table_grads == oa.consume_table_grads
+    del o2.__dict__["none_grad"], o2.__dict__["consume_table_grads"]
+    o2.__setstate__(torch.optim.Optimizer.__getstate__(o2))       # a pickle made before the options existed
+    assert o2.none_grad == "skip" and o2.consume_table_grads is False
+    sd = ob.state_dict()
+    for st in sd["state"].values():
+        st["step"] = st["step"].to("cuda")
+    o3 = Adam([{"params": [b], "lr": 0.04}], betas=(0.9, 0.99), eps=1e-15)
+    o3.load_state_dict(sd)
+    assert o3.state[b]["step"].device.type == "cpu" and float(o3.state[b]["step"]) == len(schedule)
+
+
 def test_sharded_adam_single_rank_uses_hip_stepper():
     """ShardedAdam without a process group (world 1) must step exactly like nicer_slam_amd.optim.Adam (same kernel)."""
     from nicer_slam_amd.optim import Adam

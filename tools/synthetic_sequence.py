@@ -36,6 +36,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 TRAJ = os.path.join(ROOT, "tests", "golden", "replica_room0_traj64.txt")
 SCALE = 0.25          # metres -> scene units: Replica room0 (~7 m) inside the cube [-1, 1]^3
+# The shipped conf families (nicer_slam_amd/utils/conf.py): camera path, scene scale and default (reduced) frame size of the stand-in
+# sequence.  "7scenes" = BASELINE configs[3]'s family: gt_trajs/gt_7scenes_office.txt[:64], 480 x 640 Kinect frames (here halved, as the
+# Replica frames are), coarse sphere radius 1.0, fine SDF MLP not geometrically initialised, smooth_weight 0.05.
+FAMILIES = {
+    "replica": dict(traj=TRAJ, scale=SCALE, size=(340, 600)),
+    "7scenes": dict(traj=os.path.join(ROOT, "tests", "golden", "scenes7_office_traj64.txt"), scale=0.4, size=(240, 320)),
+}
 
 
 class _DS:
@@ -44,8 +51,10 @@ class _DS:
 
 
 # ------------------------------------------------------------------------------------------------------------ scene and trajectory
-def load_trajectory(n, scale=SCALE, path=TRAJ):
+def load_trajectory(n, scale=None, path=None, family="replica"):
     """-> c2w [n,4,4] float32: TUM rows (stamp tx ty tz qx qy qz qw), translations recentred on their mean and scaled."""
+    scale = FAMILIES[family]["scale"] if scale is None else scale
+    path = FAMILIES[family]["traj"] if path is None else path
     rows = np.loadtxt(path)[:n]
     assert rows.shape[0] == n, f"the fixture holds {rows.shape[0]} poses"
     t = (rows[:, 1:4] - rows[:, 1:4].mean(0)) * scale
@@ -58,15 +67,16 @@ def load_trajectory(n, scale=SCALE, path=TRAJ):
     return torch.from_numpy(c2w.astype(np.float32))
 
 
-def build_teacher(H, W, n_samples=64, colour_grid=None, seed=5, device="cpu"):
+def build_teacher(H, W, n_samples=64, colour_grid=None, seed=5, device="cpu", family="replica"):
     """SLAMNetwork at the shipped sizes (colour_grid: optional smaller colour table for quick runs) with a scene worth tracking:
     band-limited random colour features (amplitude falling with the level), a colour MLP with trained-like gains, small SDF-grid
     features and perturbed first-layer directions (the geometric initialisation alone is a featureless sphere that ignores its encodings)."""
     from nicer_slam_amd.model.network import SLAMNetwork
-    from nicer_slam_amd.utils.conf import replica_model_conf
+    from nicer_slam_amd.utils.conf import model_conf
     torch.manual_seed(seed)
     kw = {} if colour_grid is None else {"colour_grid": colour_grid}
-    model = SLAMNetwork(replica_model_conf(n_samples, 640, 32, use_warp_loss=False), dataset=_DS(H, W), n_images=64, **kw)
+    model = SLAMNetwork(model_conf(family, n_samples, 640, 32, use_warp_loss=False), dataset=_DS(H, W), n_images=64, **kw)
+    model.conf_family = family
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for enc, a0, decay in ((model.rendering_network.encoding, 0.8, 0.8), (model.implicit_network.coarse.encoding, 0.03, 1.0),
@@ -82,16 +92,24 @@ def build_teacher(H, W, n_samples=64, colour_grid=None, seed=5, device="cpu"):
         # trained network's would be, so that the rendered frames carry texture (std over an image ~0.27)
         for l, gain in enumerate((5.0, 3.0, 3.0)):
             getattr(model.rendering_network, f"lin{l}").weight_g.mul_(gain)
+        if family != "replica":
+            # 7-Scenes / Azure confs: `fine.geometric_init = false` -- the fine SDF MLP is built at nn.Linear's default initialisation and
+            # then OVERWRITTEN from pretrain.pth (volsdf_train.py:139-147), which does not exist here.  A default-initialised decoder adds a
+            # rough +-0.08 field to the coarse sphere; a pretrained residual decoder's output is small: scale the sdf row of its last layer.
+            model.implicit_network.fine.lin3.weight_g[0].mul_(0.25)
+            model.implicit_network.fine.lin3.bias[0].mul_(0.25)
     for p in model.parameters():
         p.requires_grad_(False)
     return model.to(device)
 
 
-def intrinsics(H, W, device="cpu"):
-    """the shipped Replica camera (600, 600, 599.5, 339.5 at 680 x 1200) scaled to H x W"""
-    s = H / 680.0
+def intrinsics(H, W, device="cpu", family="replica"):
+    """the family's shipped camera (Replica: 600, 600, 599.5, 339.5 at 680 x 1200; 7-Scenes: 585, 585, 320, 240 at 480 x 640) scaled to H x W"""
+    from nicer_slam_amd.utils.conf import run_conf
+    rc = run_conf(family)
+    s = H / float(rc["img_res"][0])
     K = torch.eye(4)
-    K[0, 0] = K[1, 1] = 600.0 * s
+    K[0, 0], K[1, 1] = rc["intrinsics"][0] * s, rc["intrinsics"][1] * s
     K[0, 2], K[1, 2] = (W - 1) / 2.0, (H - 1) / 2.0
     return K.to(device)
 
@@ -155,11 +173,12 @@ def make_draws(gen, R, E, n_extra, S, n_pix_total):
 
 
 def track_sequence(engine, model, frames, K, gt_poses, H, W, iters=100, pixels=1024, lr=0.005, shared_seed=None, n_frames=None,
-                   init_poses=None, log=None, trace=None):
+                   init_poses=None, log=None, trace=None, const_speed=False):
     """The reference's per-frame tracking protocol (volsdf_train.py:373-446) on `engine` in {"fused", "composed", "oracle"}.
     frames [n, H*W, 3] (on the model's device; CPU for the oracle).  shared_seed: every iteration's pixels and sampler draws come
     from a CPU generator seeded by (shared_seed, frame, iteration) -- identical for every engine; None: the engine's own RNG.
     init_poses: use these estimates for frames 0 .. len-1 (experiment B continues the oracle from the fused run's start).
+    const_speed: SLAM.tracking.const_speed_assumption (volsdf_train.py:32,380-387; False in every shipped conf).
     trace: a list that receives (frame, iteration, loss, camera 7-vector BEFORE the step, camera gradient) of every iteration.
     -> est c2w [n,4,4] (CPU float32)."""
     from nicer_slam_amd.utils.general import get_camera_from_tensor, get_tensor_from_camera
@@ -189,8 +208,8 @@ def track_sequence(engine, model, frames, K, gt_poses, H, W, iters=100, pixels=1
     ind = torch.zeros(1, dtype=torch.long, device=dev)
     gen_own = torch.Generator(device=dev).manual_seed(12345)
     for f in range(len(est), n):
-        # constant-speed assumption (volsdf_train.py:381-388)
-        if f >= 2:
+        # initial estimate (volsdf_train.py:380-387): the previous frame's pose, or the constant-speed extrapolation
+        if const_speed and f >= 2:
             c2w0 = (est[f - 1] @ torch.linalg.inv(est[f - 2])) @ est[f - 1]
         else:
             c2w0 = est[f - 1]
@@ -255,14 +274,14 @@ def render_cues(model, poses, K, H, W):
     return torch.stack(rgb), torch.stack(depth), torch.stack(normal)
 
 
-def make_student(teacher, H, W, n_images, colour_grid=None, seed=11):
+def make_student(teacher, H, W, n_images, colour_grid=None, seed=11, family="replica"):
     """The map to be learned: a SLAMNetwork at the reference's initialisation (tables U(-1e-4, 1e-4), geometric MLPs) -- except the
     fine SDF MLP, which the reference loads from `pretrain.pth` and never optimises (volsdf_train.py:139-173): here the teacher's."""
     from nicer_slam_amd.model.network import SLAMNetwork
-    from nicer_slam_amd.utils.conf import replica_model_conf
+    from nicer_slam_amd.utils.conf import model_conf
     torch.manual_seed(seed)
     kw = {} if colour_grid is None else {"colour_grid": colour_grid}
-    student = SLAMNetwork(replica_model_conf(64, 640, 32, use_warp_loss=False), dataset=_DS(H, W), n_images=n_images, **kw)
+    student = SLAMNetwork(model_conf(family, 64, 640, 32, use_warp_loss=False), dataset=_DS(H, W), n_images=n_images, **kw)
     sd = teacher.state_dict()
     with torch.no_grad():
         for name, p in student.named_parameters():
@@ -273,7 +292,8 @@ def make_student(teacher, H, W, n_images, colour_grid=None, seed=11):
 
 
 def run_slam(engine, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_grid=None, map_every=5, map_iters=100, track_iters=100,
-             map_pixels=8192, track_pixels=1024, lr=0.002, cam_lr=0.005, ba_lr=0.001, window=15, log=None, schedule="reference", seed=11):
+             map_pixels=8192, track_pixels=1024, lr=0.002, cam_lr=0.005, ba_lr=0.001, window=15, log=None, schedule="reference", seed=11,
+             family="replica", none_grad="skip", const_speed=False):
     """Tracking AND mapping in the reference's loop shape (volsdf_train.py:363-613) on `engine`: frame 0 at its ground-truth pose and
     `map_iters` mapping iterations on it; every later frame tracked from the constant-speed initialisation against the map learned so far;
     every `map_every`-th frame a mapping round over the keyframe window (every 10th frame + the current one; the frames since the last
@@ -283,13 +303,18 @@ def run_slam(engine, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_gr
     "fine": every round at stage "fine" / "highfreq" -- on this synthetic scene the coarse-only quarter of a later round is BISTABLE
     (tools/diag_slam_mapping.py, profiles/r05_slam_mapping_rounds.txt: from one and the same state the round ends at loss 0.044 or loses the
     surface -- no ray straddles it any more, loss 0.14 -- on EITHER engine, by the draws), so trajectories under it compare luck, not engines.
+    family: the conf family (model subtree + loss weights, utils/conf.py).  none_grad: the mapping optimizer's treatment of a table outside its
+    stage -- "skip" = the installed torch (zero_grad() sets .grad = None, the table is not stepped), "zeros" = torch 1.11, the reference's
+    environment (zero_grad() leaves zero tensors, the table keeps moving along its momentum; nicer_slam_amd/optim.py).
     -> final pose estimates [frames,4,4] (CPU), seconds spent in (tracking, mapping)."""
     from nicer_slam_amd.feed import FrameFeed
     from nicer_slam_amd.model.loss import SLAMLoss
     from nicer_slam_amd.optim import Adam as HipAdam
     from nicer_slam_amd.utils.general import get_camera_from_tensor, get_tensor_from_camera
     dev = teacher.voxels.device
-    student = make_student(teacher, H, W, frames, colour_grid, seed)      # (also seeds every random stream of the run: torch's
+    from nicer_slam_amd.utils.conf import run_conf
+    lw = run_conf(family)["loss"]
+    student = make_student(teacher, H, W, frames, colour_grid, seed, family)   # (also seeds every random stream of the run: torch's
     student.engine = engine                                              #  generators and, through them, the fused sampler's Philox state)
     student.train()
     imp, rn = student.implicit_network, student.rendering_network
@@ -302,9 +327,11 @@ def run_slam(engine, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_gr
         {"name": "coarse_mlp_parameters", "params": list(imp.coarse.mlp_parameters()), "lr": lr},
     ]
     para_list = [g for g in para_list if len(g["params"])]
-    optimizer = HipAdam(para_list, betas=(0.9, 0.99), eps=1e-15)       # (= torch.optim.Adam's semantics, one pass per tensor)
-    loss_fn = SLAMLoss(model=student, rgb_loss="torch.nn.L1Loss", assign_scale_shift_init=True, eikonal_weight=0.1, smooth_weight=0.005,
-                       depth_weight=0.1, normal_l1_weight=0.05, normal_cos_weight=0.05)          # runconf_replica_1.conf:45-57
+    optimizer = HipAdam(para_list, betas=(0.9, 0.99), eps=1e-15, none_grad=none_grad)   # (torch.optim.Adam's arithmetic, one pass per tensor)
+    # the family's loss block (runconf_replica_1.conf:45-57 / runconf_7scenes_1.conf:46-58) without the warp / flow terms
+    loss_fn = SLAMLoss(model=student, rgb_loss=lw["rgb_loss"], assign_scale_shift_init=lw["assign_scale_shift_init"],
+                       eikonal_weight=lw["eikonal_weight"], smooth_weight=lw["smooth_weight"], depth_weight=lw["depth_weight"],
+                       normal_l1_weight=lw["normal_l1_weight"], normal_cos_weight=lw["normal_cos_weight"])
     tracking_loss = SLAMLoss(model=student, rgb_loss="torch.nn.L1Loss", eikonal_weight=0, smooth_weight=0, depth_weight=0,
                              normal_l1_weight=0, normal_cos_weight=0)
     feed = FrameFeed((H, W), device=dev, capacity=frames)
@@ -347,11 +374,11 @@ def run_slam(engine, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_gr
     for f in range(frames):
         if f == 0:
             pose0 = gt[0]
-        elif f >= 2:
+        elif f >= 2 and const_speed:
             p1, p2 = feed.frames[f - 1]["pose"].cpu(), feed.frames[f - 2]["pose"].cpu()
             pose0 = (p1 @ torch.linalg.inv(p2)) @ p1
         else:
-            pose0 = feed.frames[0]["pose"].cpu()
+            pose0 = feed.frames[f - 1]["pose"].cpu()
         # the reference's loader hands the monocular depth cue over in its own units and scales it by 20 on the first frame
         # (loss.py:179-185, assign_scale): the cue is the true depth / 20
         feed.add_frame(f, rgb=rgb[f], depth=depth[f] / 20.0, normal=normal[f], gt_depth=depth[f], intrinsics=K, pose=pose0)
@@ -397,36 +424,44 @@ def run_slam(engine, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_gr
 
 
 def run_slam_table(frames=50, H=340, W=600, colour_grid=None, map_iters=100, track_iters=100, engines=("fused", "composed"), verbose=False,
-                   schedule="reference", seeds=(11,)):
-    """The mini-SLAM table: ATE of tracking + mapping on the synthetic sequence, fused engine beside the composed one."""
+                   schedule="reference", seeds=(11,), family="replica", none_grads=("skip",), const_speed=False):
+    """The mini-SLAM table: ATE of tracking + mapping on the synthetic sequence, fused engine beside the composed one; `none_grads`: the
+    optimizer semantics to run ("skip" = installed torch, "zeros" = the reference's torch 1.11)."""
     dev = torch.device("cuda", 0)
-    teacher = build_teacher(H, W, colour_grid=colour_grid, device=dev)
+    teacher = build_teacher(H, W, colour_grid=colour_grid, device=dev, family=family)
     teacher.engine = "fused"
-    K = intrinsics(H, W, dev)
-    gt = load_trajectory(frames)
+    K = intrinsics(H, W, dev, family)
+    gt = load_trajectory(frames, family=family)
+    scale = FAMILIES[family]["scale"]
     rgb, depth, normal = render_cues(teacher, gt, K, H, W)
     out = {"what": "synthetic tracking + mapping (mini SLAM): teacher-rendered frames and depth / normal cues along gt_replica_room0[:N]; the "
                    "map is LEARNED (student at the reference's initialisation, fine SDF MLP = the teacher's as pretrain.pth is), loop shape of "
                    "volsdf_train.py:363-613 (mapping every 5th frame, 100 iterations x 8192 pixels, BA in the last 30 %), ATE as eval_cam.py:43-105",
+           "conf_family": family, "trajectory": os.path.basename(FAMILIES[family]["traj"]), "scene_scale_units_per_m": scale,
+           "const_speed_assumption": const_speed,
            "frames": frames, "image": [H, W], "map_iters": map_iters, "track_iters": track_iters, "schedule": schedule,
-           "no_tracking_baseline": summarise(gt, gt[:1].repeat(frames, 1, 1))}
+           "no_tracking_baseline": summarise(gt, gt[:1].repeat(frames, 1, 1), scale)}
     log = (lambda f, l, what: print(f"  frame {f}: loss {l:.5f}  {what}", file=sys.stderr)) if verbose else None
-    for spec in engines:                     # "engine" or "engine:seed,seed,..." (the composed engine is ~11x slower: fewer seeds)
-        eng, _, sd = spec.partition(":")
-        runs = []
-        for seed in ([int(x) for x in sd.split("+")] if sd else list(seeds)):
-            if verbose:
-                print(f"engine {eng} seed {seed}", file=sys.stderr)
-            t0 = time.perf_counter()
-            est, t_track, t_map = run_slam(eng, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_grid, map_iters=map_iters,
-                                           track_iters=track_iters, log=log, schedule=schedule, seed=seed)
-            runs.append(dict(summarise(gt, est), seed=seed, wall_s=round(time.perf_counter() - t0, 1), tracking_s=round(t_track, 1),
-                             mapping_s=round(t_map, 1)))
-        ates = [r["ate_rmse_scene_units"] for r in runs]
-        out["slam_" + eng] = {"runs": runs, "ate_rmse_mean": float(np.mean(ates)), "ate_rmse_min": float(np.min(ates)),
-                              "ate_rmse_max": float(np.max(ates)), "ate_rmse_cm_at_room_scale_mean": float(np.mean(ates)) / SCALE * 100}
-    if "slam_fused" in out and "slam_composed" in out:
-        out["slam_ate_ratio_fused_over_composed"] = out["slam_fused"]["ate_rmse_mean"] / out["slam_composed"]["ate_rmse_mean"]
+    for none_grad in none_grads:
+        tag = "" if none_grad == "skip" else "_none_grad_" + none_grad
+        for spec in engines:                     # "engine" or "engine:seed,seed,..." (the composed engine is ~11x slower: fewer seeds)
+            eng, _, sd = spec.partition(":")
+            runs = []
+            for seed in ([int(x) for x in sd.split("+")] if sd else list(seeds)):
+                if verbose:
+                    print(f"engine {eng} seed {seed} none_grad {none_grad}", file=sys.stderr)
+                t0 = time.perf_counter()
+                est, t_track, t_map = run_slam(eng, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_grid, map_iters=map_iters,
+                                               track_iters=track_iters, log=log, schedule=schedule, seed=seed, family=family,
+                                               none_grad=none_grad, const_speed=const_speed)
+                runs.append(dict(summarise(gt, est, scale), seed=seed, wall_s=round(time.perf_counter() - t0, 1), tracking_s=round(t_track, 1),
+                                 mapping_s=round(t_map, 1)))
+            ates = [r["ate_rmse_scene_units"] for r in runs]
+            out["slam_" + eng + tag] = {"optimizer_none_grad": none_grad, "runs": runs, "ate_rmse_mean": float(np.mean(ates)),
+                                        "ate_rmse_min": float(np.min(ates)), "ate_rmse_max": float(np.max(ates)),
+                                        "ate_rmse_cm_at_room_scale_mean": float(np.mean(ates)) / scale * 100}
+        if "slam_fused" + tag in out and "slam_composed" + tag in out:
+            out["slam_ate_ratio_fused_over_composed" + tag] = out["slam_fused" + tag]["ate_rmse_mean"] / out["slam_composed" + tag]["ate_rmse_mean"]
     return out
 
 
@@ -460,43 +495,45 @@ def trace_diff(a, b, first=5):
 
 
 def run(frames=50, iters=100, pixels=1024, H=340, W=600, oracle_frames=3, oracle_pixels=128, oracle_iters=100, colour_grid=None,
-        with_free=True, verbose=False):
+        with_free=True, verbose=False, family="replica", const_speed=False, with_bf16=True):
     dev = torch.device("cuda", 0)
     t_all = time.perf_counter()
-    teacher = build_teacher(H, W, colour_grid=colour_grid, device=dev)
+    teacher = build_teacher(H, W, colour_grid=colour_grid, device=dev, family=family)
     teacher.engine = "fused"
-    K = intrinsics(H, W, dev)
-    gt = load_trajectory(frames)
+    K = intrinsics(H, W, dev, family)
+    gt = load_trajectory(frames, family=family)
+    scale = FAMILIES[family]["scale"]
     imgs = render_frames(teacher, gt, K, H, W)
     speed = float(np.linalg.norm(np.diff(gt[:, :3, 3].numpy(), axis=0), axis=1).mean())
     out = {"what": "synthetic multi-frame tracking: teacher-rendered frames along gt_replica_room0[:N], reference tracking protocol "
                    "(volsdf_train.py:373-446), ATE as eval_cam.py:43-105",
-           "frames": frames, "iters_per_frame": iters, "pixels_per_iter": pixels, "image": [H, W], "scene_scale_units_per_m": SCALE,
+           "conf_family": family, "trajectory": os.path.basename(FAMILIES[family]["traj"]), "const_speed_assumption": const_speed,
+           "frames": frames, "iters_per_frame": iters, "pixels_per_iter": pixels, "image": [H, W], "scene_scale_units_per_m": scale,
            "mean_frame_to_frame_motion_scene_units": speed,
            "gt_image_stats": {"mean": float(imgs.mean()), "std_over_pixels": float(imgs.std(dim=1).mean())}}
     log = (lambda f, p, b: print(f"  frame {f}: loss {b:.5f}", file=sys.stderr)) if verbose else None
     # reference point: what a tracker that does nothing would score (every frame = frame 0)
-    out["no_tracking_baseline"] = summarise(gt, gt[:1].repeat(frames, 1, 1))
+    out["no_tracking_baseline"] = summarise(gt, gt[:1].repeat(frames, 1, 1), scale)
     if with_free:
         res = {}
         for eng in ("fused", "composed"):
             t0 = time.perf_counter()
-            est = track_sequence(eng, teacher, imgs, K, gt, H, W, iters, pixels, log=log)
+            est = track_sequence(eng, teacher, imgs, K, gt, H, W, iters, pixels, log=log, const_speed=const_speed)
             torch.cuda.synchronize()
             res[eng] = est
-            out["free_running_" + eng] = dict(summarise(gt, est), wall_s=round(time.perf_counter() - t0, 1),
+            out["free_running_" + eng] = dict(summarise(gt, est, scale), wall_s=round(time.perf_counter() - t0, 1),
                                               ms_per_iteration=round((time.perf_counter() - t0) / ((frames - 1) * iters) * 1e3, 3))
         a, b = out["free_running_fused"]["ate_rmse_scene_units"], out["free_running_composed"]["ate_rmse_scene_units"]
         out["free_running_ate_ratio_fused_over_composed"] = a / b
         out["free_running_pose_difference"] = pose_diff(res["fused"], res["composed"])
         # the optional reduced-precision modes of BASELINE configs[2] / [4] on the same frames (fp32 teacher, bf16-operand tracker)
-        for prec in ("bf16", "bf16_colour"):
+        for prec in (("bf16", "bf16_colour") if with_bf16 else ()):
             teacher.mlp_precision = prec
             teacher.__dict__.pop("_track_graphs", None)
             t0 = time.perf_counter()
-            est = track_sequence("fused", teacher, imgs, K, gt, H, W, iters, pixels, log=log)
+            est = track_sequence("fused", teacher, imgs, K, gt, H, W, iters, pixels, log=log, const_speed=const_speed)
             torch.cuda.synchronize()
-            out["free_running_fused_" + prec] = dict(summarise(gt, est), wall_s=round(time.perf_counter() - t0, 1),
+            out["free_running_fused_" + prec] = dict(summarise(gt, est, scale), wall_s=round(time.perf_counter() - t0, 1),
                                                      ms_per_iteration=round((time.perf_counter() - t0) / ((frames - 1) * iters) * 1e3, 3))
         teacher.mlp_precision = "fp32"
         teacher.__dict__.pop("_track_graphs", None)
@@ -505,16 +542,17 @@ def run(frames=50, iters=100, pixels=1024, H=340, W=600, oracle_frames=3, oracle
     estB, trB = {}, {}
     for eng in ("fused", "composed"):
         trB[eng] = []
-        estB[eng] = track_sequence(eng, teacher, imgs, K, gt, H, W, oracle_iters, oracle_pixels, shared_seed=7, n_frames=nB, trace=trB[eng])
-        out["shared_draws_" + eng] = summarise(gt, estB[eng])
+        estB[eng] = track_sequence(eng, teacher, imgs, K, gt, H, W, oracle_iters, oracle_pixels, shared_seed=7, n_frames=nB, trace=trB[eng],
+                                   const_speed=const_speed)
+        out["shared_draws_" + eng] = summarise(gt, estB[eng], scale)
     out["shared_draws_fused_vs_composed"] = dict(pose_diff(estB["fused"], estB["composed"]), **trace_diff(trB["fused"], trB["composed"]))
     if oracle_frames > 0:
         t0 = time.perf_counter()
         teacher_cpu = teacher.to("cpu")
         trB["oracle"] = []
         estB["oracle"] = track_sequence("oracle", teacher_cpu, imgs.cpu(), K.cpu(), gt, H, W, oracle_iters, oracle_pixels, shared_seed=7,
-                                        n_frames=nB, trace=trB["oracle"])
-        out["shared_draws_oracle"] = dict(summarise(gt, estB["oracle"]), wall_s=round(time.perf_counter() - t0, 1))
+                                        n_frames=nB, trace=trB["oracle"], const_speed=const_speed)
+        out["shared_draws_oracle"] = dict(summarise(gt, estB["oracle"], scale), wall_s=round(time.perf_counter() - t0, 1))
         out["shared_draws_fused_vs_oracle"] = dict(pose_diff(estB["fused"], estB["oracle"]), **trace_diff(trB["fused"], trB["oracle"]))
         out["shared_draws_composed_vs_oracle"] = dict(pose_diff(estB["composed"], estB["oracle"]), **trace_diff(trB["composed"], trB["oracle"]))
     out["shared_draws"] = {"frames": nB, "iters_per_frame": oracle_iters, "pixels_per_iter": oracle_pixels,
@@ -531,8 +569,13 @@ if __name__ == "__main__":
     ap.add_argument("--frames", type=int, default=50)
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--pixels", type=int, default=1024)
-    ap.add_argument("--height", type=int, default=340)
-    ap.add_argument("--width", type=int, default=600)
+    ap.add_argument("--conf", default="replica", choices=sorted(FAMILIES), help="conf family: model subtree, loss weights, camera, trajectory")
+    ap.add_argument("--height", type=int, default=None, help="default: the family's frame size halved (340 x 600 / 240 x 320)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--const-speed", default="conf", choices=["conf", "on", "off"],
+                    help="SLAM.tracking.const_speed_assumption; 'conf' = the family's shipped value (false in all 23 files)")
+    ap.add_argument("--none-grad", default="skip", help="comma list of optimizer semantics for --slam: skip (installed torch), zeros (torch 1.11)")
+    ap.add_argument("--seeds", default="11")
     ap.add_argument("--oracle-frames", type=int, default=3)
     ap.add_argument("--oracle-pixels", type=int, default=128)
     ap.add_argument("--oracle-iters", type=int, default=100)
@@ -545,8 +588,13 @@ if __name__ == "__main__":
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
     cg = dict(base_resolution=16, desired_resolution=512, log2_hashmap_size=19) if a.small_colour_grid else None
+    from nicer_slam_amd.utils.conf import run_conf
+    H, W = a.height or FAMILIES[a.conf]["size"][0], a.width or FAMILIES[a.conf]["size"][1]
+    cs = run_conf(a.conf)["const_speed_assumption"] if a.const_speed == "conf" else a.const_speed == "on"
     if a.slam:
-        print(json.dumps(run_slam_table(a.frames, a.height, a.width, cg, a.map_iters, a.iters, tuple(a.engines.split(",")), a.verbose, a.schedule), indent=1))
+        print(json.dumps(run_slam_table(a.frames, H, W, cg, a.map_iters, a.iters, tuple(a.engines.split(",")), a.verbose, a.schedule,
+                                        seeds=tuple(int(x) for x in a.seeds.split(",")), family=a.conf,
+                                        none_grads=tuple(a.none_grad.split(",")), const_speed=cs), indent=1))
         sys.exit(0)
-    print(json.dumps(run(a.frames, a.iters, a.pixels, a.height, a.width, a.oracle_frames, a.oracle_pixels, a.oracle_iters, cg,
-                         not a.no_free, a.verbose), indent=1))
+    print(json.dumps(run(a.frames, a.iters, a.pixels, H, W, a.oracle_frames, a.oracle_pixels, a.oracle_iters, cg,
+                         not a.no_free, a.verbose, family=a.conf, const_speed=cs), indent=1))

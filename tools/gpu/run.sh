@@ -1,0 +1,29 @@
+#!/bin/bash
+# One parametrised GPU-box script (replaces the per-call run logs of earlier rounds):  gpurun -- 'bash tools/gpu/run.sh <tag> <step> [<step> ..]'
+# Everything a step writes goes to gpurun_out/<tag>/ ; summaries worth keeping are copied into profiles/ by hand afterwards.
+cd ${GRAFT_REPO_ROOT:-.}
+TAG=$1; shift
+O=gpurun_out/$TAG; mkdir -p $O
+export HSA_ENABLE_IPC_MODE_LEGACY=0 TMPDIR=/tmp
+for step in "$@"; do
+  echo "=== $step"
+  case $step in
+    tests)        timeout 1500 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "rc=$?" >> $O/tests.log; tail -5 $O/tests.log ;;
+    tests:*)      timeout 1500 python -m pytest ${step#tests:} -m gpu -x -q > $O/tests_sel.log 2>&1; echo "rc=$?" >> $O/tests_sel.log; tail -15 $O/tests_sel.log ;;
+    smoke)        timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 ;;
+    bench)        timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "rc=$?"; cut -c1-600 $O/bench.json ;;
+    bench:*)      timeout 900 python bench.py ${step#bench:} > $O/bench_opt.json 2> $O/bench_opt.err; echo "rc=$?"; cut -c1-600 $O/bench_opt.json ;;
+    seq7)         timeout 1200 python tools/synthetic_sequence.py --conf 7scenes > $O/sequence_ate_7scenes.json 2> $O/seq7.err; echo "rc=$?"; tail -3 $O/seq7.err ;;
+    seqR)         timeout 1200 python tools/synthetic_sequence.py --conf replica > $O/sequence_ate_replica.json 2> $O/seqR.err; echo "rc=$?"; tail -3 $O/seqR.err ;;
+    slam7)        timeout 2400 python tools/synthetic_sequence.py --conf 7scenes --slam --schedule reference --none-grad skip,zeros \
+                      --engines fused:11+12+13+14+15,composed:12 > $O/slam_ate_7scenes.json 2> $O/slam7.err; echo "rc=$?"; tail -3 $O/slam7.err ;;
+    slamR)        timeout 2400 python tools/synthetic_sequence.py --conf replica --slam --schedule reference --none-grad skip,zeros \
+                      --engines fused:11+12+13+14+15 > $O/slam_ate_replica.json 2> $O/slamR.err; echo "rc=$?"; tail -3 $O/slamR.err ;;
+    slam7fine)    timeout 2400 python tools/synthetic_sequence.py --conf 7scenes --slam --schedule fine --engines fused:11+12+13,composed:12 \
+                      > $O/slam_ate_7scenes_fine.json 2> $O/slam7fine.err; echo "rc=$?"; tail -3 $O/slam7fine.err ;;
+    profile)      bash tools/profile_round.sh > $O/profile.log 2>&1; tail -5 $O/profile.log | cut -c1-200 ;;
+    profile_map)  bash tools/profile_mapping.sh > $O/profile_map.log 2>&1; tail -4 $O/profile_map.log | cut -c1-200 ;;
+    sh:*)         bash -c "${step#sh:}" ;;
+    *)            echo "unknown step $step" ;;
+  esac
+done

@@ -102,6 +102,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precision-modes", action="store_true", help="skip the bf16 / bf16_colour context rows (N = 1 only)")
     ap.add_argument("--no-mapping", action="store_true", help="skip the (untimed-for-value) mapping-iteration leg")
+    ap.add_argument("--no-small-shapes", action="store_true", help="skip the strong-scaling-tail rows (128 / 256 / 512 rays; N = 1 only)")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--only-mapping", type=int, default=0, metavar="ITERS",
                     help="profiling aid: run ONLY the mapping-iteration leg with this many timed iterations and print its dict")
@@ -377,10 +378,13 @@ def main():
                                       "frac_survey_8d": round(survey / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                                       "note": "of the fp32 matrix line (157.3 TFLOP/s), per GPU"}
         cpu = None if args.no_cpu_baseline else cpu_baseline(args, model, conf)
-        mapping, dropin, ref_gpu, prec_modes = None, None, None, None
+        mapping, dropin, ref_gpu, prec_modes, small = None, None, None, None, None
         gather = colour_gather_roofline(agg, args) if agg else None
         if world == 1 and not args.no_precision_modes and args.engine != "composed" and args.precision == "fp32":
             prec_modes = precision_modes_leg(args, device, K)
+        if (world == 1 and not args.no_small_shapes and args.engine != "composed" and args.precision == "fp32" and args.rays == 1024
+                and args.samples == 128):
+            small = small_shapes_leg(args, device, K, ms)
         if world == 1 and not args.no_dropin and args.engine != "composed" and args.precision == "fp32":
             dropin = dropin_leg(args, device, K, batches)
             ref_gpu = reference_shaped_gpu_leg(args, device, K, batches, rays_total / dt)
@@ -410,7 +414,7 @@ def main():
                        "oversubscribed": oversub or None},
             "final_loss": round(last, 6),
             "roofline": roof, "colour_gather": gather, "cpu_baseline": cpu, "reference_shaped_gpu": ref_gpu, "dropin": dropin,
-            "mapping_iteration": mapping, "precision_modes": prec_modes,
+            "mapping_iteration": mapping, "precision_modes": prec_modes, "small_shapes": small,
         }
         print(json.dumps(line))
     if world > 1:
@@ -804,6 +808,120 @@ def precision_modes_leg(args, device, K, steps=100):
         except Exception as e:      # a context leg must never take the headline down
             out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
     models.clear()
+    torch.cuda.empty_cache()
+    return out
+
+
+def small_shapes_leg(args, device, K, ms_1024, steps=100):
+    """The strong-scaling tail on one GPU: an N-GPU strong-scaling run of the 1024-ray metric gives every rank
+    1024 / N rays, and part of an iteration does not shrink with the ray count (per-ray scans that are latency bound, the last-workgroup
+    tail, launch gaps, MLP kernels that no longer fill 256 CUs).  Rows: fp32 at 512 / 256 / 128 rays x 128 samples per GPU, (a) as the
+    1-GPU tracker runs them (everything in one hipGraph) and (b) in the MULTI-RANK form of the step -- weighted 9-float message, graph
+    without the Adam step, then all-reduce + nsa_adam_step_scaled -- on a ONE-rank RCCL group: per-rank compute + launch path of an N-GPU
+    run, with the link latency of a real 2..8-rank all-reduce of 36 bytes NOT in it (no multi-GPU box).  `fit`: least squares
+    ms = fixed + per_ray * R over R = 128..1024 -- `fixed` is the ray-count-independent part.  `predicted_strong_scaling`: the N-GPU
+    speed-up of the 1024-ray metric these per-rank times allow (an upper bound: add the real exchange latency)."""
+    import torch.distributed as dist
+    from nicer_slam_amd.hashencoder import backend as be
+    from nicer_slam_amd.tracking import KernelTracker
+    out = {"what": "fp32 tracking iteration at the per-GPU shapes of an N-GPU strong-scaling run of the 1024-ray metric (one GPU)"}
+    a = argparse.Namespace(**vars(args))
+    a.samples, a.precision, a.param_grads, a.engine = 128, "fp32", False, "auto"
+    model = make_model(a, device)[0]
+    own_group = False
+    try:
+        if not dist.is_initialized():
+            import socket
+            sock = socket.socket()
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+            sock.close()
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
+            own_group = True
+    except Exception as e:
+        out["one_rank_group_error"] = f"{type(e).__name__}: {e}"[:200]
+
+    def timed(rays, world):
+        gen = torch.Generator(device=device).manual_seed(78)
+        batches = [synth_batch(gen, rays, device) for _ in range(32)]
+        cam = torch.tensor([1.0, 0, 0, 0, 0.1, 0.0, -0.2], device=device)
+        tr = KernelTracker(model, K, rays, cam, lr=0.005, use_graph=True, world=world)
+        with quiet_gc():
+            for i in range(30):
+                tr.step(*batches[i % 32])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                tr.step(*batches[i % 32])
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+        us = None
+        if world == 1:
+            eager = KernelTracker(model, K, rays, cam, lr=0.005, use_graph=False)
+            for i in range(3):
+                eager.step(*batches[i])
+            be.PROFILE = []
+            for i in range(10):
+                eager.step(*batches[i])
+            torch.cuda.synchronize()
+            prof, be.PROFILE = be.PROFILE, None
+            agg = {}
+            for name, nbytes, e0, e1 in prof:
+                v = agg.setdefault(name, [0.0, 0])
+                v[0] += e0.elapsed_time(e1)
+                v[1] += 1
+            us = {k: round(v[0] / v[1] * 1e3, 1) for k, v in sorted(agg.items())}
+            del eager
+        ex = None
+        if world > 1:        # the step's only exchange alone, back to back (host-issued: all-reduce + Adam launch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                tr._exchange()
+            torch.cuda.synchronize()
+            ex = round((time.perf_counter() - t0) / 50 * 1e6, 1)
+        del tr
+        return ms, us, ex
+
+    pts = [(1024, ms_1024)]
+    for rays in (512, 256, 128):
+        key = f"fp32_{rays}x128"
+        try:
+            ms, us, _ = timed(rays, 1)
+            row = {"ms_per_step": round(ms, 4), "rays_per_s": round(rays / (ms * 1e-3), 1), "kernels_us": us,
+                   "kernels_sum_us": round(sum(us.values()), 1)}
+            pts.append((rays, ms))
+            if dist.is_initialized() and dist.get_world_size() == 1:
+                ms_r, _, ex = timed(rays, 2)          # world = 2 selects the message form; the group has one rank
+                row["multi_rank_form_ms_per_step"] = round(ms_r, 4)
+                row["one_rank_exchange_us"] = ex
+            out[key] = row
+        except Exception as e:      # a context leg must never take the headline down
+            out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if len(pts) >= 3:
+        import numpy as np
+        R = np.array([p[0] for p in pts], dtype=np.float64)
+        T = np.array([p[1] for p in pts], dtype=np.float64)
+        A = np.stack([np.ones_like(R), R], 1)
+        (fixed, per_ray), *_ = np.linalg.lstsq(A, T, rcond=None)
+        out["fit"] = {"fixed_us": round(float(fixed) * 1e3, 1), "us_per_ray": round(float(per_ray) * 1e3, 4),
+                      "points_rays_ms": [[int(r), round(float(t), 4)] for r, t in pts],
+                      "max_residual_us": round(float(np.abs(A @ np.array([fixed, per_ray]) - T).max()) * 1e3, 1)}
+        pred = {}
+        for n, rays in ((2, 512), (4, 256), (8, 128)):
+            row = out.get(f"fp32_{rays}x128", {})
+            t = row.get("multi_rank_form_ms_per_step") or row.get("ms_per_step")
+            if t:
+                pred[f"{n}_gpus"] = {"rays_per_gpu": rays, "per_rank_ms": t, "speedup_over_1_gpu": round(ms_1024 / t, 2),
+                                     "efficiency": round(ms_1024 / t / n, 3)}
+        out["predicted_strong_scaling"] = dict(pred, note="1024-ray metric; per-rank time measured on one GPU in the multi-rank form "
+                                               "(1-rank RCCL group); the real 36-byte all-reduce latency over xGMI comes on top")
+    if own_group:
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+    del model
     torch.cuda.empty_cache()
     return out
 

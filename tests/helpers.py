@@ -70,3 +70,42 @@ def assert_close(a, b, atol, rtol, what=""):
         i = int(torch.argmax(err - tol))
         raise AssertionError(f"{what}: {int(bad.sum())}/{a.numel()} off; worst |{a.flatten()[i]:.8g} - "
                              f"{b.flatten()[i]:.8g}| = {err.flatten()[i]:.3g} (atol {atol}, rtol {rtol})")
+
+
+def face_samples(fx):
+    """[R,S] bool: the samples of a golden that sit ON a face of the unit cube (the far bound is the cube exit, ray_sampler.py:23-47).
+    There the grids' inclusive in-range test (hashencoder.cu:155-159) is decided by the last ulp of o + z d: the reference's two-rounding
+    torch expression, a fused multiply-add and a GPU / CPU difference in the ray direction each may land on either side, and a sample that
+    lands outside gets ZERO grid features.  Networks that listen to their grid features (the `_rw` and `7scenes` goldens) then
+    differ in that one sample by the features' whole contribution."""
+    o, d, z = tt(fx["out_cam_loc"]), tt(fx["out_ray_dirs"]), tt(fx["out_z_vals"])
+    x = o[:, None, None, :] + z.reshape(d.shape[0], d.shape[1], -1, 1) * d[:, :, None, :]
+    return ((x.abs().amax(-1) - 1.0).abs() < 2e-6).reshape(z.shape)
+
+
+def face_flips(sdf, fx, atol=2e-5, rtol=1e-4, max_frac=0.01):
+    """[R,S] bool: on-face samples whose sdf shows that this side took the OTHER in-range decision than the golden.  Any disagreement
+    off the faces is an error; the flips are counted and bounded, not ignored."""
+    face = face_samples(fx)
+    got, ref = torch.as_tensor(sdf).detach().cpu().reshape(face.shape), tt(fx["out_sdf"]).reshape(face.shape)
+    bad = (got - ref).abs() > atol + rtol * ref.abs()
+    off = bad & ~face
+    assert not bool(off.any()), f"sdf: {int(off.sum())} samples off the cube faces differ, worst {float((got - ref).abs()[off].max()):.3g}"
+    flips = bad & face
+    assert float(flips.float().mean()) <= max_frac, f"{int(flips.sum())} on-face flips of {flips.numel()} samples"
+    return flips
+
+
+def assert_outputs_close(out, fx, keys, atol=2e-5, rtol=1e-4):
+    """Output dict of a forward vs a golden, key by key.  The per-sample tensors (sdf, rgb) leave out the on-face far samples that took
+    the other in-range decision than the golden (face_flips: counted and bounded); everything else is compared whole -- the fixtures whose
+    networks listen to their grid features are built so that such a sample carries no weight (make_golden.py::full_case)."""
+    flips = face_flips(out["sdf"], fx, atol, rtol) if "out_sdf" in fx and "sdf" in out else None
+    for k in keys:
+        if "out_" + k not in fx:
+            continue
+        got, ref = torch.as_tensor(out[k]).detach().cpu(), tt(fx["out_" + k])
+        if flips is not None and k in ("sdf", "rgb") and bool(flips.any()):
+            got, ref = got.reshape(flips.shape + got.shape[flips.dim():])[~flips], ref.reshape(flips.shape + ref.shape[flips.dim():])[~flips]
+        assert_close(got, ref.numpy(), atol, rtol, k)
+    return flips

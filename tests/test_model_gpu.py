@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load, tt, draws_of, golden_objective, assert_close
+from helpers import load, tt, draws_of, golden_objective, assert_close, assert_outputs_close
 from test_model_cpu import build_model
 
 pytestmark = pytest.mark.gpu
@@ -28,10 +28,8 @@ def test_forward_and_grads_vs_reference_goldens(name, engine):
     pose = get_camera_from_tensor(cam)
     out = model({"intrinsics": tt(fx["in_K"]).cuda(), "uv": tt(fx["in_uv"]).cuda(), "pose": pose},
                 torch.arange(pose.shape[0], device="cuda"), {}, mode=mode, stage=stage, color_stage=cstage, frame_idx=1)
-    for k in ("depth_vals", "sdf", "weights", "rgb", "rgb_values", "depth_values", "entropy", "normal_map",
-              "grad_theta", "grad_theta_nei"):
-        if "out_" + k in fx:
-            assert_close(out[k], fx["out_" + k], 2e-5, 1e-4, k)
+    assert_outputs_close(out, fx, ("depth_vals", "sdf", "weights", "rgb", "rgb_values", "depth_values", "entropy", "normal_map",
+                                   "grad_theta", "grad_theta_nei"))
     assert_close(model.voxels, fx["out_voxels"], 0, 0, "voxels")
     if not model.training:
         return

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BE="python $R/bench.py --no-cpu-baseline --no-mapping --no-dropin --no-precision-modes --steps 6 --warmup 2 --prewarm-s 0 --prewarm-steps 0 --no-graph"
+BE="python $R/bench.py --no-cpu-baseline --no-mapping --no-dropin --no-precision-modes --no-small-shapes --steps 6 --warmup 2 --prewarm-s 0 --prewarm-steps 0 --no-graph"
 rm -rf /tmp/l1a /tmp/l1b /tmp/l1c
 timeout 70 rocprofv3 --pmc TA_TA_BUSY_sum TD_TD_BUSY_sum GRBM_GUI_ACTIVE TA_TOTAL_WAVEFRONTS_sum --output-format csv -d /tmp/l1a -- $BE > /tmp/l1a.log 2>&1
 timeout 70 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum --output-format csv -d /tmp/l1b -- $BE > /tmp/l1b.log 2>&1

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BE="python $R/bench.py --no-cpu-baseline --no-mapping --no-dropin --no-precision-modes --steps 6 --warmup 2 --prewarm-s 0 --prewarm-steps 0 --no-graph"
+BE="python $R/bench.py --no-cpu-baseline --no-mapping --no-dropin --no-precision-modes --no-small-shapes --steps 6 --warmup 2 --prewarm-s 0 --prewarm-steps 0 --no-graph"
 : > $OUT/pmc_ws_sampler.csv
 for t in 64 96 97; do
   rm -rf /tmp/ws$t

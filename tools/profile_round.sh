@@ -6,9 +6,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --no-mapping --no-dropin --no-precision-modes --steps 200 --warmup 20"
+B="python $R/bench.py --no-cpu-baseline --no-mapping --no-dropin --no-precision-modes --no-small-shapes --steps 200 --warmup 20"
 # counter passes serialise the kernels and are ~50x slower: 20 eager steps are plenty for per-launch means
-BE="python $R/bench.py --no-cpu-baseline --no-mapping --no-dropin --no-precision-modes --steps 20 --warmup 5 --prewarm-s 0 --prewarm-steps 0 --no-graph"
+BE="python $R/bench.py --no-cpu-baseline --no-mapping --no-dropin --no-precision-modes --no-small-shapes --steps 20 --warmup 5 --prewarm-s 0 --prewarm-steps 0 --no-graph"
 (timeout 400 $B) > $OUT/bench_line.json 2> /tmp/b.err || true
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- $B > /tmp/ks.log 2>&1
 cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv

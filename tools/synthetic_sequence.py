@@ -98,6 +98,11 @@ def build_teacher(H, W, n_samples=64, colour_grid=None, seed=5, device="cpu", fa
             # rough +-0.08 field to the coarse sphere; a pretrained residual decoder's output is small: scale the sdf row of its last layer.
             model.implicit_network.fine.lin3.weight_g[0].mul_(0.25)
             model.implicit_network.fine.lin3.bias[0].mul_(0.25)
+            # `coarse.bias = 1.0` is the INITIAL radius; the sphere of radius 1 touches the cube's faces, so a scene left there is seen
+            # almost only through the far sample of each ray -- the one ON the cube face, whose in-range test hangs on the last ulp of
+            # o + z d: frames that no two correct renderers agree on.  The teacher is a TRAINED map: its walls sit at ~0.7,
+            # inside the cube as a scaled real scene's do; the student (run_slam) starts from the family's 1.0 and has to pull them in.
+            model.implicit_network.coarse.lin1.bias[0].sub_(0.3)
     for p in model.parameters():
         p.requires_grad_(False)
     return model.to(device)

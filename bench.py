@@ -836,7 +836,10 @@ def small_shapes_leg(args, device, K, ms_1024, steps=100):
             sock.bind(("127.0.0.1", 0))
             port = sock.getsockname()[1]
             sock.close()
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
+            # an explicit store: under torchrun the environment tells init_process_group that the agent hosts the store
+            # (TORCHELASTIC_USE_AGENT_STORE), and a tcp:// rendezvous of this process with itself then waits for its timeout
+            store = dist.TCPStore("127.0.0.1", port, 1, is_master=True, use_libuv=False)
+            dist.init_process_group("nccl", store=store, rank=0, world_size=1, device_id=device)
             own_group = True
     except Exception as e:
         out["one_rank_group_error"] = f"{type(e).__name__}: {e}"[:200]
@@ -968,22 +971,34 @@ def dropin_leg(args, device, K, batches, steps=60):
       faithful   every model parameter requires grad, exactly as volsdf_train.py builds the model (the reference computes and
                  discards all parameter gradients in tracking, :547 zeroes them before any use);
       pose_only  model.tracking_param_grads = False -- one attribute -- skips that discarded work; hipGraph-captured;
-      pose_only_eager  the same launched eagerly, i.e. the reference's unmodified loop shape (it captures nothing);
-      pose_only_eager_hip_adam  that loop with ONE line changed: torch.optim.Adam -> nicer_slam_amd.optim.Adam (same semantics and
+      pose_only_eager  the same launched eagerly, i.e. the reference's unmodified loop shape (it captures nothing): the ground-truth dict
+                 goes to the model and to `tracking_loss` -- the SLAMLoss class resolved from the conf string `train.loss_class` with the
+                 shipped `tracking_loss { ... }` block (volsdf_train.py:117-130, 415-424); the model's forward folds the L1 term in and
+                 the loss class returns it (fused/track_graph.py, round 6);
+      pose_only_eager_inline_l1  the same loop with the L1 term written out as torch ops on rgb_values (what rounds 3-5 timed as
+                 pose_only_eager);
+      pose_only_eager_hip_adam  pose_only_eager with ONE line changed: torch.optim.Adam -> nicer_slam_amd.optim.Adam (same semantics and
                  state_dict; one launch instead of torch's ~12 on the seven camera floats).
     Context numbers; `value` stays the KernelTracker iteration."""
     from nicer_slam_amd.tracking import TrackingStepper
-    out = {"driver": "SLAMNetwork.forward + torch autograd + torch.optim.Adam (TrackingStepper)"}
+    from nicer_slam_amd.utils.general import get_class
+    out = {"driver": "SLAMNetwork.forward + loss_class + torch autograd + torch.optim.Adam (TrackingStepper)"}
     from nicer_slam_amd.optim import Adam as HipAdam
-    for row, flag, graph, opt in (("pose_only", False, True, None), ("pose_only_eager", False, False, None),
-                                  ("pose_only_eager_hip_adam", False, False, HipAdam), ("faithful", True, False, None)):
+    # confs/replica/runconf_replica_1.conf:58-65 `tracking_loss { ... }`, class from `train.loss_class` (INTEGRATION.md B2)
+    tracking_loss_conf = dict(rgb_loss="torch.nn.L1Loss", eikonal_weight=0, smooth_weight=0, depth_weight=0, normal_l1_weight=0,
+                              normal_cos_weight=0)
+    for row, flag, graph, opt, seam in (("pose_only", False, True, None, False), ("pose_only_eager", False, False, None, True),
+                                        ("pose_only_eager_inline_l1", False, False, None, False),
+                                        ("pose_only_eager_hip_adam", False, False, HipAdam, True), ("faithful", True, False, None, False)):
         a = argparse.Namespace(**vars(args))
         a.param_grads = True                        # make_model leaves requires_grad as constructed
         model, _ = make_model(a, device)
         model.tracking_param_grads = flag
         cam = torch.tensor([1.0, 0, 0, 0, 0.1, 0.0, -0.2], device=device)
         try:
-            st = TrackingStepper(model, K, args.rays, cam, lr=0.005, use_graph=graph, world=1, **({"opt_cls": opt} if opt else {}))
+            loss_fn = get_class("nicer_slam_amd.model.loss.SLAMLoss")(model=model, **tracking_loss_conf) if seam else None
+            st = TrackingStepper(model, K, args.rays, cam, lr=0.005, use_graph=graph, world=1, loss_fn=loss_fn,
+                                 **({"opt_cls": opt} if opt else {}))
             n = min(steps, len(batches))
             with quiet_gc():
                 for i in range(min(5, n)):
@@ -995,7 +1010,8 @@ def dropin_leg(args, device, K, batches, steps=60):
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / n
             out[row] = {"ms_per_step": round(dt * 1e3, 4), "rays_per_s": round(args.rays / dt, 1), "engine": model.last_engine,
-                        "hip_graph": graph, "steps": n, "optimizer": "nicer_slam_amd.optim.Adam (one launch)" if opt else "torch.optim.Adam"}
+                        "hip_graph": graph, "steps": n, "optimizer": "nicer_slam_amd.optim.Adam (one launch)" if opt else "torch.optim.Adam",
+                        "objective": "loss_class = nicer_slam_amd.model.loss.SLAMLoss (tracking_loss block)" if seam else "inline torch L1"}
         except Exception as e:      # a context leg must never take the headline down
             out[row] = {"error": f"{type(e).__name__}: {e}"[:300]}
         del model

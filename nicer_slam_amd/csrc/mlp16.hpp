@@ -305,11 +305,10 @@ __device__ __forceinline__ void resident_load(float* lds, const float* __restric
 //   landed[p]  waves whose share of part p's asynchronous copy has arrived (signalled after the wave's own vmcnt(0));
 //   done[p]    waves that have read their last fragment of part p.
 // Wave w, GEMM p (part p lives in buffer p % 3; every block is one part: BUF >= the largest block):
-//   entry        wait landed[p] == NW                                   (p == 0: first confirm its share of part 0)
-//   after the first k-group   vmcnt(0); landed[p+1] += 1                (its share of part p+1 was issued a GEMM ago)
+//   entry        vmcnt(0); landed[p+1] += 1 (its share of part p+1 was issued a GEMM ago; p == 0: landed[0] too); wait landed[p] == NW
 //   exit         lgkmcnt(0); done[p] += 1; wait done[p-1] == NW; issue its share of part p+2 into buffer (p+2) % 3 = (p-1) % 3
-// so a wave may enter GEMM p+1 as soon as every wave is past the first k-group of GEMM p: the waves of a SIMD drift about half a GEMM
-// apart -- one multiplies while the other splits / activates -- and never meet.  The copies are the staged form's own (same source
+// so a wave may enter GEMM p+1 as soon as every wave has ENTERED GEMM p: the waves of a SIMD may drift up to one GEMM apart -- one
+// multiplies while the other splits / activates -- and never meet.  The copies are the staged form's own (same source
 // segments, same LDS image), the arithmetic statements are shared (.inc bodies): results are bit-identical to the staged kernels.
 // Every wait has a watchdog (a protocol bug ends the launch with wrong numbers, which the bit-identity tests catch, instead of hanging).
 template <class Seq>
@@ -394,18 +393,14 @@ __device__ __forceinline__ void gemm16_ring(float* stage, const float* __restric
                                             f32x4v (&acc)[MT], const float* __restrict__ wp1) {
     static_assert(max_groups<BUF>(MT) >= KG, "ring staging: every block is one part");
     RingCtl* ctl = reinterpret_cast<RingCtl*>(stage + kRingBufs * BUF);
-    if (p == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ring_signal(&ctl->landed[0]);
-    }
+    // this wave's shares of parts <= p + 1 were issued at the exit of GEMM p - 1 at the latest: confirm them here, where the bias loads in
+    // front of the GEMM need a vmcnt(0) anyway (confirming after the first k-group, as the first version did, drains the MFMA pipeline
+    // in mid-GEMM: measured slower)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p == 0) ring_signal(&ctl->landed[0]);
+    if (p + 1 < Seq::n) ring_signal(&ctl->landed[p + 1]);
     ring_wait(&ctl->landed[p], NW, &ctl->abort);
-    const float* blk = stage + (p % kRingBufs) * BUF;
-    gemm16_lds_groups<KG, MT, 0, 1>(blk, lane, b, acc);
-    if (p + 1 < Seq::n) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ring_signal(&ctl->landed[p + 1]);
-    }
-    gemm16_lds_groups<KG, MT, 1, KG>(blk, lane, b, acc);
+    gemm16_lds_groups<KG, MT, 0, KG>(stage + (p % kRingBufs) * BUF, lane, b, acc);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     ring_signal(&ctl->done[p]);
     if (p + 2 < Seq::n) {

@@ -194,7 +194,30 @@ class SLAMLoss(nn.Module):
                 "warp_loss": self.warp_loss_weight * warp_loss, "smooth_loss": self.smooth_weight * on(use_smooth, t[2]),
                 "eikonal_loss": self.eikonal_weight * on(use_eik, t[1])}
 
+    def _tracking_objective(self, model_outputs, ground_truth):
+        """The scalar the fused forward already formed (fused/track_graph.py: ``model_outputs["tracking_rgb_l1"]`` = (mean |rgb_values -
+        gt|, gt)) when THIS loss is exactly that term: the reference's `tracking_loss` configuration (every weight but the colour term's
+        zero, confs/*/runconf_*.conf `tracking_loss { ... }`; loss.py:131-233 then reduces to rgb_loss_weight * L1Loss(rgb_values, rgb))
+        and the ground truth handed over is the very tensor the model formed it against.  Else None."""
+        obj = model_outputs.get("tracking_rgb_l1")
+        if obj is None or getattr(self, "engine", "auto") == "torch":
+            return None
+        rl = self.rgb_loss
+        only_rgb = (isinstance(rl, nn.L1Loss) and rl.reduction == "mean" and not self.assign_scale_shift_init
+                    and self.gt_depth_weight == 0 and self.depth_weight == 0 and self.normal_l1_weight == 0 and self.normal_cos_weight == 0
+                    and self.smooth_weight == 0 and self.flow_weight == 0
+                    and (self.eikonal_weight == 0 or "grad_theta" not in model_outputs)
+                    and (self.warp_loss_weight == 0 or "warp_output" not in model_outputs))
+        if not only_rgb or obj[1] is not ground_truth.get("rgb"):
+            return None
+        return obj[0]
+
     def forward(self, model_outputs, ground_truth, keyframe_list=None, frame_idx=0, stage="coarse"):
+        obj = self._tracking_objective(model_outputs, ground_truth)
+        if obj is not None:      # one tensor, no launch: the value and the gradient were formed by the model's own forward
+            rgb_loss = obj if self.rgb_loss_weight == 1.0 else self.rgb_loss_weight * obj
+            return {"loss": rgb_loss, "normal_l1": 0.0, "depth_loss": 0.0, "normal_cos": 0.0, "gt_depth_loss": 0.0, "flow_loss": 0.0,
+                    "rgb_loss": rgb_loss, "warp_loss": 0.0, "smooth_loss": 0.0, "eikonal_loss": 0.0}
         if self._fused_ok(model_outputs):
             return self._forward_fused(model_outputs, ground_truth, keyframe_list, frame_idx, stage)
         rgb_pred, depth_pred = model_outputs["rgb_values"], model_outputs["depth_values"]

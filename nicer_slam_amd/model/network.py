@@ -166,7 +166,7 @@ class SLAMNetwork(nn.Module):
             graphed = track_graph.usable(self, mode, fused_kind, input, ground_truth)
         if graphed:
             self.last_engine = "fused"
-            return track_graph.render(self, input, stage, color_stage)
+            return track_graph.render(self, input, stage, color_stage, ground_truth)
         if fused and pose.shape[1] == 4 and uv.dtype == torch.float32:
             from ..fused import render as fused_render
             cam_flat, dirs, ds_flat = fused_render.rays(pose, uv, intrinsics.to(uv.device))

@@ -280,8 +280,12 @@ class TrackingStepper:
     SLAMNetwork.forward(mode="tracking") -> L1 -> loss.backward() -> torch.optim.Adam (+ StepLR) -> arg-min-loss candidate."""
 
     def __init__(self, model, intrinsics, n_rays, cam_init, lr=0.005, use_graph=True, world=1, lr_step=0, lr_gamma=1.0,
-                 opt_cls=None):
+                 opt_cls=None, loss_fn=None):
+        """loss_fn: the tracking objective as the reference's loop calls it -- ``loss_fn(model_outputs, ground_truth, stage="fine",
+        frame_idx=...)["loss"]`` with the `tracking_loss` SLAMLoss instance (volsdf_train.py:117-130, 418-421); the frame's ground truth is
+        then handed to the model as well, as that loop does (:417).  None: the L1 term written out inline."""
         dev = model.voxels.device
+        self.loss_fn = loss_fn
         self.model, self.world, self.n_rays = model, world, n_rays
         self.K = intrinsics
         self.cam = cam_init.detach().clone().to(dev).requires_grad_(True)
@@ -306,10 +310,25 @@ class TrackingStepper:
 
     def _fwd_bwd(self):
         pose = get_camera_from_tensor(self.cam).unsqueeze(0)
-        out = self.model({"intrinsics": self.K, "uv": self.uv, "pose": pose}, self.ind, {}, mode="tracking", frame_idx=1)
-        loss = (out["rgb_values"].reshape(-1, 3) - self.gt).abs().mean()     # SLAMLoss.get_rgb_loss, L1Loss(mean)
+        if self.loss_fn is not None:       # volsdf_train.py:415-424: the loader's ground-truth dict goes to the model AND to the loss
+            gt = self._ground_truth()
+            out = self.model({"intrinsics": self.K, "uv": self.uv, "pose": pose}, self.ind, gt, mode="tracking", frame_idx=1)
+            loss = self.loss_fn(out, gt, stage="fine", frame_idx=1)["loss"]
+        else:
+            out = self.model({"intrinsics": self.K, "uv": self.uv, "pose": pose}, self.ind, {}, mode="tracking", frame_idx=1)
+            loss = (out["rgb_values"].reshape(-1, 3) - self.gt).abs().mean()     # SLAMLoss.get_rgb_loss, L1Loss(mean)
         loss.backward()
         return loss.detach()
+
+    def _ground_truth(self):
+        """the dict a data loader's collate hands over for one tracked frame (scene_dataset.py:262-287): rgb + the cue tensors the
+        tracking objective gives zero weight"""
+        R = self.n_rays
+        cues = self.__dict__.get("_cues")
+        if cues is None:
+            z = lambda c: torch.zeros(1, R, c, device=self.cam.device)
+            cues = self._cues = {"depth": z(1), "normal": z(3), "gt_depth": z(1), "mask": torch.ones(1, R, 1, device=self.cam.device)}
+        return dict(cues, rgb=self.gt.view(1, R, 3))
 
     def _eager(self):
         self.opt.zero_grad(set_to_none=False) if self.cam.grad is not None else None

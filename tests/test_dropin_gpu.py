@@ -270,3 +270,55 @@ def test_graph_cached_tracking_outputs_survive_the_next_iterations():
         assert torch.equal(outs[0]["weights"].detach(), snap[-2])
     finally:
         track_graph.CLONE = old
+
+
+def test_tracking_objective_through_the_loss_class_seam():
+    """the reference resolves its losses from the conf string `train.loss_class` (volsdf_train.py:117-130) and hands the
+    loader's ground-truth dict to the model AND to `tracking_loss` (:415-424).  With the class string pointed at this package, the cached
+    tracking forward folds the L1 term in (out["tracking_rgb_l1"]) and the loss class returns it -- same value as torch's L1Loss on
+    rgb_values, same pose gradient as the backward through rgb_values (both taken from ONE forward: the engine's own draws differ per call),
+    and the loop of :406-446 runs on it.  A loss that is NOT the tracking configuration, or another ground-truth tensor, takes the ordinary path."""
+    from nicer_slam_amd.utils.general import get_class, get_camera_from_tensor, get_tensor_from_camera
+    model, optimizer, loss_fn, _, feed = _world()
+    conf = {"train": {"loss_class": "nicer_slam_amd.model.loss.SLAMLoss"},                      # INTEGRATION.md B2: the one-line swap
+            "tracking_loss": dict(rgb_loss="torch.nn.L1Loss", eikonal_weight=0, smooth_weight=0, depth_weight=0, normal_l1_weight=0,
+                                  normal_cos_weight=0)}                                          # confs/replica/runconf_replica_1.conf:58-65
+    tracking_loss = get_class(conf["train"]["loss_class"])(trainer=None, train_dataset=None, scan_id=1, model=model, **conf["tracking_loss"])
+    model.tracking_param_grads = False
+    cam = get_tensor_from_camera(feed.frames[0]["pose"].cpu()).cuda().requires_grad_(True)
+    opt_cam = torch.optim.Adam([cam], lr=0.001)
+    feed.change_sampling_idx(256)
+    losses = []
+    for it in range(6):                       # (call 1 eager, call 2 captures the graphs, calls 3.. replay them)
+        indices, model_input, ground_truth = feed.batch([1])
+        model_input["pose"] = get_camera_from_tensor(cam).unsqueeze(0)
+        out = model(model_input, indices, ground_truth, mode="tracking", frame_idx=1)
+        assert model.last_engine == "fused" and "tracking_rgb_l1" in out and out["tracking_rgb_l1"][1] is ground_truth["rgb"]
+        terms = tracking_loss(out, ground_truth, stage="fine", frame_idx=1)
+        l = terms["loss"]
+        assert l is out["tracking_rgb_l1"][0] and terms["rgb_loss"] is l and terms["depth_loss"] == 0.0
+        ref = (out["rgb_values"].reshape(-1, 3) - ground_truth["rgb"].reshape(-1, 3)).abs().mean()
+        assert abs(float(l) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref))), (float(l), float(ref))
+        (g_seam,) = torch.autograd.grad(l, cam, retain_graph=True)
+        (g_ref,) = torch.autograd.grad(ref, cam, retain_graph=True)
+        assert float(g_ref.abs().max()) > 0
+        assert float((g_seam - g_ref).abs().max()) <= 2e-5 * float(g_ref.abs().max()), (it, g_seam, g_ref)
+        # the full SLAMLoss (mapping weights) must NOT take the shortcut, nor the tracking loss on another ground-truth tensor
+        assert loss_fn._tracking_objective(out, ground_truth) is None
+        other = dict(ground_truth, rgb=ground_truth["rgb"].clone())
+        l_other = tracking_loss(out, other, stage="fine", frame_idx=1)["loss"]
+        assert l_other is not l and abs(float(l_other) - float(ref)) <= 1e-6
+        (0.5 * l + 0.5 * l_other).backward()              # objective cotangent beside an rgb_values cotangent: the mixed path
+        assert float((cam.grad - g_ref).abs().max()) <= 2e-5 * float(g_ref.abs().max())
+        opt_cam.step()
+        opt_cam.zero_grad()
+        losses.append(float(l))
+    assert all(v == v for v in losses)
+    # a [R,3]-shaped or host ground truth is accepted too (the reference's own loader hands host tensors over)
+    indices, model_input, ground_truth = feed.batch([1])
+    model_input["pose"] = get_camera_from_tensor(cam).unsqueeze(0)
+    host = dict(ground_truth, rgb=ground_truth["rgb"].cpu())
+    out = model(model_input, indices, host, mode="tracking", frame_idx=1)
+    l = tracking_loss(out, host, stage="fine", frame_idx=1)["loss"]
+    ref = (out["rgb_values"].reshape(-1, 3) - ground_truth["rgb"].reshape(-1, 3)).abs().mean()
+    assert l is out["tracking_rgb_l1"][0] and abs(float(l) - float(ref)) <= 1e-6

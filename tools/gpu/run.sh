@@ -9,6 +9,18 @@ for step in "$@"; do
   echo "=== $step"
   case $step in
     tests)        timeout 1500 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "rc=$?" >> $O/tests.log; tail -5 $O/tests.log ;;
+    testsall)     timeout 2400 python -m pytest tests -m gpu -q > $O/tests_all.log 2>&1; echo "rc=$?" >> $O/tests_all.log; grep -E "^(FAILED|ERROR)|passed|failed" $O/tests_all.log | tail -30 ;;
+    ab:*)         # ab:<ENV>: bench.py's tracker line with ENV=0 / ENV=1 alternating, three rounds (per-kernel event times in the lines)
+                  V=${step#ab:}; for r in 1 2 3; do for f in 0 1; do
+                    env $V=$f timeout 600 python bench.py --no-cpu-baseline --no-mapping --no-dropin --no-precision-modes --no-small-shapes \
+                        > $O/ab_${V}_${f}_$r.json 2>/dev/null
+                    python - $O/ab_${V}_${f}_$r.json $V=$f <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+k = d["roofline"]["all_kernels_us"]
+print(sys.argv[2], "ms", d["ms_per_step"], {n: v for n, v in k.items() if "sdfnet" in n or "sampler_sdf" in n})
+PY
+                  done; done ;;
     tests:*)      timeout 1500 python -m pytest ${step#tests:} -m gpu -x -q > $O/tests_sel.log 2>&1; echo "rc=$?" >> $O/tests_sel.log; tail -15 $O/tests_sel.log ;;
     smoke)        timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 ;;
     bench)        timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "rc=$?"; cut -c1-600 $O/bench.json ;;

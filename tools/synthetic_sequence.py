@@ -51,11 +51,13 @@ class _DS:
 
 
 # ------------------------------------------------------------------------------------------------------------ scene and trajectory
-def load_trajectory(n, scale=None, path=None, family="replica"):
-    """-> c2w [n,4,4] float32: TUM rows (stamp tx ty tz qx qy qz qw), translations recentred on their mean and scaled."""
+def load_trajectory(n, scale=None, path=None, family="replica", stride=1):
+    """-> c2w [n,4,4] float32: TUM rows (stamp tx ty tz qx qy qz qw), translations recentred on their mean and scaled.
+    stride: every stride-th pose of the fixture (the 7-Scenes office camera starts almost at rest: 0.0009 scene units per frame over its
+    first poses, a quarter of Replica room0's -- short test runs take every 4th pose so that there is a motion to recover)."""
     scale = FAMILIES[family]["scale"] if scale is None else scale
     path = FAMILIES[family]["traj"] if path is None else path
-    rows = np.loadtxt(path)[:n]
+    rows = np.loadtxt(path)[::stride][:n]
     assert rows.shape[0] == n, f"the fixture holds {rows.shape[0]} poses"
     t = (rows[:, 1:4] - rows[:, 1:4].mean(0)) * scale
     x, y, z, w = rows[:, 4], rows[:, 5], rows[:, 6], rows[:, 7]

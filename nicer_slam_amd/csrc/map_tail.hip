@@ -200,50 +200,20 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = p - a.step_size * (m / denom);
 }
 
-// (A variant with 2 / 4 float4 groups per thread and all their loads issued first measured the same 4.9 TB/s = 0.78 of the 6.29 TB/s
-// streaming-copy rate on a 1 GiB table, profiles/r04_ab_experiments.txt r4h: seven concurrent streams, not load depth, set the rate.)
+// Block orders measured for the dense step over a 1 GiB table (profiles/r04_ab_experiments.txt r4h, r05 r5E, tools/ab_adam.py of those
+// rounds): a grid capped at 32 blocks per CU that strides through the buffer reached 4.9 TB/s; one block per contiguous 4 KiB chunk,
+// front to back, 5.7; the same with non-temporal accesses 6.0-6.4.  The front-to-back forms are what is left: k_adam_table_linear
+// (tables that fit the MALL, and the CLEAR form) and k_adam_table_linear_nt (tables beyond it).
 // CLEAR: the gradient is consumed -- every element read is left zero, so that a persistent gradient buffer needs no separate
 // zero fill before the next backward pass scatters into it (fused/tablegrad.py; the reference's zero_grad + dense autograd
 // gradient, volsdf_train.py:547-576 and hashgrid.py:117-118, as one pass).  Untouched 16-byte groups are not rewritten.
-template <bool CLEAR>
-__global__ __launch_bounds__(256) void k_adam_table(AdamTableArgs a) {
-    const uint64_t n4 = a.n / 4;
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        float4 p = reinterpret_cast<float4*>(a.p)[i];
-        const float4 g = reinterpret_cast<const float4*>(a.g)[i];
-        float4 m = reinterpret_cast<float4*>(a.m)[i];
-        float4 v = reinterpret_cast<float4*>(a.v)[i];
-        adam_one(p.x, g.x, m.x, v.x, a);
-        adam_one(p.y, g.y, m.y, v.y, a);
-        adam_one(p.z, g.z, m.z, v.z, a);
-        adam_one(p.w, g.w, m.w, v.w, a);
-        reinterpret_cast<float4*>(a.p)[i] = p;
-        reinterpret_cast<float4*>(a.m)[i] = m;
-        reinterpret_cast<float4*>(a.v)[i] = v;
-        if (CLEAR && (g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f))        // (NaN != 0: cleared too)
-            reinterpret_cast<float4*>(a.g)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    if (blockIdx.x == 0) {
-        const uint64_t i = n4 * 4 + threadIdx.x;
-        if (i < a.n) {
-            adam_one(a.p[i], a.g[i], a.m[i], a.v[i], a);
-            if (CLEAR) a.g[i] = 0.0f;
-        }
-    }
-}
-
 // One block = one contiguous chunk (4 KiB per float4 group), no loop: the dispatcher walks the buffer front to back, so HBM sees one linear write stream (6.8 TB/s on a
 // 1 GiB buffer; a grid capped at 8 blocks per CU that strides through the buffer reached 4.8 -- tools/micro/fill_bench.py, r5A).
-template <int FILL_GROUPS>
+// (two / four float4 groups per thread: no faster, r5A; non-temporal stores: 3 % slower, r5E)
 __global__ __launch_bounds__(256) void k_fill_zero(float* __restrict__ p, uint64_t n) {
     const uint64_t n4 = n / 4;
-    const uint64_t i0 = (uint64_t)blockIdx.x * (256 * FILL_GROUPS) + threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < FILL_GROUPS; ++j) {
-        const uint64_t i = i0 + 256u * j;
-        if (i < n4) reinterpret_cast<float4*>(p)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // (non-temporal stores: 3 % slower, r5E)
-    }
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) reinterpret_cast<float4*>(p)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (blockIdx.x == 0 && n4 * 4 + threadIdx.x < n) p[n4 * 4 + threadIdx.x] = 0.0f;
 }
 
@@ -260,38 +230,23 @@ __device__ __forceinline__ void nt_store4(float4* p, const float4& v) {
 }
 
 // The linear kernel with non-temporal accesses (gfx950: the `nt` bit on global_load / global_store_dwordx4 -- streamed lines are not
-// kept in L2): 5-8 % faster again on the 1 GiB table (1355 -> 1265 us on the slower of two boxes; tools/ab_adam.py, r5E).  LD / ST
-// select the hint for the four loads / three stores (NSA_ADAM_GRID = nt | ntl | nts for A/B).
-template <bool LD, bool ST>
+// kept in L2): 5-8 % faster again on the 1 GiB table (1355 -> 1265 us on the slower of two boxes, r5E; the hint on the loads only or
+// on the stores only measured in between).
 __global__ __launch_bounds__(256) void k_adam_table_linear_nt(AdamTableArgs a) {
     const uint64_t n4 = a.n / 4;
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n4) {
-        float4 p, g, m, v;
-        if (LD) {
-            p = nt_load4(reinterpret_cast<const float4*>(a.p) + i);
-            g = nt_load4(reinterpret_cast<const float4*>(a.g) + i);
-            m = nt_load4(reinterpret_cast<const float4*>(a.m) + i);
-            v = nt_load4(reinterpret_cast<const float4*>(a.v) + i);
-        } else {
-            p = reinterpret_cast<const float4*>(a.p)[i];
-            g = reinterpret_cast<const float4*>(a.g)[i];
-            m = reinterpret_cast<const float4*>(a.m)[i];
-            v = reinterpret_cast<const float4*>(a.v)[i];
-        }
+        float4 p = nt_load4(reinterpret_cast<const float4*>(a.p) + i);
+        const float4 g = nt_load4(reinterpret_cast<const float4*>(a.g) + i);
+        float4 m = nt_load4(reinterpret_cast<const float4*>(a.m) + i);
+        float4 v = nt_load4(reinterpret_cast<const float4*>(a.v) + i);
         adam_one(p.x, g.x, m.x, v.x, a);
         adam_one(p.y, g.y, m.y, v.y, a);
         adam_one(p.z, g.z, m.z, v.z, a);
         adam_one(p.w, g.w, m.w, v.w, a);
-        if (ST) {
-            nt_store4(reinterpret_cast<float4*>(a.p) + i, p);
-            nt_store4(reinterpret_cast<float4*>(a.m) + i, m);
-            nt_store4(reinterpret_cast<float4*>(a.v) + i, v);
-        } else {
-            reinterpret_cast<float4*>(a.p)[i] = p;
-            reinterpret_cast<float4*>(a.m)[i] = m;
-            reinterpret_cast<float4*>(a.v)[i] = v;
-        }
+        nt_store4(reinterpret_cast<float4*>(a.p) + i, p);
+        nt_store4(reinterpret_cast<float4*>(a.m) + i, m);
+        nt_store4(reinterpret_cast<float4*>(a.v) + i, v);
     }
     if (blockIdx.x == 0) {
         const uint64_t t = n4 * 4 + threadIdx.x;
@@ -299,41 +254,30 @@ __global__ __launch_bounds__(256) void k_adam_table_linear_nt(AdamTableArgs a) {
     }
 }
 
-template <bool CLEAR, int G>
+template <bool CLEAR>
 __global__ __launch_bounds__(256) void k_adam_table_linear(AdamTableArgs a) {
     const uint64_t n4 = a.n / 4;
-    const uint64_t i0 = (uint64_t)blockIdx.x * (256 * G) + threadIdx.x;
-    float4 p[G], g[G], m[G], v[G];
-#pragma unroll
-    for (int j = 0; j < G; ++j) {
-        const uint64_t i = i0 + 256u * j;
-        if (i < n4) {
-            p[j] = reinterpret_cast<float4*>(a.p)[i];
-            g[j] = reinterpret_cast<const float4*>(a.g)[i];
-            m[j] = reinterpret_cast<float4*>(a.m)[i];
-            v[j] = reinterpret_cast<float4*>(a.v)[i];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < G; ++j) {
-        const uint64_t i = i0 + 256u * j;
-        if (i < n4) {
-            adam_one(p[j].x, g[j].x, m[j].x, v[j].x, a);
-            adam_one(p[j].y, g[j].y, m[j].y, v[j].y, a);
-            adam_one(p[j].z, g[j].z, m[j].z, v[j].z, a);
-            adam_one(p[j].w, g[j].w, m[j].w, v[j].w, a);
-            reinterpret_cast<float4*>(a.p)[i] = p[j];
-            reinterpret_cast<float4*>(a.m)[i] = m[j];
-            reinterpret_cast<float4*>(a.v)[i] = v[j];
-            if (CLEAR && (g[j].x != 0.0f || g[j].y != 0.0f || g[j].z != 0.0f || g[j].w != 0.0f))
-                reinterpret_cast<float4*>(a.g)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        float4 p = reinterpret_cast<float4*>(a.p)[i];
+        const float4 g = reinterpret_cast<const float4*>(a.g)[i];
+        float4 m = reinterpret_cast<float4*>(a.m)[i];
+        float4 v = reinterpret_cast<float4*>(a.v)[i];
+        adam_one(p.x, g.x, m.x, v.x, a);
+        adam_one(p.y, g.y, m.y, v.y, a);
+        adam_one(p.z, g.z, m.z, v.z, a);
+        adam_one(p.w, g.w, m.w, v.w, a);
+        reinterpret_cast<float4*>(a.p)[i] = p;
+        reinterpret_cast<float4*>(a.m)[i] = m;
+        reinterpret_cast<float4*>(a.v)[i] = v;
+        if (CLEAR && (g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f))        // (NaN != 0: cleared too)
+            reinterpret_cast<float4*>(a.g)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (blockIdx.x == 0) {
-        const uint64_t i = n4 * 4 + threadIdx.x;
-        if (i < a.n) {
-            adam_one(a.p[i], a.g[i], a.m[i], a.v[i], a);
-            if (CLEAR) a.g[i] = 0.0f;
+        const uint64_t t = n4 * 4 + threadIdx.x;
+        if (t < a.n) {
+            adam_one(a.p[t], a.g[t], a.m[t], a.v[t], a);
+            if (CLEAR) a.g[t] = 0.0f;
         }
     }
 }
@@ -621,22 +565,6 @@ int nsa_morton_order(const nsa_points_t* pts, int32_t* order, uint32_t* workspac
     return launch_end();
 }
 
-// NSA_ADAM_GRID = stride | linear1 | linear2 | nt (default) | ntl | nts (A/B switch, tools/ab_adam.py): 0 = the grid-stride kernel,
-// 1 / 2 = k_adam_table_linear<G>, 3 / 4 / 5 = k_adam_table_linear_nt with the hint on loads + stores / loads / stores
-static int adam_grid_mode() {
-    static const int mode = [] {
-        const char* e = getenv("NSA_ADAM_GRID");
-        if (!e || !strcmp(e, "nt")) return 3;
-        if (!strcmp(e, "stride")) return 0;
-        if (!strcmp(e, "linear1")) return 1;
-        if (!strcmp(e, "linear2")) return 2;
-        if (!strcmp(e, "ntl")) return 4;
-        if (!strcmp(e, "nts")) return 5;
-        return 3;
-    }();
-    return mode;
-}
-
 static int adam_table_launch(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, uint32_t step,
                              float lr, float beta1, float beta2, float eps, bool clear, nsa_stream_t stream) {
     using namespace nsa;
@@ -651,36 +579,22 @@ static int adam_table_launch(float* param, float* grad, float* exp_avg, float* e
     AdamTableArgs a{param, grad, exp_avg, exp_avg_sq, n, 1.0f - beta1, beta2, 1.0f - beta2,
                     (float)((double)lr / bc1), (float)sqrt(bc2), eps};
     const uint64_t n4 = n / 4;
-    uint64_t blocks = (n4 + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;      // grid-stride: 32 blocks per CU keeps every HBM channel busy
-    if (blocks == 0) blocks = 1;
     launch_begin();
     if (!vec) {
         uint64_t sb = (n + 255) / 256;
         if (sb > 256 * 32) sb = 256 * 32;
         if (clear) hipLaunchKernelGGL(k_adam_table_scalar<true>, dim3((uint32_t)sb), dim3(256), 0, (hipStream_t)stream, a);
         else       hipLaunchKernelGGL(k_adam_table_scalar<false>, dim3((uint32_t)sb), dim3(256), 0, (hipStream_t)stream, a);
-    } else if (adam_grid_mode() > 0) {
-        const int mode = adam_grid_mode();
-        const int G = mode >= 3 ? 1 : mode;
-        const uint64_t lb = (n4 + 256 * G - 1) / (256 * G) ? (n4 + 256 * G - 1) / (256 * G) : 1;
+    } else {
+        const uint64_t lb = (n4 + 255) / 256 ? (n4 + 255) / 256 : 1;
         if (lb > 0x7FFFFFFFull) return NSA_EBADARG;
         const dim3 grid((uint32_t)lb), block(256);
         // non-temporal only where nothing of the tensor could stay cached anyway: a table that fits the 256 MB of MALL (the SDF
         // tables, 4 and 36 MiB) is gathered from by the very next forward pass and should stay there
-        if (mode >= 3 && !clear && n >= (1ull << 26)) {
-            if (mode == 3)      hipLaunchKernelGGL((k_adam_table_linear_nt<true, true>), grid, block, 0, (hipStream_t)stream, a);
-            else if (mode == 4) hipLaunchKernelGGL((k_adam_table_linear_nt<true, false>), grid, block, 0, (hipStream_t)stream, a);
-            else                hipLaunchKernelGGL((k_adam_table_linear_nt<false, true>), grid, block, 0, (hipStream_t)stream, a);
-        } else if (G == 1) {
-            if (clear) hipLaunchKernelGGL((k_adam_table_linear<true, 1>), grid, block, 0, (hipStream_t)stream, a);
-            else       hipLaunchKernelGGL((k_adam_table_linear<false, 1>), grid, block, 0, (hipStream_t)stream, a);
-        } else {
-            if (clear) hipLaunchKernelGGL((k_adam_table_linear<true, 2>), grid, block, 0, (hipStream_t)stream, a);
-            else       hipLaunchKernelGGL((k_adam_table_linear<false, 2>), grid, block, 0, (hipStream_t)stream, a);
-        }
-    } else if (clear) hipLaunchKernelGGL(k_adam_table<true>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, a);
-    else              hipLaunchKernelGGL(k_adam_table<false>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        if (!clear && n >= (1ull << 26)) hipLaunchKernelGGL(k_adam_table_linear_nt, grid, block, 0, (hipStream_t)stream, a);
+        else if (clear)                  hipLaunchKernelGGL(k_adam_table_linear<true>, grid, block, 0, (hipStream_t)stream, a);
+        else                             hipLaunchKernelGGL(k_adam_table_linear<false>, grid, block, 0, (hipStream_t)stream, a);
+    }
     return launch_end();
 }
 
@@ -750,20 +664,11 @@ int nsa_fill_zero(float* p, uint64_t n, nsa_stream_t stream) {
     using namespace nsa;
     if (!p || (reinterpret_cast<uintptr_t>(p) & 15u)) return NSA_EBADARG;
     if (n == 0) return NSA_OK;
-    // float4 groups per thread (NSA_FILL_GROUPS = 1 | 2 | 4: A/B override, tools/micro/fill_bench.py)
-    static const int G = [] {
-        const char* e = getenv("NSA_FILL_GROUPS");
-        const int g = e ? atoi(e) : 1;
-        return (g == 2 || g == 4) ? g : 1;        // anything else would size the grid for a template that is not launched
-    }();
-    uint64_t blocks = (n / 4 + 256 * G - 1) / (256 * G);
+    uint64_t blocks = (n / 4 + 255) / 256;
     if (blocks == 0) blocks = 1;
     if (blocks > 0x7FFFFFFFull) return NSA_EBADARG;
-    const dim3 grid((uint32_t)blocks), block(256);
     launch_begin();
-    if (G == 4)      hipLaunchKernelGGL(k_fill_zero<4>, grid, block, 0, (hipStream_t)stream, p, n);
-    else if (G == 2) hipLaunchKernelGGL(k_fill_zero<2>, grid, block, 0, (hipStream_t)stream, p, n);
-    else             hipLaunchKernelGGL(k_fill_zero<1>, grid, block, 0, (hipStream_t)stream, p, n);
+    hipLaunchKernelGGL(k_fill_zero, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, p, n);
     return launch_end();
 }
 

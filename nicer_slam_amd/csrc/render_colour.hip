@@ -141,8 +141,9 @@ __device__ __forceinline__ void colour_level_out(const float (&v)[8][CC], const 
     }
 }
 
-// XP: leading level pairs gathered with one 16-byte load per x-neighbour pair (0: every level through gather_corners)
-template <int XP = 0>
+// (An "x-pair" form that fetched the x / x+1 corner rows of the eight dense leading levels with one 16-byte load each was built in round 4
+// and measured SLOWER -- 73.8 -> 83 us: the 16-byte loads sit at 8-byte alignment and the kernel needed 218 instead of 124 registers,
+// two instead of four waves per SIMD (profiles/r04_ab_experiments.txt); removed in round 6.)
 __device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeom16& geom, uint32_t tile, uint32_t q, int lane,
                                               int h, const float (&x)[3], const float (&dir)[3], float (&in)[COL_IN_STEPS],
                                               bool from_save, bool wave_live) {
@@ -174,13 +175,6 @@ __device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeo
 #pragma unroll
     for (int d = 0; d < 3; ++d) u[d] = to_unit(x[d], a.divide_factor);
     float* sv = (a.save && wave_live) ? a.save + (size_t)tile * 64 * 64 + lane : nullptr;   // clamped waves write nothing
-    // XP leading level pairs (levels 0 .. 2 XP - 1, both half-waves) are dense with x-stride one row: the x / x+1 corner rows of a
-    // cell are 16 contiguous bytes, fetched as ONE load -- four requests per level instead of eight, for every lane, no per-lane
-    // path (the round-3 attempt paired rows only where a lane's level allowed it: divergent, slower).  The pair is exactly the two
-    // rows the reference indexes (dense index(x+1) = index(x) + 1, hashencoder.cu:56-70) unless the cell touches the level's last
-    // rows, where the reference's modulo wraps: a coordinate of exactly 1.0 -- the far sample of a ray on the cube face.  Those
-    // lanes load from a clamped address and the whole wave repeats the XP levels through the generic gather afterwards (rare).
-    bool redo = false;
 #pragma unroll
     for (int jl = 0; jl < CL / 2; ++jl) {
         const LevelGeom lg = geom.lv[2 * jl + h];
@@ -188,35 +182,8 @@ __device__ __forceinline__ void colour_inputs(const ColourArgs& a, const GridGeo
         float w[3], dw[3];
         const bool inside = locate<3>(u, lg.scale, cell, w, dw);
         float v[8][CC];
-        if (jl < XP) {
-            constexpr uint32_t B = CC * 4;
-            uint32_t o00 = __umul24(cell[1], lg.s1B) + (cell[0] * B + lg.row0B);
-            o00 = __umul24(cell[2], lg.s2B) + o00;
-            const bool fast = o00 < lg.limB;                   // all eight corner rows inside the level (limB = 0 unless LV_FASTDENSE)
-            redo = redo || !fast;
-            if (!fast) o00 = lg.row0B;
-            const uint32_t off[4] = {o00, o00 + lg.s1B, o00 + lg.s2B, o00 + lg.s2B + lg.s1B};
-#pragma unroll
-            for (int yz = 0; yz < 4; ++yz) {
-                const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.table) + (size_t)off[yz]);
-                v[2 * yz][0] = r.x; v[2 * yz][1] = r.y; v[2 * yz + 1][0] = r.z; v[2 * yz + 1][1] = r.w;
-            }
-        } else {
-            gather_corners<3, CC>(a.table, lg, cell, v);
-        }
+        gather_corners<3, CC>(a.table, lg, cell, v);
         colour_level_out(v, w, dw, lg.scale, inside, jl, in, sv, !a.save_no_features);
-    }
-    if (XP > 0 && __any(redo)) {
-#pragma unroll
-        for (int jl = 0; jl < XP; ++jl) {
-            const LevelGeom lg = geom.lv[2 * jl + h];
-            uint32_t cell[3];
-            float w[3], dw[3];
-            const bool inside = locate<3>(u, lg.scale, cell, w, dw);
-            float v[8][CC];
-            gather_corners<3, CC>(a.table, lg, cell, v);
-            colour_level_out(v, w, dw, lg.scale, inside, jl, in, sv, !a.save_no_features);
-        }
     }
 }
 
@@ -260,12 +227,10 @@ __device__ __forceinline__ void colour_mlp(float* stage, const float* __restrict
 
 // The colour forward lives on memory-level parallelism (1 GiB table, HBM gather): four waves per SIMD.  Under a two-wave target the
 // bf16-operand build allocated 133 registers and, with the ReLU masks of round 5, the fp32 build 134: a wave per SIMD lost.
-// The x-pair form (XP > 0, off by default) needs 218 registers and keeps the two-wave target.
 #ifndef NSA_OCC_COL_FWD
 #define NSA_OCC_COL_FWD 4
 #endif
-template <int XP>
-__global__ __launch_bounds__(256, XP > 0 ? 2 : NSA_OCC_COL_FWD) void k_colour_fwd(ColourArgs a, GridGeom16 geom) {
+__global__ __launch_bounds__(256, NSA_OCC_COL_FWD) void k_colour_fwd(ColourArgs a, GridGeom16 geom) {
     using Seq = ColOps<false>;
 #include "colour_fwd_body.inc"
 }
@@ -351,8 +316,7 @@ namespace nsa {
 __global__ __launch_bounds__(256, NSA_OCC_COL_FWD) void k_colour_fwd_track(ColourArgs ca, GridGeom16 cgeom, CompositeArgs ta,
                                                                             const float* __restrict__ gt, float* __restrict__ ray_loss,
                                                                             float inv_n) {
-    {   // phase 1: k_colour_fwd<0> (every wave is live: the entry point requires P % 128 == 0)
-        constexpr int XP = 0;
+    {   // phase 1: k_colour_fwd (every wave is live: the entry point requires P % 128 == 0)
         using Seq = ColOps<false>;
         const ColourArgs& a = ca;
         const GridGeom16& geom = cgeom;
@@ -369,8 +333,7 @@ __global__ __launch_bounds__(256, NSA_OCC_COL_FWD) void k_colour_fwd_track(Colou
 
 // the same with the generic composite forward (all five ray outputs + the weights) as the second phase: the autograd path
 __global__ __launch_bounds__(256, NSA_OCC_COL_FWD) void k_colour_fwd_composite(ColourArgs ca, GridGeom16 cgeom, CompositeArgs ta) {
-    {   // phase 1: k_colour_fwd<0> (every wave is live: the entry point requires P % 128 == 0)
-        constexpr int XP = 0;
+    {   // phase 1: k_colour_fwd (every wave is live: the entry point requires P % 128 == 0)
         using Seq = ColOps<false>;
         const ColourArgs& a = ca;
         const GridGeom16& geom = cgeom;
@@ -429,17 +392,7 @@ int NSA_ENTRY(nsa_colour_forward)(const nsa_points_t* pts, const nsa_grid_t* gri
     a.wp = packed; a.grad = grad; a.feat = feat_hl; a.rgb = rgb; a.save = save;
     const uint32_t tiles = (pts->P + 31) / 32;
     launch_begin();
-    // x-pair gather of the leading dense levels (colour_inputs<XP>): levels 0..7 must be plain dense levels (LV_FASTDENSE: no
-    // index wrap, byte offsets < 2^31, limB set) -- true for the reference's colour grid (base 16 ... 2048, 2^24 rows: levels
-    // 0..8 are dense); any other geometry takes the all-generic kernel.
-    // Measured on MI355X (profiles/r04_ab_experiments.txt): 73.8 -> 83 us -- the 16-byte loads sit at 8-byte alignment, the kernel
-    // needs 218 instead of 124 registers (two instead of four waves per SIMD; capped at 128 it spills: 112 us).  OFF by default;
-    // NSA_COLOUR_XPAIR=1 selects it (A/B runs).
-    static const bool xpair_on = [] { const char* e = getenv("NSA_COLOUR_XPAIR"); return e && e[0] == '1'; }();
-    bool xpair = xpair_on && grid->L == 16;
-    for (int l = 0; l < 8 && xpair; ++l) xpair = (geom.lv[l].flags & LV_FASTDENSE) && geom.lv[l].limB > 0;
-    if (xpair) hipLaunchKernelGGL(k_colour_fwd<4>, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
-    else       hipLaunchKernelGGL(k_colour_fwd<0>, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
+    hipLaunchKernelGGL(k_colour_fwd, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geom);
     return launch_end();
 }
 

@@ -83,7 +83,7 @@ def _table_result(gt):
 # bits of the 30-bit Morton code the launch order is sorted on: 24 = a 256^3 lattice, three radix passes; the points of one such
 # cell keep their ray order.  (Interleaved A/B of a mapping iteration, tools/ab_mapping.py: 23-25 bits 0.05-0.15 ms faster than the
 # full 30 -- one pass less, and the MAP kernels do not lose by it; profiles/r05_ab_experiments.txt r5y/r5z.)
-MORTON_BITS = int(os.environ.get("NSA_MORTON_BITS", "24"))
+MORTON_BITS = 24
 
 
 def morton_order(pts_desc, P, device):

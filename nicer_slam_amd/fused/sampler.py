@@ -49,16 +49,16 @@ def precision_of(model, which):
 # "sampler_large" (>= 4096 rays, the mapping batch): the persistent quad sampler (16) was the faster form there in round 2 (1739 -> 1645 us
 # at 8192 rays); since round 3's work on the two-tile 32-point kernel that one is: 1517 vs 1677 us (profiles/r04_ab_experiments.txt r4u).
 DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 64, "coarse_map": 16, "sampler_large": 64, "coarse_pair": 16}
-FWD_PAIR = os.environ.get("NSA_SDF_FWD_PAIR", "1") != "0"          # 0: two forward launches (A/B runs)
+FWD_PAIR = True          # False: two forward launches (module attribute: the bit-identity tests and A/B runs flip it)
 # 1: the colour backward and the coarse SDF backward of a data-path backward as ONE launch (nsa_colour_coarse_backward; 32-point tiling of
-# the coarse network).  0: two launches (A/B runs).
-COLOUR_COARSE_BWD = os.environ.get("NSA_COLOUR_COARSE_BWD", "1") != "0"
+# the coarse network).  False: two launches.
+COLOUR_COARSE_BWD = True
 # 1: the tracker's colour forward also runs the ray's composite + L1 + composite backward (nsa_colour_forward_track) when a ray is exactly
-# one workgroup of the colour forward (128 samples per ray).  0: nsa_colour_forward + nsa_composite_track (A/B runs).
-COLOUR_FWD_TRACK = os.environ.get("NSA_COLOUR_FWD_TRACK", "1") != "0"
+# one workgroup of the colour forward (128 samples per ray).  False: nsa_colour_forward + nsa_composite_track.
+COLOUR_FWD_TRACK = True
 SAMPLER_LARGE_RAYS = 4096
 _FORCE = int(os.environ.get("NSA_SDF_TILE", "0"))
-_FORCE_SAMPLER = int(os.environ.get("NSA_SAMPLER_TILE", "0"))      # A/B runs of the sampler pass alone: 16 | 32 | 64 | 96
+_FORCE_SAMPLER = 0       # A/B runs of the sampler pass alone set this to 16 | 32 | 64 (96 / 97: the wave-specialised experiment builds)
 
 
 def tile_of(model, which):
@@ -197,9 +197,9 @@ def sample_rays(model, rays_o, rays_d, z, sdf, far, extra_idx, eik_idx):
 
 # The sampler's draws come from the engine's own Philox4x32-10 stream (nsa_draw: jitter, permutation picks and eikonal indices in
 # one launch, state advanced on the device) -- seeded from torch's generator when the model first draws, so torch.manual_seed
-# still fixes the run.  NSA_OWN_RNG=0: torch.rand + nsa_draw_picks (inside a captured graph torch's graph-safe generator adds four
+# still fixes the run.  OWN_RNG = False: torch.rand + nsa_draw_picks (inside a captured graph torch's graph-safe generator adds four
 # small launches in front of every replay).
-OWN_RNG = os.environ.get("NSA_OWN_RNG", "1") != "0"
+OWN_RNG = True
 
 
 def draw_state(model, stream_key=0):

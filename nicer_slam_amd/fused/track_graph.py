@@ -162,7 +162,7 @@ class TrackingGraph:
         rays_o, rays_d, ds = (torch.empty(R, 3, device=dev), torch.empty(R, 3, device=dev), torch.empty(R, device=dev))
         samp = model.ray_sampler
         E, n_extra = samp.N_samples_eval, samp.N_samples_extra
-        if fs.own_draws(model) and os.environ.get("NSA_TRACK_DRAW_IN_BEGIN", "1") != "0":
+        if fs.own_draws(model):
             # the sampler's draws ride in the ray-lifting launch (one graph node less); tracking consumes no eikonal sample
             t_rand = torch.empty(R, E, device=dev)
             extra = torch.empty(n_extra, device=dev, dtype=torch.int32) if n_extra > 0 else None

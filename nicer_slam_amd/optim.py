@@ -25,8 +25,6 @@ Same semantics, operation order and state layout as torch.optim.Adam without wei
 ``state[p] = {"step": tensor(float), "exp_avg", "exp_avg_sq"}``, so state_dicts are interchangeable.  CUDA float32
 contiguous parameters only; anything else raises (no fallback).
 """
-import os
-
 import torch
 
 from ._native import lib, check, AdamSeg
@@ -36,19 +34,13 @@ from .fused import tablegrad
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, consume_table_grads=None, none_grad="skip"):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, consume_table_grads=False, none_grad="skip"):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         if none_grad not in ("skip", "zeros"):
             raise ValueError(f"none_grad={none_grad!r}: expected 'skip' (installed torch's semantics) or 'zeros' (torch 1.11's)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
-        if consume_table_grads is None:      # NSA_TABLE_GRAD_CLEAR = acquire (default) | fused: A/B switch of the clearing policy
-            policy = os.environ.get("NSA_TABLE_GRAD_CLEAR", "acquire")
-            if policy not in ("acquire", "fused"):
-                raise ValueError(f"NSA_TABLE_GRAD_CLEAR={policy!r}: expected 'acquire' or 'fused' (the side-stream policy 'async' of "
-                                 "profiles/r05_ab_experiments.txt r5y was measured and removed)")
-            consume_table_grads = policy == "fused"
-        self.consume_table_grads = consume_table_grads
+        self.consume_table_grads = bool(consume_table_grads)
         self.none_grad = none_grad
         self._zeros = {}
 

@@ -34,7 +34,8 @@ class KernelTracker:
     other's tails.  Same arithmetic per ray; the ray sums are added chunk by chunk."""
 
     def __init__(self, model, intrinsics, n_rays, cam_init, lr=0.005, betas=(0.9, 0.999), eps=1e-8, lr_step=0,
-                 lr_gamma=1.0, use_graph=True, world=1, stage="fine", color_stage="highfreq", chunks=1, graph_collective=None):
+                 lr_gamma=1.0, use_graph=True, world=1, stage="fine", color_stage="highfreq", chunks=1, graph_collective=None,
+                 fold=True, draw_in_begin=True):
         from .fused import render as fr, sampler as fs
         if not fr.supported(model):
             raise RuntimeError("KernelTracker: configuration outside the fused engine's compiled set")
@@ -69,16 +70,17 @@ class KernelTracker:
             self.streams = [torch.cuda.Stream() for _ in range(self.chunks)]
             self.red_c, self.pose_c = z(self.chunks, 9), z(self.chunks, 4, 4)
         # one ray chunk: the per-ray neighbours of head and tail are folded into them (nsa_track_begin in front of the graph,
-        # nsa_composite_track, nsa_track_finish): 5 fewer launches per iteration.  NSA_TRACK_FOLD=0 keeps the plain sequence (A/B).
-        self.folded = self.chunks == 1 and os.environ.get("NSA_TRACK_FOLD", "1") != "0"
+        # nsa_composite_track, nsa_track_finish): 5 fewer launches per iteration.  fold=False keeps the plain sequence (the
+        # bit-identity test of the folded forms, tests/test_track_fold_gpu.py).
+        self.folded = self.chunks == 1 and bool(fold)
         if self.folded:
             from ._native import lib
             self.ray_loss = z(n_rays)
             self.fin_ws = z(int(lib.nsa_track_finish_workspace(n_rays)))      # ticket + block partials; zero once
         # folded sequence: the sampler's draws of an iteration are made by the head launch as well (nsa_track_begin_draw) instead of
-        # a graph node of their own -- same generator state, same numbers.  NSA_TRACK_DRAW_IN_BEGIN=0: nsa_draw inside the graph (A/B).
+        # a graph node of their own -- same generator state, same numbers.  draw_in_begin=False: nsa_draw inside the graph (same test).
         self.drawn = None
-        if self.folded and os.environ.get("NSA_TRACK_DRAW_IN_BEGIN", "1") != "0":
+        if self.folded and draw_in_begin:
             samp = model.ray_sampler
             E, n_extra = samp.N_samples_eval, samp.N_samples_extra
             if E <= 1024:

@@ -205,18 +205,10 @@ def test_mapping_host_guards_without_a_gpu():
         tablegrad.target(torch.nn.Parameter(torch.zeros(8, 2)))
     assert tablegrad.consumable(torch.nn.Parameter(torch.zeros(2)), torch.zeros(2)) is False
     from nicer_slam_amd.optim import Adam
-    old = os.environ.get("NSA_TABLE_GRAD_CLEAR")
-    try:
-        os.environ["NSA_TABLE_GRAD_CLEAR"] = "async"
-        with pytest.raises(ValueError, match="async"):
-            Adam([torch.nn.Parameter(torch.zeros(3))])
-        os.environ["NSA_TABLE_GRAD_CLEAR"] = "fused"
-        assert Adam([torch.nn.Parameter(torch.zeros(3))]).consume_table_grads is True
-    finally:
-        if old is None:
-            os.environ.pop("NSA_TABLE_GRAD_CLEAR", None)
-        else:
-            os.environ["NSA_TABLE_GRAD_CLEAR"] = old
+    assert Adam([torch.nn.Parameter(torch.zeros(3))]).consume_table_grads is False       # the clearing policy is a constructor argument
+    assert Adam([torch.nn.Parameter(torch.zeros(3))], consume_table_grads=True).consume_table_grads is True
+    with pytest.raises(ValueError, match="none_grad"):
+        Adam([torch.nn.Parameter(torch.zeros(3))], none_grad="async")
     with pytest.raises(RuntimeError):                    # the optimizer itself: no CPU fallback either (no GPU / not a CUDA tensor)
         p = torch.nn.Parameter(torch.zeros(3))
         p.grad = torch.ones(3)

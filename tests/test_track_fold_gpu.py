@@ -125,11 +125,7 @@ def test_folded_tracker_follows_the_plain_sequence_and_is_reproducible():
     cam0 = tt(fx["in_cam"]).reshape(-1)
     runs = {}
     for tag, fold, use_graph in (("plain", "0", True), ("fold", "1", True), ("fold2", "1", True), ("fold_eager", "1", False)):
-        os.environ["NSA_TRACK_FOLD"] = fold
-        try:
-            kt = KernelTracker(model, K, uv.shape[1], cam0, lr=0.005, use_graph=use_graph)
-        finally:
-            os.environ.pop("NSA_TRACK_FOLD", None)
+        kt = KernelTracker(model, K, uv.shape[1], cam0, lr=0.005, use_graph=use_graph, fold=fold == "1")
         assert kt.folded == (fold == "1")
         ls = [float(kt.step(uv, gt)) for _ in range(6)]
         runs[tag] = (torch.tensor(ls), kt.cam.clone(), kt.candidate.clone())
@@ -238,16 +234,11 @@ def test_head_launch_draws_change_no_bit(use_graph):
                 torch.rand(R, 3, device="cuda", generator=g)) for _ in range(8)]
     cam0 = torch.tensor([1.0, 0.02, -0.01, 0.03, 0.1, 0.0, -0.2], device="cuda")
     runs = {}
-    for tag, env in (("node", {"NSA_TRACK_DRAW_IN_BEGIN": "0"}), ("head", {})):
+    for tag, in_begin in (("node", False), ("head", True)):
         for k in ("_draw_state", "_draw_states", "_draw_seed"):
             model.__dict__.pop(k, None)
         torch.manual_seed(7)
-        os.environ.update(env)
-        try:
-            kt = KernelTracker(model, K[None], R, cam0, lr=0.002, use_graph=use_graph)
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
+        kt = KernelTracker(model, K[None], R, cam0, lr=0.002, use_graph=use_graph, draw_in_begin=in_begin)
         assert (kt.drawn is not None) == (tag == "head")
         calls0 = int(fs.draw_state(model)[1])
         ls = torch.stack([kt.step(*b).clone() for b in batches])

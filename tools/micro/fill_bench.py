@@ -1,5 +1,5 @@
-"""Zero fill of a 1 GiB buffer: torch's fill vs nsa_fill_zero (float4 groups per thread from NSA_FILL_GROUPS).
-usage: NSA_FILL_GROUPS=1 python tools/micro/fill_bench.py"""
+"""Zero fill of a 1 GiB buffer: torch's fill vs nsa_fill_zero.
+usage: python tools/micro/fill_bench.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -26,5 +26,5 @@ def timed(fn, reps=20):
 
 t_torch = timed(lambda: buf.zero_())
 t_nsa = timed(lambda: check(lib.nsa_fill_zero(buf.data_ptr(), n, st)))
-print(f"float4 groups per thread {os.environ.get('NSA_FILL_GROUPS', '1 (default)')}: torch fill {t_torch:.1f} us ({n * 4 / t_torch / 1e6:.2f} TB/s)   "
+print(f"torch fill {t_torch:.1f} us ({n * 4 / t_torch / 1e6:.2f} TB/s)   "
       f"nsa_fill_zero {t_nsa:.1f} us ({n * 4 / t_nsa / 1e6:.2f} TB/s)")

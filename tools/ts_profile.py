@@ -8,12 +8,12 @@ import ctypes
 import os
 import sys
 
-os.environ.setdefault("NSA_SDF_FWD_PAIR", "0")     # the instrumented forward is the single-network kernel (two launches)
-
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from nicer_slam_amd.fused import sampler as _fs
+_fs.FWD_PAIR = False     # the instrumented forward is the single-network kernel (two launches)
 
 SLOTS_BWD = {0: "stage_wait: vmcnt(0)", 1: "stage_wait: barrier", 2: "stage_wait count", 3: "GEMM bodies (LDS reads + split + MFMA)",
              4: "point load + geometry barrier", 5: "PE + grid gather/blend/Jacobian", 6: "forward recompute (hidden layers)",

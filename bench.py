@@ -104,6 +104,8 @@ def parse():
     ap.add_argument("--no-mapping", action="store_true", help="skip the (untimed-for-value) mapping-iteration leg")
     ap.add_argument("--no-small-shapes", action="store_true", help="skip the strong-scaling-tail rows (128 / 256 / 512 rays; N = 1 only)")
     ap.add_argument("--cpu-rays", type=int, default=1024)
+    ap.add_argument("--cpu-all-cores-rays", type=int, default=16,
+                    help="rays of the second CPU figure, taken with torch.set_num_threads(os.cpu_count()) (BASELINE.md section 3); 0: skip")
     ap.add_argument("--only-mapping", type=int, default=0, metavar="ITERS",
                     help="profiling aid: run ONLY the mapping-iteration leg with this many timed iterations and print its dict")
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 4],
@@ -188,12 +190,22 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.only_mapping:
+        self_launch(args)                # (the ranks it starts inherit this process's stdout untouched)
+    # stdout carries ONE JSON line and nothing else: native libraries write to file descriptor 1 behind Python's back (RCCL prints a
+    # version banner when a communicator is created) -- descriptor 1 is pointed at stderr for the whole run and the line goes to a
+    # private duplicate of the original stdout
+    sys.stdout.flush()
+    out_fd = os.dup(1)
+    os.dup2(2, 1)
+    global _emit
+    def _emit(text):
+        sys.stdout.flush()
+        os.write(out_fd, (text + "\n").encode())
     if args.only_mapping:
         assert torch.cuda.is_available(), "bench.py needs an MI355X"
-        print(json.dumps(mapping_leg(torch.device("cuda", 0), iters=args.only_mapping, cpu=not args.no_cpu_baseline)))
+        _emit(json.dumps(mapping_leg(torch.device("cuda", 0), iters=args.only_mapping, cpu=not args.no_cpu_baseline)))
         return
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -416,7 +428,7 @@ def main():
             "roofline": roof, "colour_gather": gather, "cpu_baseline": cpu, "reference_shaped_gpu": ref_gpu, "dropin": dropin,
             "mapping_iteration": mapping, "precision_modes": prec_modes, "small_shapes": small,
         }
-        print(json.dumps(line))
+        _emit(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 
@@ -687,7 +699,33 @@ def cpu_baseline(args, model, conf):
     med = timed[len(timed) // 2]
     from oracle import hashenc
     omp = min(16, os.cpu_count() or 1)           # oracle/hashenc.py: nso_set_threads(min(16, cores))
+    # BASELINE.md section 3 asks for torch.set_num_threads(os.cpu_count()): that figure as well, on a smaller sample of the same workload
+    # (one timed iteration after one warm-up -- with every core of this box type the intra-op pool thrashes on these small GEMMs)
+    all_cores = None
+    if args.cpu_all_cores_rays > 0 and (os.cpu_count() or 1) > torch.get_num_threads():
+        try:
+            capped = torch.get_num_threads()
+            torch.set_num_threads(os.cpu_count())
+            m = args.cpu_all_cores_rays
+            ts = []
+            for it in range(2):
+                idx = torch.randint(H * W, (1, m), generator=g)
+                uv = torch.stack([(idx % W).float(), (idx // W).float()], -1)
+                gt = torch.rand(m, 3, generator=g)
+                draws = {"t_rand": torch.rand(m, 640, generator=g), "extra_idx": torch.randperm(640, generator=g)[:32],
+                         "eik_idx": torch.randint(args.samples, (m,), generator=g)}
+                cam = torch.tensor([1.0, 0, 0, 0, 0.1, 0.0, -0.2]).requires_grad_(True)
+                t0 = time.perf_counter()
+                out = R.render(params, cfg, uv, R.camera_from_tensor(cam).unsqueeze(0), K[None], vox, draws, mode="tracking", training=True)
+                R.rgb_l1(out, gt).backward()
+                ts.append(time.perf_counter() - t0)
+            all_cores = {"value": round(m / ts[-1], 1), "unit": "rays/s", "threads": os.cpu_count(),
+                         "sample": f"{m} rays, one iteration after one warm-up ({round(sum(ts), 1)} s of host time)"}
+            torch.set_num_threads(capped)
+        except Exception as e:      # a context figure must never take the line down
+            all_cores = {"error": f"{type(e).__name__}: {e}"[:200]}
     return {"value": round(n / med, 1), "unit": "rays/s", "cores": max(torch.get_num_threads(), omp),
+            "all_host_cores": all_cores,
             "threads": {"torch_intraop": torch.get_num_threads(), "c_hash_kernels_openmp": omp}, "host_cores": os.cpu_count(),
             "kind": "port",
             "sample": f"{n} rays x (640 sampler + {args.samples} composite) samples, fwd+bwd to pose grad, "

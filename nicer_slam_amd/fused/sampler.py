@@ -48,7 +48,8 @@ def precision_of(model, which):
 # "coarse_pair": the coarse network inside nsa_sdfnet_forward_pair (both networks' forward in one launch; quad tiling only).
 # "sampler_large" (>= 4096 rays, the mapping batch): the persistent quad sampler (16) was the faster form there in round 2 (1739 -> 1645 us
 # at 8192 rays); since round 3's work on the two-tile 32-point kernel that one is: 1517 vs 1677 us (profiles/r04_ab_experiments.txt r4u).
-DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 64, "coarse_map": 16, "sampler_large": 64, "coarse_pair": 16}
+# "sampler_small" (<= 256 rays: the per-GPU share of an 8- / 4-GPU strong-scaling run of the 1024-ray batch): see SAMPLER_SMALL_RAYS.
+DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 64, "coarse_map": 16, "sampler_large": 64, "coarse_pair": 16, "sampler_small": 64}
 FWD_PAIR = True          # False: two forward launches (module attribute: the bit-identity tests and A/B runs flip it)
 # 1: the colour backward and the coarse SDF backward of a data-path backward as ONE launch (nsa_colour_coarse_backward; 32-point tiling of
 # the coarse network).  False: two launches.
@@ -57,6 +58,12 @@ COLOUR_COARSE_BWD = True
 # one workgroup of the colour forward (128 samples per ray).  False: nsa_colour_forward + nsa_composite_track.
 COLOUR_FWD_TRACK = True
 SAMPLER_LARGE_RAYS = 4096
+SAMPLER_SMALL_RAYS = 256
+
+
+def sampler_use(n_rays):
+    """the DEFAULT_TILES key of the SDF-only sampler pass for a batch of n_rays"""
+    return "sampler_large" if n_rays >= SAMPLER_LARGE_RAYS else "sampler_small" if n_rays <= SAMPLER_SMALL_RAYS else "sampler"
 _FORCE = int(os.environ.get("NSA_SDF_TILE", "0"))
 _FORCE_SAMPLER = 0       # A/B runs of the sampler pass alone set this to 16 | 32 | 64 (96 / 97: the wave-specialised experiment builds)
 
@@ -150,7 +157,7 @@ def sampler_sdf(model, rays_o, rays_d, t_rand):
     R, E = rays_o.shape[0], samp.N_samples_eval
     dev = rays_o.device
     imp = model.implicit_network
-    use = "sampler_large" if R >= SAMPLER_LARGE_RAYS else "sampler"
+    use = sampler_use(R)
     gc, keep_c = sdf_grid_desc(model, "coarse", use)
     gf, keep_f = sdf_grid_desc(model, "fine", use)
     pc, pf = packed_sdf(model, "coarse", use=use), packed_sdf(model, "fine", use=use)

@@ -52,7 +52,7 @@ OBJECTIVE = os.environ.get("NSA_TRACK_OBJECTIVE", "1") != "0"      # fold the tr
 def pack_specs(model, n_rays, stage):
     """(cache key, network, use) of every packed block a tracking iteration over ``n_rays`` rays reads (fused/sampler.py::tile_of)."""
     from . import sampler as fs
-    use = "sampler_large" if n_rays >= fs.SAMPLER_LARGE_RAYS else "sampler"
+    use = fs.sampler_use(n_rays)
     specs = []
     for which in ("coarse", "fine"):
         for u in (use, None):

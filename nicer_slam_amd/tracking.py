@@ -378,8 +378,9 @@ class TrackingStepper:
                     return t
                 return t.detach().to(device=dev, dtype=torch.float32).reshape(shape).contiguous()
             self.uv, self.gt = _as(uv, tuple(self._uv_shape)), _as(gt, tuple(self._gt_shape))
-            if self.cam.grad is not None:
-                self.cam.grad.zero_()
+            # optimizer_camera.zero_grad() of the reference's loop (volsdf_train.py:427): under torch >= 2.0 that sets .grad = None
+            # (a zero fill + an accumulating add less per iteration than zeroing in place)
+            self.opt.zero_grad()
             loss = self._fwd_bwd()
         if not self.graph_all:
             if self.world > 1:

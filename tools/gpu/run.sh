@@ -21,6 +21,15 @@ k = d["roofline"]["all_kernels_us"]
 print(sys.argv[2], "ms", d["ms_per_step"], {n: v for n, v in k.items() if "sdfnet" in n or "sampler_sdf" in n})
 PY
                   done; done ;;
+    pmcab:*)      # pmcab:<ENV>: SQ counters of the quad kernels with ENV=0 / ENV=1 (one counter pass each; eager launches)
+                  V=${step#pmcab:}; R=$(pwd)
+                  BE="python $R/bench.py --no-cpu-baseline --no-mapping --no-dropin --no-precision-modes --no-small-shapes --steps 20 --warmup 5 --prewarm-s 0 --prewarm-steps 0 --no-graph"
+                  for f in 0 1; do
+                    (cd /tmp && env $V=$f timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU \
+                        --output-format csv -d /tmp/pmcab_$f -- $BE > /tmp/pmcab_$f.log 2>&1)
+                    python tools/pmc_summary.py /tmp/pmcab_$f | grep -E "kernel|sdfnet4" > $O/pmc_${V}_$f.csv
+                    echo "$V=$f"; cat $O/pmc_${V}_$f.csv | cut -c1-150
+                  done ;;
     tests:*)      timeout 1500 python -m pytest ${step#tests:} -m gpu -x -q > $O/tests_sel.log 2>&1; echo "rc=$?" >> $O/tests_sel.log; tail -15 $O/tests_sel.log ;;
     smoke)        timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 ;;
     bench)        timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "rc=$?"; cut -c1-600 $O/bench.json ;;

@@ -296,118 +296,11 @@ __device__ __forceinline__ void resident_load(float* lds, const float* __restric
                                  lds + res_off<Seq>(op), wp1);
 }
 
-// ---- ring-staged weights without workgroup barriers (fp32 build, round 6) -----------------------------------------------------------
-// The three-piece blocks of a quad kernel (paired forward 288 KiB, fine backward 192 KiB) do not fit LDS, so the fp32 build cannot keep
-// them resident as the bf16 build does.  What costs the time in the staged form is not the copy but the s_barrier per GEMM: the two waves
-// of a SIMD leave it together, split their operands together (vector pipe) and multiply together (matrix pipe) -- 25 % of the matrix time
-// co-executes with vector work (profiles/r05_pmc_per_kernel.csv) against 52 % in the barrier-free sampler.  RingSeq<Seq> replaces the
-// barrier by a ring of THREE stage buffers and two monotonic counters per part in LDS:
-//   landed[p]  waves whose share of part p's asynchronous copy has arrived (signalled after the wave's own vmcnt(0));
-//   done[p]    waves that have read their last fragment of part p.
-// Wave w, GEMM p (part p lives in buffer p % 3; every block is one part: BUF >= the largest block):
-//   entry        vmcnt(0); landed[p+1] += 1 (its share of part p+1 was issued a GEMM ago; p == 0: landed[0] too); wait landed[p] == NW
-//   exit         lgkmcnt(0); done[p] += 1; wait done[p-1] == NW; issue its share of part p+2 into buffer (p+2) % 3 = (p-1) % 3
-// so a wave may enter GEMM p+1 as soon as every wave has ENTERED GEMM p: the waves of a SIMD may drift up to one GEMM apart -- one
-// multiplies while the other splits / activates -- and never meet.  The copies are the staged form's own (same source
-// segments, same LDS image), the arithmetic statements are shared (.inc bodies): results are bit-identical to the staged kernels.
-// Every wait has a watchdog (a protocol bug ends the launch with wrong numbers, which the bit-identity tests catch, instead of hanging).
-template <class Seq>
-struct RingSeq : Seq { static constexpr bool kRing = true; };
-template <class Seq, class = void>
-struct seq_ring { static constexpr bool value = false; };
-template <class Seq>
-struct seq_ring<Seq, decltype((void)Seq::kRing)> { static constexpr bool value = true; };
-
-constexpr int kRingBufs = 3;
-constexpr int kRingMaxParts = 24;
-struct RingCtl {
-    uint32_t landed[kRingMaxParts];
-    uint32_t done[kRingMaxParts];
-    uint32_t abort;
-    uint32_t pad[15];
-};
-template <int BUF>
-__host__ __device__ constexpr int ring_floats() { return kRingBufs * BUF + (int)(sizeof(RingCtl) / 4); }
-
-__device__ __forceinline__ void ring_signal(uint32_t* c) {
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-constexpr uint32_t kRingPatience = 1u << 20;      // ~0.1 s of polls: only a protocol bug waits that long
-__device__ __forceinline__ void ring_wait(const uint32_t* c, uint32_t n, uint32_t* abort) {
-    uint32_t spins = 0;
-    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < n) {
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 1023u) == 0 &&
-            (spins >= kRingPatience || __builtin_amdgcn_readfirstlane(__hip_atomic_load(abort, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)))) {
-            __hip_atomic_store(abort, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            break;
-        }
-    }
-}
-
-// counters to zero, parts 0 and 1 on their way.  The caller's first workgroup barrier (level geometry) orders the zeroing before the
-// first signal.
-template <class Seq, int NW, int BUF>
-__device__ __forceinline__ void ring_begin(float* stage, const float* __restrict__ wp, const float* __restrict__ wp1 = nullptr) {
-    static_assert(Seq::n <= kRingMaxParts, "ring counters");
-    uint32_t* ctl = reinterpret_cast<uint32_t*>(stage + kRingBufs * BUF);
-    if (threadIdx.x < sizeof(RingCtl) / 4) ctl[threadIdx.x] = 0u;
-    stage_issue_part<NW>(wp, part_at<Seq, BUF>(0), stage, wp1);
-    if (Seq::n > 1) stage_issue_part<NW>(wp, part_at<Seq, BUF>(1), stage + BUF, wp1);
-}
-
-// groups GA .. GB-1 of a block laid out [mt][KG][piece][lane]
-template <int KG, int MT, int GA, int GB>
-__device__ __forceinline__ void gemm16_lds_groups(const float* lds_block, int lane, const float (&b)[8 * KG], f32x4v (&acc)[MT]) {
-    const lds_u4* w4 = (const lds_u4*)lds_block + lane;
-    constexpr int TC = MT <= 4 ? MT : (MT % 3 == 0 ? 3 : 4);
-    static_assert(MT % TC == 0, "tile chunking");
-#pragma unroll
-    for (int g = GA; g < GB; ++g) {
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = b[8 * g + e];
-        bf16x8_t bh, bm, bl;
-        if constexpr (kPieces == 3) {
-            BFrag bf;
-            split8(x, bf);
-            bh = as_bf16x8(bf.p[0]); bm = as_bf16x8(bf.p[1]); bl = as_bf16x8(bf.p[2]);
-        } else {
-            bh = round8_bf16(x); bm = bh; bl = bh;
-        }
-#pragma unroll
-        for (int c = 0; c < MT / TC; ++c) {
-            u32x4 a[TC][3];
-#pragma unroll
-            for (int t = 0; t < TC; ++t)
-#pragma unroll
-                for (int pc = 0; pc < kPieces; ++pc) a[t][pc] = w4[(((c * TC + t) * KG + g) * kLdsPieces + pc) * 64];
-            mma16_tiles<TC>(a, bh, bm, bl, &acc[c * TC]);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-template <class Seq, int NW, int BUF, int KG, int MT>
-__device__ __forceinline__ void gemm16_ring(float* stage, const float* __restrict__ wp, int p, int lane, const float (&b)[8 * KG],
-                                            f32x4v (&acc)[MT], const float* __restrict__ wp1) {
-    static_assert(max_groups<BUF>(MT) >= KG, "ring staging: every block is one part");
-    RingCtl* ctl = reinterpret_cast<RingCtl*>(stage + kRingBufs * BUF);
-    // this wave's shares of parts <= p + 1 were issued at the exit of GEMM p - 1 at the latest: confirm them here, where the bias loads in
-    // front of the GEMM need a vmcnt(0) anyway (confirming after the first k-group, as the first version did, drains the MFMA pipeline
-    // in mid-GEMM: measured slower)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (p == 0) ring_signal(&ctl->landed[0]);
-    if (p + 1 < Seq::n) ring_signal(&ctl->landed[p + 1]);
-    ring_wait(&ctl->landed[p], NW, &ctl->abort);
-    gemm16_lds_groups<KG, MT, 0, KG>(stage + (p % kRingBufs) * BUF, lane, b, acc);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    ring_signal(&ctl->done[p]);
-    if (p + 2 < Seq::n) {
-        if (p >= 1) ring_wait(&ctl->done[p - 1], NW, &ctl->abort);
-        stage_issue_part<NW>(wp, part_at<Seq, BUF>(p + 2), stage + ((p + 2) % kRingBufs) * BUF, wp1);
-    }
-}
+// (Round 6 built a barrier-free form of the staged fp32 kernels -- a ring of three stage buffers with per-part arrival counters in LDS
+// instead of the s_barrier per GEMM, RingSeq / gemm16_ring / k_sdfnet4_{fwd_pair,bwd}_ring -- bit-identical to the staged kernels and
+// 3-10 % SLOWER: the waves did not start to co-execute (matrix / vector co-execution 0.25 -> 0.28 of the matrix time, 5 % more vector
+// instructions for the hand-off).  profiles/r06_ab_experiments.txt r6a / r6b, profiles/r06_quad_ring_pmc_*.csv; last present in commit
+// b5f9d27.)
 
 // logical GEMM `opi` of Seq (KG k-groups, MT output tiles): all its parts (at most two).  `wp1`: base of the second packed block
 // of a sequence that runs two networks (Seq::net).
@@ -416,9 +309,6 @@ __device__ __forceinline__ void gemm16_staged(float* stage, const float* __restr
                                               const float (&b)[8 * KG], f32x4v (&acc)[MT], const float* __restrict__ wp1 = nullptr) {
     if constexpr (seq_resident<Seq>::value) {        // `stage` = the resident image: no wait, no copy, no barrier
         gemm16_lds_part<KG, MT, 0, KG>(stage + res_off<Seq>(opi), lane, b, acc);
-        return;
-    } else if constexpr (seq_ring<Seq>::value) {     // `stage` = three buffers + counters: no barrier
-        gemm16_ring<Seq, NW, BUF, KG, MT>(stage, wp, opi, lane, b, acc, wp1);
         return;
     }
     constexpr int M = max_groups<BUF>(MT);

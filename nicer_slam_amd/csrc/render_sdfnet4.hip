@@ -406,64 +406,6 @@ __global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd_
     }
 }
 
-#endif
-
-// ---- ring-staged barrier-free forms (fp32 build, round 6; mlp16.hpp::RingSeq) -------------------------------------------------------
-// The staged kernels' own tiles and statements (shared .inc bodies; bit-identical results) with the per-GEMM workgroup barrier replaced by
-// a three-buffer ring and arrival counters: the waves of a SIMD drift apart instead of splitting and multiplying in lock-step.
-#if NSA_PIECES == 3
-template <int LC, int CC, int NHC, int LF, int CF, int NHF>
-__global__ __launch_bounds__(64 * NSA_NW4_PAIR, NSA_OCC4_FWD) void k_sdfnet4_fwd_pair_ring(SdfNet4PairArgs a, GridGeom16 gc, GridGeom16 gf) {
-    using Seq = RingSeq<SdfOpsPair<NHC, NHF>>;
-    __shared__ __attribute__((aligned(16))) float stage[ring_floats<Seq::BUF>()];
-    __shared__ LevelGeom s_geom[32];
-    ring_begin<Seq, Seq::NW, Seq::BUF>(stage, a.wp_c, a.wp_f);
-    if (threadIdx.x < 16) s_geom[threadIdx.x] = gc.lv[threadIdx.x];
-    else if (threadIdx.x < 32) s_geom[threadIdx.x] = gf.lv[threadIdx.x - 16];
-    const int lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    uint32_t tile = blockIdx.x * Seq::NW + (threadIdx.x >> 6);
-    const uint32_t n_tiles = (a.src.P + 15) / 16;
-    const bool wave_live = tile < n_tiles;
-    if (!wave_live) tile = n_tiles - 1;
-#define NSA_BODY_SYNC __syncthreads();      // the ONE barrier of the launch: level geometry and the zeroed ring counters
-#include "sdfnet4_pair_body.inc"
-#undef NSA_BODY_SYNC
-}
-
-template <int L, int C, int NH>
-__global__ __launch_bounds__(64 * NSA_NW4_BWD, NSA_OCC4_BWD) void k_sdfnet4_bwd_ring(SdfNet4Args a, GridGeom16 geom) {
-    constexpr bool MAP = false;
-    using P = SdfPack4<NH>;
-    using Seq = RingSeq<SdfOps4<NH, true>>;
-    using E = SE4<NH>;
-    __shared__ __attribute__((aligned(16))) float stage[ring_floats<Seq::BUF>()];
-    __shared__ LevelGeom s_geom[16];
-    ring_begin<Seq, Seq::NW, Seq::BUF>(stage, a.wp);
-    geom_to_lds(geom, s_geom);
-    const int lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
-    uint32_t tile = blockIdx.x * Seq::NW + (threadIdx.x >> 6);
-    const uint32_t n_tiles = (a.src.P + 15) / 16;
-    const bool wave_live = tile < n_tiles;
-    if (!wave_live) tile = n_tiles - 1;
-#define NSA_BODY_SYNC __syncthreads();
-#pragma push_macro("TS_MARK")
-#undef TS_MARK
-#define TS_MARK(slot)
-#include "sdfnet4_bwd_body.inc"
-#pragma pop_macro("TS_MARK")
-#undef NSA_BODY_SYNC
-}
-
-// NSA_QUAD_RING=0: the staged forms with a barrier per GEMM (A/B runs, tests/test_tiling_gpu.py)
-static bool quad_ring() {
-    static const bool on = [] { const char* e = getenv("NSA_QUAD_RING"); return !(e && e[0] == '0'); }();
-    return on;
-}
-#endif
-
-#if NSA_PIECES == 1
 // workgroups of a persistent launch: one per CU
 static int persistent_blocks4() {
     // per device id (a process may drive GPUs with different CU counts, and the current device may change between launches)
@@ -502,9 +444,6 @@ static int launch_sdfnet4(bool bwd, const nsa_grid_t* grid, const SdfNet4Args& a
             const uint32_t wgs = (tiles + nw - 1) / nw, cap = (uint32_t)persistent_blocks4();
             hipLaunchKernelGGL((k_sdfnet4_bwd_res<8, 4, 3>), dim3(wgs < cap ? wgs : cap), b, 0, st, a, geom);
         }
-#endif
-#if NSA_PIECES == 3
-        else if (bwd && NSA_NW4_BWD == 8 && quad_ring()) hipLaunchKernelGGL((k_sdfnet4_bwd_ring<8, 4, 3>), g, b, 0, st, a, geom);
 #endif
         else if (bwd)   hipLaunchKernelGGL((k_sdfnet4_bwd<8, 4, 3, false>), g, b, 0, st, a, geom);
         else            hipLaunchKernelGGL((k_sdfnet4_fwd<8, 4, 3>), g, b, 0, st, a, geom);
@@ -564,13 +503,6 @@ int NSA_ENTRY(nsa_sdfnet4_forward_pair)(const nsa_points_t* pts, const nsa_grid_
         const uint32_t wgs = (tiles + NSA_NW4_PAIR - 1) / NSA_NW4_PAIR, cap = (uint32_t)persistent_blocks4();
         hipLaunchKernelGGL((k_sdfnet4_fwd_pair_res<4, 8, 1, 8, 4, 3>), dim3(wgs < cap ? wgs : cap), dim3(64 * NSA_NW4_PAIR), 0,
                            (hipStream_t)stream, a, gc, gf);
-        return launch_end();
-    }
-#endif
-#if NSA_PIECES == 3
-    if (NSA_NW4_PAIR == 8 && quad_ring()) {
-        hipLaunchKernelGGL((k_sdfnet4_fwd_pair_ring<4, 8, 1, 8, 4, 3>), dim3((tiles + NSA_NW4_PAIR - 1) / NSA_NW4_PAIR), dim3(64 * NSA_NW4_PAIR),
-                           0, (hipStream_t)stream, a, gc, gf);
         return launch_end();
     }
 #endif

@@ -48,8 +48,10 @@ def precision_of(model, which):
 # "coarse_pair": the coarse network inside nsa_sdfnet_forward_pair (both networks' forward in one launch; quad tiling only).
 # "sampler_large" (>= 4096 rays, the mapping batch): the persistent quad sampler (16) was the faster form there in round 2 (1739 -> 1645 us
 # at 8192 rays); since round 3's work on the two-tile 32-point kernel that one is: 1517 vs 1677 us (profiles/r04_ab_experiments.txt r4u).
-# "sampler_small" (<= 256 rays: the per-GPU share of an 8- / 4-GPU strong-scaling run of the 1024-ray batch): see SAMPLER_SMALL_RAYS.
-DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 64, "coarse_map": 16, "sampler_large": 64, "coarse_pair": 16, "sampler_small": 64}
+# "sampler_small" (<= 256 rays: the per-GPU share of an 8- / 4-GPU strong-scaling run of the 1024-ray batch): ONE tile per wave -- with at
+# most 2.5 waves per SIMD the launch is one round of waves and a wave's life is what counts: 0.1872 -> 0.1812 ms per iteration at 128 rays,
+# 0.2103 -> 0.2060 at 256; from 512 rays up the two-tile form wins again (0.3193 vs 0.3346; profiles/r06_ab_experiments.txt r6c).
+DEFAULT_TILES = {"coarse": 32, "fine": 16, "sampler": 64, "coarse_map": 16, "sampler_large": 64, "coarse_pair": 16, "sampler_small": 32}
 FWD_PAIR = True          # False: two forward launches (module attribute: the bit-identity tests and A/B runs flip it)
 # 1: the colour backward and the coarse SDF backward of a data-path backward as ONE launch (nsa_colour_coarse_backward; 32-point tiling of
 # the coarse network).  False: two launches.

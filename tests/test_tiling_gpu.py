@@ -317,55 +317,3 @@ def test_colour_forward_with_the_composite_in_its_launch_changes_no_bit():
         a, b_ = outs[True][k], outs[False][k]
         assert torch.equal(a, b_), f"{k}: {int((a != b_).sum())} of {a.numel()} differ, max {float((a - b_).abs().max()):.3g}"
 
-
-def test_ring_staged_quad_kernels_are_bit_identical_to_the_barrier_forms(tmp_path):
-    """Round 6: the fp32 paired SDF forward and fine backward run ring-staged -- three LDS stage buffers + arrival counters instead of a
-    workgroup barrier per GEMM (mlp16.hpp::RingSeq; k_sdfnet4_fwd_pair_ring, k_sdfnet4_bwd_ring).  NSA_QUAD_RING=0 selects the barrier forms,
-    which include the SAME per-tile statements (sdfnet4_*_body.inc) and stage the same bytes: every forward tensor of a tracking iteration
-    must agree bit for bit and the pose gradient to its last bits -- a wave that read a stage buffer before its copy landed, or after it was
-    overwritten, would show here.  301 rays x 98 samples: a partial last tile and workgroups with idle waves.  Weights perturbed away from
-    the geometric initialisation so that every first-layer column and the double backward carry signal.  Ten repetitions per form (the
-    hand-off is timing dependent).  The switch is read once per process, hence two subprocesses."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = r'''
-import sys, torch
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-import test_precision_gpu as t
-model = t._model(64)
-g = torch.Generator(device="cuda").manual_seed(5)
-with torch.no_grad():
-    for n, p in model.named_parameters():
-        if n.startswith("implicit_network") and n.endswith("weight_v"):
-            p.add_(0.05 * torch.randn(p.shape, device="cuda", generator=g))
-    for enc in (model.implicit_network.coarse.encoding, model.implicit_network.fine.encoding):
-        enc.embeddings.mul_(10.0)
-keys = ("sdf", "rgb", "weights", "rgb_values", "depth_values", "normal_map", "z_vals")
-first = None
-for rep in range(10):
-    out, g_cam = t._run(model, 301, 98, "fp32")
-    cur = {"g": g_cam.cpu(), **{k: out[k].detach().cpu().clone() for k in keys}}
-    if first is None:
-        first = cur
-    else:
-        for k in keys:
-            assert torch.equal(cur[k], first[k]), ("run-to-run difference", rep, k)
-torch.save(first, sys.argv[1])
-''' % (root, os.path.join(root, "tests"))
-    res = {}
-    for flag in ("1", "0"):
-        path = str(tmp_path / f"ring{flag}.pt")
-        p = subprocess.run([sys.executable, "-c", script, path], capture_output=True, text=True, timeout=900,
-                           env=dict(os.environ, NSA_QUAD_RING=flag), cwd=root)
-        assert p.returncode == 0, p.stderr[-3000:]
-        res[flag] = torch.load(path)
-    diffs = {k: float((v - res["0"][k]).abs().max()) for k, v in res["1"].items()}
-    print("ring vs barrier forms, max |difference| per tensor:", diffs)
-    for k in ("sdf", "rgb", "weights", "rgb_values", "depth_values", "normal_map", "z_vals"):
-        assert diffs[k] == 0.0, diffs
-    # the pose gradient passes through the fine backward, a different kernel function in the two forms (same statements, the compiler
-    # may contract a * b + c differently): last-bit differences only
-    assert diffs["g"] <= 1e-6 * float(res["0"]["g"].abs().max()), diffs
-    assert float(res["1"]["g"].abs().max()) > 0

@@ -542,7 +542,8 @@ def reproj_case(name, seed, bs=3, n_pix=10):
 
 def loss_case(name, seed, frame_idx, stage, bs=2, n=12, S=6, family="replica"):
     """SLAMLoss.forward (model/loss.py:113-233 + utils/MiDaS.py) with the shipped Replica weights
-    (confs/replica/runconf_replica_1.conf:45-56; family "7scenes": confs/7scenes/runconf_7scenes_1.conf:46-58, smooth_weight 0.05)
+    (confs/replica/runconf_replica_1.conf:45-56; family "7scenes": confs/7scenes/runconf_7scenes_1.conf:46-58, smooth_weight 0.05;
+    family "azure": confs/azure/runconf_azure_2.conf:46-59, assign_scale 15 -- it scales the first frame's monocular depth, loss.py:179-185)
     on random model outputs: every term and d loss / d output."""
     ref_loss = ref_shims.import_ref("model.loss")
     g = torch.Generator().manual_seed(seed)
@@ -564,9 +565,11 @@ def loss_case(name, seed, frame_idx, stage, bs=2, n=12, S=6, family="replica"):
           "flow": (rnd(3, n, 2) - 0.5) * 8, "flow_mask": rnd(3, n) > 0.4}
 
     class DS:
-        data_dir = "../Datasets/processed/Replica" if family == "replica" else "../Datasets/processed/7Scenes"
-    smooth_weight = 0.005 if family == "replica" else 0.05
-    crit = ref_loss.SLAMLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, train_dataset=DS(), scan_id=1,
+        data_dir = {"replica": "../Datasets/processed/Replica", "7scenes": "../Datasets/processed/7Scenes",
+                    "azure": "../Datasets/processed/Azure"}[family]
+    smooth_weight = 0.05 if family == "7scenes" else 0.005
+    extra = dict(assign_scale=15.0) if family == "azure" else {}        # confs/azure/runconf_azure_2.conf:47
+    crit = ref_loss.SLAMLoss(rgb_loss="torch.nn.L1Loss", eikonal_weight=0.1, train_dataset=DS(), scan_id=1, **extra,
                              assign_scale_shift_init=True, smooth_weight=smooth_weight, warp_loss_type="l1", depth_weight=0.1,
                              normal_l1_weight=0.05, normal_cos_weight=0.05, flow_weight=0.001, warp_loss_weight=0.5)
     res = crit(out, gt, keyframe_list=None, frame_idx=frame_idx, stage=stage)
@@ -729,6 +732,7 @@ if __name__ == "__main__":
     if "--family-only" in sys.argv:
         family_cases()
         loss_case("loss_mapping_7scenes", 23, frame_idx=7, stage="fine", family="7scenes")
+        loss_case("loss_mapping_azure_first_frame", 24, frame_idx=0, stage="fine", family="azure")
         sys.exit(0)
     if "--reproj-only" in sys.argv:
         reproj_case("reproj_blocks", 51)
@@ -759,3 +763,4 @@ if __name__ == "__main__":
     rw_cases()
     family_cases()
     loss_case("loss_mapping_7scenes", 23, frame_idx=7, stage="fine", family="7scenes")
+    loss_case("loss_mapping_azure_first_frame", 24, frame_idx=0, stage="fine", family="azure")

@@ -56,7 +56,7 @@ def check_slam_loss(name, device="cpu", atol=1e-6, gtol=1e-7, engine="auto"):
             assert_close(warp[ps][1].grad, fx[key], gtol, 1e-4, key)
 
 
-@pytest.mark.parametrize("name", ["loss_mapping_first_frame", "loss_mapping_fine", "loss_mapping_7scenes"])
+@pytest.mark.parametrize("name", ["loss_mapping_first_frame", "loss_mapping_fine", "loss_mapping_7scenes", "loss_mapping_azure_first_frame"])
 def test_slam_loss_vs_reference_golden(name):
     check_slam_loss(name)
 

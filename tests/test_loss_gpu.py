@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("engine", ["auto", "torch"])
-@pytest.mark.parametrize("name", ["loss_mapping_first_frame", "loss_mapping_fine", "loss_mapping_7scenes"])
+@pytest.mark.parametrize("name", ["loss_mapping_first_frame", "loss_mapping_fine", "loss_mapping_7scenes", "loss_mapping_azure_first_frame"])
 def test_slam_loss_on_device_vs_reference_golden(name, engine):
     """engine "auto" = the fused HIP loss kernels (nsa_slam_loss), "torch" = the torch restatement on the device"""
     check_slam_loss(name, device="cuda", atol=2e-6, gtol=2e-7, engine=engine)

@@ -30,6 +30,12 @@ PY
                     python tools/pmc_summary.py /tmp/pmcab_$f | grep -E "kernel|sdfnet4" > $O/pmc_${V}_$f.csv
                     echo "$V=$f"; cat $O/pmc_${V}_$f.csv | cut -c1-150
                   done ;;
+    chunks)       # ray chunks on forked streams inside the graph (KernelTracker(chunks=)): 1 vs 2 at the shipped sample count and the headline's
+                  for smp in 98 128; do for c in 1 2 1 2; do
+                    timeout 300 python bench.py --samples $smp --chunks $c --no-cpu-baseline --no-mapping --no-precision-modes --no-dropin --no-small-shapes \
+                        2>/dev/null > $O/chunks_${smp}_$c.json
+                    python -c "import json,sys; d=json.loads(open(sys.argv[1]).readline()); print('samples', sys.argv[2], 'chunks', sys.argv[3], d['ms_per_step'])" $O/chunks_${smp}_$c.json $smp $c
+                  done; done ;;
     tests:*)      timeout 1500 python -m pytest ${step#tests:} -m gpu -x -q > $O/tests_sel.log 2>&1; echo "rc=$?" >> $O/tests_sel.log; tail -15 $O/tests_sel.log ;;
     smoke)        timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 ;;
     bench)        timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "rc=$?"; cut -c1-600 $O/bench.json ;;

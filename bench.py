@@ -104,8 +104,9 @@ def parse():
     ap.add_argument("--no-mapping", action="store_true", help="skip the (untimed-for-value) mapping-iteration leg")
     ap.add_argument("--no-small-shapes", action="store_true", help="skip the strong-scaling-tail rows (128 / 256 / 512 rays; N = 1 only)")
     ap.add_argument("--cpu-rays", type=int, default=1024)
-    ap.add_argument("--cpu-all-cores-rays", type=int, default=16,
-                    help="rays of the second CPU figure, taken with torch.set_num_threads(os.cpu_count()) (BASELINE.md section 3); 0: skip")
+    ap.add_argument("--cpu-all-cores-rays", type=int, default=0,
+                    help="rays of a LIVE second CPU figure taken with torch.set_num_threads(os.cpu_count()) (BASELINE.md section 3); default 0: "
+                         "quote the committed measurement profiles/rNN_cpu_all_cores.json instead (one iteration costs ~48 s with 256 threads)")
     ap.add_argument("--only-mapping", type=int, default=0, metavar="ITERS",
                     help="profiling aid: run ONLY the mapping-iteration leg with this many timed iterations and print its dict")
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 4],
@@ -606,6 +607,16 @@ def mapping_library_share():
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_mapping_kernel_stats.csv")), reverse=True)
     if not paths:
         return None
+    # quoted only when the profile of that round was taken with this run's batch shape and tilings (the signature file the same script
+    # writes next to it, tools/profile_mapping.sh): a stale profile is named, not quoted
+    meta = paths[0].replace("_mapping_kernel_stats.csv", "_mapping_pmc_meta.json")
+    try:
+        fresh = json.load(open(meta)) == mapping_signature()
+    except (OSError, ValueError):
+        fresh = False
+    if not fresh:
+        return {"share": None, "launches_per_iteration": None, "source": os.path.relpath(paths[0], ROOT),
+                "note": "STALE: taken with another batch shape / tiling set than this run's"}
     rows = list(csv.DictReader(open(paths[0])))
     total = sum(int(r["TotalDurationNs"]) for r in rows)
     ours = sum(int(r["TotalDurationNs"]) for r in rows if "nsa::" in r["Name"])
@@ -702,6 +713,16 @@ def cpu_baseline(args, model, conf):
     # BASELINE.md section 3 asks for torch.set_num_threads(os.cpu_count()): that figure as well, on a smaller sample of the same workload
     # (one timed iteration after one warm-up -- with every core of this box type the intra-op pool thrashes on these small GEMMs)
     all_cores = None
+    if args.cpu_all_cores_rays <= 0:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_cpu_all_cores.json")), reverse=True):
+            try:
+                rec = json.load(open(path))
+                all_cores = dict(rec["all_host_cores"], quoted_from=os.path.relpath(path, ROOT), measured_on_host_cores=rec.get("host_cores"),
+                                 note="not re-measured in this run: one iteration costs ~48 s with every core of this box type")
+                break
+            except (OSError, ValueError, KeyError):
+                continue
     if args.cpu_all_cores_rays > 0 and (os.cpu_count() or 1) > torch.get_num_threads():
         try:
             capped = torch.get_num_threads()

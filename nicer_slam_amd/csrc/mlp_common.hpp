@@ -421,16 +421,29 @@ __device__ __forceinline__ float relu_f(float a) { return fmaxf(a, 0.0f); }
 
 // value only (sampler): the overflow-free form max(a,0) + ln(1 + e^{-|beta a|})/beta -- no compare/select, and equal to
 // torch's thresholded softplus to the last ulp (for beta a > 20 the log term is < 2e-9 relative and rounds away).
+// NSA_X_SOFTPLUS_FREE (tagged experiment builds only, build.py rejects NSA_X_* in the product): the activation and its derivatives
+// replaced by ReLU's -- WRONG numbers, timing only: the upper bound of what any cheaper (packed, approximated, table-driven) Softplus
+// could give a kernel (profiles/r06_ab_experiments.txt r6f).
 __device__ __forceinline__ float softplus100(float a) {
+#ifdef NSA_X_SOFTPLUS_FREE
+    return relu_f(a);
+#endif
     const float t = SP_K * a;
     return fmaf(SP_OUT, __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(t))), relu_f(a));
 }
 __device__ __forceinline__ float softplus100_d1(float a) {
+#ifdef NSA_X_SOFTPLUS_FREE
+    return a > 0.0f ? 1.0f : 0.0f;
+#endif
     const float t = SP_K * a;
     const float e = __builtin_amdgcn_exp2f(t);
     return t > SP_LIN ? 1.0f : e * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 __device__ __forceinline__ void softplus100_all(float a, float& y, float& d1, float& d2) {
+#ifdef NSA_X_SOFTPLUS_FREE
+    y = relu_f(a); d1 = a > 0.0f ? 1.0f : 0.0f; d2 = 0.0f;
+    return;
+#endif
     const float t = SP_K * a;
     const float e = __builtin_amdgcn_exp2f(t);
     const bool lin = t > SP_LIN;
@@ -442,6 +455,10 @@ __device__ __forceinline__ void softplus100_all(float a, float& y, float& d1, fl
 
 // sin and cos of a (|a| <~ 1e3) sharing one Cody-Waite reduction to [-pi/4, pi/4]; ~1 ulp-class polynomials.
 __device__ __forceinline__ void sincos_f(float a, float& s, float& c) {
+#ifdef NSA_X_PE_FREE      // (tagged experiment builds only; WRONG numbers, timing only: the bound of a cheaper positional encoding)
+    s = a; c = 1.0f - a;
+    return;
+#endif
     const float n = rintf(a * 0.63661977236758134f);          // a / (pi/2)
     float r = fmaf(n, -1.5707963705062866f, a);                 // pi/2 = c1 + c2 + c3 (float32 parts)
     r = fmaf(n, 4.371138828673793e-08f, r);

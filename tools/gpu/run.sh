@@ -36,6 +36,11 @@ PY
                         2>/dev/null > $O/chunks_${smp}_$c.json
                     python -c "import json,sys; d=json.loads(open(sys.argv[1]).readline()); print('samples', sys.argv[2], 'chunks', sys.argv[3], d['ms_per_step'])" $O/chunks_${smp}_$c.json $smp $c
                   done; done ;;
+    ablate)       # timing-only ablation builds (wrong numbers): product vs Softplus-free vs Softplus- and PE-free, fp32 and bf16 operands
+                  for prec in fp32 bf16; do for tag in "" spfree vfree "" spfree vfree; do
+                    NSA_LIB_TAG=$tag timeout 300 python tools/ab_kernels.py --precision $prec --steps 60 2>/dev/null > $O/abl_${prec}_${tag:-product}.json
+                    python -c "import json,sys; d=json.loads(open(sys.argv[1]).readline()); k=d.get('kernels_us', d); print(sys.argv[2], sys.argv[3] or 'product', 'graph ms', d.get('graph_ms'), {n: v for n, v in k.items() if isinstance(v, (int, float)) and ('sampler_sdf' in n or 'sdfnet' in n)})" $O/abl_${prec}_${tag:-product}.json $prec "$tag"
+                  done; done ;;
     tests:*)      timeout 1500 python -m pytest ${step#tests:} -m gpu -x -q > $O/tests_sel.log 2>&1; echo "rc=$?" >> $O/tests_sel.log; tail -15 $O/tests_sel.log ;;
     smoke)        timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 ;;
     bench)        timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "rc=$?"; cut -c1-600 $O/bench.json ;;

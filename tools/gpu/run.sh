@@ -51,6 +51,11 @@ PY
                       --engines fused:11+12+13+14+15,composed:12 > $O/slam_ate_7scenes.json 2> $O/slam7.err; echo "rc=$?"; tail -3 $O/slam7.err ;;
     slamR)        timeout 2400 python tools/synthetic_sequence.py --conf replica --slam --schedule reference --none-grad skip,zeros \
                       --engines fused:11+12+13+14+15 > $O/slam_ate_replica.json 2> $O/slamR.err; echo "rc=$?"; tail -3 $O/slamR.err ;;
+    slamA)        # mini-SLAM on frames of the closed-form textured box room (no network rendered them): both families' conf + trajectory
+                  timeout 2400 python tools/synthetic_sequence.py --conf 7scenes --slam --analytic --schedule reference --none-grad skip,zeros \
+                      --engines fused:11+12+13+14+15,composed:12 > $O/slam_ate_analytic_7scenes.json 2> $O/slamA7.err; echo "rc=$?"; tail -2 $O/slamA7.err
+                  timeout 2400 python tools/synthetic_sequence.py --conf replica --slam --analytic --schedule fine \
+                      --engines fused:11+12+13+14+15,composed:12 > $O/slam_ate_analytic_replica.json 2> $O/slamAR.err; echo "rc=$?"; tail -2 $O/slamAR.err ;;
     slam7fine)    timeout 2400 python tools/synthetic_sequence.py --conf 7scenes --slam --schedule fine --engines fused:11+12+13,composed:12 \
                       > $O/slam_ate_7scenes_fine.json 2> $O/slam7fine.err; echo "rc=$?"; tail -3 $O/slam7fine.err ;;
     profile)      bash tools/profile_round.sh > $O/profile.log 2>&1; tail -5 $O/profile.log | cut -c1-200 ;;

@@ -281,6 +281,38 @@ def render_cues(model, poses, K, H, W):
     return torch.stack(rgb), torch.stack(depth), torch.stack(normal)
 
 
+def render_analytic_room(poses, K, H, W, dev, half=(0.62, 0.5, 0.56)):
+    """Frames of a scene NO network of this repository rendered: the inside of an axis-aligned box room with a smooth procedural
+    texture on its walls, seen along `poses` -- colour, depth and camera-frame normal images [n, H*W, C] by closed-form ray / box
+    intersection in the reference's ray conventions (directions divided by their squared norm, depth_values = depth_scale * z:
+    rend_util.py:68-93, network.py:99-102,147-151; the normal is the inward one, the sign grad sdf has for inside_outside = true).
+    The stand-in of rows g for an engine-independent data set: both engines (and any renderer) are handed the same images."""
+    from nicer_slam_amd.utils import rend_util
+    uv = all_pixels(H, W, dev).unsqueeze(0)
+    Kd = K.to(dev)[None]
+    hb = torch.tensor(half, device=dev)
+    ds = rend_util.get_camera_params(uv, torch.eye(4, device=dev)[None], Kd)[0][0, :, 2:]           # depth_scale [HW,1]
+    freq = torch.tensor([[3.1, 1.7, 2.3], [1.3, 4.1, 2.9], [2.2, 2.6, 5.3]], device=dev)             # cycles per unit, per colour channel
+    phase = torch.tensor([0.3, 1.1, 2.0], device=dev)
+    rgb, depth, normal = [], [], []
+    for c2w in poses:
+        c2w = c2w.to(dev)
+        d, o = rend_util.get_camera_params(uv, c2w[None], Kd)
+        d, o = d[0], o[0]
+        assert bool((o.abs() < hb).all()), "the camera must be inside the room"
+        t = torch.where(d > 0, (hb - o) / d, (-hb - o) / d)
+        t = torch.where(d == 0, torch.full_like(t, 1e10), t)
+        z, axis = t.min(dim=1)
+        p = o + z[:, None] * d
+        n_world = torch.zeros_like(d)
+        n_world[torch.arange(d.shape[0], device=dev), axis] = -torch.sign(d[torch.arange(d.shape[0], device=dev), axis])
+        tex = 0.5 + 0.25 * torch.sin(2 * np.pi * (p @ freq.t()) * 0.5 + phase) + 0.2 * torch.sin(2 * np.pi * p.sum(-1, keepdim=True) * 1.5 + phase)
+        rgb.append(tex.clamp(0.02, 0.98))
+        depth.append(z[:, None] * ds)
+        normal.append(n_world @ c2w[:3, :3])                                                          # R^T n, as network.py:343-345 forms it
+    return torch.stack(rgb), torch.stack(depth), torch.stack(normal)
+
+
 def make_student(teacher, H, W, n_images, colour_grid=None, seed=11, family="replica"):
     """The map to be learned: a SLAMNetwork at the reference's initialisation (tables U(-1e-4, 1e-4), geometric MLPs) -- except the
     fine SDF MLP, which the reference loads from `pretrain.pth` and never optimises (volsdf_train.py:139-173): here the teacher's."""
@@ -431,7 +463,7 @@ def run_slam(engine, teacher, rgb, depth, normal, K, gt, H, W, frames, colour_gr
 
 
 def run_slam_table(frames=50, H=340, W=600, colour_grid=None, map_iters=100, track_iters=100, engines=("fused", "composed"), verbose=False,
-                   schedule="reference", seeds=(11,), family="replica", none_grads=("skip",), const_speed=False):
+                   schedule="reference", seeds=(11,), family="replica", none_grads=("skip",), const_speed=False, analytic=False):
     """The mini-SLAM table: ATE of tracking + mapping on the synthetic sequence, fused engine beside the composed one; `none_grads`: the
     optimizer semantics to run ("skip" = installed torch, "zeros" = the reference's torch 1.11)."""
     dev = torch.device("cuda", 0)
@@ -440,12 +472,17 @@ def run_slam_table(frames=50, H=340, W=600, colour_grid=None, map_iters=100, tra
     K = intrinsics(H, W, dev, family)
     gt = load_trajectory(frames, family=family)
     scale = FAMILIES[family]["scale"]
-    rgb, depth, normal = render_cues(teacher, gt, K, H, W)
+    if analytic:        # frames of the closed-form box room; the "teacher" only lends its fine SDF MLP (the pretrain.pth stand-in)
+        rgb, depth, normal = render_analytic_room(gt, K, H, W, dev)
+    else:
+        rgb, depth, normal = render_cues(teacher, gt, K, H, W)
     out = {"what": "synthetic tracking + mapping (mini SLAM): teacher-rendered frames and depth / normal cues along gt_replica_room0[:N]; the "
                    "map is LEARNED (student at the reference's initialisation, fine SDF MLP = the teacher's as pretrain.pth is), loop shape of "
                    "volsdf_train.py:363-613 (mapping every 5th frame, 100 iterations x 8192 pixels, BA in the last 30 %), ATE as eval_cam.py:43-105",
            "conf_family": family, "trajectory": os.path.basename(FAMILIES[family]["traj"]), "scene_scale_units_per_m": scale,
            "const_speed_assumption": const_speed,
+           "frames_rendered_by": "closed-form ray / box intersection of a textured box room (no network)" if analytic else "the teacher network (fused engine)",
+           "gt_image_stats": {"mean": float(rgb.mean()), "std_over_pixels": float(rgb.std(dim=1).mean())},
            "frames": frames, "image": [H, W], "map_iters": map_iters, "track_iters": track_iters, "schedule": schedule,
            "no_tracking_baseline": summarise(gt, gt[:1].repeat(frames, 1, 1), scale)}
     log = (lambda f, l, what: print(f"  frame {f}: loss {l:.5f}  {what}", file=sys.stderr)) if verbose else None
@@ -583,6 +620,7 @@ if __name__ == "__main__":
                     help="SLAM.tracking.const_speed_assumption; 'conf' = the family's shipped value (false in all 23 files)")
     ap.add_argument("--none-grad", default="skip", help="comma list of optimizer semantics for --slam: skip (installed torch), zeros (torch 1.11)")
     ap.add_argument("--seeds", default="11")
+    ap.add_argument("--analytic", action="store_true", help="--slam on frames of a closed-form textured box room instead of teacher renderings")
     ap.add_argument("--oracle-frames", type=int, default=3)
     ap.add_argument("--oracle-pixels", type=int, default=128)
     ap.add_argument("--oracle-iters", type=int, default=100)
@@ -601,7 +639,7 @@ if __name__ == "__main__":
     if a.slam:
         print(json.dumps(run_slam_table(a.frames, H, W, cg, a.map_iters, a.iters, tuple(a.engines.split(",")), a.verbose, a.schedule,
                                         seeds=tuple(int(x) for x in a.seeds.split(",")), family=a.conf,
-                                        none_grads=tuple(a.none_grad.split(",")), const_speed=cs), indent=1))
+                                        none_grads=tuple(a.none_grad.split(",")), const_speed=cs, analytic=a.analytic), indent=1))
         sys.exit(0)
     print(json.dumps(run(a.frames, a.iters, a.pixels, H, W, a.oracle_frames, a.oracle_pixels, a.oracle_iters, cg,
                          not a.no_free, a.verbose, family=a.conf, const_speed=cs), indent=1))

@@ -122,6 +122,13 @@ def _check_shape(Rn, S, poisson):
     loss.backward()
     assert_close(loss, l_ref, 1e-6, 1e-5, "loss")
     assert_close(cam2.grad, cam_c.grad, 1e-3 * float(cam_c.grad.abs().max()), 1e-3, "pose gradient")
+    # ... and component by component ("1e-3 of the largest component" says little about the small ones): every one of the
+    # seven within 1e-3 of ITSELF plus a floor of 5e-5 of the largest (the ray sums of ~1e5 fp32 terms in two summation orders)
+    g_h, g_c = cam2.grad.detach().cpu().double(), cam_c.grad.double()
+    per = ((g_h - g_c).abs() / g_c.abs().clamp_min(1e-30)).tolist()
+    print("pose gradient, relative error per component:", ["%.1e" % v for v in per], " components / max:",
+          ["%.2f" % v for v in (g_c.abs() / g_c.abs().max()).tolist()])
+    assert bool(((g_h - g_c).abs() <= 1e-3 * g_c.abs() + 5e-5 * g_c.abs().max()).all()), per
 
 
 @pytest.mark.parametrize("Rn,S", [(256, 64), (1024, 128)])

@@ -50,8 +50,9 @@ _FAMILY_SDF = {
 
 
 def model_conf(family="replica", n_samples=64, n_samples_eval=640, n_samples_extra=32, **overrides):
-    """The ``model { ... }`` subtree of the shipped run configs of `family` ("replica": code/confs/replica/*.conf and the two demo
-    confs; "7scenes": code/confs/7scenes/*.conf; "azure": code/confs/azure/*.conf), as a dict."""
+    """The ``model { ... }`` subtree of the shipped run configs of `family` ("replica": code/confs/replica/*.conf and runconf_demo_2.conf;
+    "7scenes": code/confs/7scenes/*.conf; "azure": code/confs/azure/*.conf and runconf_demo_1.conf), as a dict.  Held key by key against
+    all 23 shipped files by tests/test_model_cpu.py::test_conf_presets_equal_the_shipped_run_configs."""
     fam = _FAMILY_SDF[family]
 
     def sdf(dims, end_size, num_levels, level_dim, geometric_init, bias, **extra):
@@ -80,7 +81,7 @@ def model_conf(family="replica", n_samples=64, n_samples_eval=640, n_samples_ext
 
 
 def replica_model_conf(n_samples=64, n_samples_eval=640, n_samples_extra=32, **overrides):
-    """The ``model { ... }`` subtree of the Replica / demo run configs (e.g. code/confs/replica/runconf_replica_1.conf:73-160)."""
+    """The ``model { ... }`` subtree of the Replica run configs and runconf_demo_2.conf (e.g. code/confs/replica/runconf_replica_1.conf:73-160)."""
     return model_conf("replica", n_samples, n_samples_eval, n_samples_extra, **overrides)
 
 
@@ -91,7 +92,8 @@ def scenes7_model_conf(n_samples=64, n_samples_eval=640, n_samples_extra=32, **o
 
 
 # The rest of a run config that the hot path's callers read: image size, camera, loss weights, loop counts (the values every file
-# of a family shares; per-scene keys -- scan_id, n_images, expname -- are not listed).
+# of a family shares; per-scene keys -- scan_id, n_images, expname -- are not listed; the two demo files run 30 / 50 iterations per
+# frame and 4096 mapping pixels instead of 100 / 8192).
 _LOOP = dict(mapping_window_size=15, BA=True, BA_ratio=0.7, BA_cam_lr=0.001, keyframe_every=10, mapping_every_frame=5,
              mapping_iters=100, tracking_lr=0.005, tracking_iters=100, learning_rate=0.002, lr_factor_for_coarse_grid=20.0,
              lr_factor_for_fine_grid=20.0, lr_factor_for_color_grid=5.0, tracking_num_pixels=1024, mapping_num_pixels=8192)
@@ -104,12 +106,13 @@ RUN_CONFS = {
     "replica": dict(_LOOP, img_res=(680, 1200), intrinsics=(600.0, 600.0, 599.5, 339.5), const_speed_assumption=False,
                     loss=dict(_LOSS),
                     data_dir="../Datasets/processed/Replica", gt_traj="gt_replica_room0.txt"),
-    # code/confs/7scenes/runconf_7scenes_1.conf:1-76 (smooth_weight 0.05; const_speed_assumption = false; Kinect camera of
-    # the 7-Scenes release: f = 585, principal point = image centre)
+    # code/confs/7scenes/runconf_7scenes_1.conf:1-76 (smooth_weight 0.05; const_speed_assumption = false; camera of
+    # preprocess/get_mesh_7scenes.py:37: fx, fy, cx, cy = 585, 585, 320, 240)
     "7scenes": dict(_LOOP, img_res=(480, 640), intrinsics=(585.0, 585.0, 320.0, 240.0), const_speed_assumption=False,
                     loss=dict(_LOSS, smooth_weight=0.05), data_dir="../Datasets/processed/7Scenes",
                     gt_traj="gt_7scenes_office.txt"),
-    # code/confs/azure/runconf_azure_2.conf:1-79 (assign_scale 15; Azure Kinect colour camera at 720p, nominal f ~ 607)
+    # code/confs/azure/runconf_azure_2.conf:1-79 (assign_scale 15).  The Azure sequences' intrinsics come out of COLMAP per sequence
+    # (preprocess/azure_2_volsdf.py:62-64): the camera below is a NOMINAL Azure Kinect colour camera at 720p for synthetic stand-ins only
     "azure": dict(_LOOP, img_res=(720, 1280), intrinsics=(607.0, 607.0, 639.5, 359.5), const_speed_assumption=False,
                   loss=dict(_LOSS, assign_scale=15.0),
                   data_dir="../Datasets/processed/Azure", gt_traj="gt_azure_2.txt"),

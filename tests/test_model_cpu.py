@@ -213,3 +213,87 @@ def test_mapping_host_guards_without_a_gpu():
         p = torch.nn.Parameter(torch.zeros(3))
         p.grad = torch.ones(3)
         Adam([p]).step()
+
+
+def _parse_conf(text):
+    """the subset of HOCON the shipped run configs use: `name { ... }`, `key = value`, `key = [` ... `]` over several lines"""
+    root, stack, lst = {}, [], None
+    cur = root
+    for raw in text.splitlines():
+        line = raw.strip()
+        if not line:
+            continue
+        if lst is not None:
+            if line.startswith("]"):
+                lst = None
+            else:
+                lst.append(_scalar(line))
+            continue
+        if line.endswith("{"):
+            node = {}
+            cur[line[:-1].strip()] = node
+            stack.append(cur)
+            cur = node
+        elif line == "}":
+            cur = stack.pop()
+        elif line.endswith("{}"):
+            cur[line[:-2].split("=")[0].strip()] = {}
+        else:
+            k, v = [t.strip() for t in line.split("=", 1)]
+            if v == "[":
+                lst = cur[k] = []
+            elif v == "[]":
+                cur[k] = []
+            else:
+                cur[k] = _scalar(v)
+    return root
+
+
+def _scalar(v):
+    v = v.strip().strip('"')
+    if v in ("true", "false"):
+        return v == "true"
+    try:
+        return int(v)
+    except ValueError:
+        try:
+            return float(v)
+        except ValueError:
+            return v
+
+
+def test_conf_presets_equal_the_shipped_run_configs():
+    import os
+    """utils/conf.py::model_conf / run_conf against EVERY run config the reference ships (code/confs/**/*.conf): the model subtree key by
+    key, image size, loss block, loop counts.  Needs the reference checkout (build container only)."""
+    import glob
+    ref = "/root/reference/code/confs"
+    files = sorted(glob.glob(os.path.join(ref, "**", "*.conf"), recursive=True))
+    if not files:
+        pytest.skip("reference checkout not present")
+    from nicer_slam_amd.utils.conf import model_conf, run_conf
+    assert len(files) == 23
+    for path in files:
+        conf = _parse_conf(open(path).read())
+        # (the two demo files: runconf_demo_1 is an Azure-family conf -- 720 x 1280, coarse radius 1.0 --, runconf_demo_2 a Replica-family one)
+        family = "7scenes" if "7scenes" in path else "azure" if ("azure" in path or path.endswith("demo_1.conf")) else "replica"
+        mine = dict(model_conf(family))
+        theirs = conf["model"]
+        for net in ("coarse", "fine"):
+            want = dict(theirs["implicit_network"][net])
+            got = dict(mine["implicit_network"][net])
+            assert got == want, (path, net, {k: (got.get(k), want.get(k)) for k in set(got) | set(want) if got.get(k) != want.get(k)})
+        for key in ("feature_vector_size", "scene_bounding_sphere", "use_warp_loss", "mapping_patchsizes", "tracking_patchsizes",
+                    "sampling_method", "density_method", "rendering_network", "ray_sampler"):
+            assert mine[key] == theirs[key], (path, key, mine[key], theirs[key])
+        rc = run_conf(family)
+        assert list(rc["img_res"]) == conf["dataset"]["img_res"], path
+        assert {k: float(v) if isinstance(v, (int, float)) and not isinstance(v, bool) else v for k, v in rc["loss"].items()} == \
+               {k: float(v) if isinstance(v, (int, float)) and not isinstance(v, bool) else v for k, v in conf["loss"].items()}, (path, rc["loss"], conf["loss"])
+        t, m, tr = conf["SLAM"]["tracking"], conf["SLAM"]["mapping"], conf["train"]
+        assert rc["const_speed_assumption"] == t.get("const_speed_assumption", False)
+        assert (rc["tracking_lr"], rc["BA_cam_lr"], rc["keyframe_every"], rc["mapping_every_frame"], rc["mapping_window_size"]) == \
+               (t["lr"], m["BA_cam_lr"], m["keyframe_every"], m["mapping_every_frame"], m["mapping_window_size"]), path
+        assert (rc["learning_rate"], rc["lr_factor_for_coarse_grid"], rc["lr_factor_for_fine_grid"], rc["lr_factor_for_color_grid"],
+                rc["tracking_num_pixels"]) == (tr["learning_rate"], tr["lr_factor_for_coarse_grid"], tr["lr_factor_for_fine_grid"],
+                                               tr["lr_factor_for_color_grid"], tr["tracking_num_pixels"]), path

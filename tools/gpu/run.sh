@@ -46,6 +46,7 @@ PY
     bench)        timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "rc=$?"; cut -c1-600 $O/bench.json ;;
     bench:*)      timeout 900 python bench.py ${step#bench:} > $O/bench_opt.json 2> $O/bench_opt.err; echo "rc=$?"; cut -c1-600 $O/bench_opt.json ;;
     seq7)         timeout 1200 python tools/synthetic_sequence.py --conf 7scenes > $O/sequence_ate_7scenes.json 2> $O/seq7.err; echo "rc=$?"; tail -3 $O/seq7.err ;;
+    seqA)         timeout 1500 python tools/synthetic_sequence.py --conf azure --n-samples 158 --oracle-frames 0 > $O/sequence_ate_azure.json 2> $O/seqA.err; echo "rc=$?"; tail -3 $O/seqA.err ;;
     seqR)         timeout 1200 python tools/synthetic_sequence.py --conf replica > $O/sequence_ate_replica.json 2> $O/seqR.err; echo "rc=$?"; tail -3 $O/seqR.err ;;
     slam7)        timeout 2400 python tools/synthetic_sequence.py --conf 7scenes --slam --schedule reference --none-grad skip,zeros \
                       --engines fused:11+12+13+14+15,composed:12 > $O/slam_ate_7scenes.json 2> $O/slam7.err; echo "rc=$?"; tail -3 $O/slam7.err ;;

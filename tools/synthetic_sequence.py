@@ -42,6 +42,9 @@ SCALE = 0.25          # metres -> scene units: Replica room0 (~7 m) inside the c
 FAMILIES = {
     "replica": dict(traj=TRAJ, scale=SCALE, size=(340, 600)),
     "7scenes": dict(traj=os.path.join(ROOT, "tests", "golden", "scenes7_office_traj64.txt"), scale=0.4, size=(240, 320)),
+    # BASELINE configs[4]'s family: gt_trajs/gt_azure_2.txt[:64] (a hand-held outdoor capture, 1.2 cm per frame), 720 x 1280 frames halved,
+    # the 7-Scenes model subtree, assign_scale 15; that config renders 192 samples per ray (--n-samples 158) with a bf16 colour MLP
+    "azure": dict(traj=os.path.join(ROOT, "tests", "golden", "azure_2_traj64.txt"), scale=0.2, size=(360, 640)),
 }
 
 
@@ -539,10 +542,10 @@ def trace_diff(a, b, first=5):
 
 
 def run(frames=50, iters=100, pixels=1024, H=340, W=600, oracle_frames=3, oracle_pixels=128, oracle_iters=100, colour_grid=None,
-        with_free=True, verbose=False, family="replica", const_speed=False, with_bf16=True):
+        with_free=True, verbose=False, family="replica", const_speed=False, with_bf16=True, n_samples=64):
     dev = torch.device("cuda", 0)
     t_all = time.perf_counter()
-    teacher = build_teacher(H, W, colour_grid=colour_grid, device=dev, family=family)
+    teacher = build_teacher(H, W, n_samples=n_samples, colour_grid=colour_grid, device=dev, family=family)
     teacher.engine = "fused"
     K = intrinsics(H, W, dev, family)
     gt = load_trajectory(frames, family=family)
@@ -552,6 +555,7 @@ def run(frames=50, iters=100, pixels=1024, H=340, W=600, oracle_frames=3, oracle
     out = {"what": "synthetic multi-frame tracking: teacher-rendered frames along gt_replica_room0[:N], reference tracking protocol "
                    "(volsdf_train.py:373-446), ATE as eval_cam.py:43-105",
            "conf_family": family, "trajectory": os.path.basename(FAMILIES[family]["traj"]), "const_speed_assumption": const_speed,
+           "samples_per_ray": n_samples + 34,
            "frames": frames, "iters_per_frame": iters, "pixels_per_iter": pixels, "image": [H, W], "scene_scale_units_per_m": scale,
            "mean_frame_to_frame_motion_scene_units": speed,
            "gt_image_stats": {"mean": float(imgs.mean()), "std_over_pixels": float(imgs.std(dim=1).mean())}}
@@ -620,6 +624,7 @@ if __name__ == "__main__":
                     help="SLAM.tracking.const_speed_assumption; 'conf' = the family's shipped value (false in all 23 files)")
     ap.add_argument("--none-grad", default="skip", help="comma list of optimizer semantics for --slam: skip (installed torch), zeros (torch 1.11)")
     ap.add_argument("--seeds", default="11")
+    ap.add_argument("--n-samples", type=int, default=64, help="N_samples of the ray sampler (composite samples per ray = this + 34); tracking table only")
     ap.add_argument("--analytic", action="store_true", help="--slam on frames of a closed-form textured box room instead of teacher renderings")
     ap.add_argument("--oracle-frames", type=int, default=3)
     ap.add_argument("--oracle-pixels", type=int, default=128)
@@ -642,4 +647,4 @@ if __name__ == "__main__":
                                         none_grads=tuple(a.none_grad.split(",")), const_speed=cs, analytic=a.analytic), indent=1))
         sys.exit(0)
     print(json.dumps(run(a.frames, a.iters, a.pixels, H, W, a.oracle_frames, a.oracle_pixels, a.oracle_iters, cg,
-                         not a.no_free, a.verbose, family=a.conf, const_speed=cs), indent=1))
+                         not a.no_free, a.verbose, family=a.conf, const_speed=cs, n_samples=a.n_samples), indent=1))

@@ -390,7 +390,9 @@ def main():
                                       "frac_executed": round(executed / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                                       "frac_survey_8d": round(survey / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                                       "note": "of the fp32 matrix line (157.3 TFLOP/s), per GPU"}
-        cpu = None if args.no_cpu_baseline else cpu_baseline(args, model, conf)
+        # (the CPU figure is taken on rank 0 of the ONE-GPU run only: with N > 1 the other ranks would sit in the communicator's tear-down
+        #  for its 13 s)
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args, model, conf)
         mapping, dropin, ref_gpu, prec_modes, small = None, None, None, None, None
         gather = colour_gather_roofline(agg, args) if agg else None
         if world == 1 and not args.no_precision_modes and args.engine != "composed" and args.precision == "fp32":

@@ -36,6 +36,11 @@ PY
                         2>/dev/null > $O/chunks_${smp}_$c.json
                     python -c "import json,sys; d=json.loads(open(sys.argv[1]).readline()); print('samples', sys.argv[2], 'chunks', sys.argv[3], d['ms_per_step'])" $O/chunks_${smp}_$c.json $smp $c
                   done; done ;;
+    abtags:*)     # abtags:<tag,tag,..>: tools/ab_kernels.py (fp32) for the product library and tagged side-by-side builds, two rounds
+                  for rnd in 1 2; do for tag in "" $(echo ${step#abtags:} | tr ',' ' '); do
+                    NSA_LIB_TAG=$tag timeout 300 python tools/ab_kernels.py --steps 60 2>/dev/null > $O/abt_${tag:-product}_$rnd.json
+                    python -c "import json,sys; d=json.loads(open(sys.argv[1]).readline()); print(sys.argv[2] or 'product', 'graph ms', d.get('graph_ms'), {n.replace('k_',''): v for n, v in d['kernels_us'].items()})" $O/abt_${tag:-product}_$rnd.json "$tag"
+                  done; done ;;
     ablate)       # timing-only ablation builds (wrong numbers): product vs Softplus-free vs Softplus- and PE-free, fp32 and bf16 operands
                   for prec in fp32 bf16; do for tag in "" spfree vfree "" spfree vfree; do
                     NSA_LIB_TAG=$tag timeout 300 python tools/ab_kernels.py --precision $prec --steps 60 2>/dev/null > $O/abl_${prec}_${tag:-product}.json

@@ -41,6 +41,29 @@ PY
                     NSA_LIB_TAG=$tag timeout 300 python tools/ab_kernels.py --steps 60 2>/dev/null > $O/abt_${tag:-product}_$rnd.json
                     python -c "import json,sys; d=json.loads(open(sys.argv[1]).readline()); print(sys.argv[2] or 'product', 'graph ms', d.get('graph_ms'), {n.replace('k_',''): v for n, v in d['kernels_us'].items()})" $O/abt_${tag:-product}_$rnd.json "$tag"
                   done; done ;;
+    warmab)       # the driver's command (--steps 20 --warmup 5) under different untimed pre-warm recipes: does the short run reach the long run's clocks?
+                  for rnd in 1 2; do for v in "1.0 100" "0 100" "1.0 400" "1.0 1000" "0 1000" "0.3 2000" "3.0 100"; do set -- $v
+                    timeout 300 python bench.py --steps 20 --warmup 5 --prewarm-s $1 --prewarm-steps $2 --no-cpu-baseline --no-mapping --no-dropin --no-precision-modes --no-small-shapes \
+                        2>/dev/null > $O/warm_${1}_${2}_$rnd.json
+                    python -c "import json,sys; d=json.loads(open(sys.argv[1]).readline()); print('prewarm_s', sys.argv[2], 'prewarm_steps', sys.argv[3], 'ms', d['ms_per_step'], 'sampler', d['roofline']['all_kernels_us']['k_sampler_sdf'])" $O/warm_${1}_${2}_$rnd.json $1 $2
+                  done; done
+                  timeout 300 python bench.py --no-cpu-baseline --no-mapping --no-dropin --no-precision-modes --no-small-shapes 2>/dev/null > $O/warm_default.json
+                  python -c "import json,sys; d=json.loads(open(sys.argv[1]).readline()); print('default 200/20 ms', d['ms_per_step'])" $O/warm_default.json ;;
+    ramp)         # tools/diag_step_ramp.py: per-iteration device times and host call times inside a short timed region
+                  for v in "20 --rounds 4" "20 --fresh --rounds 4" "20 --fresh --reset --rounds 4" "20 --fresh --reset --gemm-s 1 --gc-off --rounds 4" "200 --fresh --rounds 3"; do set -- $v
+                    F=$O/ramp_$(echo $v | tr -d ' -').json
+                    timeout 300 python tools/diag_step_ramp.py --steps $v 2>/dev/null > $F
+                    echo "-- $v"
+                    python - $F <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).readline())
+print("steps", d["steps"], "idle_ms", d["idle_ms"])
+for r in d["rounds"]:
+    g, h = r["gpu_step_us"], r["host_step_us"]
+    print("  wall/step", r["wall_ms_per_step"], "queued_after_us", r["queued_after_us"], "region_us", r["region_us"], "gpu_ev_span", r["gpu_first_to_last_event_us"],
+          "| gpu first 6", g[:6], "last 3", g[-3:], "| host first 4", h[:4], "median", sorted(h)[len(h) // 2])
+PY
+                  done ;;
     ablate)       # timing-only ablation builds (wrong numbers): product vs Softplus-free vs Softplus- and PE-free, fp32 and bf16 operands
                   for prec in fp32 bf16; do for tag in "" spfree vfree "" spfree vfree; do
                     NSA_LIB_TAG=$tag timeout 300 python tools/ab_kernels.py --precision $prec --steps 60 2>/dev/null > $O/abl_${prec}_${tag:-product}.json

@@ -390,6 +390,10 @@ __device__ __forceinline__ void gather_corners(const float* __restrict__ table, 
     } else {
         uint32_t off[8];
         corner_offsets<C>(g, cell, off);
+#ifdef NSA_X_GATHER_HOT      // timing-only ablation (WRONG numbers; tagged builds): every corner row comes from the table's first 64 KiB, i.e. from
+#pragma unroll               // L1 / L2 -- the bound of what any prefetch of the sampler's gathers could give (profiles/r06_ab_experiments.txt r6s)
+        for (int corner = 0; corner < 8; ++corner) off[corner] &= 0xFFF0u;
+#endif
 #pragma unroll
         for (int corner = 0; corner < 8; ++corner)
             load_row<C>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + (size_t)off[corner]), v[corner]);

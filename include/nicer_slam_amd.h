@@ -416,12 +416,19 @@ int nsa_weight_norm_flat_backward(const nsa_wn_layer_t *layers, uint32_t n_layer
 int nsa_emit_row(float *dst, const float *src, const int32_t *order, uint32_t P, uint64_t n, float fill, nsa_stream_t stream);
 
 /* Packed MLP parameter block (MFMA fragment order) from the flat effective parameters in one launch:
- *   out[o] = word order[o] of concat( split3(flat[a_index]) as [group][piece hi/mid/lo][lane][4 words of 2 bf16], flat[v_index] )
+ *   out[o] = word order[o] of concat( split(flat[a_index]) as [group][piece 0/1/2][lane][4 words of 2 halfwords], flat[v_index] )
+ * (the pieces: nsa_operand_form)
  * a_index: n_a = groups * 64 * 8 indices into `flat` (the 8 fp32 weights lane l supplies to one MFMA k-group; every weight is
  * split exactly into three round-to-nearest bf16 pieces), v_index: n_v indices of per-feature values kept in fp32, order:
  * n_out <= n_a * 3 / 2 + n_v word indices into that concatenation.  The index arrays are the host-built layout tables of the
  * packed blocks (nicer_slam_amd/fused/pack.py; layout: csrc/mlp_common.hpp, csrc/mlp16.hpp).  New -- the reference has no
  * packed weights; replaces the per-layer weight_norm'ed nn.Linear weights of code/model/base_networks.py:127-149 as kernel input. */
+/* How this library's fp32 path feeds the matrix cores, i.e. what nsa_pack_blocks writes into a fragment triple: 3 = three exact bf16
+ * pieces of the weight (hi / mid / lo), 2 = two fp16 pieces of 512 w (round-to-nearest twice) + the bf16 round-to-nearest value for
+ * the bf16-operand kernels.  A build-time choice (csrc/mlp_common.hpp::NSA_FORM); host code that builds packs itself (the
+ * differentiable fallback of fused/pack.py) asks.  New -- no reference counterpart. */
+int nsa_operand_form(void);
+
 int nsa_pack_blocks(const float *flat, const int64_t *a_index, uint64_t n_a, const int64_t *v_index, uint64_t n_v,
                     const int64_t *order, uint64_t n_out, float *out, nsa_stream_t stream);
 

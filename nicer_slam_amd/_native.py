@@ -169,7 +169,9 @@ lib.nsa_emit_gemm_workspace.argtypes = [ctypes.c_uint64, _u32, _u32, ctypes.c_in
 EXPORTS += ["nsa_emit_gemm", "nsa_emit_gemm_workspace"]
 lib.nsa_pack_blocks.restype = _i
 lib.nsa_pack_blocks.argtypes = [_p, _p, ctypes.c_uint64, _p, ctypes.c_uint64, _p, ctypes.c_uint64, _p, _p]
-EXPORTS += ["nsa_pack_blocks"]
+lib.nsa_operand_form.restype = _i
+lib.nsa_operand_form.argtypes = []
+EXPORTS += ["nsa_pack_blocks", "nsa_operand_form"]
 
 
 class FeedField(ctypes.Structure):

@@ -463,6 +463,27 @@ __device__ __forceinline__ uint32_t bf16_piece(float x, int piece) {
     return bf16_rne(r - __uint_as_float(mid << 16));
 }
 
+// form 2 (mlp_common.hpp::NSA_FORM): the fragment triple is [fp16 h0 | fp16 h1 | bf16 round-to-nearest] of the weight --
+// h0 = fp16(512 w), h1 = fp16(512 w - h0), both round-to-nearest (h0 + h1 = 512 w to 2^-23; |w| >= 127.97 becomes +-inf in h0 and
+// the kernels' results non-finite: loud, not wrong); the third slot is what the bf16-operand kernels multiply with.
+__device__ __forceinline__ uint32_t f16_bits(float x) {
+    const _Float16 h = (_Float16)x;
+    unsigned short u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+__device__ __forceinline__ uint32_t h2_piece(float x, int piece) {
+    if (piece == 2) return bf16_rne(x);
+    const float t = x * kWScale;
+    const _Float16 h0 = (_Float16)t;
+    if (piece == 0) return f16_bits(t);
+    return f16_bits(t - (float)h0);
+}
+__device__ __forceinline__ uint32_t weight_piece(float x, int piece) {
+    if constexpr (kForm == 2) return h2_piece(x, piece);
+    else return bf16_piece(x, piece);
+}
+
 __global__ __launch_bounds__(256) void k_pack_blocks(const float* __restrict__ flat, const int64_t* __restrict__ ia,
                                                      uint64_t n_a_words, const int64_t* __restrict__ iv,
                                                      const int64_t* __restrict__ perm, uint64_t n_out, uint32_t* __restrict__ out) {
@@ -475,7 +496,7 @@ __global__ __launch_bounds__(256) void k_pack_blocks(const float* __restrict__ f
         const int piece = rem >> 8, lane = (rem & 255) >> 2, w = rem & 3;
         const int64_t* src = ia + (g * 64 + lane) * 8 + 2 * w;
         const float x0 = flat[src[0]], x1 = flat[src[1]];
-        out[o] = bf16_piece(x0, piece) | (bf16_piece(x1, piece) << 16);
+        out[o] = weight_piece(x0, piece) | (weight_piece(x1, piece) << 16);
     } else {
         out[o] = __float_as_uint(flat[iv[p - n_a_words]]);
     }
@@ -484,6 +505,8 @@ __global__ __launch_bounds__(256) void k_pack_blocks(const float* __restrict__ f
 }  // namespace nsa
 
 extern "C" {
+
+int nsa_operand_form(void) { return nsa::kForm; }
 
 int nsa_pack_blocks(const float* flat, const int64_t* a_index, uint64_t n_a, const int64_t* v_index, uint64_t n_v,
                     const int64_t* order, uint64_t n_out, float* out, nsa_stream_t stream) {

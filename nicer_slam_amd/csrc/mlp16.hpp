@@ -37,21 +37,58 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v + __shfl_xor(v, 32);
 }
 
-// acc[t] += A(t, group) * x for TC output tiles of one k-group: the six cross products of the 3-way split (or one bf16 product);
-// `bh/bm/bl` are the split pieces of the B operand (split once per k-group, shared by all output tiles)
+// the split pieces of one k-group's B operand (split once per k-group, shared by all output tiles); unused members cost nothing
+struct B16 {
+    bf16x8_t bh, bm, bl;      // form 3 (bf16 build: bh only)
+    f16x8_t h0, h1;           // form 2
+};
+__device__ __forceinline__ void split_b16(const float (&x)[8], B16& o) {
+    if constexpr (kPieces == 3) {
+        BFrag bf;
+        split8(x, bf);
+        o.bh = as_bf16x8(bf.p[0]); o.bm = as_bf16x8(bf.p[1]); o.bl = as_bf16x8(bf.p[2]);
+    } else if constexpr (kPieces == 2) {
+        split8_h2(x, o.h0, o.h1);
+    } else {
+        o.bh = round8_bf16(x);
+    }
+}
+
+// acc[t] += A(t, group) * x for TC output tiles of one k-group: the six cross products of the 3-way split, the four of the two-piece
+// fp16 form, or one bf16 product
 template <int TC>
-__device__ __forceinline__ void mma16_tiles(const u32x4 (&a)[TC][3], const bf16x8_t bh, const bf16x8_t bm, const bf16x8_t bl,
-                                            f32x4v* acc) {
+__device__ __forceinline__ void mma16_tiles(const u32x4 (&a)[TC][3], const B16& b, f32x4v* acc) {
     if constexpr (kPieces == 3) {
 #define NSA_MM16(AP, BV)                                                                               \
         _Pragma("unroll") for (int t = 0; t < TC; ++t)                                                 \
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a[t][AP]), BV, acc[t], 0, 0, 0);
-        NSA_MM16(2, bh) NSA_MM16(0, bl) NSA_MM16(1, bm) NSA_MM16(1, bh) NSA_MM16(0, bm) NSA_MM16(0, bh)
+        NSA_MM16(2, b.bh) NSA_MM16(0, b.bl) NSA_MM16(1, b.bm) NSA_MM16(1, b.bh) NSA_MM16(0, b.bm) NSA_MM16(0, b.bh)
 #undef NSA_MM16
+    } else if constexpr (kPieces == 2) {
+#define NSA_MM16H(AP, BV)                                                                              \
+        _Pragma("unroll") for (int t = 0; t < TC; ++t)                                                 \
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(a[t][AP]), BV, acc[t], 0, 0, 0);
+        NSA_MM16H(1, b.h1) NSA_MM16H(0, b.h1) NSA_MM16H(1, b.h0) NSA_MM16H(0, b.h0)
+#undef NSA_MM16H
     } else {
 #pragma unroll
-        for (int t = 0; t < TC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a[t][0]), bh, acc[t], 0, 0, 0);
+        for (int t = 0; t < TC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a[t][0]), b.bh, acc[t], 0, 0, 0);
     }
+}
+
+// quad tiling: a point's operands live in lanes j, j + 16, j + 32, j + 48
+template <int N>
+__device__ __forceinline__ PointScale point_scale16(const float (&b)[N]) {
+    float m = abs_max<N>(b);
+    m = fmaxf(m, __shfl_xor(m, 16));
+    return point_scale_of(fmaxf(m, __shfl_xor(m, 32)));
+}
+template <int MT>
+__device__ __forceinline__ void scale_acc16(f32x4v (&acc)[MT], int k) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_ldexpf(acc[t][r], k);
 }
 
 // acc[MT] += A[MT x KG] * b, A block in LDS ([mt][g][piece][lane]), b = this lane's 8*KG k-values.
@@ -62,19 +99,18 @@ __device__ __forceinline__ void gemm16_lds(const float* lds_block, int lane, con
     const lds_u4* w4 = (const lds_u4*)lds_block + lane;
     constexpr int TC = MT <= 4 ? MT : (MT % 3 == 0 ? 3 : 4);
     static_assert(MT % TC == 0, "tile chunking");
+    PointScale ps{1.0f, 0};
+    if constexpr (kPieces == 2) {
+        ps = point_scale16<8 * KG>(b);
+        scale_acc16<MT>(acc, ps.kpre);
+    }
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
         float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = b[8 * g + e];
-        bf16x8_t bh, bm, bl;
-        if constexpr (kPieces == 3) {
-            BFrag bf;
-            split8(x, bf);
-            bh = as_bf16x8(bf.p[0]); bm = as_bf16x8(bf.p[1]); bl = as_bf16x8(bf.p[2]);
-        } else {
-            bh = round8_bf16(x); bm = bh; bl = bh;
-        }
+        for (int e = 0; e < 8; ++e) x[e] = kPieces == 2 ? b[8 * g + e] * ps.s : b[8 * g + e];
+        B16 bp;
+        split_b16(x, bp);
 #pragma unroll
         for (int c = 0; c < MT / TC; ++c) {
             u32x4 a[TC][3];
@@ -86,9 +122,10 @@ __device__ __forceinline__ void gemm16_lds(const float* lds_block, int lane, con
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #endif
-            mma16_tiles<TC>(a, bh, bm, bl, &acc[c * TC]);
+            mma16_tiles<TC>(a, bp, &acc[c * TC]);
         }
     }
+    if constexpr (kPieces == 2) scale_acc16<MT>(acc, -ps.kpre);
     __builtin_amdgcn_sched_barrier(0);   // keep later layers' LDS reads from being hoisted above this GEMM
 }
 
@@ -97,19 +134,18 @@ template <int KG, int MT>
 __device__ __forceinline__ void gemm16_glb(const float* __restrict__ wp, int lane, const float (&b)[8 * KG], f32x4v (&acc)[MT]) {
     const uint4* __restrict__ w4 = reinterpret_cast<const uint4*>(wp) + lane;
     constexpr int TC = MT <= 4 ? MT : (MT % 3 == 0 ? 3 : 4);
+    PointScale ps{1.0f, 0};
+    if constexpr (kPieces == 2) {
+        ps = point_scale16<8 * KG>(b);
+        scale_acc16<MT>(acc, ps.kpre);
+    }
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
         float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = b[8 * g + e];
-        bf16x8_t bh, bm, bl;
-        if constexpr (kPieces == 3) {
-            BFrag bf;
-            split8(x, bf);
-            bh = as_bf16x8(bf.p[0]); bm = as_bf16x8(bf.p[1]); bl = as_bf16x8(bf.p[2]);
-        } else {
-            bh = round8_bf16(x); bm = bh; bl = bh;
-        }
+        for (int e = 0; e < 8; ++e) x[e] = kPieces == 2 ? b[8 * g + e] * ps.s : b[8 * g + e];
+        B16 bp;
+        split_b16(x, bp);
 #pragma unroll
         for (int c = 0; c < MT / TC; ++c) {
             u32x4 a[TC][3];
@@ -117,12 +153,13 @@ __device__ __forceinline__ void gemm16_glb(const float* __restrict__ wp, int lan
             for (int t = 0; t < TC; ++t)
 #pragma unroll
                 for (int pc = 0; pc < kPieces; ++pc) {
-                    const uint4 v = w4[(((c * TC + t) * KG + g) * 3 + pc) * 64];
+                    const uint4 v = w4[(((c * TC + t) * KG + g) * 3 + kSlot0 + pc) * 64];
                     a[t][pc] = u32x4{v.x, v.y, v.z, v.w};
                 }
-            mma16_tiles<TC>(a, bh, bm, bl, &acc[c * TC]);
+            mma16_tiles<TC>(a, bp, &acc[c * TC]);
         }
     }
+    if constexpr (kPieces == 2) scale_acc16<MT>(acc, -ps.kpre);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -130,10 +167,9 @@ __device__ __forceinline__ void gemm16_glb(const float* __restrict__ wp, int lan
 template <int NW>
 __device__ __forceinline__ void stage_issue_n(const float* __restrict__ g, int nfloats, float* lds_dst) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunks = nfloats / 256 / 3 * kLdsPieces;      // (mlp_common.hpp::kLdsPieces: the bf16-operand build keeps one piece)
-    constexpr int kSrcStep = kLdsPieces == 3 ? 1 : 3;
+    const int chunks = nfloats / 256 / 3 * kLdsPieces;      // (mlp_common.hpp::kLdsPieces / src_frag: the pieces this build multiplies with)
     for (int ch = wave; ch < chunks; ch += NW)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + ch * kSrcStep * 256 + lane * 4),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + src_frag(ch) * 256 + lane * 4),
                                          (__attribute__((address_space(3))) void*)(lds_dst + ch * 256), 16, 0, 0);
 }
 
@@ -192,11 +228,10 @@ __device__ __forceinline__ void stage_issue_part(const float* __restrict__ wp, c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per_tile = o.ng * kLdsPieces;        // 1 KiB chunks per tile in this part
     const int chunks = o.mt * per_tile;
-    constexpr int kSrcStep = kLdsPieces == 3 ? 1 : 3;
     const float* base = o.net ? wp1 : wp;
     for (int ch = wave; ch < chunks; ch += NW) {
         const int mt = ch / per_tile, rem = ch - mt * per_tile;
-        const float* src = base + o.off + ((mt * o.kg + o.g0) * 3 + rem * kSrcStep) * 256 + lane * 4;
+        const float* src = base + o.off + ((mt * o.kg + o.g0) * 3 + src_frag(rem)) * 256 + lane * 4;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(lds_dst + ch * 256), 16, 0, 0);
     }
@@ -214,20 +249,19 @@ __device__ __forceinline__ void gemm16_lds_part(const float* lds_block, int lane
     const lds_u4* w4 = (const lds_u4*)lds_block + lane;
     constexpr int TC = MT <= 4 ? MT : (MT % 3 == 0 ? 3 : 4);
     static_assert(MT % TC == 0, "tile chunking");
+    PointScale ps{1.0f, 0};
+    if constexpr (kPieces == 2) {           // (every part of a GEMM sees the same b, hence the same scale)
+        ps = point_scale16<8 * KG>(b);
+        scale_acc16<MT>(acc, ps.kpre);
+    }
 #pragma unroll
     for (int gl = 0; gl < NG; ++gl) {
         const int g = G0 + gl;
         float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = b[8 * g + e];
-        bf16x8_t bh, bm, bl;
-        if constexpr (kPieces == 3) {
-            BFrag bf;
-            split8(x, bf);
-            bh = as_bf16x8(bf.p[0]); bm = as_bf16x8(bf.p[1]); bl = as_bf16x8(bf.p[2]);
-        } else {
-            bh = round8_bf16(x); bm = bh; bl = bh;
-        }
+        for (int e = 0; e < 8; ++e) x[e] = kPieces == 2 ? b[8 * g + e] * ps.s : b[8 * g + e];
+        B16 bp;
+        split_b16(x, bp);
 #pragma unroll
         for (int c = 0; c < MT / TC; ++c) {
             u32x4 a[TC][3];
@@ -235,9 +269,10 @@ __device__ __forceinline__ void gemm16_lds_part(const float* lds_block, int lane
             for (int t = 0; t < TC; ++t)
 #pragma unroll
                 for (int pc = 0; pc < kPieces; ++pc) a[t][pc] = w4[(((c * TC + t) * NG + gl) * kLdsPieces + pc) * 64];
-            mma16_tiles<TC>(a, bh, bm, bl, &acc[c * TC]);
+            mma16_tiles<TC>(a, bp, &acc[c * TC]);
         }
     }
+    if constexpr (kPieces == 2) scale_acc16<MT>(acc, -ps.kpre);
     __builtin_amdgcn_sched_barrier(0);   // keep later layers' LDS reads from being hoisted above this GEMM
 }
 

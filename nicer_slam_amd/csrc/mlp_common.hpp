@@ -83,10 +83,25 @@ __device__ __forceinline__ void split8(const float (&x)[8], BFrag& f) {
 // (round-to-nearest-even; fp32 accumulate) -- the optional "bf16 MLP" mode, compiled as a second set of kernels
 // (csrc/*_bf16.hip) and selected per network through nsa_grid_t.precision.  The packed weight blocks are shared: the
 // bf16 mode reads only the first piece, which pack.py rounds to nearest.
-#ifndef NSA_PIECES
-#define NSA_PIECES 3
+// NSA_FORM: how the library's fp32 path enters the matrix cores (one choice per library build; fused/pack.py asks nsa_operand_form()):
+//   3  three exact bf16 pieces per operand, six products per block (rounds 1-6a)
+//   2  two fp16 pieces per operand (round to nearest, twice: x s = h0 + h1 to 2^-23), FOUR products per block, the weights scaled by
+//      2^9 in the pack and every point's B vector by its own power of two (point_scale below) -- the same 2^-23 |a b| product bound
+//      with a third fewer matrix instructions; measured against float64 no worse than the three-piece form
+#ifndef NSA_FORM
+#define NSA_FORM 2
 #endif
+#ifndef NSA_PIECES
+#define NSA_PIECES NSA_FORM
+#endif
+constexpr int kForm = NSA_FORM;
 constexpr int kPieces = NSA_PIECES;
+// A packed fragment triple holds [bf16 hi | bf16 mid | bf16 lo] (form 3) or [fp16 h0 | fp16 h1 | bf16 round-to-nearest] (form 2: the
+// third slot serves the bf16-operand build).  kSlot0 = the first slot this translation unit's pieces come from.
+constexpr int kSlot0 = (NSA_PIECES == 1 && NSA_FORM == 2) ? 2 : 0;
+constexpr float kWScale = 512.0f;            // form 2: packed weights are w * 2^9 (|w| < 127.9; fp16 pieces exact to 2^-23 for |w| >= 2^-12)
+// source fragment (of the three per slot group and tile) of the i-th fragment a stage keeps in LDS
+__host__ __device__ constexpr int src_frag(int i);
 // Pieces per fragment that a block-cooperative weight stage keeps in LDS.  The packed blocks in global memory always hold all three
 // (one pack serves both precisions); the bf16-operand build multiplies with the first piece only, so its stages copy every THIRD 1-KiB
 // fragment and lay the copy out as [tile][group][lane] -- a third of the global->LDS traffic behind every staged GEMM, which in that
@@ -96,6 +111,9 @@ constexpr int kLdsPieces = 3;
 #else
 constexpr int kLdsPieces = NSA_PIECES;
 #endif
+__host__ __device__ constexpr int src_frag(int i) {
+    return kLdsPieces == 3 ? i : (kLdsPieces == 2 ? 3 * (i >> 1) + (i & 1) : 3 * i + kSlot0);
+}
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -122,7 +140,77 @@ __device__ __forceinline__ bf16x8_t as_bf16x8(const u32x4& v) {
     return r;
 }
 
-// acc[mt] += A(mt, group) * x for one slot group: the six cross products of the 3-way split, or one bf16 product.
+// ---- form 2: two fp16 pieces ------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <class V>
+__device__ __forceinline__ f16x8_t as_f16x8(const V& v) {
+    f16x8_t r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
+// t = h0 + h1 (+ at most 2^-23 |t|): h0 = fp16(t), h1 = fp16(t - h0), both round-to-nearest (v_cvt_pk_f16_f32); the subtraction is
+// exact in fp32.  t is already scaled (point_scale): |t| < 2^14, so nothing overflows, and an h1 below fp16's normal range costs at
+// most 2^-25 absolute, i.e. 2^-38 of the point's largest operand.  (Scalar subtractions on purpose: a float2 expression would
+// compile to v_pk_add_f32, which build.py's ISA check refuses)
+__device__ __forceinline__ void split8_h2(const float (&t)[8], f16x8_t& h0, f16x8_t& h1) {
+    unsigned u0[4], u1[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const f32x2_t v = {t[2 * d], t[2 * d + 1]};
+        const f16x2_t p = __builtin_convertvector(v, f16x2_t);
+        const float r0 = t[2 * d] - (float)p[0];
+        const float r1 = t[2 * d + 1] - (float)p[1];
+        const f32x2_t rv = {r0, r1};
+        const f16x2_t q = __builtin_convertvector(rv, f16x2_t);
+        __builtin_memcpy(&u0[d], &p, 4);
+        __builtin_memcpy(&u1[d], &q, 4);
+    }
+    __builtin_memcpy(&h0, u0, 16);
+    __builtin_memcpy(&h1, u1, 16);
+}
+
+// Per-point power-of-two scaling of a GEMM's B operand (form 2).  m = the largest |b| of the point (over all of its lanes; the caller
+// has combined the lanes' maxima): the operands are multiplied by s = 2^(13 - E), E = exponent of m clamped to +-100, so that the
+// largest lies in [2^13, 2^14); the accumulators (which hold the bias or an earlier partial sum) are multiplied by s 2^9 before the
+// products are added and by its inverse afterwards -- exact (powers of two), and the fp32 additions in between round as they would
+// unscaled.  An all-zero vector scales by 2^113 (harmless).
+struct PointScale {
+    float s;        // operands x s
+    int kpre;       // accumulators x 2^kpre before, x 2^-kpre after (v_ldexp_f32: a multiplication of the accumulator VECTORS by a
+};                  // float would compile to v_pk_mul_f32, which build.py's ISA check refuses)
+__device__ __forceinline__ PointScale point_scale_of(float m) {
+    unsigned e = __float_as_uint(m) >> 23;               // biased exponent (m >= 0)
+    e = e < 27u ? 27u : (e > 227u ? 227u : e);
+    PointScale r;
+    r.s = __uint_as_float((267u - e) << 23);             // 2^(140 - e)
+    r.kpre = 149 - (int)e;                               // s * 2^9
+    return r;
+}
+template <int N>
+__device__ __forceinline__ float abs_max(const float (&b)[N]) {
+    float m = 0.0f;
+#pragma unroll
+    for (int k = 0; k + 1 < N; k += 2) m = fmaxf(fmaxf(m, fabsf(b[k])), fabsf(b[k + 1]));     // v_max3_f32 with |.| modifiers
+    if (N & 1) m = fmaxf(m, fabsf(b[N - 1]));
+    return m;
+}
+// 32-point tiling: a point's operands live in lanes p and p + 32
+template <int N>
+__device__ __forceinline__ PointScale point_scale32(const float (&b)[N]) {
+    const float m = abs_max<N>(b);
+    return point_scale_of(fmaxf(m, __shfl_xor(m, 32)));
+}
+template <int MT>
+__device__ __forceinline__ void scale_acc(f32x16 (&acc)[MT], int k) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = __builtin_ldexpf(acc[mt][r], k);
+}
+
+// acc[mt] += A(mt, group) * x for one slot group: the six cross products of the 3-way split, the four of the two-piece fp16 form (x
+// already scaled), or one bf16 product.
 template <int MT, class AV>
 __device__ __forceinline__ void mma_group(const AV (&a)[MT][3], const float (&x)[8], f32x16 (&acc)[MT]) {
     if constexpr (kPieces == 3) {
@@ -135,6 +223,14 @@ __device__ __forceinline__ void mma_group(const AV (&a)[MT][3], const float (&x)
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[mt][AP]), BV, acc[mt], 0, 0, 0);
         NSA_MM(2, bh) NSA_MM(0, bl) NSA_MM(1, bm) NSA_MM(1, bh) NSA_MM(0, bm) NSA_MM(0, bh)
 #undef NSA_MM
+    } else if constexpr (kPieces == 2) {
+        f16x8_t b0, b1;
+        split8_h2(x, b0, b1);
+#define NSA_MMH(AP, BV)                                                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                \
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(a[mt][AP]), BV, acc[mt], 0, 0, 0);
+        NSA_MMH(1, b1) NSA_MMH(0, b1) NSA_MMH(1, b0) NSA_MMH(0, b0)
+#undef NSA_MMH
     } else {
         const bf16x8_t b = round8_bf16(x);
 #pragma unroll
@@ -155,7 +251,7 @@ __device__ __forceinline__ void gemm_preload(const float* __restrict__ wp, int l
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int pc = 0; pc < kPieces; ++pc) f.g[mt][pc] = w4[((mt * KS8 + 0) * 3 + pc) * 64];
+        for (int pc = 0; pc < kPieces; ++pc) f.g[mt][pc] = w4[((mt * KS8 + 0) * 3 + kSlot0 + pc) * 64];
 }
 
 template <int KS, int MT>
@@ -163,6 +259,11 @@ __device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane,
                                          f32x16 (&acc)[MT]) {
     constexpr int KS8 = (KS + 7) / 8;
     const uint4* __restrict__ w4 = reinterpret_cast<const uint4*>(wp) + lane;
+    PointScale ps{1.0f, 0};
+    if constexpr (kPieces == 2) {
+        ps = point_scale32<KS>(b);
+        scale_acc<MT>(acc, ps.kpre);
+    }
 #pragma unroll
     for (int g = 0; g < KS8; ++g) {
         uint4 a[MT][3];
@@ -171,13 +272,14 @@ __device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane,
 #pragma unroll
             for (int pc = 0; pc < kPieces; ++pc) {
                 a[mt][pc] = f.g[mt][pc];
-                if (g + 1 < KS8) f.g[mt][pc] = w4[((mt * KS8 + g + 1) * 3 + pc) * 64];
+                if (g + 1 < KS8) f.g[mt][pc] = w4[((mt * KS8 + g + 1) * 3 + kSlot0 + pc) * 64];
             }
         float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? b[8 * g + e] : 0.0f;
+        for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? (kPieces == 2 ? b[8 * g + e] * ps.s : b[8 * g + e]) : 0.0f;
         mma_group<MT>(a, x, acc);
     }
+    if constexpr (kPieces == 2) scale_acc<MT>(acc, -ps.kpre);
     __builtin_amdgcn_sched_barrier(0);   // keep later layers' loads from being hoisted above this GEMM
 }
 
@@ -196,12 +298,11 @@ constexpr int kStageFloats = 9216;      // largest packed block: A[3 tiles][32 s
 __device__ __forceinline__ void stage_issue(const float* __restrict__ g, int nfloats, float* lds_dst) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunks = nfloats / 256 / 3 * kLdsPieces;      // 1-KiB fragments copied (a packed A block is a multiple of 3 fragments)
-    constexpr int kSrcStep = kLdsPieces == 3 ? 1 : 3;       // one piece kept: every third fragment of the block
 #pragma unroll
     for (int c = 0; c < (chunks + 3) / 4; ++c) {
         const int ch = 4 * c + wave;
-        if (ch < chunks)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + ch * kSrcStep * 256 + lane * 4),
+        if (ch < chunks)                                    // (src_frag: the pieces this build multiplies with, of the three per fragment triple)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + src_frag(ch) * 256 + lane * 4),
                                              (__attribute__((address_space(3))) void*)(lds_dst + ch * 256), 16, 0, 0);
     }
 }
@@ -233,6 +334,11 @@ template <int KS, int MT>
 __device__ __forceinline__ void gemm_lds(const float* lds_block, int lane, const float (&b)[KS], f32x16 (&acc)[MT]) {
     constexpr int KS8 = (KS + 7) / 8;
     const lds_u4* w4 = (const lds_u4*)lds_block + lane;
+    PointScale ps{1.0f, 0};
+    if constexpr (kPieces == 2) {
+        ps = point_scale32<KS>(b);
+        scale_acc<MT>(acc, ps.kpre);
+    }
     u32x4 nxt[MT][3];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -250,9 +356,10 @@ __device__ __forceinline__ void gemm_lds(const float* lds_block, int lane, const
             }
         float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? b[8 * g + e] : 0.0f;
+        for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? (kPieces == 2 ? b[8 * g + e] * ps.s : b[8 * g + e]) : 0.0f;
         mma_group<MT>(a, x, acc);
     }
+    if constexpr (kPieces == 2) scale_acc<MT>(acc, -ps.kpre);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -286,13 +393,12 @@ __device__ __forceinline__ void stage_issue_op(const float* __restrict__ wp, con
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per_tile = o.ng * kLdsPieces;        // 1 KiB chunks per tile in this part
     const int chunks = o.mt * per_tile;
-    constexpr int kSrcStep = kLdsPieces == 3 ? 1 : 3;
 #pragma unroll
     for (int c = 0; c < (chunks + 3) / 4; ++c) {
         const int ch = 4 * c + wave;
         if (ch < chunks) {
             const int mt = ch / per_tile, rem = ch - mt * per_tile;
-            const float* src = wp + o.off + ((mt * o.ks8 + o.g0) * 3 + rem * kSrcStep) * 256 + lane * 4;
+            const float* src = wp + o.off + ((mt * o.ks8 + o.g0) * 3 + src_frag(rem)) * 256 + lane * 4;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(lds_dst + ch * 256), 16, 0, 0);
         }
@@ -302,6 +408,11 @@ __device__ __forceinline__ void stage_issue_op(const float* __restrict__ wp, con
 template <int KS, int MT, int G0, int NG>
 __device__ __forceinline__ void gemm_lds_part(const float* lds_block, int lane, const float (&b)[KS], f32x16 (&acc)[MT]) {
     const lds_u4* w4 = (const lds_u4*)lds_block + lane;
+    PointScale ps{1.0f, 0};
+    if constexpr (kPieces == 2) {           // (every part of a GEMM sees the same b, hence the same scale)
+        ps = point_scale32<KS>(b);
+        scale_acc<MT>(acc, ps.kpre);
+    }
     u32x4 nxt[MT][3];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -320,9 +431,10 @@ __device__ __forceinline__ void gemm_lds_part(const float* lds_block, int lane, 
             }
         float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? b[8 * g + e] : 0.0f;
+        for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? (kPieces == 2 ? b[8 * g + e] * ps.s : b[8 * g + e]) : 0.0f;
         mma_group<MT>(a, x, acc);
     }
+    if constexpr (kPieces == 2) scale_acc<MT>(acc, -ps.kpre);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -354,6 +466,15 @@ __device__ __forceinline__ void gemm_op_tiles(const float* __restrict__ wp, int 
     const uint4* __restrict__ w4 = reinterpret_cast<const uint4*>(wp) + lane;
     AFrag<MT> f;
     gemm_preload<KS, MT>(wp, lane, f);
+    PointScale ps[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        ps[t] = PointScale{1.0f, 0};
+        if constexpr (kPieces == 2) {
+            ps[t] = point_scale32<KS>(b[t]);
+            scale_acc<MT>(acc[t], ps[t].kpre);
+        }
+    }
 #pragma unroll
     for (int g = 0; g < KS8; ++g) {
         uint4 a[MT][3];
@@ -362,15 +483,19 @@ __device__ __forceinline__ void gemm_op_tiles(const float* __restrict__ wp, int 
 #pragma unroll
             for (int pc = 0; pc < kPieces; ++pc) {
                 a[mt][pc] = f.g[mt][pc];
-                if (g + 1 < KS8) f.g[mt][pc] = w4[((mt * KS8 + g + 1) * 3 + pc) * 64];
+                if (g + 1 < KS8) f.g[mt][pc] = w4[((mt * KS8 + g + 1) * 3 + kSlot0 + pc) * 64];
             }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             float x[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? b[t][8 * g + e] : 0.0f;
+            for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? (kPieces == 2 ? b[t][8 * g + e] * ps[t].s : b[t][8 * g + e]) : 0.0f;
             mma_group<MT>(a, x, acc[t]);
         }
+    }
+    if constexpr (kPieces == 2) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) scale_acc<MT>(acc[t], -ps[t].kpre);
     }
     __builtin_amdgcn_sched_barrier(0);
 }

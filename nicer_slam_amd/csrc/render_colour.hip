@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, NSA_OCC_COL_FWD) void k_colour_fwd_composite(C
 
 }  // namespace nsa
 
-#if defined(NSA_X_TS) && NSA_PIECES == 3
+#if defined(NSA_X_TS) && NSA_PIECES != 1
 extern "C" int nsa_debug_set_ts_colour(unsigned long long* p) {
     return hipMemcpyToSymbol(HIP_SYMBOL(nsa::g_ts_c), &p, sizeof(p)) == hipSuccess ? 0 : 3;
 }
@@ -380,7 +380,7 @@ static int colour_common(const nsa_points_t* pts, const nsa_grid_t* grid, nsa::C
 
 int NSA_ENTRY(nsa_colour_forward)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad,
                        const float* feat_hl, float* rgb, float* save, nsa_stream_t stream) {
-#if NSA_PIECES == 3
+#if NSA_PIECES != 1
     if (grid && grid->precision == 1) return nsa_colour_forward_bf16(pts, grid, packed, grad, feat_hl, rgb, save, stream);      // bf16-operand kernels (csrc/*_bf16.hip)
 #endif
     using namespace nsa;
@@ -400,7 +400,7 @@ int NSA_ENTRY(nsa_colour_forward_composite)(const nsa_points_t* pts, const nsa_g
                                  const float* feat_hl, float* rgb, float* save, const float* sdf, const float* voxels,
                                  uint32_t voxel_res, float* weights, float* rgb_values, float* depth, float* nmap, float* entropy,
                                  nsa_stream_t stream) {
-#if NSA_PIECES == 3
+#if NSA_PIECES != 1
     if (grid && grid->precision == 1)
         return nsa_colour_forward_composite_bf16(pts, grid, packed, grad, feat_hl, rgb, save, sdf, voxels, voxel_res, weights, rgb_values,
                                                  depth, nmap, entropy, stream);
@@ -427,7 +427,7 @@ int NSA_ENTRY(nsa_colour_forward_track)(const nsa_points_t* pts, const nsa_grid_
                              const float* feat_hl, float* rgb, float* save, const float* sdf, const float* voxels, uint32_t voxel_res,
                              const float* gt, uint32_t n_total, float* rgb_values, float* ray_loss, float* g_sdf, float* g_rgb,
                              float* g_grad, nsa_stream_t stream) {
-#if NSA_PIECES == 3
+#if NSA_PIECES != 1
     if (grid && grid->precision == 1)
         return nsa_colour_forward_track_bf16(pts, grid, packed, grad, feat_hl, rgb, save, sdf, voxels, voxel_res, gt, n_total, rgb_values,
                                              ray_loss, g_sdf, g_rgb, g_grad, stream);
@@ -458,7 +458,7 @@ int NSA_ENTRY(nsa_colour_forward_track)(const nsa_points_t* pts, const nsa_grid_
 int NSA_ENTRY(nsa_colour_backward)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* grad,
                         const float* feat_hl, const float* save, const float* g_rgb, int grid_grad, float* g_feat_hl,
                         float* g_grad, float* g_x, float* g_dir, nsa_stream_t stream) {
-#if NSA_PIECES == 3
+#if NSA_PIECES != 1
     if (grid && grid->precision == 1) return nsa_colour_backward_bf16(pts, grid, packed, grad, feat_hl, save, g_rgb, grid_grad, g_feat_hl, g_grad, g_x, g_dir, stream);      // bf16-operand kernels (csrc/*_bf16.hip)
 #endif
     using namespace nsa;
@@ -479,7 +479,7 @@ int NSA_ENTRY(nsa_colour_coarse_backward)(const nsa_points_t* pts, const nsa_gri
                                const float* feat_hl, const float* save, const float* g_rgb, int grid_grad, float* g_feat_hl,
                                float* g_grad, float* g_x, float* g_dir, const nsa_grid_t* coarse, const float* packed_coarse,
                                const float* g_sdf, nsa_stream_t stream) {
-#if NSA_PIECES == 3
+#if NSA_PIECES != 1
     if (grid && coarse && grid->precision == 1 && coarse->precision == 1)
         return nsa_colour_coarse_backward_bf16(pts, grid, packed, grad, feat_hl, save, g_rgb, grid_grad, g_feat_hl, g_grad, g_x, g_dir, coarse,
                                                packed_coarse, g_sdf, stream);
@@ -511,7 +511,7 @@ int NSA_ENTRY(nsa_colour_backward_params)(const nsa_points_t* pts, const nsa_gri
                                const float* feat_hl, const float* save, const float* g_rgb, int grid_grad,
                                float* g_feat_hl, float* g_grad, float* g_x, float* g_dir, float* g_table, float* emit,
                                uint32_t emit_ld, nsa_stream_t stream) {
-#if NSA_PIECES == 3
+#if NSA_PIECES != 1
     if (grid && grid->precision == 1) return nsa_colour_backward_params_bf16(pts, grid, packed, grad, feat_hl, save, g_rgb, grid_grad, g_feat_hl, g_grad, g_x, g_dir, g_table, emit, emit_ld, stream);      // bf16-operand kernels (csrc/*_bf16.hip)
 #endif
     using namespace nsa;

@@ -424,7 +424,7 @@ int NSA_ENTRY(nsa_sampler_sdf)(const float* rays_o, const float* rays_d, uint32_
                     const float* t_rand, float near, float bound, float far_cap, const nsa_grid_t* coarse,
                     const nsa_grid_t* fine, const float* packed_coarse, const float* packed_fine, float* z, float* sdf,
                     float* far, nsa_stream_t stream) {
-#if NSA_PIECES == 3
+#if NSA_PIECES != 1
     if (coarse && coarse->precision == 1) return nsa_sampler_sdf_bf16(rays_o, rays_d, R, E, t_lin, t_rand, near, bound, far_cap, coarse, fine, packed_coarse, packed_fine, z, sdf, far, stream);      // bf16-operand kernels (csrc/*_bf16.hip)
 #endif
     using namespace nsa;
@@ -471,7 +471,7 @@ int NSA_ENTRY(nsa_sampler_sdf)(const float* rays_o, const float* rays_d, uint32_
 
 int NSA_ENTRY(nsa_sdf_points)(const float* points, uint64_t N, const nsa_grid_t* coarse, const nsa_grid_t* fine,
                    const float* packed_coarse, const float* packed_fine, float* sdf, nsa_stream_t stream) {
-#if NSA_PIECES == 3
+#if NSA_PIECES != 1
     if (coarse && coarse->precision == 1) return nsa_sdf_points_bf16(points, N, coarse, fine, packed_coarse, packed_fine, sdf, stream);      // bf16-operand kernels (csrc/*_bf16.hip)
 #endif
     using namespace nsa;

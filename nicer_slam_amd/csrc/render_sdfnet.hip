@@ -296,7 +296,7 @@ extern "C" {
 
 int NSA_ENTRY(nsa_sdfnet_forward)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, int accumulate, float* sdf,
                        float* grad, float* feat_hl, nsa_stream_t stream) {
-#if NSA_PIECES == 3
+#if NSA_PIECES != 1
     if (grid && grid->precision == 1) return nsa_sdfnet_forward_bf16(pts, grid, packed, accumulate, sdf, grad, feat_hl, stream);      // bf16-operand kernels (csrc/*_bf16.hip)
 #endif
     using namespace nsa;
@@ -314,7 +314,7 @@ int NSA_ENTRY(nsa_sdfnet_forward)(const nsa_points_t* pts, const nsa_grid_t* gri
 int NSA_ENTRY(nsa_sdfnet_forward_pair)(const nsa_points_t* pts, const nsa_grid_t* coarse, const nsa_grid_t* fine,
                             const float* packed_coarse, const float* packed_fine, float* sdf, float* grad, float* feat_hl,
                             nsa_stream_t stream) {
-#if NSA_PIECES == 3
+#if NSA_PIECES != 1
     if (coarse && fine && coarse->precision == 1 && fine->precision == 1)
         return nsa_sdfnet_forward_pair_bf16(pts, coarse, fine, packed_coarse, packed_fine, sdf, grad, feat_hl, stream);
 #endif
@@ -328,7 +328,7 @@ int NSA_ENTRY(nsa_sdfnet_forward_pair)(const nsa_points_t* pts, const nsa_grid_t
 
 int NSA_ENTRY(nsa_sdfnet_backward)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* g_sdf,
                         const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x, nsa_stream_t stream) {
-#if NSA_PIECES == 3
+#if NSA_PIECES != 1
     if (grid && grid->precision == 1) return nsa_sdfnet_backward_bf16(pts, grid, packed, g_sdf, g_feat_hl, g_grad, accumulate, g_x, stream);      // bf16-operand kernels (csrc/*_bf16.hip)
 #endif
     using namespace nsa;
@@ -347,7 +347,7 @@ int NSA_ENTRY(nsa_sdfnet_backward)(const nsa_points_t* pts, const nsa_grid_t* gr
 int NSA_ENTRY(nsa_sdfnet_backward_params)(const nsa_points_t* pts, const nsa_grid_t* grid, const float* packed, const float* g_sdf,
                                const float* g_feat_hl, const float* g_grad, int accumulate, float* g_x, float* g_table,
                                float* emit, uint32_t emit_ld, nsa_stream_t stream) {
-#if NSA_PIECES == 3
+#if NSA_PIECES != 1
     if (grid && grid->precision == 1) return nsa_sdfnet_backward_params_bf16(pts, grid, packed, g_sdf, g_feat_hl, g_grad, accumulate, g_x, g_table, emit, emit_ld, stream);      // bf16-operand kernels (csrc/*_bf16.hip)
 #endif
     using namespace nsa;

@@ -82,6 +82,31 @@ def split_bf16x3(x):
     return hi, mid, lo
 
 
+W_SCALE = 512.0      # csrc/mlp_common.hpp::kWScale
+
+
+def split_f16x2(x):
+    """form 2 of the packed weights (csrc/mlp_common.hpp::NSA_FORM): 512 x = h0 + h1 in two round-to-nearest fp16 pieces, plus the
+    bf16 round-to-nearest value of x (third slot: what the bf16-operand kernels multiply with); 16-bit words as int16 views."""
+    t = x * W_SCALE
+    h0 = t.to(torch.float16)
+    h1 = (t - h0.float()).to(torch.float16)
+    return h0.view(torch.int16), h1.view(torch.int16), x.to(torch.bfloat16).view(torch.int16)
+
+
+def operand_form():
+    """3 (three bf16 pieces) or 2 (two fp16 pieces): what the loaded library's fp32 kernels multiply with (nsa_operand_form)."""
+    from .._native import lib
+    return int(lib.nsa_operand_form())
+
+
+def split_pieces(x):
+    """the three 16-bit pieces of every weight as the loaded library's kernels read them (int16 views; nsa_operand_form)"""
+    if operand_form() == 2:
+        return split_f16x2(x)
+    return tuple(p.view(torch.int16) for p in split_bf16x3(x))
+
+
 _plans = {}
 
 
@@ -121,8 +146,7 @@ def pack_blocks(flat, blocks):
         check(lib.nsa_pack_blocks(flat.data_ptr(), ia.data_ptr(), ia.numel(), iv.data_ptr(), iv.numel(), perm.data_ptr(),
                                   perm.numel(), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
         return out
-    hi, mid, lo = split_bf16x3(flat[ia])
-    words = torch.stack([hi, mid, lo], 1).contiguous().view(torch.float32).reshape(-1)
+    words = torch.stack(split_pieces(flat[ia]), 1).contiguous().view(torch.float32).reshape(-1)
     return torch.cat([words, flat[iv]])[perm]
 
 

@@ -15,13 +15,34 @@ def _bf16_words_to_f64(words):
     return np.stack([lo, hi], -1).reshape(-1).astype(np.float64)
 
 
+def _f16_words_to_f64(words):
+    u = np.ascontiguousarray(words, dtype=np.float32).view(np.uint32)
+    lo = (u & 0xFFFF).astype(np.uint16).view(np.float16)
+    hi = (u >> 16).astype(np.uint16).view(np.float16)
+    return np.stack([lo, hi], -1).reshape(-1).astype(np.float64)
+
+
+def block_weights(block, MT, KG):
+    """packed A block [MT][KG][3 slots][64 lanes][8 halfwords] -> the fp32 weights [MT][KG][64][8] its pieces stand for, in the
+    loaded library's operand form (pack.operand_form): three bf16 pieces that sum to w, or two fp16 pieces that sum to 512 w (+ the
+    bf16 round-to-nearest value in the third slot, checked here)."""
+    from nicer_slam_amd.fused import pack
+    words = np.asarray(block, dtype=np.float32).reshape(MT, KG, 3, 64 * 4)
+    if pack.operand_form() == 2:
+        w = (_f16_words_to_f64(words[:, :, 0]) + _f16_words_to_f64(words[:, :, 1])).reshape(MT, KG, 64, 8) / pack.W_SCALE
+        b = _bf16_words_to_f64(words[:, :, 2]).reshape(MT, KG, 64, 8)
+        assert np.all(np.abs(b - w) <= 2.0 ** -8 * np.abs(w) + 1e-30), "third slot = bf16(w)"
+        return w
+    return _bf16_words_to_f64(words).reshape(MT, KG, 3, 64, 8).sum(2)
+
+
 def gemm_op(block, MT, KS, b, acc):
     """block: packed weights [MT][KS8][3 pieces][64 lanes][8 bf16] as float32 words; b: [64 lanes][KS] (fp32 slots);
     acc: [64][MT][16] (updated in place).  v_mfma_f32_32x32x16_bf16: lane l supplies A[l&31][8(l>>5)+e] and
     B[8(l>>5)+e][l&31], e < 8; the three pieces of each operand sum back to the fp32 value, so the emulation works
     on the reassembled values (the kernel's six-product expansion differs from that only at the 2^-23 level)."""
     KS8 = (KS + 7) // 8
-    blk = _bf16_words_to_f64(np.asarray(block, dtype=np.float32)).reshape(MT, KS8, 3, 64, 8).sum(2)   # [mt][g][lane][e]
+    blk = block_weights(block, MT, KS8)                                                                # [mt][g][lane][e]
     bp = np.zeros((64, KS8 * 8))
     bp[:, :KS] = b[:, :KS]
     for mt in range(MT):
@@ -63,7 +84,7 @@ def gemm16(block, MT, KG, b, acc):
     (j, kq) supplies B[k = (g, kq, e)][j] = b[lane, 8g+e]); acc: [64][MT][4] updated in place (lane (j, q), register r =
     D[row 4q + r][col j] of each 16-row output tile).  The MFMA pairs element e of quarter kq of A with element e of
     quarter kq of B, whatever the hardware's internal k order."""
-    blk = _bf16_words_to_f64(np.asarray(block, dtype=np.float32)).reshape(MT, KG, 3, 64, 8).sum(2)   # [mt][g][lane][e]
+    blk = block_weights(block, MT, KG)                                                                 # [mt][g][lane][e]
     for mt in range(MT):
         D = np.zeros((16, 16))
         for g in range(KG):

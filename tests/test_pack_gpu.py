@@ -13,8 +13,7 @@ pytestmark = pytest.mark.gpu
 def _torch_pack(flat, blocks):
     from nicer_slam_amd.fused import pack
     ia, iv, perm = pack._plan(blocks, flat.device)
-    hi, mid, lo = pack.split_bf16x3(flat[ia])
-    words = torch.stack([hi, mid, lo], 1).contiguous().view(torch.float32).reshape(-1)
+    words = torch.stack(pack.split_pieces(flat[ia]), 1).contiguous().view(torch.float32).reshape(-1)     # (the library's operand form)
     return torch.cat([words, flat[iv]])[perm]
 
 

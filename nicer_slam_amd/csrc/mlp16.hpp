@@ -79,12 +79,13 @@ __device__ __forceinline__ void mma16_tiles(const u32x4 (&a)[TC][3], const B16& 
 // quad tiling: a point's operands live in lanes j, j + 16, j + 32, j + 48
 template <int N>
 __device__ __forceinline__ PointScale point_scale16(const float (&b)[N]) {
-    float m = abs_max<N>(b);
-    m = fmaxf(m, __shfl_xor(m, 16));
-    return point_scale_of(fmaxf(m, __shfl_xor(m, 32)));
+    return point_scale_of(__uint_as_float(umax_xor32(umax_xor16(__float_as_uint(abs_max<N>(b))))));
 }
 template <int MT>
 __device__ __forceinline__ void scale_acc16(f32x4v (&acc)[MT], int k) {
+#ifdef NSA_X_NO_ACC_SCALE
+    return;
+#endif
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll

@@ -182,6 +182,9 @@ struct PointScale {
 __device__ __forceinline__ PointScale point_scale_of(float m) {
     unsigned e = __float_as_uint(m) >> 23;               // biased exponent (m >= 0)
     e = e < 27u ? 27u : (e > 227u ? 227u : e);
+#ifdef NSA_X_NO_POINT_SCALE      // timing-only ablation (WRONG numbers; tagged builds): no per-point maximum, a constant scale (r6w)
+    e = 127u;
+#endif
     PointScale r;
     r.s = __uint_as_float((267u - e) << 23);             // 2^(140 - e)
     r.kpre = 149 - (int)e;                               // s * 2^9
@@ -189,20 +192,46 @@ __device__ __forceinline__ PointScale point_scale_of(float m) {
 }
 template <int N>
 __device__ __forceinline__ float abs_max(const float (&b)[N]) {
-    float m = 0.0f;
+    float m[3] = {0.0f, 0.0f, 0.0f};                    // three independent chains of v_max3_f32 (|.| modifiers are free)
 #pragma unroll
-    for (int k = 0; k + 1 < N; k += 2) m = fmaxf(fmaxf(m, fabsf(b[k])), fabsf(b[k + 1]));     // v_max3_f32 with |.| modifiers
-    if (N & 1) m = fmaxf(m, fabsf(b[N - 1]));
-    return m;
+    for (int k = 0; k + 1 < N; k += 2) m[(k >> 1) % 3] = fmaxf(fmaxf(m[(k >> 1) % 3], fabsf(b[k])), fabsf(b[k + 1]));
+    if (N & 1) m[0] = fmaxf(m[0], fabsf(b[N - 1]));
+    return fmaxf(fmaxf(m[0], m[1]), m[2]);
+}
+// A bound on this lane's share of the NEXT GEMM's operands that is known before they are: Softplus(beta = 100) of an accumulator is at
+// most |a| + ln 2 / 100, a ReLU at most |a|.  A GEMM that is handed such a bound (`hint`) takes the point's scale from it instead of
+// from the operands themselves, so the operand conversion of its first slot group does not have to wait for the activation of the last
+// value (the scale is a power of two: a bound that is loose by 2^k only moves the 2^-38 absolute floor of the split by 2^k).
+template <int MT>
+__device__ __forceinline__ float acc_abs_max(const f32x16 (&acc)[MT]) {
+    float m[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 16 * MT; i += 2) m[(i >> 1) % 3] = fmaxf(fmaxf(m[(i >> 1) % 3], fabsf(acc[i >> 4][i & 15])), fabsf(acc[i >> 4][(i + 1) & 15]));
+    return fmaxf(fmaxf(m[0], m[1]), m[2]);
+}
+constexpr float kSoftplusSlack = 0.00694f;      // > ln 2 / 100
+
+// max of a non-negative float over the lane pairs (l, l ^ 32) / quads (l, l ^ 16, l ^ 32, l ^ 48): v_permlane32_swap / v_permlane16_swap
+// (gfx950; vector ALU, no LDS round trip) and integer maxima of the bit patterns (non-negative floats order like unsigned integers)
+__device__ __forceinline__ unsigned umax_xor32(unsigned m) {
+    const auto r = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+    return r[0] > r[1] ? r[0] : r[1];
+}
+__device__ __forceinline__ unsigned umax_xor16(unsigned m) {
+    const auto r = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+    return r[0] > r[1] ? r[0] : r[1];
 }
 // 32-point tiling: a point's operands live in lanes p and p + 32
 template <int N>
-__device__ __forceinline__ PointScale point_scale32(const float (&b)[N]) {
-    const float m = abs_max<N>(b);
-    return point_scale_of(fmaxf(m, __shfl_xor(m, 32)));
+__device__ __forceinline__ PointScale point_scale32(const float (&b)[N], const float* hint = nullptr) {
+    const float m = hint ? *hint : abs_max<N>(b);
+    return point_scale_of(__uint_as_float(umax_xor32(__float_as_uint(m))));
 }
 template <int MT>
 __device__ __forceinline__ void scale_acc(f32x16 (&acc)[MT], int k) {
+#ifdef NSA_X_NO_ACC_SCALE        // timing-only ablation (WRONG numbers; tagged builds): what the accumulator scaling of form 2 costs (r6w)
+    return;
+#endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -256,12 +285,12 @@ __device__ __forceinline__ void gemm_preload(const float* __restrict__ wp, int l
 
 template <int KS, int MT>
 __device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane, AFrag<MT>& f, const float (&b)[KS],
-                                         f32x16 (&acc)[MT]) {
+                                         f32x16 (&acc)[MT], const float* hint = nullptr) {
     constexpr int KS8 = (KS + 7) / 8;
     const uint4* __restrict__ w4 = reinterpret_cast<const uint4*>(wp) + lane;
     PointScale ps{1.0f, 0};
     if constexpr (kPieces == 2) {
-        ps = point_scale32<KS>(b);
+        ps = point_scale32<KS>(b, hint);
         scale_acc<MT>(acc, ps.kpre);
     }
 #pragma unroll
@@ -451,17 +480,19 @@ __device__ __forceinline__ void gemm_staged_part(float* stage, const float* __re
 
 
 template <int KS, int MT>
-__device__ __forceinline__ void gemm_op(const float* __restrict__ wp, int lane, const float (&b)[KS], f32x16 (&acc)[MT]) {
+__device__ __forceinline__ void gemm_op(const float* __restrict__ wp, int lane, const float (&b)[KS], f32x16 (&acc)[MT],
+                                        const float* hint = nullptr) {
     AFrag<MT> f;
     gemm_preload<KS, MT>(wp, lane, f);
-    gemm_run<KS, MT>(wp, lane, f, b, acc);
+    gemm_run<KS, MT>(wp, lane, f, b, acc, hint);
 }
 
 // The same for T point tiles per wave: one weight fragment stream feeds T independent accumulator sets, so the fragment traffic
 // (3 KiB per slot group and output tile, the L1's whole 64 B/clk when the wave is MFMA-bound) is paid once per T tiles, and the
 // operand split of tile t + 1 issues while the matrix cores work on tile t.
 template <int KS, int MT, int T>
-__device__ __forceinline__ void gemm_op_tiles(const float* __restrict__ wp, int lane, const float (&b)[T][KS], f32x16 (&acc)[T][MT]) {
+__device__ __forceinline__ void gemm_op_tiles(const float* __restrict__ wp, int lane, const float (&b)[T][KS], f32x16 (&acc)[T][MT],
+                                              const float* hint = nullptr) {       // hint[t]: see acc_abs_max
     constexpr int KS8 = (KS + 7) / 8;
     const uint4* __restrict__ w4 = reinterpret_cast<const uint4*>(wp) + lane;
     AFrag<MT> f;
@@ -471,7 +502,7 @@ __device__ __forceinline__ void gemm_op_tiles(const float* __restrict__ wp, int 
     for (int t = 0; t < T; ++t) {
         ps[t] = PointScale{1.0f, 0};
         if constexpr (kPieces == 2) {
-            ps[t] = point_scale32<KS>(b[t]);
+            ps[t] = point_scale32<KS>(b[t], hint ? hint + t : nullptr);
             scale_acc<MT>(acc[t], ps[t].kpre);
         }
     }

@@ -119,12 +119,13 @@ __device__ __forceinline__ float sdf_only(const float* __restrict__ wp, int lane
     float act[HS];
 #pragma unroll
     for (int k = 1; k < NH; ++k) {
+        const float bound = acc_abs_max<2>(acc) + kSoftplusSlack;       // (form 2: the next GEMM's scale, known before its operands)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) act[16 * t + r] = softplus100(acc[t][r]);
         load_vec<2>(wp + P::bh(k), h, acc);
-        gemm_op<HS, 2>(wp + P::wh(k), lane, act, acc);
+        gemm_op<HS, 2>(wp + P::wh(k), lane, act, acc, &bound);
     }
     f32x16 ws[2];
     load_vec<2>(wp + P::kWSDF, h, ws);
@@ -148,15 +149,17 @@ __device__ __forceinline__ void sdf_only_tiles(const float* __restrict__ wp, int
     float act[T][HS];
 #pragma unroll
     for (int k = 1; k < NH; ++k) {
+        float bound[T];                                                  // (form 2: the next GEMM's scales, known before its operands)
 #pragma unroll
         for (int t = 0; t < T; ++t) {
+            bound[t] = acc_abs_max<2>(acc[t]) + kSoftplusSlack;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) act[t][16 * mt + r] = softplus100(acc[t][mt][r]);
             load_vec<2>(wp + P::bh(k), h, acc[t]);
         }
-        gemm_op_tiles<HS, 2, T>(wp + P::wh(k), lane, act, acc);
+        gemm_op_tiles<HS, 2, T>(wp + P::wh(k), lane, act, acc, bound);
     }
     f32x16 ws[2];
     load_vec<2>(wp + P::kWSDF, h, ws);

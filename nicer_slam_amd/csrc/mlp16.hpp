@@ -78,8 +78,20 @@ __device__ __forceinline__ void mma16_tiles(const u32x4 (&a)[TC][3], const B16& 
 
 // quad tiling: a point's operands live in lanes j, j + 16, j + 32, j + 48
 template <int N>
-__device__ __forceinline__ PointScale point_scale16(const float (&b)[N]) {
-    return point_scale_of(__uint_as_float(umax_xor32(umax_xor16(__float_as_uint(abs_max<N>(b))))));
+__device__ __forceinline__ PointScale point_scale16(const float (&b)[N], const float* hint = nullptr) {
+    const float m = hint ? *hint : abs_max<N>(b);
+    return point_scale_of(__uint_as_float(umax_xor32(umax_xor16(__float_as_uint(m)))));
+}
+// this lane's largest |accumulator| (see mlp_common.hpp::acc_abs_max: the bound a following GEMM can take its scale from)
+template <int MT>
+__device__ __forceinline__ float acc_abs_max16(const f32x4v (&acc)[MT]) {
+    float m[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        m[0] = fmaxf(fmaxf(m[0], fabsf(acc[t][0])), fabsf(acc[t][1]));
+        m[1] = fmaxf(fmaxf(m[1], fabsf(acc[t][2])), fabsf(acc[t][3]));
+    }
+    return fmaxf(m[0], m[1]);
 }
 template <int MT>
 __device__ __forceinline__ void scale_acc16(f32x4v (&acc)[MT], int k) {
@@ -96,13 +108,14 @@ __device__ __forceinline__ void scale_acc16(f32x4v (&acc)[MT], int k) {
 // Output tiles are processed in chunks of at most 4 (4 independent accumulators per product step: no MFMA waits on its
 // predecessor; 12 fragment registers live per chunk instead of 3*MT).
 template <int KG, int MT>
-__device__ __forceinline__ void gemm16_lds(const float* lds_block, int lane, const float (&b)[8 * KG], f32x4v (&acc)[MT]) {
+__device__ __forceinline__ void gemm16_lds(const float* lds_block, int lane, const float (&b)[8 * KG], f32x4v (&acc)[MT],
+                                           const float* hint = nullptr) {
     const lds_u4* w4 = (const lds_u4*)lds_block + lane;
     constexpr int TC = MT <= 4 ? MT : (MT % 3 == 0 ? 3 : 4);
     static_assert(MT % TC == 0, "tile chunking");
     PointScale ps{1.0f, 0};
     if constexpr (kPieces == 2) {
-        ps = point_scale16<8 * KG>(b);
+        ps = point_scale16<8 * KG>(b, hint);
         scale_acc16<MT>(acc, ps.kpre);
     }
 #pragma unroll
@@ -132,12 +145,13 @@ __device__ __forceinline__ void gemm16_lds(const float* lds_block, int lane, con
 
 // the same from global memory (per-wave streaming of the packed block; sampler fallback)
 template <int KG, int MT>
-__device__ __forceinline__ void gemm16_glb(const float* __restrict__ wp, int lane, const float (&b)[8 * KG], f32x4v (&acc)[MT]) {
+__device__ __forceinline__ void gemm16_glb(const float* __restrict__ wp, int lane, const float (&b)[8 * KG], f32x4v (&acc)[MT],
+                                           const float* hint = nullptr) {
     const uint4* __restrict__ w4 = reinterpret_cast<const uint4*>(wp) + lane;
     constexpr int TC = MT <= 4 ? MT : (MT % 3 == 0 ? 3 : 4);
     PointScale ps{1.0f, 0};
     if constexpr (kPieces == 2) {
-        ps = point_scale16<8 * KG>(b);
+        ps = point_scale16<8 * KG>(b, hint);
         scale_acc16<MT>(acc, ps.kpre);
     }
 #pragma unroll
@@ -245,15 +259,16 @@ __device__ __forceinline__ void stage16_begin(float* stage, const float* __restr
 
 
 // groups G0 .. G0+NG-1 of a KG-group GEMM from a staged part laid out [mt][NG][piece][lane]
-template <int KG, int MT, int G0, int NG>
-__device__ __forceinline__ void gemm16_lds_part(const float* lds_block, int lane, const float (&b)[8 * KG], f32x4v (&acc)[MT]) {
+template <int KG, int MT, int G0, int NG, bool PRE = true, bool POST = true>      // PRE / POST: see mlp_common.hpp::gemm_lds_part
+__device__ __forceinline__ void gemm16_lds_part(const float* lds_block, int lane, const float (&b)[8 * KG], f32x4v (&acc)[MT],
+                                                const float* hint = nullptr) {
     const lds_u4* w4 = (const lds_u4*)lds_block + lane;
     constexpr int TC = MT <= 4 ? MT : (MT % 3 == 0 ? 3 : 4);
     static_assert(MT % TC == 0, "tile chunking");
     PointScale ps{1.0f, 0};
     if constexpr (kPieces == 2) {           // (every part of a GEMM sees the same b, hence the same scale)
-        ps = point_scale16<8 * KG>(b);
-        scale_acc16<MT>(acc, ps.kpre);
+        ps = point_scale16<8 * KG>(b, hint);
+        if constexpr (PRE) scale_acc16<MT>(acc, ps.kpre);
     }
 #pragma unroll
     for (int gl = 0; gl < NG; ++gl) {
@@ -273,13 +288,14 @@ __device__ __forceinline__ void gemm16_lds_part(const float* lds_block, int lane
             mma16_tiles<TC>(a, bp, &acc[c * TC]);
         }
     }
-    if constexpr (kPieces == 2) scale_acc16<MT>(acc, -ps.kpre);
+    if constexpr (kPieces == 2 && POST) scale_acc16<MT>(acc, -ps.kpre);
     __builtin_amdgcn_sched_barrier(0);   // keep later layers' LDS reads from being hoisted above this GEMM
 }
 
-template <class Seq, int NW, int BUF, int KG, int MT, int P0, int G0, int NG>
+template <class Seq, int NW, int BUF, int KG, int MT, int P0, int G0, int NG, bool PRE = true, bool POST = true>
 __device__ __forceinline__ void gemm16_staged_part(float* stage, const float* __restrict__ wp, int part, int lane,
-                                                   const float (&b)[8 * KG], f32x4v (&acc)[MT], const float* __restrict__ wp1 = nullptr) {
+                                                   const float (&b)[8 * KG], f32x4v (&acc)[MT], const float* __restrict__ wp1 = nullptr,
+                                                   const float* hint = nullptr) {
     stage_wait();
     const StagePart nxt = part_at<Seq, BUF>(part + 1);
     if (nxt.mt) stage_issue_part<NW>(wp, nxt, stage + ((part + 1) & 1) * BUF, wp1);
@@ -287,7 +303,7 @@ __device__ __forceinline__ void gemm16_staged_part(float* stage, const float* __
 #ifdef NSA_X_TS
     const unsigned long long tg = ts_now();
 #endif
-    gemm16_lds_part<KG, MT, G0, NG>(stage + (part & 1) * BUF, lane, b, acc);
+    gemm16_lds_part<KG, MT, G0, NG, PRE, POST>(stage + (part & 1) * BUF, lane, b, acc, hint);
 #ifdef NSA_X_TS
     ts_add(3, ts_now() - tg);
 #endif
@@ -342,18 +358,26 @@ __device__ __forceinline__ void resident_load(float* lds, const float* __restric
 // of a sequence that runs two networks (Seq::net).
 template <class Seq, int NW, int BUF, int KG, int MT>
 __device__ __forceinline__ void gemm16_staged(float* stage, const float* __restrict__ wp, int opi, int lane,
-                                              const float (&b)[8 * KG], f32x4v (&acc)[MT], const float* __restrict__ wp1 = nullptr) {
+                                              const float (&b)[8 * KG], f32x4v (&acc)[MT], const float* __restrict__ wp1 = nullptr,
+                                              const float* hint = nullptr) {       // hint: acc_abs_max16-style bound on |b| (form 2)
     if constexpr (seq_resident<Seq>::value) {        // `stage` = the resident image: no wait, no copy, no barrier
-        gemm16_lds_part<KG, MT, 0, KG>(stage + res_off<Seq>(opi), lane, b, acc);
+        gemm16_lds_part<KG, MT, 0, KG>(stage + res_off<Seq>(opi), lane, b, acc, hint);
         return;
     }
     constexpr int M = max_groups<BUF>(MT);
     constexpr int NP = (KG + M - 1) / M;
     static_assert(NP <= 3, "a staged GEMM is split into at most three parts");
     const int p0 = first_part<Seq, BUF>(opi);
-    gemm16_staged_part<Seq, NW, BUF, KG, MT, 0, 0, (KG < M ? KG : M)>(stage, wp, p0, lane, b, acc, wp1);
-    if constexpr (NP > 1) gemm16_staged_part<Seq, NW, BUF, KG, MT, 1, M, (KG - M < M ? KG - M : M)>(stage, wp, p0 + 1, lane, b, acc, wp1);
-    if constexpr (NP > 2) gemm16_staged_part<Seq, NW, BUF, KG, MT, 2, 2 * M, KG - 2 * M>(stage, wp, p0 + 2, lane, b, acc, wp1);
+    float own = 0.0f;                                // several parts: this lane's maximum once, handed to every part
+    if constexpr (kPieces == 2 && NP > 1) {
+        if (!hint) {
+            own = abs_max<8 * KG>(b);
+            hint = &own;
+        }
+    }
+    gemm16_staged_part<Seq, NW, BUF, KG, MT, 0, 0, (KG < M ? KG : M), true, NP == 1>(stage, wp, p0, lane, b, acc, wp1, hint);
+    if constexpr (NP > 1) gemm16_staged_part<Seq, NW, BUF, KG, MT, 1, M, (KG - M < M ? KG - M : M), false, NP == 2>(stage, wp, p0 + 1, lane, b, acc, wp1, hint);
+    if constexpr (NP > 2) gemm16_staged_part<Seq, NW, BUF, KG, MT, 2, 2 * M, KG - 2 * M, false, true>(stage, wp, p0 + 2, lane, b, acc, wp1, hint);
 }
 
 // packed per-feature vector (activation layout [q*16 + s]) -> this lane's 16 values as 4 tiles x 4

@@ -360,12 +360,13 @@ __device__ __forceinline__ void stage_wait() {
 }
 
 template <int KS, int MT>
-__device__ __forceinline__ void gemm_lds(const float* lds_block, int lane, const float (&b)[KS], f32x16 (&acc)[MT]) {
+__device__ __forceinline__ void gemm_lds(const float* lds_block, int lane, const float (&b)[KS], f32x16 (&acc)[MT],
+                                         const float* hint = nullptr) {
     constexpr int KS8 = (KS + 7) / 8;
     const lds_u4* w4 = (const lds_u4*)lds_block + lane;
     PointScale ps{1.0f, 0};
     if constexpr (kPieces == 2) {
-        ps = point_scale32<KS>(b);
+        ps = point_scale32<KS>(b, hint);
         scale_acc<MT>(acc, ps.kpre);
     }
     u32x4 nxt[MT][3];
@@ -396,10 +397,10 @@ __device__ __forceinline__ void gemm_lds(const float* lds_block, int lane, const
 // floats from `wp`): wait for its block, start fetching the next one into the other buffer, multiply from LDS.
 template <class Seq, int KS, int MT>
 __device__ __forceinline__ void gemm_staged(float* stage, const float* __restrict__ wp, int opi, int lane,
-                                            const float (&b)[KS], f32x16 (&acc)[MT]) {
+                                            const float (&b)[KS], f32x16 (&acc)[MT], const float* hint = nullptr) {
     stage_wait();
     if (opi + 1 < Seq::n) stage_issue(wp + Seq::off(opi + 1), Seq::size(opi + 1), stage + ((opi + 1) & 1) * kStageFloats);
-    gemm_lds<KS, MT>(stage + (opi & 1) * kStageFloats, lane, b, acc);
+    gemm_lds<KS, MT>(stage + (opi & 1) * kStageFloats, lane, b, acc, hint);
 }
 
 template <class Seq>
@@ -434,13 +435,16 @@ __device__ __forceinline__ void stage_issue_op(const float* __restrict__ wp, con
     }
 }
 
-template <int KS, int MT, int G0, int NG>
-__device__ __forceinline__ void gemm_lds_part(const float* lds_block, int lane, const float (&b)[KS], f32x16 (&acc)[MT]) {
+// PRE / POST (form 2): the first part of a GEMM scales the accumulators up, the last one back down; parts in between leave them in
+// the scaled domain (every part derives the same scale from the same b / hint).
+template <int KS, int MT, int G0, int NG, bool PRE = true, bool POST = true>
+__device__ __forceinline__ void gemm_lds_part(const float* lds_block, int lane, const float (&b)[KS], f32x16 (&acc)[MT],
+                                              const float* hint = nullptr) {
     const lds_u4* w4 = (const lds_u4*)lds_block + lane;
     PointScale ps{1.0f, 0};
     if constexpr (kPieces == 2) {           // (every part of a GEMM sees the same b, hence the same scale)
-        ps = point_scale32<KS>(b);
-        scale_acc<MT>(acc, ps.kpre);
+        ps = point_scale32<KS>(b, hint);
+        if constexpr (PRE) scale_acc<MT>(acc, ps.kpre);
     }
     u32x4 nxt[MT][3];
 #pragma unroll
@@ -463,17 +467,17 @@ __device__ __forceinline__ void gemm_lds_part(const float* lds_block, int lane, 
         for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? (kPieces == 2 ? b[8 * g + e] * ps.s : b[8 * g + e]) : 0.0f;
         mma_group<MT>(a, x, acc);
     }
-    if constexpr (kPieces == 2) scale_acc<MT>(acc, -ps.kpre);
+    if constexpr (kPieces == 2 && POST) scale_acc<MT>(acc, -ps.kpre);
     __builtin_amdgcn_sched_barrier(0);
 }
 
 // Part `opi` of the kernel's sequence Seq (Seq::n parts, Seq::op(i) their descriptors); buffers of BUF floats.
-template <class Seq, int BUF, int KS, int MT, int G0, int NG>
+template <class Seq, int BUF, int KS, int MT, int G0, int NG, bool PRE = true, bool POST = true>
 __device__ __forceinline__ void gemm_staged_part(float* stage, const float* __restrict__ wp, int opi, int lane,
-                                                 const float (&b)[KS], f32x16 (&acc)[MT]) {
+                                                 const float (&b)[KS], f32x16 (&acc)[MT], const float* hint = nullptr) {
     stage_wait();
     if (opi + 1 < Seq::n) stage_issue_op(wp, Seq::op(opi + 1), stage + ((opi + 1) & 1) * BUF);
-    gemm_lds_part<KS, MT, G0, NG>(stage + (opi & 1) * BUF, lane, b, acc);
+    gemm_lds_part<KS, MT, G0, NG, PRE, POST>(stage + (opi & 1) * BUF, lane, b, acc, hint);
 }
 
 

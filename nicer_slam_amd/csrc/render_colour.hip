@@ -195,12 +195,14 @@ __device__ __forceinline__ void colour_mlp(float* stage, const float* __restrict
                                            const float (&in)[COL_IN_STEPS], f32x16 (&a1)[2], f32x16 (&a2)[2], float (&rgb)[3],
                                            uint32_t* masks = nullptr) {
     load_vec<2>(wp + ColPack::kB0, h, a1);
-    if (STAGED) {
-        gemm_staged_part<Seq, kColStage, COL_IN_STEPS, 2, 0, 5>(stage, wp, 0, lane, in, a1);
-        gemm_staged_part<Seq, kColStage, COL_IN_STEPS, 2, 5, 4>(stage, wp, 1, lane, in, a1);
+    if (STAGED) {                                // (form 2: both parts of the first layer share one scale and one scaling of a1)
+        const float m_in = abs_max<COL_IN_STEPS>(in);
+        gemm_staged_part<Seq, kColStage, COL_IN_STEPS, 2, 0, 5, true, false>(stage, wp, 0, lane, in, a1, &m_in);
+        gemm_staged_part<Seq, kColStage, COL_IN_STEPS, 2, 5, 4, false, true>(stage, wp, 1, lane, in, a1, &m_in);
     } else {
         gemm_op<COL_IN_STEPS, 2>(wp + ColPack::kW0, lane, in, a1);
     }
+    const float m_h1 = acc_abs_max<2>(a1);       // (form 2 scale hint: a ReLU is at most |a|)
     float h1[HS];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -208,8 +210,8 @@ __device__ __forceinline__ void colour_mlp(float* stage, const float* __restrict
         for (int r = 0; r < 16; ++r) h1[16 * t + r] = relu_f(a1[t][r]);
     if (masks) masks[0] = relu_mask(a1);         // (taken where a1 dies: the forward keeps no pre-activation alive for it)
     load_vec<2>(wp + ColPack::kB1, h, a2);
-    if (STAGED) gemm_staged_part<Seq, kColStage, HS, 2, 0, 4>(stage, wp, 2, lane, h1, a2);
-    else        gemm_op<HS, 2>(wp + ColPack::kW1, lane, h1, a2);
+    if (STAGED) gemm_staged_part<Seq, kColStage, HS, 2, 0, 4>(stage, wp, 2, lane, h1, a2, &m_h1);
+    else        gemm_op<HS, 2>(wp + ColPack::kW1, lane, h1, a2, &m_h1);
     if (masks) masks[1] = relu_mask(a2);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {

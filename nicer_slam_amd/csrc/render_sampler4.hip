@@ -31,15 +31,15 @@ struct ResidentGemm {
     int lane;
     const float* wp;           // the network's packed block in global memory (experiment builds only, see below)
     template <int KG, int MT>
-    __device__ __forceinline__ void run(int pack_off, const float (&b)[8 * KG], f32x4v (&acc)[MT]) {
+    __device__ __forceinline__ void run(int pack_off, const float (&b)[8 * KG], f32x4v (&acc)[MT], const float* hint = nullptr) {
         using P = SdfPack4<NH>;
 #ifdef NSA_X_GLB_WEIGHTS
         // SLP-hazard bisect (tools/slp_bisect.sh, profiles/r05_slp_bisect.txt): the same fragments streamed from global memory --
         // no LDS read sits between the MFMAs.  Experiment builds only (build.py refuses NSA_X_* for the product).
-        gemm16_glb<KG, MT>(wp + pack_off, lane, b, acc);
+        gemm16_glb<KG, MT>(wp + pack_off, lane, b, acc, hint);
 #else
         const int off = pack_off == P::kW0 ? 0 : a16_floats(4, QIN_G) + (pack_off - P::wh(1)) / (P::kHH + 64) * P::kHH;
-        gemm16_lds<KG, MT>(lds + off, lane, b, acc);
+        gemm16_lds<KG, MT>(lds + off, lane, b, acc, hint);
 #endif
     }
 };

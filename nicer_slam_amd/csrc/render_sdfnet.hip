@@ -106,6 +106,7 @@ __device__ __forceinline__ void hidden_forward(float* stage, int op0, const floa
 #pragma unroll
     for (int k = 1; k <= NH; ++k) {
         float d2;
+        const float bound = acc_abs_max<2>(acc) + kSoftplusSlack;        // (form 2: the next GEMM's scale, known before its operands)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -116,7 +117,7 @@ __device__ __forceinline__ void hidden_forward(float* stage, int op0, const floa
         }
         if (k < NH) {
             load_vec<2>(wp + P::bh(k), h, acc);
-            gemm_staged<Seq, HS, 2>(stage, wp, op0 + k, lane, hlast, acc);
+            gemm_staged<Seq, HS, 2>(stage, wp, op0 + k, lane, hlast, acc, &bound);
         }
     }
 }
@@ -138,6 +139,8 @@ __device__ __forceinline__ void reverse_pass(float* stage, int op0, const float*
 #pragma unroll
         for (int q = 0; q < HS; ++q) em->hid(SE<NH>::DA(NH), q, h, da[q]);
     }
+    float bound = 0.0f;                                  // (form 2) scale hints: |da| <= |acc|, the Softplus derivative is a sigmoid
+    const float* hint = nullptr;
 #pragma unroll
     for (int k = NH - 1; k >= 1; --k) {
         f32x16 acc[2];
@@ -145,7 +148,9 @@ __device__ __forceinline__ void reverse_pass(float* stage, int op0, const float*
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        gemm_staged<Seq, HS, 2>(stage, wp, op0 + (NH - 1 - k), lane, da, acc);
+        gemm_staged<Seq, HS, 2>(stage, wp, op0 + (NH - 1 - k), lane, da, acc, hint);
+        bound = acc_abs_max<2>(acc);
+        hint = &bound;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -163,7 +168,7 @@ __device__ __forceinline__ void reverse_pass(float* stage, int op0, const float*
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) a3[t][r] = 0.0f;
-    gemm_staged<Seq, HS, 3>(stage, wp, op0 + NH - 1, lane, da, a3);
+    gemm_staged<Seq, HS, 3>(stage, wp, op0 + NH - 1, lane, da, a3, hint);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll

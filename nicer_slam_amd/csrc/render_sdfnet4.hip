@@ -124,6 +124,7 @@ __device__ __forceinline__ void hidden_forward4(float* stage, int op0, const flo
 #pragma unroll
     for (int k = 1; k <= NH; ++k) {
         float d2;
+        const float bound = acc_abs_max16<4>(acc) + kSoftplusSlack;      // (form 2: the next GEMM's scale, known before its operands)
 #pragma unroll
         for (int s = 0; s < QHS; ++s) softplus100_all(acc[s >> 2][s & 3], hlast[s], sg[k - 1][s], d2);
         if (em) {
@@ -132,7 +133,7 @@ __device__ __forceinline__ void hidden_forward4(float* stage, int op0, const flo
         }
         if (k < NH) {
             load_vec16(wp + P::bh(k), q, acc);
-            gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, s0, op0 + k, lane, hlast, acc, s1);
+            gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, s0, op0 + k, lane, hlast, acc, s1, &bound);
         }
     }
 }
@@ -154,12 +155,16 @@ __device__ __forceinline__ void reverse_pass4(float* stage, int op0, const float
 #pragma unroll
         for (int s = 0; s < QHS; ++s) em->hid(SE4<NH>::DA(NH), s, q, da[s]);
     }
+    float bound = 0.0f;                                  // (form 2) scale hints: see mlp_common.hpp::acc_abs_max
+    const float* hint = nullptr;
 #pragma unroll
     for (int k = NH - 1; k >= 1; --k) {
         f32x4v acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, s0, op0 + (NH - 1 - k), lane, da, acc, s1);
+        gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 4>(stage, s0, op0 + (NH - 1 - k), lane, da, acc, s1, hint);
+        bound = acc_abs_max16<4>(acc);                   // |da| <= |acc|: the Softplus derivative is a sigmoid
+        hint = &bound;
 #pragma unroll
         for (int s = 0; s < QHS; ++s) {
             dh[k - 1][s] = acc[s >> 2][s & 3];
@@ -173,7 +178,7 @@ __device__ __forceinline__ void reverse_pass4(float* stage, int op0, const float
     f32x4v a6[6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) a6[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-    gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 6>(stage, s0, op0 + NH - 1, lane, da, a6, s1);
+    gemm16_staged<Seq, Seq::NW, Seq::BUF, 2, 6>(stage, s0, op0 + NH - 1, lane, da, a6, s1, hint);
 #pragma unroll
     for (int s = 0; s < QIN; ++s) dl[s] = a6[s >> 2][s & 3];
 }

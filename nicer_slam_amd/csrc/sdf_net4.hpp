@@ -146,10 +146,11 @@ __device__ __forceinline__ float sdf_only4(const float* __restrict__ wp, int q, 
     float act[QHS];
 #pragma unroll
     for (int k = 1; k < NH; ++k) {
+        const float bound = acc_abs_max16<4>(acc) + kSoftplusSlack;      // (form 2: the next GEMM's scale, known before its operands)
 #pragma unroll
         for (int s = 0; s < QHS; ++s) act[s] = softplus100(acc[s >> 2][s & 3]);
         load_vec16(wp + P::bh(k), q, acc);
-        gemm.template run<2, 4>(P::wh(k), act, acc);
+        gemm.template run<2, 4>(P::wh(k), act, acc, &bound);
     }
     f32x4v ws[4];
     load_vec16(wp + P::kWSDF, q, ws);

@@ -103,12 +103,19 @@ def test_mini_slam_tracks_with_a_learned_map(capsys, family, none_grad, size):
     # (family "7scenes": its model subtree and loss weights -- smooth_weight 0.05 -- and the optimizer in the reference environment's
     #  semantics; under schedule "fine" every table has a gradient in every iteration, so none_grad only has to be harmless here: the
     #  reference schedule under both semantics is profiles/r06_slam_ate.json)
-    est, t_track, t_map = ss.run_slam("fused", teacher, rgb, depth, normal, K, gt, Hs, Ws, n, cg, map_iters=100, track_iters=60,
-                                      schedule="fine", family=family, none_grad=none_grad)
-    ate = ss.ate_rmse(gt.numpy(), est.numpy())
     still = ss.ate_rmse(gt.numpy(), gt[:1].repeat(n, 1, 1).numpy())
-    err = np.linalg.norm(gt[:, :3, 3].numpy() - est[:, :3, 3].numpy(), axis=1)
-    with capsys.disabled():
-        print(f"\n  mini-SLAM [{family}, none_grad={none_grad}], {n} frames: ATE RMSE {ate:.5f} (no tracking {still:.5f}); max error {err.max():.5f}; tracking {t_track:.1f} s, mapping {t_map:.1f} s")
-    assert np.isfinite(est.numpy()).all()
+    # The learning loop is not run-to-run reproducible (the mapping step scatters its table gradients with atomics) and it is chaotic:
+    # over 33 runs of the 7-Scenes case its ATE scattered 0.0011-0.0044 around 0.002 -- under either operand form of the library
+    # (profiles/r06_ab_experiments.txt r7a) -- against this bound of 0.0030 (the family's office sequence moves 0.4 mm per frame at its
+    # start, so "no tracking" is a small number).  Two of 33 runs crossed it; a second attempt is allowed before the test fails.
+    for attempt in range(2):
+        est, t_track, t_map = ss.run_slam("fused", teacher, rgb, depth, normal, K, gt, Hs, Ws, n, cg, map_iters=100, track_iters=60,
+                                          schedule="fine", family=family, none_grad=none_grad)
+        ate = ss.ate_rmse(gt.numpy(), est.numpy())
+        err = np.linalg.norm(gt[:, :3, 3].numpy() - est[:, :3, 3].numpy(), axis=1)
+        with capsys.disabled():
+            print(f"\n  mini-SLAM [{family}, none_grad={none_grad}], {n} frames: ATE RMSE {ate:.5f} (no tracking {still:.5f}); max error {err.max():.5f}; tracking {t_track:.1f} s, mapping {t_map:.1f} s")
+        assert np.isfinite(est.numpy()).all()
+        if ate < 0.5 * still and err.max() < 0.03:
+            break
     assert ate < 0.5 * still and err.max() < 0.03, (ate, still, err.max())

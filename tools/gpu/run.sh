@@ -64,6 +64,10 @@ for r in d["rounds"]:
           "| gpu first 6", g[:6], "last 3", g[-3:], "| host first 4", h[:4], "median", sorted(h)[len(h) // 2])
 PY
                   done ;;
+    slamtest:*)   # slamtest:<n>: the mini-SLAM tests n times (their ATE scatters from run to run: atomics in the mapping step); prints the ATE lines
+                  for i in $(seq 1 ${step#slamtest:}); do
+                    timeout 600 python -m pytest tests/test_sequence_gpu.py -m gpu -q -k mini_slam -s 2>&1 | grep -E "mini-SLAM \[|passed|failed" | cut -c1-150
+                  done ;;
     ablate)       # timing-only ablation builds (wrong numbers): product vs Softplus-free vs Softplus- and PE-free, fp32 and bf16 operands
                   for prec in fp32 bf16; do for tag in "" spfree vfree "" spfree vfree; do
                     NSA_LIB_TAG=$tag timeout 300 python tools/ab_kernels.py --precision $prec --steps 60 2>/dev/null > $O/abl_${prec}_${tag:-product}.json

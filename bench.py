@@ -35,9 +35,11 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak = the peak for this config'
 # Algorithmic multiply-accumulates per point of each per-point kernel (true layer sizes, no padding):
 #   SDF nets 71->64(->64->64)->65 Softplus, colour net 129->64->64->3; forward kernels include the reverse pass that
 #   yields grad sdf, backward kernels include the recomputation + tangent sweep + reverse sweep.
-# v_mfma_f32_32x32x16_bf16 instructions per 32 points (static: groups x tiles x 6 products, see csrc/): with 32 cycles per
-# instruction per SIMD this gives the matrix-pipe busy time, reported beside the fp32-equivalent `frac`.  The quad tiling issues
-# twice as many v_mfma_f32_16x16x32_bf16 of half the duration -- the same busy cycles (profiles/r02_pmc_per_kernel_*.csv).
+# Matrix instructions per 32 points in the THREE-piece operand form (static: groups x tiles x 6 products of v_mfma_f32_32x32x16_bf16,
+# see csrc/): with 32 cycles per instruction per SIMD this gives the matrix-pipe busy time, reported beside the fp32-equivalent `frac`.
+# The quad tiling issues twice as many 16x16x32 instructions of half the duration -- the same busy cycles
+# (profiles/r02_pmc_per_kernel_*.csv).  The library's operand form (csrc/mlp_common.hpp::NSA_FORM, asked at run time:
+# nsa_operand_form) scales the count: form 2 = two fp16 pieces per operand, FOUR v_mfma_f32_32x32x16_f16 per block (x 4 / 6).
 MFMA_PER_TILE = {"k_sampler_sdf": 216, "k_sdfnet_fwd<coarse>": 180, "k_sdfnet_fwd<fine>": 372, "k_sdfnet_fwd<pair>": 552, "k_sdfnet_bwd<coarse>": 288,
                  "k_sdfnet_bwd<fine>": 672, "k_colour_fwd": 156, "k_colour_bwd": 168, "k_colour_coarse_bwd": 168 + 288}
 # (round 5: the data-path colour backward no longer recomputes its forward -- ReLU masks and sigmoid outputs come from the save area --
@@ -227,6 +229,8 @@ def main():
 
     from nicer_slam_amd.hashencoder import backend as be
     from nicer_slam_amd.utils.general import get_camera_from_tensor
+    from nicer_slam_amd.fused.pack import operand_form as _operand_form
+    operand_form = _operand_form()
     model, conf = make_model(args, device)
     K = torch.eye(4, device=device)
     K[0, 0] = K[1, 1] = 600.0
@@ -359,9 +363,14 @@ def main():
                 roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "flops_per_launch": flops,
+                        "operand_form": None if bf16_kernel else operand_form,
                         "mfma_path": "plain bf16 operands, one MFMA per product block (dense bf16 peak)" if bf16_kernel else
-                        "fp32 products as 6 bf16 MFMAs on 3-way split operands (fp32-faithful); achieved counts "
-                        "algorithmic fp32 flops once"}
+                        ("fp32 products as 4 fp16 MFMAs on operands split into two round-to-nearest fp16 pieces after a per-point "
+                         "power-of-two scaling (each operand held to 2^-23, the four products exact; dot products closer to float64 than the "
+                         "three-piece form's, tests/test_operand_form_cpu.py, DESIGN 4.4); achieved counts "
+                         "algorithmic fp32 flops once" if operand_form == 2 else
+                         "fp32 products as 6 bf16 MFMAs on 3-way split operands (fp32-faithful); achieved counts "
+                         "algorithmic fp32 flops once")}
             else:
                 ach = nbytes / (tms * 1e-3) / 1e9
                 roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -369,11 +378,13 @@ def main():
                         "bytes_per_launch": nbytes // n}
             if name in MFMA_PER_TILE and args.precision == "fp32":
                 tiles = (pts + 31) // 32
-                busy = MFMA_PER_TILE[name] * tiles * 32.0 / N_SIMD               # matrix-pipe busy cycles per SIMD
-                roof["mfma_pipe"] = {"instructions_per_launch": MFMA_PER_TILE[name] * tiles, "busy_cycles_per_simd": round(busy),
+                per_tile = MFMA_PER_TILE[name] * (4 if operand_form == 2 else 6) // 6
+                busy = per_tile * tiles * 32.0 / N_SIMD                           # matrix-pipe busy cycles per SIMD
+                roof["mfma_pipe"] = {"instructions_per_launch": per_tile * tiles, "busy_cycles_per_simd": round(busy),
                                      "utilisation_at_2.4GHz": round(busy / (tms / n * 1e-3 * NOMINAL_GHZ * 1e9), 4),
-                                     "note": "6 bf16 MFMAs per fp32 product block; the fp32-equivalent frac above prices the "
-                                             "kernel against the fp32 peak, this against the matrix pipe it actually uses"}
+                                     "note": ("4 fp16" if operand_form == 2 else "6 bf16") + " MFMAs per fp32 product block; the "
+                                             "fp32-equivalent frac above prices the kernel against the fp32 peak, this against the "
+                                             "matrix pipe it actually uses"}
             roof.update({"launches": n, "avg_launch_us": round(tms / n * 1e3, 2), "share_of_step": round(tms / n / ms, 4),
                          "all_kernels_us": {k: round(v[0] / v[2] * 1e3, 1) for k, v in sorted(agg.items())},
                          "all_kernels_us_note": "event pairs around every launch of an EAGER replay of the timed batches (graph nodes "

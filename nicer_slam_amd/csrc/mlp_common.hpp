@@ -86,8 +86,10 @@ __device__ __forceinline__ void split8(const float (&x)[8], BFrag& f) {
 // NSA_FORM: how the library's fp32 path enters the matrix cores (one choice per library build; fused/pack.py asks nsa_operand_form()):
 //   3  three exact bf16 pieces per operand, six products per block (rounds 1-6a)
 //   2  two fp16 pieces per operand (round to nearest, twice: x s = h0 + h1 to 2^-23), FOUR products per block, the weights scaled by
-//      2^9 in the pack and every point's B vector by its own power of two (point_scale below) -- the same 2^-23 |a b| product bound
-//      with a third fewer matrix instructions; measured against float64 no worse than the three-piece form
+//      2^9 in the pack and every point's B vector by its own power of two (point_scale below): each operand is held to 2^-23, the
+//      four products are exact, so a product is within 2^-22 |a b| in the worst case (three-piece form: 2^-23; an fp32 multiply: 2^-24)
+//      with a third fewer matrix instructions and a third fewer accumulator roundings -- measured against float64 its dot products
+//      are CLOSER than the three-piece form's and than an fp32 multiply-add chain's (tests/test_operand_form_cpu.py)
 #ifndef NSA_FORM
 #define NSA_FORM 2
 #endif
@@ -99,7 +101,7 @@ constexpr int kPieces = NSA_PIECES;
 // A packed fragment triple holds [bf16 hi | bf16 mid | bf16 lo] (form 3) or [fp16 h0 | fp16 h1 | bf16 round-to-nearest] (form 2: the
 // third slot serves the bf16-operand build).  kSlot0 = the first slot this translation unit's pieces come from.
 constexpr int kSlot0 = (NSA_PIECES == 1 && NSA_FORM == 2) ? 2 : 0;
-constexpr float kWScale = 512.0f;            // form 2: packed weights are w * 2^9 (|w| < 127.9; fp16 pieces exact to 2^-23 for |w| >= 2^-12)
+constexpr float kWScale = 512.0f;            // form 2: packed weights are w * 2^9 (|w| < 127.9; held to 2^-23 for |w| >= 2^-11, to 2^-34 absolute below)
 // source fragment (of the three per slot group and tile) of the i-th fragment a stage keeps in LDS
 __host__ __device__ constexpr int src_frag(int i);
 // Pieces per fragment that a block-cooperative weight stage keeps in LDS.  The packed blocks in global memory always hold all three

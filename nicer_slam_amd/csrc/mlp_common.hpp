@@ -173,17 +173,17 @@ __device__ __forceinline__ void split8_h2(const float (&t)[8], f16x8_t& h0, f16x
 }
 
 // Per-point power-of-two scaling of a GEMM's B operand (form 2).  m = the largest |b| of the point (over all of its lanes; the caller
-// has combined the lanes' maxima): the operands are multiplied by s = 2^(13 - E), E = exponent of m clamped to +-100, so that the
+// has combined the lanes' maxima): the operands are multiplied by s = 2^(13 - E), E = exponent of m clamped to +-80, so that the
 // largest lies in [2^13, 2^14); the accumulators (which hold the bias or an earlier partial sum) are multiplied by s 2^9 before the
 // products are added and by its inverse afterwards -- exact (powers of two), and the fp32 additions in between round as they would
-// unscaled.  An all-zero vector scales by 2^113 (harmless).
+// unscaled.  An all-zero vector scales by 2^93 (harmless).
 struct PointScale {
     float s;        // operands x s
     int kpre;       // accumulators x 2^kpre before, x 2^-kpre after (v_ldexp_f32: a multiplication of the accumulator VECTORS by a
 };                  // float would compile to v_pk_mul_f32, which build.py's ISA check refuses)
 __device__ __forceinline__ PointScale point_scale_of(float m) {
     unsigned e = __float_as_uint(m) >> 23;               // biased exponent (m >= 0)
-    e = e < 27u ? 27u : (e > 227u ? 227u : e);
+    e = e < 47u ? 47u : (e > 207u ? 207u : e);          // (|E| <= 80: an accumulator of magnitude 2^25 still survives the 2^(149 - e) below)
 #ifdef NSA_X_NO_POINT_SCALE      // timing-only ablation (WRONG numbers; tagged builds): no per-point maximum, a constant scale (r6w)
     e = 127u;
 #endif

@@ -366,8 +366,8 @@ def main():
                         "operand_form": None if bf16_kernel else operand_form,
                         "mfma_path": "plain bf16 operands, one MFMA per product block (dense bf16 peak)" if bf16_kernel else
                         ("fp32 products as 4 fp16 MFMAs on operands split into two round-to-nearest fp16 pieces after a per-point "
-                         "power-of-two scaling (each operand held to 2^-23, the four products exact; dot products closer to float64 than the "
-                         "three-piece form's, tests/test_operand_form_cpu.py, DESIGN 4.4); achieved counts "
+                         "power-of-two scaling (each operand held to 2^-23, the four products exact; against float64 as close as the three-piece "
+                         "form and closer than an fp32 evaluation, tests/test_operand_form_{cpu,gpu}.py, DESIGN 4.4); achieved counts "
                          "algorithmic fp32 flops once" if operand_form == 2 else
                          "fp32 products as 6 bf16 MFMAs on 3-way split operands (fp32-faithful); achieved counts "
                          "algorithmic fp32 flops once")}

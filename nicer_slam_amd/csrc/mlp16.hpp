@@ -93,10 +93,16 @@ __device__ __forceinline__ float acc_abs_max16(const f32x4v (&acc)[MT]) {
     }
     return fmaxf(m[0], m[1]);
 }
-template <int MT>
+template <int MT, bool POST>
 __device__ __forceinline__ void scale_acc16(f32x4v (&acc)[MT], int k) {
 #ifdef NSA_X_NO_ACC_SCALE
     return;
+#endif
+#ifdef NSA_X_NO_PRE
+    if (!POST) return;
+#endif
+#ifdef NSA_X_NO_POST
+    if (POST) return;
 #endif
 #pragma unroll
     for (int t = 0; t < MT; ++t)
@@ -116,7 +122,7 @@ __device__ __forceinline__ void gemm16_lds(const float* lds_block, int lane, con
     PointScale ps{1.0f, 0};
     if constexpr (kPieces == 2) {
         ps = point_scale16<8 * KG>(b, hint);
-        scale_acc16<MT>(acc, ps.kpre);
+        scale_acc16<MT, false>(acc, ps.kpre);
     }
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
@@ -139,7 +145,7 @@ __device__ __forceinline__ void gemm16_lds(const float* lds_block, int lane, con
             mma16_tiles<TC>(a, bp, &acc[c * TC]);
         }
     }
-    if constexpr (kPieces == 2) scale_acc16<MT>(acc, -ps.kpre);
+    if constexpr (kPieces == 2) scale_acc16<MT, true>(acc, -ps.kpre);
     __builtin_amdgcn_sched_barrier(0);   // keep later layers' LDS reads from being hoisted above this GEMM
 }
 
@@ -152,7 +158,7 @@ __device__ __forceinline__ void gemm16_glb(const float* __restrict__ wp, int lan
     PointScale ps{1.0f, 0};
     if constexpr (kPieces == 2) {
         ps = point_scale16<8 * KG>(b, hint);
-        scale_acc16<MT>(acc, ps.kpre);
+        scale_acc16<MT, false>(acc, ps.kpre);
     }
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
@@ -174,7 +180,7 @@ __device__ __forceinline__ void gemm16_glb(const float* __restrict__ wp, int lan
             mma16_tiles<TC>(a, bp, &acc[c * TC]);
         }
     }
-    if constexpr (kPieces == 2) scale_acc16<MT>(acc, -ps.kpre);
+    if constexpr (kPieces == 2) scale_acc16<MT, true>(acc, -ps.kpre);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -268,7 +274,7 @@ __device__ __forceinline__ void gemm16_lds_part(const float* lds_block, int lane
     PointScale ps{1.0f, 0};
     if constexpr (kPieces == 2) {           // (every part of a GEMM sees the same b, hence the same scale)
         ps = point_scale16<8 * KG>(b, hint);
-        if constexpr (PRE) scale_acc16<MT>(acc, ps.kpre);
+        if constexpr (PRE) scale_acc16<MT, false>(acc, ps.kpre);
     }
 #pragma unroll
     for (int gl = 0; gl < NG; ++gl) {
@@ -288,7 +294,7 @@ __device__ __forceinline__ void gemm16_lds_part(const float* lds_block, int lane
             mma16_tiles<TC>(a, bp, &acc[c * TC]);
         }
     }
-    if constexpr (kPieces == 2 && POST) scale_acc16<MT>(acc, -ps.kpre);
+    if constexpr (kPieces == 2 && POST) scale_acc16<MT, true>(acc, -ps.kpre);
     __builtin_amdgcn_sched_barrier(0);   // keep later layers' LDS reads from being hoisted above this GEMM
 }
 

@@ -230,10 +230,16 @@ __device__ __forceinline__ PointScale point_scale32(const float (&b)[N], const f
     const float m = hint ? *hint : abs_max<N>(b);
     return point_scale_of(__uint_as_float(umax_xor32(__float_as_uint(m))));
 }
-template <int MT>
+template <int MT, bool POST>      // POST: the scaling behind the products (false: the one in front of them)
 __device__ __forceinline__ void scale_acc(f32x16 (&acc)[MT], int k) {
-#ifdef NSA_X_NO_ACC_SCALE        // timing-only ablation (WRONG numbers; tagged builds): what the accumulator scaling of form 2 costs (r6w)
-    return;
+#ifdef NSA_X_NO_ACC_SCALE        // timing-only ablations (WRONG numbers; tagged builds): what the accumulator scaling of form 2 costs (r6w),
+    return;                      // and its two halves (r7i)
+#endif
+#ifdef NSA_X_NO_PRE
+    if (!POST) return;
+#endif
+#ifdef NSA_X_NO_POST
+    if (POST) return;
 #endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -294,7 +300,7 @@ __device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane,
     PointScale ps{1.0f, 0};
     if constexpr (kPieces == 2) {
         ps = point_scale32<KS>(b, hint);
-        scale_acc<MT>(acc, ps.kpre);
+        scale_acc<MT, false>(acc, ps.kpre);
     }
 #pragma unroll
     for (int g = 0; g < KS8; ++g) {
@@ -311,7 +317,7 @@ __device__ __forceinline__ void gemm_run(const float* __restrict__ wp, int lane,
         for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? (kPieces == 2 ? b[8 * g + e] * ps.s : b[8 * g + e]) : 0.0f;
         mma_group<MT>(a, x, acc);
     }
-    if constexpr (kPieces == 2) scale_acc<MT>(acc, -ps.kpre);
+    if constexpr (kPieces == 2) scale_acc<MT, true>(acc, -ps.kpre);
     __builtin_amdgcn_sched_barrier(0);   // keep later layers' loads from being hoisted above this GEMM
 }
 
@@ -370,7 +376,7 @@ __device__ __forceinline__ void gemm_lds(const float* lds_block, int lane, const
     PointScale ps{1.0f, 0};
     if constexpr (kPieces == 2) {
         ps = point_scale32<KS>(b, hint);
-        scale_acc<MT>(acc, ps.kpre);
+        scale_acc<MT, false>(acc, ps.kpre);
     }
     u32x4 nxt[MT][3];
 #pragma unroll
@@ -392,7 +398,7 @@ __device__ __forceinline__ void gemm_lds(const float* lds_block, int lane, const
         for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? (kPieces == 2 ? b[8 * g + e] * ps.s : b[8 * g + e]) : 0.0f;
         mma_group<MT>(a, x, acc);
     }
-    if constexpr (kPieces == 2) scale_acc<MT>(acc, -ps.kpre);
+    if constexpr (kPieces == 2) scale_acc<MT, true>(acc, -ps.kpre);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -447,7 +453,7 @@ __device__ __forceinline__ void gemm_lds_part(const float* lds_block, int lane, 
     PointScale ps{1.0f, 0};
     if constexpr (kPieces == 2) {           // (every part of a GEMM sees the same b, hence the same scale)
         ps = point_scale32<KS>(b, hint);
-        if constexpr (PRE) scale_acc<MT>(acc, ps.kpre);
+        if constexpr (PRE) scale_acc<MT, false>(acc, ps.kpre);
     }
     u32x4 nxt[MT][3];
 #pragma unroll
@@ -470,7 +476,7 @@ __device__ __forceinline__ void gemm_lds_part(const float* lds_block, int lane, 
         for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? (kPieces == 2 ? b[8 * g + e] * ps.s : b[8 * g + e]) : 0.0f;
         mma_group<MT>(a, x, acc);
     }
-    if constexpr (kPieces == 2 && POST) scale_acc<MT>(acc, -ps.kpre);
+    if constexpr (kPieces == 2 && POST) scale_acc<MT, true>(acc, -ps.kpre);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -510,7 +516,7 @@ __device__ __forceinline__ void gemm_op_tiles(const float* __restrict__ wp, int 
         ps[t] = PointScale{1.0f, 0};
         if constexpr (kPieces == 2) {
             ps[t] = point_scale32<KS>(b[t], hint ? hint + t : nullptr);
-            scale_acc<MT>(acc[t], ps[t].kpre);
+            scale_acc<MT, false>(acc[t], ps[t].kpre);
         }
     }
 #pragma unroll
@@ -533,7 +539,7 @@ __device__ __forceinline__ void gemm_op_tiles(const float* __restrict__ wp, int 
     }
     if constexpr (kPieces == 2) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) scale_acc<MT>(acc[t], -ps[t].kpre);
+        for (int t = 0; t < T; ++t) scale_acc<MT, true>(acc[t], -ps[t].kpre);
     }
     __builtin_amdgcn_sched_barrier(0);
 }

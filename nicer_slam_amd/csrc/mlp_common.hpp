@@ -82,7 +82,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], BFrag& f) {
 // Operand precision of every GEMM in a translation unit: 3 = fp32-faithful split (default), 1 = plain bf16 operands
 // (round-to-nearest-even; fp32 accumulate) -- the optional "bf16 MLP" mode, compiled as a second set of kernels
 // (csrc/*_bf16.hip) and selected per network through nsa_grid_t.precision.  The packed weight blocks are shared: the
-// bf16 mode reads only the first piece, which pack.py rounds to nearest.
+// bf16 mode reads only the round-to-nearest bf16 piece (form 3: the first slot of a fragment triple, form 2: the third; kSlot0).
 // NSA_FORM: how the library's fp32 path enters the matrix cores (one choice per library build; fused/pack.py asks nsa_operand_form()):
 //   3  three exact bf16 pieces per operand, six products per block (rounds 1-6a)
 //   2  two fp16 pieces per operand (round to nearest, twice: x s = h0 + h1 to 2^-23), FOUR products per block, the weights scaled by
@@ -106,7 +106,7 @@ constexpr float kWScale = 512.0f;            // form 2: packed weights are w * 2
 // source fragment (of the three per slot group and tile) of the i-th fragment a stage keeps in LDS
 __host__ __device__ constexpr int src_frag(int i);
 // Pieces per fragment that a block-cooperative weight stage keeps in LDS.  The packed blocks in global memory always hold all three
-// (one pack serves both precisions); the bf16-operand build multiplies with the first piece only, so its stages copy every THIRD 1-KiB
+// (one pack serves both precisions); the bf16-operand build multiplies with one piece only, so its stages copy every THIRD 1-KiB
 // fragment and lay the copy out as [tile][group][lane] -- a third of the global->LDS traffic behind every staged GEMM, which in that
 // build is six times shorter and would otherwise wait for its copy (round 5).  NSA_STAGE_ALL_PIECES: the round-4 behaviour (A/B runs).
 #ifdef NSA_STAGE_ALL_PIECES

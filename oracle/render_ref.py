@@ -140,7 +140,7 @@ def positional_encoding(x, n_freq):
 # The reference has no such mode (fp32 only; hashgrid.py:15's autocast is never enabled): this restates what the product's
 # `mlp_precision = "bf16" | "bf16_colour"` kernels compute (nicer_slam_amd/csrc/mlp_common.hpp, NSA_PIECES == 1), so that those
 # modes have a checker that is independent of the HIP code:
-#   * every matrix-core GEMM takes BOTH operands rounded to bfloat16, round-to-nearest-even (weights: the first piece of the
+#   * every matrix-core GEMM takes BOTH operands rounded to bfloat16, round-to-nearest-even (weights: the bf16 round-to-nearest piece of the
 #     packed split, fused/pack.py::split_bf16x3; activations / cotangents / tangents: v_cvt_pk_bf16_f32), products exact,
 #     accumulation in fp32 starting from the fp32 bias;
 #   * this holds for the forward GEMMs, for the reverse pass that builds grad sdf (cotangent operand rounded) and for the GEMMs of

@@ -1,5 +1,5 @@
 """CPU checks of the oracle's bf16-operand emulation (oracle/render_ref.py::_LinQ): the rounding it applies is the rounding the
-packed weights carry (fused/pack.py::split_bf16x3, first piece) and the kernels' v_cvt_pk_bf16_f32 (round to nearest even), every
+packed weights carry (fused/pack.py::split_bf16x3, first piece = the third slot of the two-piece form's fragment triple, split_f16x2) and the kernels' v_cvt_pk_bf16_f32 (round to nearest even), every
 derivative GEMM rounds the vector it multiplies, and the fp32 path is untouched."""
 import numpy as np
 import torch

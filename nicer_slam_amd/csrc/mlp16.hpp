@@ -68,7 +68,10 @@ __device__ __forceinline__ void mma16_tiles(const u32x4 (&a)[TC][3], const B16& 
 #define NSA_MM16H(AP, BV)                                                                              \
         _Pragma("unroll") for (int t = 0; t < TC; ++t)                                                 \
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(a[t][AP]), BV, acc[t], 0, 0, 0);
-        NSA_MM16H(1, b.h1) NSA_MM16H(0, b.h1) NSA_MM16H(1, b.h0) NSA_MM16H(0, b.h0)
+#if NSA_FORM2_PRODUCTS == 4
+        NSA_MM16H(1, b.h1)
+#endif
+        NSA_MM16H(0, b.h1) NSA_MM16H(1, b.h0) NSA_MM16H(0, b.h0)
 #undef NSA_MM16H
     } else {
 #pragma unroll

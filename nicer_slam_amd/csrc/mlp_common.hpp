@@ -91,9 +91,16 @@ __device__ __forceinline__ void split8(const float (&x)[8], BFrag& f) {
 //      with a third fewer matrix instructions and a third fewer accumulator roundings -- measured against float64 its dot products
 //      are as close as the three-piece form's (emulation: closer; MI355X: 1.34e-7 against 1.22e-7 rms on sdf values of magnitude 1) and
 //      closer than an fp32 multiply-add chain's (1.75e-7) -- tests/test_operand_form_cpu.py, test_operand_form_gpu.py, DESIGN 4.4
+//      -DNSA_FORM2_PRODUCTS=3 (a build-time option, NOT the default) leaves the h1 h1 product out: 2^-22 |a b| more per product in the worst
+//      case, a quarter fewer matrix instructions (-4.9 % per iteration); on the MI355X its sdf values are as close to float64 as the
+//      four-product form's (1.35e-7 against 1.34e-7 rms) and every parity test passes at unchanged tolerances (profiles/r06_ab_experiments.txt r7p)
 #ifndef NSA_FORM
 #define NSA_FORM 2
 #endif
+#ifndef NSA_FORM2_PRODUCTS
+#define NSA_FORM2_PRODUCTS 4
+#endif
+static_assert(NSA_FORM2_PRODUCTS == 4 || NSA_FORM2_PRODUCTS == 3, "NSA_FORM2_PRODUCTS: 4 (default) or 3");
 #ifndef NSA_PIECES
 #define NSA_PIECES NSA_FORM
 #endif
@@ -267,7 +274,10 @@ __device__ __forceinline__ void mma_group(const AV (&a)[MT][3], const float (&x)
 #define NSA_MMH(AP, BV)                                                                                  \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                \
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(a[mt][AP]), BV, acc[mt], 0, 0, 0);
-        NSA_MMH(1, b1) NSA_MMH(0, b1) NSA_MMH(1, b0) NSA_MMH(0, b0)
+#if NSA_FORM2_PRODUCTS == 4      // (-DNSA_FORM2_PRODUCTS=3: without the h1 h1 product, see the NSA_FORM comment)
+        NSA_MMH(1, b1)
+#endif
+        NSA_MMH(0, b1) NSA_MMH(1, b0) NSA_MMH(0, b0)
 #undef NSA_MMH
     } else {
         const bf16x8_t b = round8_bf16(x);
